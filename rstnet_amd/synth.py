@@ -1,0 +1,151 @@
+"""Seeded synthetic MimiCodec weights (random-init, reference ``state_dict`` keys).
+
+There is no network and no checkpoint on the build/GPU boxes, so every test, fixture and
+benchmark runs on weights generated here.  The generator is pure CPU torch with an explicit
+``torch.Generator`` so the very same numbers are produced in the build container (where the
+reference is imported to make golden fixtures) and on the GPU box.
+
+Recipe: Xavier-uniform conv / linear weights as in the reference's own
+tests (``MLLM_v2/moshi/modules/conv_test.py:53-60``), small random biases, LayerScale 0.01,
+LayerNorm affine near identity, and *independent* Gaussian codebooks per RVQ level whose scale
+follows the residual at that level (data-sampled codebooks create exact fp32 ties and are useless
+for parity).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+import os
+
+import numpy as np
+
+# Per-level centre (mean residual vector, [K, D]) and scale (std of the centred residual, [K]) of
+# the default-config codebooks: measured offline on a calibration clip by
+# tests/golden/calibrate_codebooks.py (CPU oracle) and stored as data next to this file.  A
+# codebook is  centre_l + scale_l * N_l  with N_l ~ randn drawn from the seeded generator, so the
+# codes are spread over many entries and top-2 gaps are well conditioned.
+_CALIB_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "synth_calib.npz")
+_FALLBACK_STD = 0.08
+
+
+def load_codebook_calibration():
+    if not os.path.exists(_CALIB_FILE):
+        return None
+    d = np.load(_CALIB_FILE)
+    return {"seed": int(d["seed"]), "center": torch.from_numpy(d["center"]), "scale": torch.from_numpy(d["scale"])}
+
+
+def _xavier(gen: torch.Generator, *shape: int) -> torch.Tensor:
+    """nn.init.xavier_uniform_ semantics for conv / linear weight shapes."""
+    receptive = 1
+    for s in shape[2:]:
+        receptive *= s
+    fan_in, fan_out = shape[1] * receptive, shape[0] * receptive
+    bound = math.sqrt(6.0 / (fan_in + fan_out))
+    return (torch.rand(*shape, generator=gen) * 2 - 1) * bound
+
+
+def mimi_state_dict(seed: int = 0, *, n_filters: int = 64, ratios: Optional[List[int]] = None,
+                    latent_dim: int = 512, kernel_size: int = 7, last_kernel_size: int = 3,
+                    residual_kernel_size: int = 3, compress: int = 2, codebook_size: int = 2048,
+                    codebook_dim: int = 256, rvq_layers: int = 8, num_layers: int = 8,
+                    dim_feedforward: int = 2048, layer_scale: float = 0.01,
+                    resample_stride: int = 2, calib: Optional[dict] = "default") -> Dict[str, torch.Tensor]:
+    """Returns a CPU fp32 state_dict with exactly the keys of the reference ``MimiCodec``
+    (``MLLM_v2/tools/tokenizer/MimiCodec/model/models/MimiCodec.py:26-72``), minus the
+    training-only ``semantic_mapping_layer``."""
+    ratios = list(ratios) if ratios is not None else [8, 6, 5, 4]
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(key: str, cout: int, cin: int, k: int, bias: bool = True):
+        sd[f"{key}.weight"] = _xavier(g, cout, cin, k)
+        if bias:
+            sd[f"{key}.bias"] = 0.02 * torch.randn(cout, generator=g)
+
+    def convtr(key: str, cin: int, cout: int, k: int):
+        sd[f"{key}.weight"] = _xavier(g, cin, cout, k)
+        sd[f"{key}.bias"] = 0.02 * torch.randn(cout, generator=g)
+
+    def resblock(prefix: str, dim: int):
+        conv(f"{prefix}.block.1.conv.conv", dim // compress, dim, residual_kernel_size)
+        conv(f"{prefix}.block.3.conv.conv", dim, dim // compress, 1)
+
+    # SEANet encoder (modules/seanet.py:184-235)
+    i, mult = 0, 1
+    conv(f"encoder.model.{i}.conv.conv", n_filters, 1, kernel_size)
+    i += 1
+    for r in reversed(ratios):
+        resblock(f"encoder.model.{i}", mult * n_filters)
+        i += 2
+        conv(f"encoder.model.{i}.conv.conv", mult * n_filters * 2, mult * n_filters, 2 * r)
+        i += 1
+        mult *= 2
+    i += 1
+    conv(f"encoder.model.{i}.conv.conv", latent_dim, mult * n_filters, last_kernel_size)
+
+    # SEANet decoder (modules/seanet.py:317-390)
+    i, mult = 0, 2 ** len(ratios)
+    conv(f"decoder.model.{i}.conv.conv", mult * n_filters, latent_dim, kernel_size)
+    i += 1
+    for r in ratios:
+        i += 1
+        convtr(f"decoder.model.{i}.convtr.convtr", mult * n_filters, mult * n_filters // 2, 2 * r)
+        i += 1
+        resblock(f"decoder.model.{i}", mult * n_filters // 2)
+        i += 1
+        mult //= 2
+    i += 1
+    conv(f"decoder.model.{i}.conv.conv", 1, n_filters, last_kernel_size)
+
+    # resampling (modules/resample.py)
+    conv("downsample.conv.conv.conv", latent_dim, latent_dim, 2 * resample_stride, bias=False)
+    sd["upsample.convtr.convtr.convtr.weight"] = _xavier(g, latent_dim, 1, 2 * resample_stride)
+
+    # transformers (modules/transformer.py:434-750)
+    for name in ("encoder_transformer", "decoder_transformer"):
+        for l in range(num_layers):
+            p = f"{name}.transformer.layers.{l}"
+            sd[f"{p}.self_attn.in_proj_weight"] = _xavier(g, 3 * latent_dim, latent_dim)
+            sd[f"{p}.self_attn.out_proj.weight"] = _xavier(g, latent_dim, latent_dim)
+            for n in ("norm1", "norm2"):
+                sd[f"{p}.{n}.weight"] = 1.0 + 0.05 * torch.randn(latent_dim, generator=g)
+                sd[f"{p}.{n}.bias"] = 0.05 * torch.randn(latent_dim, generator=g)
+            sd[f"{p}.linear1.weight"] = _xavier(g, dim_feedforward, latent_dim)
+            sd[f"{p}.linear2.weight"] = _xavier(g, latent_dim, dim_feedforward)
+            sd[f"{p}.layer_scale_1.scale"] = torch.full((latent_dim,), layer_scale)
+            sd[f"{p}.layer_scale_2.scale"] = torch.full((latent_dim,), layer_scale)
+
+    # split RVQ (quantization/vq.py:200-246, core_vq.py:104-127)
+    if calib == "default":
+        calib = load_codebook_calibration()
+        if calib is not None and (calib["seed"] != seed or tuple(calib["center"].shape) != (rvq_layers, codebook_dim)):
+            calib = None  # calibration was measured for another seed / shape
+
+    def rvq(prefix: str, n_q: int, first_level: int):
+        conv(f"{prefix}.input_proj", codebook_dim, latent_dim, 1, bias=False)
+        conv(f"{prefix}.output_proj", latent_dim, codebook_dim, 1, bias=False)
+        for j in range(n_q):
+            p = f"{prefix}.vq.layers.{j}._codebook"
+            usage = 0.5 + 1.5 * torch.rand(codebook_size, generator=g)
+            noise = torch.randn(codebook_size, codebook_dim, generator=g)
+            if calib is not None:
+                emb = calib["center"][first_level + j][None, :] + calib["scale"][first_level + j] * noise
+            else:
+                emb = _FALLBACK_STD * noise
+            sd[f"{p}._initialized"] = torch.ones(1)
+            sd[f"{p}.cluster_usage"] = usage
+            sd[f"{p}.embedding_sum"] = emb * usage[:, None]
+
+    rvq("quantizer.rvq_first", 1, 0)
+    rvq("quantizer.rvq_rest", rvq_layers - 1, 1)
+    return sd
+
+
+def synth_audio(batch: int, samples: int, seed: int = 0) -> torch.Tensor:
+    """0.1 * randn(B, 1, T) fp32 -- the synthetic 24 kHz mono input of BASELINE.md section 3."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    return 0.1 * torch.randn(batch, 1, samples, generator=g)

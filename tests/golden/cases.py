@@ -1,0 +1,80 @@
+"""Seeded inputs shared by tests/golden/make_golden.py (reference side) and the tests (oracle / HIP side).
+
+Everything here is deterministic CPU torch, so both sides see identical inputs and weights without
+any of them being stored.
+"""
+import zlib
+
+import torch
+
+from rstnet_amd import synth
+
+MIMI_SEED = 0
+TRANSFORMER_LAYER_SCALE = 0.25  # large enough that attention / FFN errors are visible in the output
+
+# name -> (batch, samples, audio seed).  cfg1 = BASELINE.json configs[0]; ragged = length that is not a
+# multiple of the 1920-sample hop (ceil(T/hop) frames, decode returns F*1920 samples).
+MIMI_E2E = {
+    "cfg1": (1, 24000, 0),
+    "ragged": (2, 30001, 1),
+}
+
+# name -> (B, Cin, Cout, T, K, stride); first four = MLLM_v2/moshi/modules/conv_test.py:11-28, the strided
+# ones are the SEANet encoder shapes at reduced width.
+CONV_CASES = {
+    "small1": (3, 4, 5, 10, 6, 1),
+    "small2": (4, 5, 6, 10, 7, 1),
+    "small3": (5, 6, 7, 10, 2, 1),
+    "large1": (1, 512, 512, 256, 7, 1),
+    "stride4": (2, 16, 32, 103, 8, 4),
+    "stride5": (2, 32, 64, 57, 10, 5),
+    "stride6": (1, 64, 128, 40, 12, 6),
+    "stride8": (2, 128, 256, 35, 16, 8),
+}
+# name -> (B, Cin, Cout, T, K, stride); first four = conv_test.py:30-48
+CONVTR_CASES = {
+    "small1": (3, 4, 5, 10, 6, 1),
+    "small2": (4, 5, 6, 10, 7, 2),
+    "small3": (5, 6, 7, 10, 4, 3),
+    "large1": (1, 512, 512, 256, 7, 2),
+    "stride8": (2, 256, 128, 9, 16, 8),
+    "stride6": (1, 128, 64, 21, 12, 6),
+    "stride5": (2, 64, 32, 33, 10, 5),
+    "stride4": (2, 32, 16, 50, 8, 4),
+}
+# name -> (B, dim, T)   (seanet_test.py:111-160 shapes + SEANet widths)
+RESBLOCK_CASES = {
+    "dim8": (2, 8, 40),
+    "dim64": (2, 64, 300),
+    "dim512": (1, 512, 50),
+}
+
+
+def _seed(name: str) -> int:
+    return 41 + (zlib.crc32(name.encode()) & 0xFFFF)
+
+
+def layer_tensors(name, wshape, nbias, xshape):
+    """Xavier-uniform weight (as conv_test.py:53-60, generator seeded from the case name), small random
+    bias and torch.rand input."""
+    g = torch.Generator().manual_seed(_seed(name))
+    w = synth._xavier(g, *wshape)
+    b = 0.1 * torch.randn(nbias, generator=g)
+    x = torch.rand(*xshape, generator=g)
+    return w, b, x
+
+
+def rvq_latent(sd, n_batch: int = 4, n_frames: int = 250):
+    """A seeded latent [B,512,F] with the statistics of the real encoder output: the calibrated centre of
+    level 0 pulled back through the (pseudo-inverse of the) input projection plus white noise."""
+    g = torch.Generator().manual_seed(77)
+    calib = synth.load_codebook_calibration()
+    w = sd["quantizer.rvq_first.input_proj.weight"][:, :, 0]  # [256, 512]
+    centre = torch.linalg.lstsq(w, calib["center"][0][:, None]).solution[:, 0]  # [512]
+    z = centre[None, :, None] + 0.07 * torch.randn(n_batch, 512, n_frames, generator=g)
+    return z
+
+
+def transformer_input(batch: int = 1, frames: int = 300):
+    g = torch.Generator().manual_seed(78)
+    return torch.randn(batch, 512, frames, generator=g)

@@ -1,0 +1,123 @@
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference, read-only, imported in place; nothing
+from it is copied).  The GPU box and the CPU test-suite only ever read the .npz files written here.
+
+    NO_TORCH_COMPILE=1 python -B tests/golden/make_golden.py
+
+Weights are never stored: they are regenerated from ``rstnet_amd.synth.mimi_state_dict(seed)``
+(or a seeded Xavier init for the layer-level cases), which is bit-reproducible on CPU.
+"""
+import os
+import sys
+
+os.environ["NO_TORCH_COMPILE"] = "1"  # eager fp32, no Inductor
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference/MLLM_v2")
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from rstnet_amd import synth  # noqa: E402
+from tests.golden import cases  # noqa: E402
+
+from tools.tokenizer.MimiCodec.model.models.MimiCodec import MimiCodec  # noqa: E402
+from tools.tokenizer.MimiCodec.model.modules.conv import StreamingConv1d, StreamingConvTranspose1d  # noqa: E402
+from tools.tokenizer.MimiCodec.model.modules.seanet import SEANetResnetBlock  # noqa: E402
+
+
+def ref_mimi(sd):
+    m = MimiCodec(encoder_rates=[8, 6, 5, 4], codebook_size=2048, codebook_dim=256, rvq_layers=8).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("semantic_mapping_layer") for k in missing), (missing, unexpected)
+    return m
+
+
+@torch.no_grad()
+def gen_mimi_e2e():
+    """F5: MimiCodec.encode / decode (models/MimiCodec.py:93-110) on config-1 style clips."""
+    sd = synth.mimi_state_dict(cases.MIMI_SEED)
+    m = ref_mimi(sd)
+    out = {}
+    for name, (B, T, aseed) in cases.MIMI_E2E.items():
+        audio = synth.synth_audio(B, T, aseed)
+        z = m.downsample(m.encoder_transformer(m.encoder(audio))[0])
+        codes = m.encode(audio)
+        wav = m.decode(codes)
+        # top-2 gap of every RVQ decision, so that a mismatch can be attributed to a near tie
+        gaps = []
+        for rvq in (m.quantizer.rvq_first, m.quantizer.rvq_rest):
+            r = rvq.input_proj(z).transpose(1, 2).reshape(-1, 256)
+            for layer in rvq.vq.layers:
+                d = torch.cdist(r[None], layer.embedding[None])[0]
+                t2 = d.topk(2, largest=False)
+                gaps.append(((t2.values[:, 1] - t2.values[:, 0]) / t2.values[:, 0]).view(B, -1))
+                r = r - layer.embedding[t2.indices[:, 0]]
+        out[f"{name}.latent"] = z.numpy()
+        out[f"{name}.codes"] = codes.numpy().astype(np.int16)
+        out[f"{name}.wav"] = wav.numpy()
+        out[f"{name}.rel_gap"] = torch.stack(gaps, 1).numpy()
+        print(name, tuple(codes.shape), tuple(wav.shape), "min rel gap %.2e" % torch.stack(gaps).min())
+    np.savez(os.path.join(HERE, "mimi_e2e.npz"), **out)
+
+
+@torch.no_grad()
+def gen_rvq():
+    """F3: SplitResidualVectorQuantizer.encode/decode (quantization/vq.py:305-323) on a seeded latent."""
+    sd = synth.mimi_state_dict(cases.MIMI_SEED)
+    m = ref_mimi(sd)
+    z = cases.rvq_latent(sd)
+    codes = m.quantizer.encode(z)
+    zq = m.quantizer.decode(codes)
+    np.savez(os.path.join(HERE, "rvq.npz"), codes=codes.numpy().astype(np.int16), zq0=zq[:1].numpy())  # first item only (size)
+    print("rvq", tuple(codes.shape), tuple(zq.shape))
+
+
+@torch.no_grad()
+def gen_transformer():
+    """F4: ProjectedTransformer (modules/transformer.py:738-750), T > context so the window matters."""
+    sd = synth.mimi_state_dict(cases.MIMI_SEED, layer_scale=cases.TRANSFORMER_LAYER_SCALE)
+    m = ref_mimi(sd)
+    x = cases.transformer_input()
+    y = m.encoder_transformer(x)[0]
+    np.savez(os.path.join(HERE, "transformer.npz"), y=y.numpy())
+    print("transformer", tuple(y.shape), float(y.abs().max()))
+
+
+@torch.no_grad()
+def gen_layers():
+    """F2: the reference's own conv / conv-transpose / resnet-block test shapes
+    (MLLM_v2/moshi/modules/conv_test.py:11-48, seanet_test.py) with seed-41 Xavier weights."""
+    out = {}
+    for name, (B, cin, cout, T, K, S) in cases.CONV_CASES.items():
+        layer = StreamingConv1d(cin, cout, K, stride=S, causal=True, norm="none", pad_mode="constant")
+        w, b, x = cases.layer_tensors(name, (cout, cin, K), cout, (B, cin, T))
+        layer.conv.conv.weight.copy_(w)
+        layer.conv.conv.bias.copy_(b)
+        out[f"conv.{name}"] = layer(x).numpy()
+    for name, (B, cin, cout, T, K, S) in cases.CONVTR_CASES.items():
+        layer = StreamingConvTranspose1d(cin, cout, K, S, causal=True, norm="none")
+        w, b, x = cases.layer_tensors(name, (cin, cout, K), cout, (B, cin, T))
+        layer.convtr.convtr.weight.copy_(w)
+        layer.convtr.convtr.bias.copy_(b)
+        out[f"convtr.{name}"] = layer(x).numpy()
+    for name, (B, dim, T) in cases.RESBLOCK_CASES.items():
+        blk = SEANetResnetBlock(dim, kernel_sizes=[3, 1], dilations=[1, 1], causal=True, pad_mode="constant", compress=2)
+        w1, b1, x = cases.layer_tensors(name + ".1", (dim // 2, dim, 3), dim // 2, (B, dim, T))
+        w2, b2, _ = cases.layer_tensors(name + ".3", (dim, dim // 2, 1), dim, (1, 1, 1))
+        blk.block[1].conv.conv.weight.copy_(w1)
+        blk.block[1].conv.conv.bias.copy_(b1)
+        blk.block[3].conv.conv.weight.copy_(w2)
+        blk.block[3].conv.conv.bias.copy_(b2)
+        out[f"resblock.{name}"] = blk(x).numpy()
+    np.savez(os.path.join(HERE, "layers.npz"), **out)
+    print("layers", len(out))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e"]
+    for w in which:
+        globals()[f"gen_{w}"]()

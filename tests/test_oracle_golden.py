@@ -1,0 +1,94 @@
+"""Pin the CPU oracle (oracle/mimi_oracle.py) against fixtures produced by the real reference
+(tests/golden/make_golden.py).  Integer codes must match exactly, floats to 1e-5 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mimi_oracle as O
+from rstnet_amd import synth
+from tests.golden import cases
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def mimi_sd():
+    return synth.mimi_state_dict(cases.MIMI_SEED)
+
+
+@pytest.mark.parametrize("name", list(cases.CONV_CASES))
+def test_conv_matches_reference(name):
+    B, cin, cout, T, K, S = cases.CONV_CASES[name]
+    w, b, x = cases.layer_tensors(name, (cout, cin, K), cout, (B, cin, T))
+    ref = torch.from_numpy(np.load(os.path.join(G, "layers.npz"))[f"conv.{name}"])
+    y = O.causal_conv1d(x, w, b, stride=S)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < 1e-6
+
+
+@pytest.mark.parametrize("name", list(cases.CONVTR_CASES))
+def test_convtr_matches_reference(name):
+    B, cin, cout, T, K, S = cases.CONVTR_CASES[name]
+    w, b, x = cases.layer_tensors(name, (cin, cout, K), cout, (B, cin, T))
+    ref = torch.from_numpy(np.load(os.path.join(G, "layers.npz"))[f"convtr.{name}"])
+    y = O.causal_convtr1d(x, w, b, stride=S)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < 1e-6
+
+
+@pytest.mark.parametrize("name", list(cases.RESBLOCK_CASES))
+def test_resblock_matches_reference(name):
+    B, dim, T = cases.RESBLOCK_CASES[name]
+    w1, b1, x = cases.layer_tensors(name + ".1", (dim // 2, dim, 3), dim // 2, (B, dim, T))
+    w2, b2, _ = cases.layer_tensors(name + ".3", (dim, dim // 2, 1), dim, (1, 1, 1))
+    sd = {"p.block.1.conv.conv.weight": w1, "p.block.1.conv.conv.bias": b1,
+          "p.block.3.conv.conv.weight": w2, "p.block.3.conv.conv.bias": b2}
+    ref = torch.from_numpy(np.load(os.path.join(G, "layers.npz"))[f"resblock.{name}"])
+    assert rel_err(O.resnet_block(sd, "p", x), ref) < 1e-6
+
+
+def test_rvq_matches_reference(mimi_sd):
+    cfg = O.MimiConfig()
+    g = np.load(os.path.join(G, "rvq.npz"))
+    z = cases.rvq_latent(mimi_sd)
+    codes = O.rvq_encode(mimi_sd, cfg, z)
+    assert codes.dtype == torch.int64
+    assert torch.equal(codes, torch.from_numpy(g["codes"]).long())
+    zq = O.rvq_decode(mimi_sd, cfg, codes[:1])
+    assert rel_err(zq, torch.from_numpy(g["zq0"])) < 1e-6
+
+
+def test_rvq_empty(mimi_sd):
+    codes = O.rvq_encode(mimi_sd, O.MimiConfig(), torch.zeros(2, 512, 0))
+    assert codes.shape == (2, 8, 0) and codes.dtype == torch.int64
+
+
+def test_transformer_matches_reference():
+    sd = synth.mimi_state_dict(cases.MIMI_SEED, layer_scale=cases.TRANSFORMER_LAYER_SCALE)
+    ref = torch.from_numpy(np.load(os.path.join(G, "transformer.npz"))["y"])
+    y = O.projected_transformer(sd, "encoder_transformer", O.MimiConfig(), cases.transformer_input())
+    assert rel_err(y, ref) < 1e-5
+
+
+@pytest.mark.parametrize("name", list(cases.MIMI_E2E))
+def test_mimi_encode_decode_matches_reference(mimi_sd, name):
+    cfg = O.MimiConfig()
+    g = np.load(os.path.join(G, "mimi_e2e.npz"))
+    B, T, aseed = cases.MIMI_E2E[name]
+    audio = synth.synth_audio(B, T, aseed)
+    with torch.no_grad():
+        z = O.encode_latent(mimi_sd, cfg, audio)
+        codes = O.encode(mimi_sd, cfg, audio)
+        wav = O.decode(mimi_sd, cfg, codes)
+    ref_codes = torch.from_numpy(g[f"{name}.codes"]).long()
+    frames = -(-T // cfg.hop_length)  # ceil
+    assert codes.shape == (B, 8, frames) and wav.shape == (B, 1, frames * cfg.hop_length)
+    assert rel_err(z, torch.from_numpy(g[f"{name}.latent"])) < 1e-5
+    assert torch.equal(codes, ref_codes)
+    assert rel_err(wav, torch.from_numpy(g[f"{name}.wav"])) < 1e-5
