@@ -1,0 +1,121 @@
+/*
+ * librstnet_hip.so -- C ABI of the MI355X (gfx950) kernels behind RSTnet's real-time generation hot path.
+ *
+ * The reference (yangdongchao/RSTnet) has no FFI layer: its "operators" are the PyTorch ATen calls issued by the
+ * Kyutai streaming modules.  Each entry point below replaces one of those call sites; the file:line given is the
+ * reference interface it stands in for (paths relative to MLLM_v2/tools/tokenizer/MimiCodec/model/ unless noted).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer; the library never allocates, frees or synchronises (hipGraph-capturable);
+ *   - the library is stateless: weights, activations, streaming history and KV rings are caller-owned;
+ *   - activations are fp32, CHANNELS-LAST: [B][T][C] with C contiguous (the reference's [B][C][T] tensors are
+ *     converted at the model boundary with rst_transpose_f32);  codes are int64 [B][K][F] as in the reference;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and re-entrant;
+ *   - return value: 0 ok, <0 error (RST_ERR_*); rst_last_error() gives the message of the calling thread.
+ */
+#ifndef RSTNET_HIP_H
+#define RSTNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RST_OK 0
+#define RST_ERR_INVALID_ARG (-1)
+#define RST_ERR_UNSUPPORTED (-2)
+#define RST_ERR_LAUNCH (-3)
+
+#define RST_ACT_NONE 0
+#define RST_ACT_ELU 1   /* act_in : ELU(alpha=1) applied to the input on load (nn.ELU before every SEANet conv) */
+#define RST_ACT_GELU 1  /* act_out: exact erf GELU (F.gelu, modules/transformer.py:551-569) */
+#define RST_PAD_ZERO 0
+#define RST_PAD_REPLICATE 1
+
+typedef void* rst_stream_t;
+
+int rst_version(void);
+const char* rst_last_error(void);
+
+/* Generic windowed GEMM:
+ *   y[b*T_out + t][n] = epi( sum_{k<K} act_in(A(b,t,k)) * w[n][k] + bias[n] ),  A(b,t,k) = xflat_b[(t*S - P)*C + k]
+ *   epi(v) = res ? res + (scale ? scale[n] : 1) * act_out(v) : act_out(v)
+ * Elements before the start of a batch item come from hist ([B][P][C]) if given, else are zero / replicated;
+ * elements past the end are zero.  All three named wrappers below are thin fronts for it. */
+int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const float* bias, const float* res,
+                     const float* scale, float* y, int B, int T_in, int T_out, int C, int K, int N, int S, int P,
+                     int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, rst_stream_t stream);
+
+/* Causal Conv1d.  Replaces F.conv1d in RawStreamingConv1d.forward (modules/streaming.py:216-244) together with the
+ * padding logic of StreamingConv1d.forward (modules/conv.py:232-254).
+ *   x [B][T_in][Cin];  w_packed [Cout][Kw_eff*Cin] with w_packed[co][tap*Cin + ci] = weight[co][ci][tap] (dilated taps
+ *   zero-filled);  y [B][T_out][Cout];  left padding P = Kw_eff - stride steps (zeros / replicate / hist [B][P][Cin]).
+ *   res (optional, layout of y) is added to the result (SEANetResnetBlock skip, modules/seanet.py:92-94). */
+int rst_conv1d_causal_f32(const float* x, const float* hist, const float* w_packed, const float* bias,
+                          const float* res, float* y, int B, int T_in, int T_out, int Cin, int Cout, int Kw_eff,
+                          int stride, int pad_mode, int act_in, rst_stream_t stream);
+
+/* Causal ConvTranspose1d, right-trimmed (trim_right_ratio = 1).  Replaces F.conv_transpose1d in
+ * RawStreamingConvTranspose1d.forward (modules/streaming.py:271-303) + the trim of StreamingConvTranspose1d.forward
+ * (modules/conv.py:305-329).  With q = ceil(Kw/stride):
+ *   w_packed [stride*Cout][q*Cin],  w_packed[j*Cout + co][i*Cin + ci] = weight[ci][co][j + (q-1-i)*stride] (0 if >= Kw)
+ *   bias_tiled [stride*Cout] (bias repeated `stride` times) or NULL;   x [B][T_in][Cin] -> y [B][T_in*stride][Cout].
+ *   hist [B][q-1][Cin] = the q-1 input steps preceding x (streaming) or NULL (zeros). */
+int rst_convtr1d_causal_f32(const float* x, const float* hist, const float* w_packed, const float* bias_tiled,
+                            float* y, int B, int T_in, int Cin, int Cout, int Kw, int stride, int act_in,
+                            rst_stream_t stream);
+
+/* y[M][N] = epi(x[M][K] * w[N][K]^T + bias): F.linear call sites of modules/transformer.py:395,421,562 and the 1x1
+ * Conv1d projections of quantization/vq.py:88-96. */
+int rst_linear_f32(const float* x, const float* w, const float* bias, const float* res, const float* scale, float* y,
+                   int64_t M, int K, int N, int act_out, rst_stream_t stream);
+
+/* nn.LayerNorm(D, eps) over the last dim (modules/transformer.py:113-114). */
+int rst_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int D, float eps,
+                      rst_stream_t stream);
+
+/* "b t (p h d) -> p b h t d" split + interleaved RoPE (modules/rope.py:11-68) + KV placement
+ * (RingKVCache.complete index_copy_, modules/transformer.py:255-262).  qkv [B][T][3*H*D]; q [B][H][T][D];
+ * k, v [B][H][cap][D].  ring = 0: slot = t;  ring = 1: slot = (pos + t) % cap.  pos = *pos_dev if given else pos0. */
+int rst_rope_split_f32(const float* qkv, float* q, float* k, float* v, const int64_t* pos_dev, int64_t pos0, int B,
+                       int T, int H, int D, int cap, int ring, int rope, float rope_coef, rst_stream_t stream);
+
+/* Masked attention = F.scaled_dot_product_attention(q, k, v, attn_bias) of modules/transformer.py:404-416.
+ * Mask: key position >= 0, 0 <= pos_q - pos_k (< context if context > 0).  ring = 1 reproduces the slot->position map of
+ * RingKVCache.complete including its `delta <= 0` behaviour.  out [B][T][H*D]. */
+int rst_attention_f32(const float* q, const float* k, const float* v, float* out, const int64_t* pos_dev, int64_t pos0,
+                      int B, int T, int H, int D, int cap, int ring, int context, rst_stream_t stream);
+
+/* Codebook preparation for rst_rvq_search_f32: packed [D/8][n_codes][2][4], e2[n_codes] = |e|^2 (k-ordered fmaf). */
+int rst_rvq_pack_f32(const float* emb, float* packed, float* e2, int n_codes, int D, rst_stream_t stream);
+
+/* Residual VQ nearest-codeword search, all levels fused: EuclideanCodebook._quantize + the residual loop of
+ * ResidualVectorQuantization.encode (quantization/core_vq.py:179-185, 365-376).  x [M][ldx] holds the projected
+ * latents of group g in columns [g*D, (g+1)*D); group g runs levels [group_begin[g], +group_count[g]).
+ * codes [B][L][F] int64 with M = B*F.  dist (optional) [L][M] = winning score |e|^2 - 2 x.e. */
+int rst_rvq_search_f32(const float* x, const float* emb, const float* packed, const float* e2, int64_t* codes,
+                       float* dist, int M, int F, int ldx, int D, int n_codes, int L, int n_groups,
+                       const int* group_begin, const int* group_count, rst_stream_t stream);
+
+/* Sum of codebook rows per group = ResidualVectorQuantization.decode (core_vq.py:378-384): out [M][n_groups*D]. */
+int rst_rvq_gather_f32(const int64_t* codes, const float* emb, float* out, int M, int F, int D, int n_codes, int L,
+                       int n_groups, const int* group_begin, const int* group_count, rst_stream_t stream);
+
+/* Depth-wise causal ConvTranspose1d (ConvTrUpsample1d channel_wise, modules/resample.py:109-119): w [C][Kw]. */
+int rst_convtr_depthwise_f32(const float* x, const float* hist, const float* w, float* y, int B, int T_in, int C,
+                             int Kw, int stride, rst_stream_t stream);
+
+/* Layout adapter [B][R][C] -> [B][C][R] (reference [B,C,T] <-> channels-last). */
+int rst_transpose_f32(const float* x, float* y, int B, int R, int C, rst_stream_t stream);
+
+/* Streaming history roll: hist_out [P_out steps] = last P_out steps of concat(hist_in [P_in steps], x [T_in steps])
+ * (the `previous` buffer of RawStreamingConv1d, modules/streaming.py:224-236; conv-transpose keeps its input history the
+ * same way instead of the reference's `partial` output buffer).  hist_out must not alias hist_in. */
+int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, int B, int T_in, int P_in, int P_out,
+                        int C, rst_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSTNET_HIP_H */

@@ -1,0 +1,71 @@
+"""ctypes binding of ``librstnet_hip.so`` (see ``include/rstnet_hip.h``).
+
+There is deliberately NO fallback: if the shared library is missing or an entry point is absent the
+import of any op raises.  The product path never computes on the CPU and never touches ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librstnet_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_f = C.c_float
+
+# name -> argtypes (all functions return int); mirrors include/rstnet_hip.h one to one
+SIGNATURES = {
+    "rst_gemm_win_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _i, _i, _p],
+    "rst_conv1d_causal_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rst_convtr1d_causal_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rst_linear_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p],
+    "rst_layernorm_f32": [_p, _p, _p, _p, _l, _i, _f, _p],
+    "rst_rope_split_f32": [_p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "rst_attention_f32": [_p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rst_rvq_pack_f32": [_p, _p, _p, _i, _i, _p],
+    "rst_rvq_search_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _p],
+    "rst_rvq_gather_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _p],
+    "rst_convtr_depthwise_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "rst_transpose_f32": [_p, _p, _i, _i, _i, _p],
+    "rst_hist_update_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class RstError(RuntimeError):
+    """An entry point of librstnet_hip.so returned a non-zero status."""
+
+
+def lib() -> C.CDLL:
+    """Loads the library once; raises (never falls back) if it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C rstnet_amd/csrc`).  rstnet_amd has no CPU / PyTorch fallback.")
+    handle = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _i
+    handle.rst_version.restype = _i
+    handle.rst_version.argtypes = []
+    handle.rst_last_error.restype = C.c_char_p
+    handle.rst_last_error.argtypes = []
+    _lib = handle
+    return handle
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().rst_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"librstnet_hip: {msg}")
+        raise RstError(f"librstnet_hip error {rc}: {msg}")

@@ -1,0 +1,218 @@
+// fp32 attention for the Mimi transformers: RoPE + head split (+ ring-KV append) and a flash-style
+// masked attention on the f32 matrix cores.
+//
+// The attention kernel works on the TRANSPOSED score tile  S^T = K * Q^T  (32 keys x 32 queries per
+// v_mfma_f32_32x32x2_f32 accumulator): a lane then owns ONE query column, so the online-softmax row
+// reductions are 16 in-register ops + one cross-half shuffle, and the probabilities P^T sit in exactly the
+// lane/register positions the second product  O^T = V^T * P^T  needs for its B operand -- no LDS round
+// trip for P.  One wave per (batch, head, 32-query tile); K/V tiles are staged through LDS.
+#include "rst_common.h"
+#include "rst_kernels.h"
+#include <math.h>
+
+namespace {
+
+__global__ __launch_bounds__(256) void rope_split_kernel(const RopeSplitParams p) {
+    const int half = p.D / 2;
+    const long total = (long)p.B * p.T * p.H * half;
+    const long pos0 = p.pos_dev ? *p.pos_dev : p.pos0;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int i = (int)(idx % half);
+        const int h = (int)((idx / half) % p.H);
+        const int t = (int)((idx / ((long)half * p.H)) % p.T);
+        const long b = idx / ((long)half * p.H * p.T);
+        const float* src = p.qkv + ((b * p.T + t) * 3) * (long)(p.H * p.D) + (long)h * p.D + 2 * i;
+        const float qr = src[0], qi = src[1];
+        const float kr = src[(long)p.H * p.D], ki = src[(long)p.H * p.D + 1];
+        const float vr = src[2L * p.H * p.D], vi = src[2L * p.H * p.D + 1];
+        float c = 1.0f, s = 0.0f;
+        if (p.rope) {
+            // modules/rope.py:37-40: freqs = exp(ds * coef) (fp32), ts = offset.float() + arange(T).float()
+            const float fr = expf((float)i * p.rope_coef);
+            const float ang = fr * ((float)pos0 + (float)t);
+            c = cosf(ang);
+            s = sinf(ang);
+        }
+        const int slot = p.ring ? (int)((pos0 + t) % p.cap) : t;
+        float* qd = p.q + ((b * p.H + h) * p.T + t) * (long)p.D + 2 * i;
+        float* kd = p.k + ((b * p.H + h) * p.cap + slot) * (long)p.D + 2 * i;
+        float* vd = p.v + ((b * p.H + h) * p.cap + slot) * (long)p.D + 2 * i;
+        qd[0] = qr * c - qi * s;
+        qd[1] = qr * s + qi * c;
+        kd[0] = kr * c - ki * s;
+        kd[1] = kr * s + ki * c;
+        vd[0] = vr;
+        vd[1] = vi;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void attention_kernel(const AttentionParams p) {
+    constexpr int DT = D / 32;
+    constexpr int KS = D / 8;
+    constexpr int KLD = D + 4;
+    __shared__ __attribute__((aligned(16))) float Ks[32 * KLD];  // K tile; reused to stage O
+    __shared__ __attribute__((aligned(16))) float Vs[32 * D];
+
+    const int lane = threadIdx.x;
+    const int j = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 32;
+    const int head = blockIdx.y;
+    const long b = blockIdx.z;
+    const long pos0 = p.pos_dev ? *p.pos_dev : p.pos0;
+    const float scale = 1.0f / sqrtf((float)D);
+    const float NEG_INF = -INFINITY;
+
+    const float* qb = p.q + ((b * p.H + head) * p.T) * (long)D;
+    const float* kb = p.k + ((b * p.H + head) * p.cap) * (long)D;
+    const float* vb = p.v + ((b * p.H + head) * p.cap) * (long)D;
+
+    f32x4 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        qf[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q0 + j < p.T) qf[s] = *reinterpret_cast<const f32x4*>(qb + (long)(q0 + j) * D + 8 * s + 4 * h);
+    }
+
+    // slots that can be visible to this query tile
+    int lo = 0, hi = p.cap - 1;
+    if (!p.ring) {
+        hi = min(p.cap - 1, q0 + 31);
+        if (p.context > 0) lo = max(0, q0 - p.context + 1);
+    }
+    const long end_offset = pos0 + p.T;             // RingKVCache.end_offset after the append
+    const int end_index = (int)(end_offset % p.cap);
+    const long pq = pos0 + q0 + j;                  // this lane's query position
+
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+    float m_run = NEG_INF, l_run = 0.f;
+
+    for (int s0 = (lo / 32) * 32; s0 <= hi; s0 += 32) {
+        __syncthreads();
+        // stage K / V tile (32 slots x D), zero beyond cap
+#pragma unroll
+        for (int i = 0; i < (32 * D / 4) / 64; ++i) {
+            const int idx = lane + 64 * i;
+            const int row = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (s0 + row < p.cap) {
+                kv = *reinterpret_cast<const f32x4*>(kb + (long)(s0 + row) * D + c4);
+                vv = *reinterpret_cast<const f32x4*>(vb + (long)(s0 + row) * D + c4);
+            }
+            *reinterpret_cast<f32x4*>(Ks + row * KLD + c4) = kv;
+            *reinterpret_cast<f32x4*>(Vs + row * D + c4) = vv;
+        }
+        __syncthreads();
+
+        f32x16 sacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + j * KLD + 8 * s + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[s][e], sacc, 0, 0, 0);
+        }
+
+        // mask + online softmax; lane owns query column j, rows (keys) rst_mfma32_row(r, lane)
+        float mt = NEG_INF;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int slot = s0 + rst_mfma32_row(r, lane);
+            long pk;
+            if (!p.ring) {
+                pk = pos0 + slot;
+            } else {
+                // RingKVCache.complete (modules/transformer.py:254-278), including the `delta <= 0` quirk
+                const int delta = slot - end_index;
+                pk = delta <= 0 ? end_offset + delta : end_offset + delta - p.cap;
+                if (slot >= end_offset) pk = -1;
+            }
+            const long dlt = pq - pk;
+            bool ok = slot < p.cap && pk >= 0 && dlt >= 0;
+            if (p.context > 0) ok = ok && dlt < p.context;
+            const float sv = ok ? sacc[r] * scale : NEG_INF;
+            sacc[r] = sv;
+            mt = fmaxf(mt, sv);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = (m_run == NEG_INF) ? 1.0f : expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = (sacc[r] == NEG_INF) ? 0.0f : expf(sacc[r] - m_new);
+            sacc[r] = pv;
+            psum += pv;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = rst_mfma32_row(r, lane);
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const float vf = Vs[key * D + d * 32 + j];
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, sacc[r], oacc[d], 0, 0, 0);
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ks[j * KLD + d * 32 + rst_mfma32_row(r, lane)] = oacc[d][r] * inv;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (32 * D / 4) / 64; ++i) {
+        const int idx = lane + 64 * i;
+        const int row = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
+        if (q0 + row < p.T)
+            *reinterpret_cast<f32x4*>(p.out + ((b * p.T + q0 + row) * p.H + head) * (long)D + c4) =
+                *reinterpret_cast<const f32x4*>(Ks + row * KLD + c4);
+    }
+}
+
+}  // namespace
+
+int rst_launch_rope_split(const RopeSplitParams& p, hipStream_t stream) {
+    RST_REQUIRE(p.B >= 0 && p.T >= 0 && p.H > 0 && p.D > 0 && p.D % 2 == 0 && p.cap > 0, "rope_split: bad sizes");
+    if (p.B == 0 || p.T == 0) return RST_OK;
+    RST_REQUIRE(p.qkv && p.q && p.k && p.v, "rope_split: null pointer");
+    RST_REQUIRE(p.ring || p.cap >= p.T, "rope_split: cap (%d) < T (%d) without ring", p.cap, p.T);
+    RST_REQUIRE(!p.ring || p.T <= p.cap, "rope_split: T (%d) > ring capacity (%d)", p.T, p.cap);
+    const long total = (long)p.B * p.T * p.H * (p.D / 2);
+    if (total == 0) return RST_OK;
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(rope_split_kernel, dim3((unsigned)g), dim3(256), 0, stream, p);
+    return rst_check_launch("rope_split");
+}
+
+int rst_launch_attention(const AttentionParams& p, hipStream_t stream) {
+    RST_REQUIRE(p.B >= 0 && p.T >= 0 && p.H > 0 && p.cap > 0, "attention: bad sizes");
+    RST_REQUIRE(p.B <= 65535 && p.H <= 65535, "attention: grid too large");
+    if (p.B == 0 || p.T == 0) return RST_OK;
+    RST_REQUIRE(p.q && p.k && p.v && p.out, "attention: null pointer");
+    const dim3 grid((p.T + 31) / 32, p.H, p.B);
+    switch (p.D) {
+        case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64), 0, stream, p); break;
+        case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64), 0, stream, p); break;
+        case 128: hipLaunchKernelGGL(attention_kernel<128>, grid, dim3(64), 0, stream, p); break;
+        default:
+            rst_set_error("attention: head dim %d unsupported (32, 64, 128)", p.D);
+            return RST_ERR_UNSUPPORTED;
+    }
+    return rst_check_launch("attention");
+}

@@ -1,0 +1,138 @@
+// extern "C" boundary of librstnet_hip.so -- argument checking and parameter marshalling only.
+#include "../../include/rstnet_hip.h"
+#include "rst_kernels.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void rst_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int rst_check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        rst_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return RST_ERR_LAUNCH;
+    }
+    return RST_OK;
+}
+
+extern "C" {
+
+int rst_version(void) { return 100; }
+const char* rst_last_error(void) { return g_err; }
+
+int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const float* bias, const float* res,
+                     const float* scale, float* y, int B, int T_in, int T_out, int C, int K, int N, int S, int P,
+                     int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, rst_stream_t stream) {
+    RST_REQUIRE(ldy >= N, "gemm_win: ldy (%d) < N (%d)", ldy, N);
+    RST_REQUIRE(act_in == 0 || act_in == 1, "gemm_win: unknown act_in %d", act_in);
+    RST_REQUIRE(act_out == 0 || act_out == 1, "gemm_win: unknown act_out %d", act_out);
+    RST_REQUIRE(pad_mode == 0 || pad_mode == 1, "gemm_win: unknown pad_mode %d", pad_mode);
+    GemmWinParams p;
+    p.x = x; p.hist = hist; p.w = w; p.bias = bias; p.res = res; p.scale = scale; p.y = y;
+    p.B = B; p.T_in = T_in; p.T_out = T_out; p.C = C; p.K = K; p.N = N; p.S = S; p.P = P;
+    p.pad_mode = pad_mode; p.x_bstride = x_bstride; p.ldy = ldy; p.act_in = act_in; p.act_out = act_out;
+    return rst_launch_gemm_win(p, (hipStream_t)stream);
+}
+
+int rst_conv1d_causal_f32(const float* x, const float* hist, const float* w_packed, const float* bias,
+                          const float* res, float* y, int B, int T_in, int T_out, int Cin, int Cout, int Kw_eff,
+                          int stride, int pad_mode, int act_in, rst_stream_t stream) {
+    RST_REQUIRE(Kw_eff >= stride && stride > 0, "conv1d: kernel (%d) must be >= stride (%d)", Kw_eff, stride);
+    return rst_gemm_win_f32(x, hist, w_packed, bias, res, nullptr, y, B, T_in, T_out, Cin, Kw_eff * Cin, Cout, stride,
+                            Kw_eff - stride, pad_mode, (int64_t)T_in * Cin, Cout, act_in, 0, stream);
+}
+
+int rst_convtr1d_causal_f32(const float* x, const float* hist, const float* w_packed, const float* bias_tiled,
+                            float* y, int B, int T_in, int Cin, int Cout, int Kw, int stride, int act_in,
+                            rst_stream_t stream) {
+    RST_REQUIRE(Kw >= stride && stride > 0, "convtr1d: kernel (%d) must be >= stride (%d)", Kw, stride);
+    const int q = (Kw + stride - 1) / stride;
+    return rst_gemm_win_f32(x, hist, w_packed, bias_tiled, nullptr, nullptr, y, B, T_in, T_in, Cin, q * Cin,
+                            stride * Cout, 1, q - 1, 0, (int64_t)T_in * Cin, stride * Cout, act_in, 0, stream);
+}
+
+int rst_linear_f32(const float* x, const float* w, const float* bias, const float* res, const float* scale, float* y,
+                   int64_t M, int K, int N, int act_out, rst_stream_t stream) {
+    RST_REQUIRE(M >= 0 && M < 0x7fffffffLL, "linear: M out of range");
+    return rst_gemm_win_f32(x, nullptr, w, bias, res, scale, y, 1, (int)M, (int)M, K, K, N, 1, 0, 0, M * K, N, 0,
+                            act_out, stream);
+}
+
+int rst_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int D, float eps,
+                      rst_stream_t stream) {
+    return rst_launch_layernorm(x, gamma, beta, y, rows, D, eps, (hipStream_t)stream);
+}
+
+int rst_rope_split_f32(const float* qkv, float* q, float* k, float* v, const int64_t* pos_dev, int64_t pos0, int B,
+                       int T, int H, int D, int cap, int ring, int rope, float rope_coef, rst_stream_t stream) {
+    RopeSplitParams p;
+    p.qkv = qkv; p.q = q; p.k = k; p.v = v; p.pos_dev = (const long*)pos_dev; p.pos0 = pos0;
+    p.B = B; p.T = T; p.H = H; p.D = D; p.cap = cap; p.ring = ring; p.rope = rope; p.rope_coef = rope_coef;
+    return rst_launch_rope_split(p, (hipStream_t)stream);
+}
+
+int rst_attention_f32(const float* q, const float* k, const float* v, float* out, const int64_t* pos_dev, int64_t pos0,
+                      int B, int T, int H, int D, int cap, int ring, int context, rst_stream_t stream) {
+    AttentionParams p;
+    p.q = q; p.k = k; p.v = v; p.out = out; p.pos_dev = (const long*)pos_dev; p.pos0 = pos0;
+    p.B = B; p.T = T; p.H = H; p.D = D; p.cap = cap; p.ring = ring; p.context = context;
+    return rst_launch_attention(p, (hipStream_t)stream);
+}
+
+int rst_rvq_pack_f32(const float* emb, float* packed, float* e2, int n_codes, int D, rst_stream_t stream) {
+    return rst_launch_rvq_pack(emb, packed, e2, n_codes, D, (hipStream_t)stream);
+}
+
+int rst_rvq_search_f32(const float* x, const float* emb, const float* packed, const float* e2, int64_t* codes,
+                       float* dist, int M, int F, int ldx, int D, int n_codes, int L, int n_groups,
+                       const int* group_begin, const int* group_count, rst_stream_t stream) {
+    RST_REQUIRE(n_groups >= 1 && n_groups <= 2 && group_begin && group_count, "rvq_search: bad groups");
+    RvqSearchParams p;
+    p.x = x; p.emb = emb; p.packed = packed; p.e2 = e2; p.codes = (long*)codes; p.dist = dist;
+    p.M = M; p.F = F; p.ldx = ldx; p.D = D; p.n_codes = n_codes; p.L = L; p.n_groups = n_groups;
+    for (int g = 0; g < 2; ++g) {
+        p.group_begin[g] = g < n_groups ? group_begin[g] : 0;
+        p.group_count[g] = g < n_groups ? group_count[g] : 0;
+        RST_REQUIRE(p.group_begin[g] >= 0 && p.group_count[g] >= 0 && p.group_begin[g] + p.group_count[g] <= L,
+                    "rvq_search: group %d out of range", g);
+    }
+    return rst_launch_rvq_search(p, (hipStream_t)stream);
+}
+
+int rst_rvq_gather_f32(const int64_t* codes, const float* emb, float* out, int M, int F, int D, int n_codes, int L,
+                       int n_groups, const int* group_begin, const int* group_count, rst_stream_t stream) {
+    RST_REQUIRE(n_groups >= 1 && n_groups <= 2 && group_begin && group_count, "rvq_gather: bad groups");
+    RvqGatherParams p;
+    p.codes = (const long*)codes; p.emb = emb; p.out = out;
+    p.M = M; p.F = F; p.D = D; p.n_codes = n_codes; p.L = L; p.n_groups = n_groups;
+    for (int g = 0; g < 2; ++g) {
+        p.group_begin[g] = g < n_groups ? group_begin[g] : 0;
+        p.group_count[g] = g < n_groups ? group_count[g] : 0;
+        RST_REQUIRE(p.group_begin[g] >= 0 && p.group_count[g] >= 0 && p.group_begin[g] + p.group_count[g] <= L,
+                    "rvq_gather: group %d out of range", g);
+    }
+    return rst_launch_rvq_gather(p, (hipStream_t)stream);
+}
+
+int rst_convtr_depthwise_f32(const float* x, const float* hist, const float* w, float* y, int B, int T_in, int C,
+                             int Kw, int stride, rst_stream_t stream) {
+    return rst_launch_convtr_depthwise(x, hist, w, y, B, T_in, C, Kw, stride, (hipStream_t)stream);
+}
+
+int rst_transpose_f32(const float* x, float* y, int B, int R, int C, rst_stream_t stream) {
+    return rst_launch_transpose(x, y, B, R, C, (hipStream_t)stream);
+}
+
+int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, int B, int T_in, int P_in, int P_out,
+                        int C, rst_stream_t stream) {
+    return rst_launch_hist_update(x, hist_in, hist_out, B, T_in, P_in, P_out, C, (hipStream_t)stream);
+}
+
+}  // extern "C"

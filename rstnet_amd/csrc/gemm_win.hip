@@ -1,0 +1,260 @@
+// Windowed fp32 GEMM on the gfx950 f32 matrix cores -- the one contraction kernel behind every causal
+// Conv1d / ConvTranspose1d / Linear of the MimiCodec path.
+//
+// Activations are kept channels-last ([B][T][C], C contiguous).  In that layout a causal convolution with
+// kernel Kw, stride S over C input channels is a plain GEMM whose A rows are *overlapping windows* of the
+// flat activation array:
+//      y[b, t, n] = sum_{k < Kw*C} A(b,t,k) * W[n][k],      A(b,t,k) = xflat_b[(t*S - P)*C + k]
+// (P = Kw_eff - S left padding; out-of-range elements are 0, or replicated, or come from a caller-owned
+// history buffer in streaming mode).  A transposed convolution with kernel q*S, stride S is the same thing
+// with window q steps (S_rows = 1, P = q-1) and N = S*Cout output columns, written as S consecutive output
+// time steps; a Linear layer is the degenerate window (Kw=1).  See DESIGN.md section 3.
+//
+// Tile: 4 waves, each TM x TN tiles of v_mfma_f32_32x32x2_f32, BK = 32, register-prefetched double-buffered
+// LDS ([rows][36] floats: a 16-lane ds_read_b128 group covers 16 distinct 16-byte slots -> conflict free).
+// K order inside a BK chunk is permuted (lane half h owns k = 8s + 4h .. +3) so that fragments are read with
+// one ds_read_b128 per four MFMAs; both operands use the same permutation so the product is unchanged.
+#include "rst_common.h"
+#include "rst_kernels.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;  // floats per LDS row
+
+template <int TM, int TN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
+    constexpr int BM = 32 * TM * WM;
+    constexpr int BN = 32 * TN * WN;
+    constexpr int RA = BM / 32;  // A rows staged per thread
+    constexpr int RB = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                     // [2][BM][LDS_LD]
+    float* Bs = smem + 2 * BM * LDS_LD;   // [2][BN][LDS_LD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: blocks that land on one XCD (bid % 8) walk consecutive tiles, n fastest, so
+    // the A rows they share stay in that XCD's L2.
+    const int nblk = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+
+    const int M = p.B * p.T_out;
+    const int TC = p.T_in * p.C;
+    const int PC = p.P * p.C;
+
+    // ---- per-thread staging coordinates
+    const int lrow = tid >> 3;       // 0..31
+    const int lk = (tid & 7) * 4;    // 0,4,..,28
+    long a_off[RA];                  // float offset of the batch inside x
+    long h_off[RA];                  // float offset of the batch inside hist
+    int a_f0[RA];                    // flat index of the window start inside the batch (may be < 0)
+    bool a_ok[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int m = m0 + lrow + 32 * j;
+        a_ok[j] = m < M;
+        const int mm = a_ok[j] ? m : 0;
+        const int b = mm / p.T_out;
+        const int t = mm - b * p.T_out;
+        a_off[j] = (long)b * p.x_bstride;
+        h_off[j] = (long)b * PC;
+        a_f0[j] = (t * p.S - p.P) * p.C;
+    }
+
+    f32x4 ra[RA], rb[RB];
+
+    auto load_elem_a = [&](int j, int f) -> float {
+        float v = 0.0f;
+        if (f >= 0) {
+            if (f < TC) v = p.x[a_off[j] + f];
+            else if (p.pad_mode == 1) v = p.x[a_off[j] + TC - p.C + f % p.C];  // F.pad(mode="replicate") on the right
+        } else if (p.hist) {
+            v = p.hist[h_off[j] + PC + f];
+        } else if (p.pad_mode == 1) {
+            int c = f % p.C;
+            if (c < 0) c += p.C;
+            v = p.x[a_off[j] + c];
+        }
+        return v;
+    };
+
+    auto load_tiles = [&](int kt) {
+        const int k = kt * BK + lk;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a_ok[j]) {
+                if (VEC) {
+                    if (k < p.K) {
+                        const int f = a_f0[j] + k;
+                        if (f >= 0) {
+                            if (f < TC) v = *reinterpret_cast<const f32x4*>(p.x + a_off[j] + f);
+                            else if (p.pad_mode == 1)  // F.pad(mode="replicate") also replicates the right extra padding
+                                v = *reinterpret_cast<const f32x4*>(p.x + a_off[j] + TC - p.C + f % p.C);
+                        } else if (p.hist) {
+                            v = *reinterpret_cast<const f32x4*>(p.hist + h_off[j] + PC + f);
+                        } else if (p.pad_mode == 1) {
+                            int c = f % p.C;
+                            if (c < 0) c += p.C;
+                            v = *reinterpret_cast<const f32x4*>(p.x + a_off[j] + c);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < p.K) v[e] = load_elem_a(j, a_f0[j] + k + e);
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int n = n0 + lrow + 32 * j;
+            if (n < p.N) {
+                const float* wp = p.w + (long)n * p.K + k;
+                if (VEC) {
+                    if (k < p.K) v = *reinterpret_cast<const f32x4*>(wp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < p.K) v[e] = wp[e];
+                }
+            }
+            rb[j] = v;
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* a = As + buf * BM * LDS_LD;
+        float* b = Bs + buf * BN * LDS_LD;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            f32x4 v = ra[j];
+            if (p.act_in == 1) {
+                v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]);
+            }
+            *reinterpret_cast<f32x4*>(a + (lrow + 32 * j) * LDS_LD + lk) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+            *reinterpret_cast<f32x4*>(b + (lrow + 32 * j) * LDS_LD + lk) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 4;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        const float* a = As + buf * BM * LDS_LD + (wm * TM * 32 + frag_row) * LDS_LD + frag_k;
+        const float* b = Bs + buf * BN * LDS_LD + (wn * TN * 32 + frag_row) * LDS_LD + frag_k;
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ++ks) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS_LD + ks * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS_LD + ks * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias -> activation -> (residual + scale *) -> store, 32 consecutive columns per half wave
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.0f;
+        const float scale = p.scale ? p.scale[n] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * TM + i) * 32 + rst_mfma32_row(e, lane);
+                if (m >= M) continue;
+                float v = acc[i][j][e] + bias;
+                if (p.act_out == 1) v = rst_gelu(v);
+                const long o = (long)m * p.ldy + n;
+                if (p.res) v = p.res[o] + scale * v;
+                p.y[o] = v;
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    const long M = (long)p.B * p.T_out;
+    const long tiles = ((M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    if (tiles <= 0) return RST_OK;
+    if (tiles > 0x7fffffffL) {
+        rst_set_error("gemm_win: too many tiles (%ld)", tiles);
+        return RST_ERR_UNSUPPORTED;
+    }
+    const size_t lds = 2 * (BM + BN) * LDS_LD * sizeof(float);
+    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_win_kernel<TM, TN, WM, WN, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_win_kernel<TM, TN, WM, WN, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (vec)
+        hipLaunchKernelGGL((gemm_win_kernel<TM, TN, WM, WN, true>), dim3((unsigned)tiles), dim3(256), lds, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_win_kernel<TM, TN, WM, WN, false>), dim3((unsigned)tiles), dim3(256), lds, stream, p);
+    return rst_check_launch("gemm_win");
+}
+
+}  // namespace
+
+int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
+    RST_REQUIRE(p.B >= 0 && p.T_in >= 0 && p.T_out >= 0 && p.C > 0 && p.K > 0 && p.N > 0 && p.S > 0 && p.P >= 0,
+                "gemm_win: bad sizes B=%d T_in=%d T_out=%d C=%d K=%d N=%d S=%d P=%d", p.B, p.T_in, p.T_out, p.C,
+                p.K, p.N, p.S, p.P);
+    if (p.B == 0 || p.T_out == 0) return RST_OK;
+    RST_REQUIRE(p.w && p.y && (p.x || p.T_in == 0), "gemm_win: null pointer");
+    RST_REQUIRE((long)p.T_in * p.C < 0x7fffffffL && (long)p.T_out * p.S * p.C < 0x7fffffffL,
+                "gemm_win: per-batch activation too large for 32-bit indexing");
+    const bool vec = (p.C % 4 == 0) && (p.K % 4 == 0) && (p.x_bstride % 4 == 0) &&
+                     ((uintptr_t)p.x % 16 == 0) && ((uintptr_t)p.w % 16 == 0) &&
+                     (!p.hist || (uintptr_t)p.hist % 16 == 0);
+    const long M = (long)p.B * p.T_out;
+    if (p.N > 64 && M > 64) return launch_cfg<2, 2, 2, 2>(p, vec, stream);   // 128 x 128
+    if (p.N > 64) return launch_cfg<1, 1, 1, 4>(p, vec, stream);             // 32 x 128 (few rows: streaming steps)
+    if (p.N > 32) return launch_cfg<1, 2, 4, 1>(p, vec, stream);             // 128 x 64
+    return launch_cfg<2, 1, 4, 1>(p, vec, stream);                           // 256 x 32
+}

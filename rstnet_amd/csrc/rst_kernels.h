@@ -1,0 +1,89 @@
+// Internal launcher interface between the C-ABI (capi.hip) and the kernel files.
+#pragma once
+#include "rst_common.h"
+
+// ---- gemm_win.hip -----------------------------------------------------------------------------
+struct GemmWinParams {
+    const float* x;      // [B][T_in][C] channels-last activations
+    const float* hist;   // [B][P][C] rows preceding x (streaming state) or nullptr
+    const float* w;      // [N][K] packed weights, K contiguous, K index = tap*C + c
+    const float* bias;   // [N] or nullptr
+    const float* res;    // residual with the layout of y, or nullptr
+    const float* scale;  // [N] LayerScale (y = res + scale*acc) or nullptr
+    float* y;            // [B*T_out][ldy]
+    int B, T_in, T_out;
+    int C;               // floats per input time step
+    int K, N;
+    int S;               // input time steps advanced per output row
+    int P;               // left padding in time steps
+    int pad_mode;        // 0: zeros, 1: replicate first / last step (left side ignored when hist != nullptr)
+    long x_bstride;      // floats between consecutive batches of x
+    int ldy;             // floats between consecutive output rows (>= N)
+    int act_in;          // 0: none, 1: ELU applied to A on load
+    int act_out;         // 0: none, 1: exact GELU
+};
+int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream);
+
+// ---- norm_elt.hip -----------------------------------------------------------------------------
+int rst_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D,
+                         float eps, hipStream_t stream);
+int rst_launch_transpose(const float* x, float* y, int B, int R, int Ccols, hipStream_t stream);  // [B][R][C]->[B][C][R]
+int rst_launch_convtr_depthwise(const float* x, const float* hist, const float* w, float* y, int B, int T_in, int C,
+                                int K, int S, hipStream_t stream);
+// hist_out [P_out rows] = last P_out rows of concat(hist_in [P_in rows], x [T_in rows]); no aliasing
+int rst_launch_hist_update(const float* x, const float* hist_in, float* hist_out, int B, int T_in, int P_in, int P_out,
+                           int C, hipStream_t stream);
+
+// ---- attention.hip ----------------------------------------------------------------------------
+struct RopeSplitParams {
+    const float* qkv;   // [B][T][3][H][D]
+    float* q;           // [B][H][T][D]
+    float* k;           // [B][H][cap][D]
+    float* v;           // [B][H][cap][D]
+    const long* pos_dev;  // optional device scalar: position of the first new step (overrides pos0)
+    long pos0;          // position of the first new step
+    int B, T, H, D, cap;
+    int ring;           // 0: k/v slot = t (cap == T), 1: slot = (pos0 + t) % cap
+    int rope;           // 0: none, 1: interleaved pairs (modules/rope.py)
+    float rope_coef;    // -ln(max_period) * 2 / D
+};
+int rst_launch_rope_split(const RopeSplitParams& p, hipStream_t stream);
+
+struct AttentionParams {
+    const float* q;     // [B][H][T][D]
+    const float* k;     // [B][H][cap][D]
+    const float* v;     // [B][H][cap][D]
+    float* out;         // [B][T][H*D]
+    const long* pos_dev;  // optional device scalar, as above
+    long pos0;          // position of query 0
+    int B, T, H, D, cap;
+    int ring;           // 0: slot s holds position s; 1: ring cache, end_offset = pos0 + T (RingKVCache.complete)
+    int context;        // <= 0: unlimited
+};
+int rst_launch_attention(const AttentionParams& p, hipStream_t stream);
+
+// ---- rvq.hip ----------------------------------------------------------------------------------
+// packed codebook for one level: [D/8][n_codes][2][4] floats followed by nothing; e2: [n_codes]
+int rst_launch_rvq_pack(const float* emb, float* packed, float* e2, int n_codes, int D, hipStream_t stream);
+struct RvqSearchParams {
+    const float* x;        // [M][ldx], group g reads columns [g*D, (g+1)*D)
+    const float* emb;      // [L][n_codes][D] plain codebooks (residual update)
+    const float* packed;   // [L][D/8][n_codes][2][4]
+    const float* e2;       // [L][n_codes]
+    long* codes;           // [B][L][F] int64, M = B*F
+    float* dist;           // optional [L][M] winning score (debug / tests) or nullptr
+    int M, F, ldx, D, n_codes, L;
+    int n_groups;          // 1 or 2
+    int group_begin[2];    // first level of each group
+    int group_count[2];
+};
+int rst_launch_rvq_search(const RvqSearchParams& p, hipStream_t stream);
+struct RvqGatherParams {
+    const long* codes;     // [B][L][F]
+    const float* emb;      // [L][n_codes][D]
+    float* out;            // [M][n_groups*D]
+    int M, F, D, n_codes, L, n_groups;
+    int group_begin[2];
+    int group_count[2];
+};
+int rst_launch_rvq_gather(const RvqGatherParams& p, hipStream_t stream);

@@ -1,0 +1,187 @@
+// Residual vector quantiser: nearest-codeword search (all levels of a group fused, residual kept in LDS) and the
+// decode-side gather.
+//
+// Arithmetic contract (bit-exact against oracle/rvq_ref.c):
+//     dot(x, e)  = fmaf chain over k = 0 .. D-1 in ascending order, starting from 0
+//     e2(e)      = fmaf chain  e2 = fmaf(e[k], e[k], e2), k ascending
+//     score      = fmaf(-2, dot, e2)              (= |x-e|^2 - |x|^2: same argmin as cdist, core_vq.py:179-185)
+//     code       = lowest index among the minimal scores;   residual -= emb[code]   (exact fp32)
+// v_mfma_f32_32x32x2_f32 is bitwise a k-ordered fmaf chain, so feeding it k = 2s (lane half 0) and 2s+1 (lane half 1)
+// at step s reproduces that order exactly.  The codebook is pre-packed so that the A operand of four consecutive
+// MFMA steps is ONE coalesced 16-byte global load per lane (codebook levels are 2 MiB: L2 resident).
+#include "rst_common.h"
+#include "rst_kernels.h"
+#include <math.h>
+
+namespace {
+
+constexpr int FR = 32;       // frames per workgroup
+constexpr int NW = 8;        // waves per workgroup
+
+__device__ __forceinline__ int pk_off(int k) { return (k >> 3) * 8 + (k & 1) * 4 + ((k >> 1) & 3); }
+
+__global__ __launch_bounds__(256) void rvq_pack_kernel(const float* __restrict__ emb, float* __restrict__ packed,
+                                                       float* __restrict__ e2, int n_codes, int D) {
+    const long total = (long)n_codes * D;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int k = (int)(idx % D);
+        const long code = idx / D;
+        // [k/8][code][k&1][(k>>1)&3]
+        packed[((long)(k >> 3) * n_codes + code) * 8 + (k & 1) * 4 + ((k >> 1) & 3)] = emb[idx];
+    }
+    for (long code = (long)blockIdx.x * 256 + threadIdx.x; code < n_codes; code += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < D; ++k) s = fmaf(emb[code * D + k], emb[code * D + k], s);
+        e2[code] = s;
+    }
+}
+
+__global__ __launch_bounds__(64 * NW) void rvq_search_kernel(const RvqSearchParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int D = p.D, LD = D + 4;
+    float* r_pk = smem;                       // [FR][LD] residual, k-permuted (pk_off)
+    float* e2s = r_pk + FR * LD;              // [n_codes]
+    float* red_s = e2s + p.n_codes;           // [NW][FR]
+    int* red_i = reinterpret_cast<int*>(red_s + NW * FR);  // [NW][FR]
+    int* win = red_i + NW * FR;               // [FR]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * FR;
+    const int g = blockIdx.y;
+    const int tiles = p.n_codes / 32;
+    const int tpw = (tiles + NW - 1) / NW;
+
+    for (int idx = tid; idx < FR * D; idx += 64 * NW) {
+        const int f = idx / D, k = idx - f * D;
+        const int m = m0 + f;
+        r_pk[f * LD + pk_off(k)] = m < p.M ? p.x[(long)m * p.ldx + g * D + k] : 0.f;
+    }
+
+    for (int li = 0; li < p.group_count[g]; ++li) {
+        const int lvl = p.group_begin[g] + li;
+        const float* packed = p.packed + (long)lvl * p.n_codes * D;
+        const float* emb = p.emb + (long)lvl * p.n_codes * D;
+        for (int c = tid; c < p.n_codes; c += 64 * NW) e2s[c] = p.e2[(long)lvl * p.n_codes + c];
+        __syncthreads();
+
+        float best = INFINITY;
+        int bidx = 0x7fffffff;
+        const float* rrow = r_pk + j * LD + h * 4;
+        for (int ct = wave * tpw; ct < min(tiles, (wave + 1) * tpw); ++ct) {
+            const int c0 = ct * 32;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            const float* ap = packed + (long)(c0 + j) * 8 + h * 4;
+#pragma unroll 8
+            for (int kq = 0; kq < D / 8; ++kq) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ap + (long)kq * p.n_codes * 8);
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(rrow + kq * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bq[e], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int code = c0 + rst_mfma32_row(r, lane);
+                const float sc = fmaf(-2.0f, acc[r], e2s[code]);
+                if (sc < best) { best = sc; bidx = code; }
+            }
+        }
+        {   // the two lane halves hold different codes of the same frame
+            const float ob = __shfl_xor(best, 32);
+            const int oi = __shfl_xor(bidx, 32);
+            if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        }
+        if (h == 0) { red_s[wave * FR + j] = best; red_i[wave * FR + j] = bidx; }
+        __syncthreads();
+        if (tid < FR) {
+            float bs = red_s[tid];
+            int bi = red_i[tid];
+            for (int w = 1; w < NW; ++w) {
+                const float s = red_s[w * FR + tid];
+                const int i = red_i[w * FR + tid];
+                if (s < bs || (s == bs && i < bi)) { bs = s; bi = i; }
+            }
+            if (bi < 0 || bi >= p.n_codes) bi = 0;  // only reachable with NaN inputs
+            win[tid] = bi;
+            const int m = m0 + tid;
+            if (m < p.M) {
+                const int b = m / p.F, f = m - b * p.F;
+                p.codes[((long)b * p.L + lvl) * p.F + f] = bi;
+                if (p.dist) p.dist[(long)lvl * p.M + m] = bs;
+            }
+        }
+        __syncthreads();
+        if (li + 1 < p.group_count[g]) {
+            for (int idx = tid; idx < FR * D; idx += 64 * NW) {
+                const int f = idx / D, k = idx - f * D;
+                r_pk[f * LD + pk_off(k)] -= emb[(long)win[f] * D + k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void rvq_gather_kernel(const RvqGatherParams p) {
+    const int ND = p.n_groups * p.D;
+    const long total = (long)p.M * ND;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int col = (int)(idx % ND);
+        const long m = idx / ND;
+        const int g = col / p.D, k = col - g * p.D;
+        const long b = m / p.F, f = m - b * p.F;
+        // ResidualVectorQuantization.decode (core_vq.py:378-384): 0 + q_0 + q_1 + ... in level order
+        float acc = 0.f;
+        for (int li = 0; li < p.group_count[g]; ++li) {
+            const int lvl = p.group_begin[g] + li;
+            long c = p.codes[(b * p.L + lvl) * p.F + f];
+            c = c < 0 ? 0 : (c >= p.n_codes ? p.n_codes - 1 : c);
+            acc = acc + p.emb[((long)lvl * p.n_codes + c) * p.D + k];
+        }
+        p.out[idx] = acc;
+    }
+}
+
+}  // namespace
+
+int rst_launch_rvq_pack(const float* emb, float* packed, float* e2, int n_codes, int D, hipStream_t stream) {
+    RST_REQUIRE(emb && packed && e2 && n_codes > 0 && D > 0 && D % 8 == 0, "rvq_pack: bad arguments (D must be a multiple of 8)");
+    long g = ((long)n_codes * D + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(rvq_pack_kernel, dim3((unsigned)g), dim3(256), 0, stream, emb, packed, e2, n_codes, D);
+    return rst_check_launch("rvq_pack");
+}
+
+int rst_launch_rvq_search(const RvqSearchParams& p, hipStream_t stream) {
+    if (p.M == 0) return RST_OK;
+    RST_REQUIRE(p.x && p.emb && p.packed && p.e2 && p.codes, "rvq_search: null pointer");
+    RST_REQUIRE(p.M >= 0 && p.F > 0 && p.D > 0 && p.D % 8 == 0 && p.n_codes > 0 && p.n_codes % 32 == 0,
+                "rvq_search: need D %% 8 == 0 and n_codes %% 32 == 0 (D=%d n_codes=%d)", p.D, p.n_codes);
+    RST_REQUIRE(p.n_groups >= 1 && p.n_groups <= 2, "rvq_search: n_groups must be 1 or 2");
+    RST_REQUIRE(p.M % p.F == 0, "rvq_search: M (%d) is not a multiple of F (%d)", p.M, p.F);
+    if (p.M == 0) return RST_OK;
+    const size_t lds = ((size_t)FR * (p.D + 4) + p.n_codes + 2 * NW * FR + FR) * sizeof(float);
+    RST_REQUIRE(lds <= 160 * 1024, "rvq_search: D=%d n_codes=%d needs %zu bytes of LDS", p.D, p.n_codes, lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rvq_search_kernel, dim3((p.M + FR - 1) / FR, p.n_groups), dim3(64 * NW), lds, stream, p);
+    return rst_check_launch("rvq_search");
+}
+
+int rst_launch_rvq_gather(const RvqGatherParams& p, hipStream_t stream) {
+    if (p.M == 0) return RST_OK;
+    RST_REQUIRE(p.codes && p.emb && p.out, "rvq_gather: null pointer");
+    RST_REQUIRE(p.M >= 0 && p.F > 0 && p.D > 0 && p.n_codes > 0 && p.n_groups >= 1 && p.n_groups <= 2 && p.M % p.F == 0,
+                "rvq_gather: bad sizes");
+    const long total = (long)p.M * p.n_groups * p.D;
+    if (total == 0) return RST_OK;
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(rvq_gather_kernel, dim3((unsigned)g), dim3(256), 0, stream, p);
+    return rst_check_launch("rvq_gather");
+}

@@ -1,0 +1,208 @@
+"""Tensor-level front of the C ABI: PyTorch is used for device memory and streams only.
+
+Every function takes / returns CUDA (HIP) fp32 tensors in the CHANNELS-LAST layout ``[B, T, C]`` unless
+stated otherwise, launches on ``torch.cuda.current_stream()`` and raises if handed CPU tensors -- there is no
+host fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_ELU, ACT_GELU = 0, 1, 1
+PAD_ZERO, PAD_REPLICATE = 0, 1
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr() if t.numel() > 0 else None
+
+
+def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32) -> None:
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"rstnet_amd.ops: `{name}` is on {t.device}; the HIP path needs a CUDA/HIP tensor (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"rstnet_amd.ops: `{name}` must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"rstnet_amd.ops: `{name}` must be contiguous")
+
+
+def gemm_win(x: torch.Tensor, w: torch.Tensor, *, B: int, T_in: int, T_out: int, C_: int, S: int, P: int, N: int,
+             hist: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+             res: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, pad_mode: int = PAD_ZERO,
+             act_in: int = ACT_NONE, act_out: int = ACT_NONE, out: Optional[torch.Tensor] = None,
+             out_shape: Optional[Tuple[int, ...]] = None) -> torch.Tensor:
+    """rst_gemm_win_f32.  ``w`` is ``[N, K]``; the output is ``[B*T_out, N]`` reshaped to ``out_shape``."""
+    for t, n in ((x, "x"), (w, "w"), (hist, "hist"), (bias, "bias"), (res, "res"), (scale, "scale")):
+        _chk(t, n)
+    K = w.shape[1]
+    assert w.shape[0] == N
+    if out is None:
+        out = torch.empty(out_shape if out_shape is not None else (B, T_out, N), device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, "out")
+    assert out.numel() == B * T_out * N, (tuple(out.shape), B, T_out, N)
+    if res is not None:
+        assert res.numel() == out.numel()
+    if hist is not None:
+        assert hist.numel() == B * P * C_, (tuple(hist.shape), B, P, C_)
+    _lib.check(_lib.lib().rst_gemm_win_f32(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out),
+                                           B, T_in, T_out, C_, K, N, S, P, pad_mode, T_in * C_, N, act_in, act_out,
+                                           _stream()))
+    return out
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, res: Optional[torch.Tensor] = None,
+           scale: Optional[torch.Tensor] = None, act_out: int = ACT_NONE) -> torch.Tensor:
+    """``y = epi(x @ w.T + bias)`` over the last dim of ``x`` (rst_linear_f32)."""
+    for t, n in ((x, "x"), (w, "w"), (bias, "bias"), (res, "res"), (scale, "scale")):
+        _chk(t, n)
+    K = x.shape[-1]
+    N = w.shape[0]
+    assert w.shape[1] == K
+    M = x.numel() // K if K else 0
+    out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_linear_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, K, N,
+                                         act_out, _stream()))
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    for t, n in ((x, "x"), (gamma, "gamma"), (beta, "beta")):
+        _chk(t, n)
+    D = x.shape[-1]
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().rst_layernorm_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), x.numel() // D, D, eps, _stream()))
+    return out
+
+
+def rope_coef(max_period: float, D: int) -> float:
+    """The fp32 scalar multiplying ``arange(D/2)`` in the reference (modules/rope.py:37-38)."""
+    return float(torch.tensor(-math.log(max_period) * 2 / D, dtype=torch.float32))
+
+
+def rope_split(qkv: torch.Tensor, H: int, *, q: Optional[torch.Tensor] = None, k: Optional[torch.Tensor] = None,
+               v: Optional[torch.Tensor] = None, pos0: int = 0, pos_dev: Optional[torch.Tensor] = None, ring: bool = False,
+               rope: bool = True, max_period: float = 10000.0):
+    """qkv ``[B,T,3*H*D]`` -> q ``[B,H,T,D]`` and k/v written into ``[B,H,cap,D]`` buffers (allocated if None)."""
+    _chk(qkv, "qkv")
+    B, T, E3 = qkv.shape
+    D = E3 // (3 * H)
+    if q is None:
+        q = torch.empty(B, H, T, D, device=qkv.device, dtype=torch.float32)
+    if k is None:
+        assert not ring
+        k = torch.empty(B, H, T, D, device=qkv.device, dtype=torch.float32)
+        v = torch.empty(B, H, T, D, device=qkv.device, dtype=torch.float32)
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, n)
+    if pos_dev is not None:
+        _chk(pos_dev, "pos_dev", torch.int64)
+    cap = k.shape[2]
+    _lib.check(_lib.lib().rst_rope_split_f32(_ptr(qkv), _ptr(q), _ptr(k), _ptr(v), _ptr(pos_dev), pos0, B, T, H, D, cap,
+                                             int(ring), int(rope), rope_coef(max_period, D), _stream()))
+    return q, k, v
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, pos0: int = 0, pos_dev: Optional[torch.Tensor] = None,
+              ring: bool = False, context: Optional[int] = None) -> torch.Tensor:
+    """q ``[B,H,T,D]``, k/v ``[B,H,cap,D]`` -> ``[B,T,H*D]``."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, n)
+    B, H, T, D = q.shape
+    cap = k.shape[2]
+    out = torch.empty(B, T, H * D, device=q.device, dtype=torch.float32)
+    if pos_dev is not None:
+        _chk(pos_dev, "pos_dev", torch.int64)
+    _lib.check(_lib.lib().rst_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(pos_dev), pos0, B, T, H, D, cap,
+                                            int(ring), int(context) if context else 0, _stream()))
+    return out
+
+
+def rvq_pack(emb: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """emb ``[L, n_codes, D]`` -> (packed ``[L, D/8, n_codes, 2, 4]``, e2 ``[L, n_codes]``)."""
+    _chk(emb, "emb")
+    L, n_codes, D = emb.shape
+    packed = torch.empty(L, D // 8, n_codes, 2, 4, device=emb.device, dtype=torch.float32)
+    e2 = torch.empty(L, n_codes, device=emb.device, dtype=torch.float32)
+    for l in range(L):
+        _lib.check(_lib.lib().rst_rvq_pack_f32(_ptr(emb[l]), _ptr(packed[l]), _ptr(e2[l]), n_codes, D, _stream()))
+    return packed, e2
+
+
+def _int_array(vals: Sequence[int]):
+    return (C.c_int * len(vals))(*vals)
+
+
+def rvq_search(x: torch.Tensor, emb: torch.Tensor, packed: torch.Tensor, e2: torch.Tensor, B: int, F: int,
+               groups: Sequence[Tuple[int, int]], return_dist: bool = False):
+    """x ``[B*F, n_groups*D]`` projected latents -> codes ``[B, L, F]`` int64 (levels outside ``groups`` untouched)."""
+    for t, n in ((x, "x"), (emb, "emb"), (packed, "packed"), (e2, "e2")):
+        _chk(t, n)
+    L, n_codes, D = emb.shape
+    M = B * F
+    assert x.shape == (M, len(groups) * D), (tuple(x.shape), M, len(groups), D)
+    codes = torch.zeros(B, L, F, device=x.device, dtype=torch.int64)
+    dist = torch.zeros(L, M, device=x.device, dtype=torch.float32) if return_dist else None
+    _lib.check(_lib.lib().rst_rvq_search_f32(_ptr(x), _ptr(emb), _ptr(packed), _ptr(e2), _ptr(codes), _ptr(dist), M, max(F, 1),
+                                             x.shape[1], D, n_codes, L, len(groups), _int_array([g[0] for g in groups]),
+                                             _int_array([g[1] for g in groups]), _stream()))
+    return (codes, dist) if return_dist else codes
+
+
+def rvq_gather(codes: torch.Tensor, emb: torch.Tensor, groups: Sequence[Tuple[int, int]]) -> torch.Tensor:
+    """codes ``[B, L, F]`` int64 -> ``[B*F, n_groups*D]`` sums of codebook rows per group."""
+    _chk(codes, "codes", torch.int64)
+    _chk(emb, "emb")
+    B, L, F = codes.shape
+    _, n_codes, D = emb.shape
+    out = torch.empty(B * F, len(groups) * D, device=codes.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_rvq_gather_f32(_ptr(codes), _ptr(emb), _ptr(out), B * F, max(F, 1), D, n_codes, L, len(groups),
+                                             _int_array([g[0] for g in groups]), _int_array([g[1] for g in groups]),
+                                             _stream()))
+    return out
+
+
+def convtr_depthwise(x: torch.Tensor, w: torch.Tensor, stride: int, hist: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x ``[B,T,C]``, w ``[C,Kw]`` -> ``[B,T*stride,C]``."""
+    for t, n in ((x, "x"), (w, "w"), (hist, "hist")):
+        _chk(t, n)
+    B, T, Cc = x.shape
+    out = torch.empty(B, T * stride, Cc, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_convtr_depthwise_f32(_ptr(x), _ptr(hist), _ptr(w), _ptr(out), B, T, Cc, w.shape[1], stride,
+                                                   _stream()))
+    return out
+
+
+def transpose12(x: torch.Tensor) -> torch.Tensor:
+    """``[B, R, C] -> [B, C, R]`` (layout adapter between the reference's [B,C,T] and channels-last)."""
+    _chk(x, "x")
+    B, R, Cc = x.shape
+    if R == 1 or Cc == 1:
+        return x.reshape(B, Cc, R)
+    out = torch.empty(B, Cc, R, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_transpose_f32(_ptr(x), _ptr(out), B, R, Cc, _stream()))
+    return out
+
+
+def hist_update(x: torch.Tensor, hist_in: Optional[torch.Tensor], P_out: int) -> torch.Tensor:
+    """Last ``P_out`` steps of concat(hist_in, x) along time; x ``[B,T,C]``, hist ``[B,P,C]``."""
+    _chk(x, "x")
+    _chk(hist_in, "hist_in")
+    B, T, Cc = x.shape
+    P_in = hist_in.shape[1] if hist_in is not None else 0
+    out = torch.empty(B, P_out, Cc, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_hist_update_f32(_ptr(x), _ptr(hist_in), _ptr(out), B, T, P_in, P_out, Cc, _stream()))
+    return out

@@ -1,0 +1,249 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle and the reference-generated golden fixtures.
+
+Tolerances: integer outputs (RVQ codes) bit-exact; fp32 outputs <= 1e-4 relative to the tensor's max (the HIP
+kernels accumulate in a different order than oneDNN/MKL; the north-star budget is 1e-3).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mimi_oracle as O
+from oracle import rvq_ref
+from rstnet_amd import ops, synth
+from rstnet_amd.codec import functional as RF
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def nlc(x):  # [B,C,T] cpu -> [B,T,C] gpu
+    return x.transpose(1, 2).contiguous().to(DEV)
+
+
+def ncl(y):  # [B,T,C] gpu -> [B,C,T] cpu
+    return y.transpose(1, 2).contiguous().cpu()
+
+
+@pytest.mark.parametrize("name", list(cases.CONV_CASES))
+def test_conv1d(name):
+    B, cin, cout, T, K, S = cases.CONV_CASES[name]
+    w, b, x = cases.layer_tensors(name, (cout, cin, K), cout, (B, cin, T))
+    gold = torch.from_numpy(np.load(os.path.join(G, "layers.npz"))[f"conv.{name}"])
+    y = RF.conv1d(nlc(x), RF.pack_conv_weight(w).to(DEV), b.to(DEV), k_eff=K, stride=S)
+    assert ncl(y).shape == gold.shape
+    assert rel_err(ncl(y), gold) < TOL
+    assert rel_err(ncl(y), O.causal_conv1d(x, w, b, stride=S)) < TOL
+
+
+@pytest.mark.parametrize("dilation,pad_mode", [(2, "constant"), (1, "replicate"), (3, "replicate")])
+def test_conv1d_dilation_and_replicate(dilation, pad_mode):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 16, 37, generator=g)
+    w = torch.randn(24, 16, 3, generator=g) * 0.2
+    y = RF.conv1d(nlc(x), RF.pack_conv_weight(w, dilation).to(DEV), None, k_eff=(3 - 1) * dilation + 1, stride=1,
+                  pad_mode=ops.PAD_REPLICATE if pad_mode == "replicate" else ops.PAD_ZERO)
+    assert rel_err(ncl(y), O.causal_conv1d(x, w, None, dilation=dilation, pad_mode=pad_mode)) < TOL
+
+
+def test_conv1d_downsample_replicate():
+    """ConvDownsample1d: dense 512->512 k4 s2, replicate padding, no bias."""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 512, 25, generator=g)
+    w = synth._xavier(g, 512, 512, 4)
+    y = RF.conv1d(nlc(x), RF.pack_conv_weight(w).to(DEV), None, k_eff=4, stride=2, pad_mode=ops.PAD_REPLICATE)
+    ref = O.causal_conv1d(x, w, None, stride=2, pad_mode="replicate")
+    assert ncl(y).shape == ref.shape == (2, 512, 13)
+    assert rel_err(ncl(y), ref) < TOL
+
+
+@pytest.mark.parametrize("name", list(cases.CONVTR_CASES))
+def test_convtr1d(name):
+    B, cin, cout, T, K, S = cases.CONVTR_CASES[name]
+    w, b, x = cases.layer_tensors(name, (cin, cout, K), cout, (B, cin, T))
+    gold = torch.from_numpy(np.load(os.path.join(G, "layers.npz"))[f"convtr.{name}"])
+    y = RF.convtr1d(nlc(x), RF.pack_convtr_weight(w, S).to(DEV), b.repeat(S).to(DEV), kernel=K, stride=S)
+    assert ncl(y).shape == gold.shape
+    assert rel_err(ncl(y), gold) < TOL
+
+
+@pytest.mark.parametrize("name", list(cases.RESBLOCK_CASES))
+def test_resblock(name):
+    B, dim, T = cases.RESBLOCK_CASES[name]
+    w1, b1, x = cases.layer_tensors(name + ".1", (dim // 2, dim, 3), dim // 2, (B, dim, T))
+    w2, b2, _ = cases.layer_tensors(name + ".3", (dim, dim // 2, 1), dim, (1, 1, 1))
+    gold = torch.from_numpy(np.load(os.path.join(G, "layers.npz"))[f"resblock.{name}"])
+    xg = nlc(x)
+    h = RF.conv1d(xg, RF.pack_conv_weight(w1).to(DEV), b1.to(DEV), k_eff=3, act_in=ops.ACT_ELU)
+    y = RF.conv1d(h, RF.pack_conv_weight(w2).to(DEV), b2.to(DEV), k_eff=1, act_in=ops.ACT_ELU, res=xg)
+    assert rel_err(ncl(y), gold) < TOL
+
+
+@pytest.mark.parametrize("chunk", [1, 3, 7])
+@pytest.mark.parametrize("K,S", [(7, 1), (3, 1), (8, 4), (10, 5), (4, 2)])
+def test_conv1d_streaming_equals_batch(K, S, chunk):
+    """Mirror of conv_test.py:85-109 / streaming.py:306-358: chunked calls with a history buffer == one call."""
+    g = torch.Generator().manual_seed(K * 10 + S)
+    B, cin, cout, T = 2, 8, 12, 41
+    x = torch.rand(B, cin, T, generator=g)
+    w = synth._xavier(g, cout, cin, K)
+    b = 0.1 * torch.randn(cout, generator=g)
+    wp, bd = RF.pack_conv_weight(w).to(DEV), b.to(DEV)
+    full = O.causal_conv1d(x, w, b, stride=S)
+    xg = nlc(x)
+    hist = torch.zeros(B, K - S, cin, device=DEV)
+    outs = []
+    for s in range(0, T, chunk):
+        xc = xg[:, s:s + chunk].contiguous()
+        y = RF.conv1d(xc, wp, bd, k_eff=K, stride=S, hist=hist)
+        consumed = y.shape[1] * S
+        hist = ops.hist_update(xc, hist, hist.shape[1] + xc.shape[1] - consumed)
+        outs.append(y)
+    y = torch.cat(outs, 1)
+    n = y.shape[1]
+    assert n == T // S  # floor-mode frame count
+    assert rel_err(ncl(y), full[..., :n]) < TOL
+
+
+@pytest.mark.parametrize("chunk", [1, 2, 5])
+@pytest.mark.parametrize("K,S", [(16, 8), (10, 5), (7, 2), (4, 3), (6, 1)])
+def test_convtr1d_streaming_equals_batch(K, S, chunk):
+    g = torch.Generator().manual_seed(K * 10 + S)
+    B, cin, cout, T = 2, 8, 6, 11
+    x = torch.rand(B, cin, T, generator=g)
+    w = synth._xavier(g, cin, cout, K)
+    b = 0.1 * torch.randn(cout, generator=g)
+    wp, bt = RF.pack_convtr_weight(w, S).to(DEV), b.repeat(S).to(DEV)
+    full = O.causal_convtr1d(x, w, b, stride=S)
+    q = -(-K // S)
+    xg = nlc(x)
+    hist = torch.zeros(B, q - 1, cin, device=DEV)
+    outs = []
+    for s in range(0, T, chunk):
+        xc = xg[:, s:s + chunk].contiguous()
+        outs.append(RF.convtr1d(xc, wp, bt, kernel=K, stride=S, hist=hist))
+        hist = ops.hist_update(xc, hist, q - 1)
+    assert rel_err(ncl(torch.cat(outs, 1)), full) < TOL
+
+
+@pytest.mark.parametrize("rows,D", [(5, 512), (1000, 512), (7, 48), (3, 30)])
+def test_layernorm(rows, D):
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, D, generator=g) * 3 + 1
+    gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    y = ops.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5)
+    assert rel_err(y, F.layer_norm(x, (D,), gamma, beta, 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("B,M,K,N,act", [(1, 300, 512, 1536, 0), (1, 77, 512, 2048, 1), (1, 1, 2048, 512, 0), (1, 130, 36, 20, 0)])
+def test_linear_epilogues(B, M, K, N, act):
+    g = torch.Generator().manual_seed(M)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    res, scale = torch.randn(M, N, generator=g), torch.rand(N, generator=g)
+    ref = F.linear(x, w)
+    if act:
+        ref = F.gelu(ref)
+    y = ops.linear(x.to(DEV), w.to(DEV), act_out=act)
+    assert rel_err(y, ref) < TOL
+    y2 = ops.linear(x.to(DEV), w.to(DEV), res=res.to(DEV), scale=scale.to(DEV), act_out=act)
+    assert rel_err(y2, res + scale * ref) < TOL
+
+
+@pytest.mark.parametrize("T,context,H,D", [(250, 250, 8, 64), (300, 250, 8, 64), (37, None, 2, 64), (100, 10, 4, 32), (65, 33, 2, 128)])
+def test_rope_attention_batch(T, context, H, D):
+    g = torch.Generator().manual_seed(T)
+    B = 2
+    qkv = torch.randn(B, T, 3 * H * D, generator=g)
+    q, k, v = qkv.view(B, T, 3, H, D).permute(2, 0, 3, 1, 4)
+    qr, kr = O.rope_interleaved(q.contiguous(), k.contiguous(), 0, 10000.0)
+    ref = F.scaled_dot_product_attention(qr, kr, v, O.attention_mask(T, context)).permute(0, 2, 1, 3).reshape(B, T, H * D)
+    qg, kg, vg = ops.rope_split(qkv.to(DEV), H)
+    assert rel_err(qg, qr) < 1e-5 and rel_err(kg, kr) < 1e-5 and torch.equal(vg.cpu(), v.contiguous())
+    out = ops.attention(qg, kg, vg, context=context)
+    assert rel_err(out, ref) < TOL
+
+
+def test_rvq_search_bit_exact_vs_c_oracle_and_reference():
+    sd = synth.mimi_state_dict(cases.MIMI_SEED)
+    cfg = O.MimiConfig()
+    z = cases.rvq_latent(sd)  # [4,512,250]
+    B, _, Fr = z.shape
+    gold = torch.from_numpy(np.load(os.path.join(G, "rvq.npz"))["codes"]).long()
+    xf = F.conv1d(z, sd["quantizer.rvq_first.input_proj.weight"]).transpose(1, 2).reshape(-1, 256)
+    xr = F.conv1d(z, sd["quantizer.rvq_rest.input_proj.weight"]).transpose(1, 2).reshape(-1, 256)
+    emb = torch.stack([O.codebook(sd, "quantizer.rvq_first.vq.layers.0")] +
+                      [O.codebook(sd, f"quantizer.rvq_rest.vq.layers.{j}") for j in range(7)])
+    x = torch.cat([xf, xr], 1).contiguous().to(DEV)
+    embg = emb.to(DEV)
+    packed, e2 = ops.rvq_pack(embg)
+    codes, dist = ops.rvq_search(x, embg, packed, e2, B, Fr, [(0, 1), (1, 7)], return_dist=True)
+    torch.cuda.synchronize()
+    c_first, d_first = rvq_ref.rvq_search(xf.numpy(), emb[:1].numpy())
+    c_rest, d_rest = rvq_ref.rvq_search(xr.numpy(), emb[1:].numpy())
+    c_ref = torch.from_numpy(np.concatenate([c_first, c_rest])).view(8, B, Fr).transpose(0, 1)
+    d_ref = torch.from_numpy(np.concatenate([d_first, d_rest]))
+    assert torch.equal(codes.cpu(), c_ref), "HIP codes differ from the C oracle"
+    assert torch.equal(dist.cpu(), d_ref), "HIP winning scores are not bit-identical to the C oracle's fmaf chain"
+    assert torch.equal(codes.cpu(), gold), "HIP codes differ from the reference-generated fixture"
+    # decode side
+    zq = ops.rvq_gather(codes, embg, [(0, 1), (1, 7)])
+    ref_first = O.rvq_levels_decode(sd, "quantizer.rvq_first", gold[:, :1].transpose(0, 1)).transpose(1, 2).reshape(-1, 256)
+    ref_rest = O.rvq_levels_decode(sd, "quantizer.rvq_rest", gold[:, 1:].transpose(0, 1)).transpose(1, 2).reshape(-1, 256)
+    assert torch.equal(zq.cpu(), torch.cat([ref_first, ref_rest], 1))
+
+
+@pytest.mark.parametrize("M,F_", [(1, 1), (33, 33), (64, 32), (95, 19)])
+def test_rvq_search_ragged_sizes(M, F_):
+    g = torch.Generator().manual_seed(M)
+    emb = torch.randn(3, 64, 16, generator=g)
+    x = torch.randn(M, 16, generator=g)
+    embg = emb.to(DEV)
+    packed, e2 = ops.rvq_pack(embg)
+    codes, dist = ops.rvq_search(x.to(DEV), embg, packed, e2, M // F_, F_, [(0, 3)], return_dist=True)
+    c_ref, d_ref = rvq_ref.rvq_search(x.numpy(), emb.numpy())
+    assert torch.equal(codes.cpu(), torch.from_numpy(c_ref).view(3, M // F_, F_).transpose(0, 1))
+    assert torch.equal(dist.cpu(), torch.from_numpy(d_ref))
+
+
+def test_rvq_tie_takes_lowest_index():
+    emb = torch.randn(1, 64, 16)
+    emb[0, 40] = emb[0, 7]  # exact duplicate rows -> exact tie
+    x = emb[0, 40:41].clone()
+    embg = emb.to(DEV)
+    packed, e2 = ops.rvq_pack(embg)
+    codes = ops.rvq_search(x.to(DEV), embg, packed, e2, 1, 1, [(0, 1)])
+    assert codes.item() == 7
+
+
+def test_convtr_depthwise_upsample():
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 512, 13, generator=g)
+    w = synth._xavier(g, 512, 1, 4)
+    y = ops.convtr_depthwise(nlc(x), w[:, 0].contiguous().to(DEV), 2)
+    assert rel_err(ncl(y), O.causal_convtr1d(x, w, None, stride=2, groups=512)) < 1e-6
+
+
+def test_transpose_and_hist_update():
+    x = torch.randn(3, 37, 70)
+    assert torch.equal(ops.transpose12(x.to(DEV)).cpu(), x.transpose(1, 2).contiguous())
+    h = torch.randn(3, 5, 70)
+    for P_out in (0, 3, 5, 20, 42):
+        ref = torch.cat([h, x], 1)[:, 42 - P_out:]
+        assert torch.equal(ops.hist_update(x.to(DEV), h.to(DEV), P_out).cpu(), ref)
+
+
+def test_empty_inputs():
+    w = torch.randn(8, 4 * 3).to(DEV)
+    y = RF.conv1d(torch.zeros(2, 0, 4, device=DEV), w, None, k_eff=3)
+    assert y.shape == (2, 0, 8)
+    assert ops.linear(torch.zeros(0, 12, device=DEV), w).shape == (0, 8)
