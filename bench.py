@@ -1,0 +1,163 @@
+"""Headline benchmark: MimiCodec encode -> RVQ -> decode, batch = 64 x 10 s synthetic 24 kHz audio per GPU
+(BASELINE.json configs[1]); metric = 12.5 Hz code frames per second, whole job.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (encode + decode) over one batch that is already resident in HBM.
+Multi-GPU: utterances are independent, so each rank owns its own batch (weak scaling); the only collective is the
+one-off RCCL broadcast of the weights from rank 0.  Rank 0 prints ONE JSON line with the contract fields plus
+`roofline` (dominant kernel: the fp32-MFMA windowed GEMM, timed per launch with HIP events on the launch stream in an
+extra instrumented step) and `cpu_baseline` (the CPU oracle timed on this host on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("NO_TORCH_COMPILE", "1")
+
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FRAME_HOP = 1920
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also report the code exact-match rate against the CPU oracle on a sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, seconds_per_clip: float, batch: int = 4):
+    """The CPU restatement (oracle/mimi_oracle.py, validated bit-exact against the imported reference) on this host."""
+    from oracle import mimi_oracle as O
+    from rstnet_amd import synth
+    cfg = O.MimiConfig()
+    audio = synth.synth_audio(batch, int(seconds_per_clip * 24000), seed=11)
+    best = None
+    with torch.no_grad():
+        for _ in range(2):
+            t0 = time.perf_counter()
+            codes = O.encode(sd, cfg, audio)
+            O.decode(sd, cfg, codes)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    frames = codes.shape[0] * codes.shape[2]
+    return {"value": round(frames / best, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle encode+decode of {batch} x {seconds_per_clip:g} s clips, fp32, torch CPU, min of 2 runs "
+                      f"({best:.2f} s); host has {os.cpu_count()} logical cores"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from rstnet_amd import ops, synth
+    from rstnet_amd.codec.mimi import MimiCodec
+    from rstnet_amd.parallel import broadcast_state_dict
+
+    # weights: generated on rank 0 only, then ONE RCCL broadcast over xGMI
+    sd_cpu = synth.mimi_state_dict(0) if rank == 0 else None
+    if world > 1:
+        sd_dev = broadcast_state_dict(sd_cpu, dev, src=0, template=lambda: synth.mimi_state_dict(0))
+        model = MimiCodec.from_state_dict({k: v for k, v in sd_dev.items()}).to(dev)
+    else:
+        model = MimiCodec.from_state_dict(sd_cpu).to(dev)
+
+    T = int(args.seconds * 24000)
+    audio = synth.synth_audio(args.batch, T, seed=100 + rank).to(dev)   # rank-private utterances, resident in HBM
+    frames_per_step = args.batch * (-(-T // FRAME_HOP))
+
+    def step():
+        codes = model.encode(audio)
+        return codes, model.decode(codes)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        codes, wav = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel: one extra instrumented step, HIP events around every GEMM launch
+    roofline = None
+    if rank == 0:
+        ops.PROFILE = []
+        step()
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        tot_ms = sum(e0.elapsed_time(e1) for _, e0, e1, *_ in recs)
+        tot_flops = sum(r[3] for r in recs)
+        t_step_ms = elapsed / args.steps * 1e3
+        roofline = {"bound": "mfma", "kernel": "gemm_win_kernel (fp32 v_mfma_f32_32x32x2)",
+                    "achieved": round(tot_flops / (tot_ms * 1e-3) / 1e12, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(tot_flops / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": len(recs), "kernel_ms_per_step": round(tot_ms, 3),
+                    "share_of_step": round(tot_ms / t_step_ms, 3),
+                    "algorithmic_gflop_per_step": round(tot_flops / 1e9, 1)}
+
+    result = None
+    if rank == 0:
+        total_frames = frames_per_step * world * args.steps
+        result = {
+            "metric": "codec+LM audio frames/sec (24 kHz, 12.5 Hz tokens) at batch=1 and batch=64; RVQ code-index exact-match",
+            "value": round(total_frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MimiCodec encode->RVQ(8x2048x256)->decode, BASELINE.json configs[1]",
+                       "batch_per_gpu": args.batch, "clip_seconds": args.seconds, "sample_rate": 24000,
+                       "frames_per_step_per_gpu": frames_per_step, "weights": "random-init (rstnet_amd.synth seed 0)",
+                       "parallelism": f"replica x{world}, utterances sharded, RCCL weight broadcast only"},
+            "x_realtime_per_stream": round(total_frames / elapsed / 12.5 / (args.batch * world), 1),
+            "roofline": roofline,
+        }
+        if args.check:
+            from oracle import mimi_oracle as O
+            n = min(2, args.batch)
+            with torch.no_grad():
+                ref = O.encode(sd_cpu, O.MimiConfig(), audio[:n].cpu())
+            result["code_exact_match_vs_cpu_oracle"] = round(float((codes[:n].cpu() == ref).float().mean()), 6)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sd_cpu, args.seconds)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -106,6 +106,9 @@ int rst_rvq_gather_f32(const int64_t* codes, const float* emb, float* out, int M
 int rst_convtr_depthwise_f32(const float* x, const float* hist, const float* w, float* y, int B, int T_in, int C,
                              int Kw, int stride, rst_stream_t stream);
 
+/* Stand-alone elementwise activation (nn.ELU / F.gelu module calls that are not fused into a GEMM): act 1 = ELU, 2 = GELU. */
+int rst_act_f32(const float* x, float* y, int64_t n, int act, rst_stream_t stream);
+
 /* Layout adapter [B][R][C] -> [B][C][R] (reference [B,C,T] <-> channels-last). */
 int rst_transpose_f32(const float* x, float* y, int B, int R, int C, rst_stream_t stream);
 

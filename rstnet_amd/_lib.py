@@ -30,6 +30,7 @@ SIGNATURES = {
     "rst_rvq_search_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _p],
     "rst_rvq_gather_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _p],
     "rst_convtr_depthwise_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "rst_act_f32": [_p, _p, _l, _i, _p],
     "rst_transpose_f32": [_p, _p, _i, _i, _i, _p],
     "rst_hist_update_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
 }

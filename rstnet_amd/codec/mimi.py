@@ -1,0 +1,113 @@
+"""``MimiCodec`` -- drop-in for the reference's ``tools/tokenizer/MimiCodec/model/models/MimiCodec.py`` (and its
+``AudioCodec/MimiCodec`` twin): same constructor keywords, same ``state_dict`` keys, same
+``encode(audio[B,1,T]) -> codes[B,K,ceil(T/hop)]`` / ``decode(codes) -> wav[B,1,F*hop]`` contract.
+
+The whole path stays channels-last on the device: audio ``[B,1,T]`` *is* ``[B,T,1]``, the RVQ kernel writes the
+``[B,K,F]`` code tensor directly and the last convolution writes ``[B,T,1]`` = ``[B,1,T]`` -- no layout
+conversion kernel runs in ``encode`` / ``decode``.
+"""
+from __future__ import annotations
+
+import json
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import transformer as Stransformer
+from .quantization import SplitResidualVectorQuantizer
+from .resample import ConvDownsample1d, ConvTrUpsample1d
+from .seanet import SEANetDecoder, SEANetEncoder
+from .streaming import StreamingContainer
+
+
+class MimiCodec(StreamingContainer):
+    def __init__(self, sample_rate: int = 24000, n_filters: int = 64, encoder_rates: List[int] = [4, 5, 6, 8],
+                 compress: int = 2, causal: bool = True, latent_dim: int = 512, codebook_size: int = 4096,
+                 codebook_dim: int = 32, rvq_layers: int = 8, num_heads: int = 8, num_layers: int = 8,
+                 layer_scale: float = 0.01, context: int = 250, dim_feedforward: int = 2048,
+                 semantic_feature_dim: int = 1024, target_frame_rate: float = 12.5):
+        super().__init__()
+        self.sample_rate = sample_rate
+        seanet_kwargs = dict(channels=1, dimension=latent_dim, causal=causal, n_filters=n_filters, n_residual_layers=1,
+                             activation="ELU", compress=compress, dilation_base=2, disable_norm_outer_blocks=0, kernel_size=7,
+                             residual_kernel_size=3, last_kernel_size=3, norm="none", pad_mode="constant",
+                             ratios=list(encoder_rates), true_skip=True)
+        quantizer_kwargs = dict(dimension=codebook_dim, n_q=rvq_layers, bins=codebook_size, input_dimension=latent_dim,
+                                output_dimension=latent_dim)
+        transformer_kwargs = dict(d_model=latent_dim, num_heads=num_heads, num_layers=num_layers, causal=causal,
+                                  layer_scale=layer_scale, context=context, conv_layout=True, max_period=10000,
+                                  gating="none", norm="layer_norm", positional_embedding="rope",
+                                  dim_feedforward=dim_feedforward, input_dimension=latent_dim,
+                                  output_dimensions=[latent_dim])
+        self.encoder = SEANetEncoder(**seanet_kwargs)
+        self.decoder = SEANetDecoder(**seanet_kwargs)
+        self.hop_length = 1
+        for r in encoder_rates:
+            self.hop_length *= r
+        self.encoder_frame_rate = sample_rate / self.hop_length
+        self.target_frame_rate = target_frame_rate
+        self.learnt = True
+        stride = int(self.encoder_frame_rate / self.target_frame_rate)
+        self.downsample = ConvDownsample1d(stride, dimension=latent_dim, learnt=True, causal=causal)
+        self.upsample = ConvTrUpsample1d(stride, dimension=latent_dim, learnt=True, causal=causal, channel_wise=True)
+        self.encoder_transformer = Stransformer.ProjectedTransformer(**transformer_kwargs)
+        self.decoder_transformer = Stransformer.ProjectedTransformer(**transformer_kwargs)
+        self.quantizer = SplitResidualVectorQuantizer(**quantizer_kwargs)
+        self.frame_hop = self.hop_length * stride  # samples per code frame (1920 for Mimi)
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, audio_data: torch.Tensor, semantic_features: torch.Tensor):
+        raise NotImplementedError("the GAN / distillation training forward is out of scope of the inference hot path")
+
+    def encode_latent(self, audio_data: torch.Tensor) -> torch.Tensor:
+        """audio ``[B, 1, T]`` -> un-quantised 12.5 Hz latent, channels-last ``[B, F, latent_dim]``."""
+        B, C, T = audio_data.shape
+        assert C == 1, "MimiCodec is mono"
+        x = audio_data.contiguous().view(B, T, 1)
+        z = self.encoder.forward_nlc(x)
+        z = self.encoder_transformer.forward_nlc(z)[0]
+        return self.downsample.forward_nlc(z)
+
+    @torch.no_grad()
+    def encode(self, audio_data: torch.Tensor) -> torch.Tensor:
+        """``[B, 1, T]`` fp32 -> ``[B, K, ceil(T / 1920)]`` int64 (streaming: floor, remainder kept in the conv states)."""
+        return self.quantizer.encode_nlc(self.encode_latent(audio_data))
+
+    @torch.no_grad()
+    def decode(self, codes: torch.Tensor) -> torch.Tensor:
+        """``[B, K, F]`` int64 -> ``[B, 1, F * 1920]`` fp32 (not trimmed, as in the reference)."""
+        z = self.quantizer.decode_nlc(codes.contiguous())
+        z = self.upsample.forward_nlc(z)
+        z = self.decoder_transformer.forward_nlc(z)[0]
+        y = self.decoder.forward_nlc(z)
+        return y.view(y.shape[0], 1, y.shape[1])
+
+    @classmethod
+    def from_config(cls, config_path: str) -> "MimiCodec":
+        with open(config_path, "r") as f:
+            return cls(**json.load(f))
+
+    # ------------------------------------------------------------------ conveniences
+    @classmethod
+    def from_state_dict(cls, sd: Dict[str, torch.Tensor], **overrides) -> "MimiCodec":
+        """Build a model whose hyper-parameters are read off the tensor shapes of a reference ``state_dict``."""
+        n_filters = sd["encoder.model.0.conv.conv.weight"].shape[0]
+        rates, i = [], 3
+        while f"encoder.model.{i}.conv.conv.weight" in sd and sd[f"encoder.model.{i}.conv.conv.weight"].shape[2] > 3:
+            rates.append(sd[f"encoder.model.{i}.conv.conv.weight"].shape[2] // 2)
+            i += 3
+        n_layers = len({k.split(".")[3] for k in sd if k.startswith("encoder_transformer.transformer.layers.")})
+        emb = sd["quantizer.rvq_first.vq.layers.0._codebook.embedding_sum"]
+        rest = len({k.split(".")[4] for k in sd if k.startswith("quantizer.rvq_rest.vq.layers.")})
+        kw = dict(n_filters=n_filters, encoder_rates=list(reversed(rates)), latent_dim=sd["downsample.conv.conv.conv.weight"].shape[0],
+                  codebook_size=emb.shape[0], codebook_dim=emb.shape[1], rvq_layers=1 + rest, num_layers=n_layers,
+                  dim_feedforward=sd["encoder_transformer.transformer.layers.0.linear1.weight"].shape[0])
+        kw.update(overrides)
+        model = cls(**kw)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        missing = [k for k in missing if not k.startswith("semantic_mapping_layer")]
+        unexpected = [k for k in unexpected if not k.startswith("semantic_mapping_layer")]
+        if missing or unexpected:
+            raise RuntimeError(f"state_dict mismatch: missing={missing[:5]} unexpected={unexpected[:5]}")
+        return model.eval()

@@ -1,0 +1,189 @@
+"""SEANet encoder / decoder with the reference's module surface (``modules/seanet.py`` of the MimiCodec copy).
+
+The ``nn.Sequential`` index layout of ``.model`` is kept (ELU modules occupy their slots) so that ``state_dict``
+keys such as ``encoder.model.3.conv.conv.weight`` line up with reference checkpoints.  The forward pass is
+fused: every ELU is applied by the following convolution's operand load and the residual add lives in the
+epilogue of the block's 1x1 convolution -- one kernel per convolution, channels-last throughout.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from .conv import StreamingConv1d, StreamingConvTranspose1d, _to_ncl, _to_nlc
+from .streaming import StreamingAdd, StreamingContainer
+
+
+class ELU(nn.Module):
+    """Slot-compatible stand-in for ``nn.ELU`` -- fused into the next convolution by the containers below;
+    a direct call runs the stand-alone HIP activation kernel."""
+
+    def __init__(self, alpha: float = 1.0):
+        super().__init__()
+        if alpha != 1.0:
+            raise NotImplementedError("ELU alpha != 1")
+        self.alpha = alpha
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.activation(x.contiguous(), "elu")
+
+
+def _activation(name: str, params: dict) -> nn.Module:
+    if name != "ELU":
+        raise NotImplementedError(f"activation {name!r}: the MimiCodec path uses ELU")
+    return ELU(**params)
+
+
+def _run_fused(model: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """Walk a SEANet ``Sequential`` channels-last, folding each ELU into the layer that follows it."""
+    pending = ops.ACT_NONE
+    for layer in model:
+        if isinstance(layer, ELU):
+            assert pending == ops.ACT_NONE
+            pending = ops.ACT_ELU
+        elif isinstance(layer, (StreamingConv1d, StreamingConvTranspose1d)):
+            x = layer.forward_nlc(x, act_in=pending)
+            pending = ops.ACT_NONE
+        elif isinstance(layer, SEANetResnetBlock):
+            assert pending == ops.ACT_NONE
+            x = layer.forward_nlc(x)
+        else:
+            raise NotImplementedError(f"unexpected layer {type(layer).__name__} in SEANet")
+    if pending != ops.ACT_NONE:
+        x = ops.activation(x, "elu")
+    return x
+
+
+class SEANetResnetBlock(StreamingContainer):
+    """``x + conv_k1(ELU(conv_k3(ELU(x))))`` (``modules/seanet.py:21-94``)."""
+
+    def __init__(self, dim: int, kernel_sizes: List[int] = [3, 1], dilations: List[int] = [1, 1], activation: str = "ELU",
+                 activation_params: dict = {"alpha": 1.0}, norm: str = "none", norm_params: Dict[str, Any] = {},
+                 causal: bool = False, pad_mode: str = "reflect", compress: int = 2, true_skip: bool = True):
+        super().__init__()
+        assert len(kernel_sizes) == len(dilations), "Number of kernel sizes should match number of dilations"
+        hidden = dim // compress
+        block: List[nn.Module] = []
+        for i, (kernel_size, dilation) in enumerate(zip(kernel_sizes, dilations)):
+            in_chs = dim if i == 0 else hidden
+            out_chs = dim if i == len(kernel_sizes) - 1 else hidden
+            block += [_activation(activation, activation_params),
+                      StreamingConv1d(in_chs, out_chs, kernel_size=kernel_size, dilation=dilation, norm=norm,
+                                      norm_kwargs=norm_params, causal=causal, pad_mode=pad_mode)]
+        self.block = nn.Sequential(*block)
+        self.add = StreamingAdd()
+        self.shortcut: nn.Module
+        if true_skip:
+            self.shortcut = nn.Identity()
+        else:
+            self.shortcut = StreamingConv1d(dim, dim, kernel_size=1, norm=norm, norm_kwargs=norm_params, causal=causal,
+                                            pad_mode=pad_mode)
+
+    def forward_nlc(self, x: torch.Tensor) -> torch.Tensor:
+        u = x if isinstance(self.shortcut, nn.Identity) else self.shortcut.forward_nlc(x)
+        convs = [m for m in self.block if isinstance(m, StreamingConv1d)]
+        h = x
+        for conv in convs[:-1]:
+            h = conv.forward_nlc(h, act_in=ops.ACT_ELU)
+        last = convs[-1]
+        if h.shape[1] == u.shape[1] and last._stride == 1 and last._effective_kernel_size == 1:
+            return last.forward_nlc(h, act_in=ops.ACT_ELU, res=u)  # skip-add fused into the epilogue
+        v = last.forward_nlc(h, act_in=ops.ACT_ELU)
+        return _to_nlc(self.add(_to_ncl(u), _to_ncl(v)))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return _to_ncl(self.forward_nlc(_to_nlc(x)))
+
+
+class SEANetEncoder(StreamingContainer):
+    """``modules/seanet.py:97-241``; ``forward`` takes ``[B, channels, T]`` and returns ``[B, dimension, T/hop]``."""
+
+    def __init__(self, channels: int = 1, dimension: int = 128, n_filters: int = 32, n_residual_layers: int = 3,
+                 ratios: List[int] = [8, 5, 4, 2], activation: str = "ELU", activation_params: dict = {"alpha": 1.0},
+                 norm: str = "none", norm_params: Dict[str, Any] = {}, kernel_size: int = 7, last_kernel_size: int = 7,
+                 residual_kernel_size: int = 3, dilation_base: int = 2, causal: bool = False, pad_mode: str = "reflect",
+                 true_skip: bool = True, compress: int = 2, disable_norm_outer_blocks: int = 0,
+                 mask_fn: Optional[nn.Module] = None, mask_position: Optional[int] = None):
+        super().__init__()
+        if mask_fn is not None:
+            raise NotImplementedError("mask_fn is a training-time feature")
+        self.channels, self.dimension, self.n_filters = channels, dimension, n_filters
+        self.ratios = list(reversed(ratios))
+        self.n_residual_layers = n_residual_layers
+        self.hop_length = int(np.prod(self.ratios))
+        self.n_blocks = len(self.ratios) + 2
+        self.disable_norm_outer_blocks = disable_norm_outer_blocks
+        assert 0 <= disable_norm_outer_blocks <= self.n_blocks
+        mult = 1
+        model: List[nn.Module] = [StreamingConv1d(channels, mult * n_filters, kernel_size, norm=norm, norm_kwargs=norm_params,
+                                                  causal=causal, pad_mode=pad_mode)]
+        for ratio in self.ratios:
+            for j in range(n_residual_layers):
+                model += [SEANetResnetBlock(mult * n_filters, kernel_sizes=[residual_kernel_size, 1],
+                                            dilations=[dilation_base ** j, 1], norm=norm, norm_params=norm_params,
+                                            activation=activation, activation_params=activation_params, causal=causal,
+                                            pad_mode=pad_mode, compress=compress, true_skip=true_skip)]
+            model += [_activation(activation, activation_params),
+                      StreamingConv1d(mult * n_filters, mult * n_filters * 2, kernel_size=ratio * 2, stride=ratio, norm=norm,
+                                      norm_kwargs=norm_params, causal=causal, pad_mode=pad_mode)]
+            mult *= 2
+        model += [_activation(activation, activation_params),
+                  StreamingConv1d(mult * n_filters, dimension, last_kernel_size, norm=norm, norm_kwargs=norm_params,
+                                  causal=causal, pad_mode=pad_mode)]
+        self.model = nn.Sequential(*model)
+
+    def forward_nlc(self, x: torch.Tensor) -> torch.Tensor:
+        return _run_fused(self.model, x)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return _to_ncl(self.forward_nlc(_to_nlc(x)))
+
+
+class SEANetDecoder(StreamingContainer):
+    """``modules/seanet.py:244-395``; ``forward`` takes ``[B, dimension, T]`` and returns ``[B, channels, T*hop]``."""
+
+    def __init__(self, channels: int = 1, dimension: int = 128, n_filters: int = 32, n_residual_layers: int = 3,
+                 ratios: List[int] = [8, 5, 4, 2], activation: str = "ELU", activation_params: dict = {"alpha": 1.0},
+                 final_activation: Optional[str] = None, final_activation_params: Optional[dict] = None, norm: str = "none",
+                 norm_params: Dict[str, Any] = {}, kernel_size: int = 7, last_kernel_size: int = 7,
+                 residual_kernel_size: int = 3, dilation_base: int = 2, causal: bool = False, pad_mode: str = "reflect",
+                 true_skip: bool = True, compress: int = 2, disable_norm_outer_blocks: int = 0,
+                 trim_right_ratio: float = 1.0):
+        super().__init__()
+        if final_activation is not None:
+            raise NotImplementedError("final_activation is not used by MimiCodec")
+        self.dimension, self.channels, self.n_filters = dimension, channels, n_filters
+        self.ratios = list(ratios)
+        self.n_residual_layers = n_residual_layers
+        self.hop_length = int(np.prod(self.ratios))
+        self.n_blocks = len(self.ratios) + 2
+        self.disable_norm_outer_blocks = disable_norm_outer_blocks
+        assert 0 <= disable_norm_outer_blocks <= self.n_blocks
+        mult = int(2 ** len(self.ratios))
+        model: List[nn.Module] = [StreamingConv1d(dimension, mult * n_filters, kernel_size, norm=norm, norm_kwargs=norm_params,
+                                                  causal=causal, pad_mode=pad_mode)]
+        for ratio in self.ratios:
+            model += [_activation(activation, activation_params),
+                      StreamingConvTranspose1d(mult * n_filters, mult * n_filters // 2, kernel_size=ratio * 2, stride=ratio,
+                                               norm=norm, norm_kwargs=norm_params, causal=causal,
+                                               trim_right_ratio=trim_right_ratio)]
+            for j in range(n_residual_layers):
+                model += [SEANetResnetBlock(mult * n_filters // 2, kernel_sizes=[residual_kernel_size, 1],
+                                            dilations=[dilation_base ** j, 1], activation=activation,
+                                            activation_params=activation_params, norm=norm, norm_params=norm_params,
+                                            causal=causal, pad_mode=pad_mode, compress=compress, true_skip=true_skip)]
+            mult //= 2
+        model += [_activation(activation, activation_params),
+                  StreamingConv1d(n_filters, channels, last_kernel_size, norm=norm, norm_kwargs=norm_params, causal=causal,
+                                  pad_mode=pad_mode)]
+        self.model = nn.Sequential(*model)
+
+    def forward_nlc(self, z: torch.Tensor) -> torch.Tensor:
+        return _run_fused(self.model, z)
+
+    def forward(self, z: torch.Tensor) -> torch.Tensor:
+        return _to_ncl(self.forward_nlc(_to_nlc(z)))

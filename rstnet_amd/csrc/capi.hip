@@ -126,6 +126,10 @@ int rst_convtr_depthwise_f32(const float* x, const float* hist, const float* w, 
     return rst_launch_convtr_depthwise(x, hist, w, y, B, T_in, C, Kw, stride, (hipStream_t)stream);
 }
 
+int rst_act_f32(const float* x, float* y, int64_t n, int act, rst_stream_t stream) {
+    return rst_launch_act(x, y, n, act, (hipStream_t)stream);
+}
+
 int rst_transpose_f32(const float* x, float* y, int B, int R, int C, rst_stream_t stream) {
     return rst_launch_transpose(x, y, B, R, C, (hipStream_t)stream);
 }

@@ -118,6 +118,11 @@ __global__ __launch_bounds__(256) void hist_update_kernel(const float* __restric
     }
 }
 
+__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        y[i] = act == 1 ? rst_elu(x[i]) : (act == 2 ? rst_gelu(x[i]) : x[i]);
+}
+
 inline unsigned grid_for(long total) {
     long g = (total + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
@@ -166,4 +171,12 @@ int rst_launch_hist_update(const float* x, const float* hist_in, float* hist_out
     hipLaunchKernelGGL(hist_update_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, hist_in, hist_out, B, T_in, P_in,
                        P_out, C);
     return rst_check_launch("hist_update");
+}
+
+int rst_launch_act(const float* x, float* y, long n, int act, hipStream_t stream) {
+    RST_REQUIRE(n >= 0 && act >= 0 && act <= 2, "act: bad arguments");
+    if (n == 0) return RST_OK;
+    RST_REQUIRE(x && y, "act: null pointer");
+    hipLaunchKernelGGL(act_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n, act);
+    return rst_check_launch("act");
 }

@@ -34,6 +34,8 @@ int rst_launch_convtr_depthwise(const float* x, const float* hist, const float* 
 int rst_launch_hist_update(const float* x, const float* hist_in, float* hist_out, int B, int T_in, int P_in, int P_out,
                            int C, hipStream_t stream);
 
+int rst_launch_act(const float* x, float* y, long n, int act, hipStream_t stream);  // 1: ELU, 2: GELU
+
 // ---- attention.hip ----------------------------------------------------------------------------
 struct RopeSplitParams {
     const float* qkv;   // [B][T][3][H][D]

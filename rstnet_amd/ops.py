@@ -18,6 +18,11 @@ ACT_NONE, ACT_ELU, ACT_GELU = 0, 1, 1
 PAD_ZERO, PAD_REPLICATE = 0, 1
 
 
+# Optional per-launch instrumentation (bench.py's roofline leg): a list that receives
+# (kernel name, start event, end event, algorithmic flops, algorithmic bytes) for every GEMM launch.
+PROFILE = None
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -58,9 +63,17 @@ def gemm_win(x: torch.Tensor, w: torch.Tensor, *, B: int, T_in: int, T_out: int,
         assert res.numel() == out.numel()
     if hist is not None:
         assert hist.numel() == B * P * C_, (tuple(hist.shape), B, P, C_)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.lib().rst_gemm_win_f32(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out),
                                            B, T_in, T_out, C_, K, N, S, P, pad_mode, T_in * C_, N, act_in, act_out,
                                            _stream()))
+    if prof is not None:
+        e1.record()
+        nbytes = 4 * (x.numel() + w.numel() + out.numel() + (res.numel() if res is not None else 0))
+        prof.append(("gemm_win", e0, e1, 2.0 * B * T_out * N * K, nbytes, (B * T_out, N, K)))
     return out
 
 
@@ -74,8 +87,16 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     assert w.shape[1] == K
     M = x.numel() // K if K else 0
     out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.lib().rst_linear_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, K, N,
                                          act_out, _stream()))
+    if prof is not None:
+        e1.record()
+        nbytes = 4 * (x.numel() + w.numel() + out.numel() + (res.numel() if res is not None else 0))
+        prof.append(("gemm_win", e0, e1, 2.0 * M * N * K, nbytes, (M, N, K)))
     return out
 
 
@@ -183,6 +204,14 @@ def convtr_depthwise(x: torch.Tensor, w: torch.Tensor, stride: int, hist: Option
     out = torch.empty(B, T * stride, Cc, device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().rst_convtr_depthwise_f32(_ptr(x), _ptr(hist), _ptr(w), _ptr(out), B, T, Cc, w.shape[1], stride,
                                                    _stream()))
+    return out
+
+
+def activation(x: torch.Tensor, act: str) -> torch.Tensor:
+    """Stand-alone ELU / GELU (only used when an activation module is called outside a fused container)."""
+    _chk(x, "x")
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().rst_act_f32(_ptr(x), _ptr(out), x.numel(), {"elu": 1, "gelu": 2}[act], _stream()))
     return out
 
 

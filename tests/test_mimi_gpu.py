@@ -1,0 +1,186 @@
+"""GPU parity of the MimiCodec drop-in (module surface) against the reference-generated fixtures and the CPU oracle,
+plus mirrors of the reference's own module tests (MLLM_v2/moshi/modules/conv_test.py, seanet_test.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mimi_oracle as O
+from rstnet_amd import synth
+from rstnet_amd.codec.conv import StreamingConv1d, StreamingConvTranspose1d
+from rstnet_amd.codec.mimi import MimiCodec
+from rstnet_amd.codec.seanet import SEANetDecoder, SEANetEncoder, SEANetResnetBlock
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def mimi():
+    sd = synth.mimi_state_dict(cases.MIMI_SEED)
+    return sd, MimiCodec.from_state_dict(sd).to(DEV)
+
+
+@pytest.mark.parametrize("name", list(cases.MIMI_E2E))
+def test_encode_decode_matches_reference_fixture(mimi, name):
+    sd, model = mimi
+    g = np.load(os.path.join(G, "mimi_e2e.npz"))
+    B, T, aseed = cases.MIMI_E2E[name]
+    audio = synth.synth_audio(B, T, aseed).to(DEV)
+    z = model.encode_latent(audio)
+    codes = model.encode(audio)
+    ref_codes = torch.from_numpy(g[f"{name}.codes"]).long()
+    assert codes.dtype == torch.int64 and tuple(codes.shape) == tuple(ref_codes.shape)
+    assert rel_err(z.transpose(1, 2), torch.from_numpy(g[f"{name}.latent"])) < 1e-3
+    # bit-exact codes: every decision of these fixtures has a top-2 gap >= 1e-5 relative (stored in rel_gap)
+    mism = (codes.cpu() != ref_codes)
+    assert not mism.any(), f"{int(mism.sum())} code mismatches; min fixture gap {g[f'{name}.rel_gap'].min():.2e}"
+    wav = model.decode(ref_codes.to(DEV))
+    ref_wav = torch.from_numpy(g[f"{name}.wav"])
+    assert tuple(wav.shape) == tuple(ref_wav.shape)
+    assert rel_err(wav, ref_wav) < 1e-3
+
+
+def test_state_dict_keys_match_reference(mimi):
+    sd, model = mimi
+    assert set(model.state_dict().keys()) == set(sd.keys())
+
+
+def test_decode_fewer_codebooks(mimi):
+    sd, model = mimi
+    cfg = O.MimiConfig()
+    codes = torch.randint(0, 2048, (2, 8, 5), generator=torch.Generator().manual_seed(3))
+    for n in (1, 3, 8):
+        zq = model.quantizer.decode_nlc(codes[:, :n].contiguous().to(DEV))
+        ref = O.rvq_decode(sd, cfg, codes[:, :n])
+        assert rel_err(zq.transpose(1, 2), ref) < 1e-5
+
+
+def test_streaming_encode_decode_equals_batch(mimi):
+    """Frame-by-frame streaming (1920-sample chunks) == one batch call: codes identical, waveform to fp32 round-off."""
+    sd, model = mimi
+    B, frames = 2, 6
+    audio = synth.synth_audio(B, frames * 1920, seed=5).to(DEV)
+    codes_full = model.encode(audio)
+    wav_full = model.decode(codes_full)
+    codes_s, wav_s = [], []
+    with model.streaming(B):
+        for f in range(frames):
+            c = model.encode(audio[:, :, f * 1920:(f + 1) * 1920].contiguous())
+            assert c.shape == (B, 8, 1)
+            codes_s.append(c)
+            wav_s.append(model.decode(c))
+    codes_s, wav_s = torch.cat(codes_s, -1), torch.cat(wav_s, -1)
+    assert torch.equal(codes_s, codes_full)
+    assert rel_err(wav_s, wav_full) < 1e-4
+    assert not model.is_streaming
+
+
+# ---- mirrors of the reference's own unit tests -------------------------------------------------------------------
+
+CONV1D_DATA = [(3, 4, 5, 10, 6), (4, 5, 6, 10, 7), (5, 6, 7, 10, 2), (1, 512, 512, 256, 7)]
+CONVTR_DATA = [(3, 4, 5, 10, 6, 1), (4, 5, 6, 10, 7, 2), (5, 6, 7, 10, 4, 3), (1, 512, 512, 256, 7, 2)]
+
+
+def _init_weights(module, generator):
+    for name, p in module.named_parameters():
+        if "bias" in name:
+            torch.nn.init.constant_(p, 0.0)
+        else:
+            torch.nn.init.xavier_uniform_(p, generator=generator)
+
+
+def _close(a, b):
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("batch_size, in_channels, out_channels, seq_len, kernel_size", CONV1D_DATA)
+def test_conv1d_causal_and_streaming(batch_size, in_channels, out_channels, seq_len, kernel_size):
+    """conv_test.py:63-109: outputs do not change when more input arrives; chunked streaming == full."""
+    layer = StreamingConv1d(in_channels, out_channels, kernel_size, causal=True, norm="none", pad_mode="constant")
+    _init_weights(layer, torch.Generator().manual_seed(41))
+    layer = layer.to(DEV)
+    x = torch.rand(batch_size, in_channels, seq_len).to(DEV)
+    expected = layer(x)
+    for end in range(kernel_size, seq_len + 1, 3):
+        actual = layer(x[..., :end].contiguous())
+        _close(actual, expected[..., :actual.shape[-1]])
+    outs, start = [], 0
+    with layer.streaming(batch_size=batch_size):
+        for end in range(kernel_size, seq_len + 1):
+            outs.append(layer(x[..., start:end].contiguous()))
+            start = end
+    _close(torch.cat(outs, -1), expected)
+
+
+@pytest.mark.parametrize("batch_size, in_channels, out_channels, seq_len, kernel_size, stride", CONVTR_DATA)
+def test_conv1d_transpose_causal_and_streaming(batch_size, in_channels, out_channels, seq_len, kernel_size, stride):
+    """conv_test.py:112-157."""
+    layer = StreamingConvTranspose1d(in_channels, out_channels, kernel_size, stride, causal=True, norm="none")
+    _init_weights(layer, torch.Generator().manual_seed(41))
+    layer = layer.to(DEV)
+    x = torch.rand(batch_size, in_channels, seq_len).to(DEV)
+    expected = layer(x)
+    for end in range(kernel_size, seq_len + 1, 3):
+        actual = layer(x[..., :end].contiguous())
+        _close(actual, expected[..., :actual.shape[-1]])
+    outs, start = [], 0
+    with layer.streaming(batch_size=batch_size):
+        for end in range(kernel_size, seq_len + 1):
+            outs.append(layer(x[..., start:end].contiguous()))
+            start = end
+    _close(torch.cat(outs, -1), expected)
+
+
+@pytest.mark.parametrize("dim,T", [(8, 20), (64, 33)])
+def test_resnet_block_streaming(dim, T):
+    """seanet_test.py:111-160."""
+    blk = SEANetResnetBlock(dim, kernel_sizes=[3, 1], dilations=[1, 1], causal=True, pad_mode="constant", compress=2)
+    _init_weights(blk, torch.Generator().manual_seed(41))
+    blk = blk.to(DEV)
+    x = torch.rand(2, dim, T).to(DEV)
+    expected = blk(x)
+    outs = []
+    with blk.streaming(2):
+        for t in range(0, T, 4):
+            outs.append(blk(x[..., t:t + 4].contiguous()))
+    _close(torch.cat(outs, -1), expected)
+
+
+@pytest.mark.parametrize("dimension,n_filters,ratios,T", [(8, 4, [5], 10), (8, 4, [5], 1), (512, 64, [8, 6, 5, 4], 2), (512, 64, [8, 6, 5, 4], 10)])
+def test_nonstreaming_causal_decode(dimension, n_filters, ratios, T):
+    """seanet_test.py:163-187: decoding a prefix gives a prefix of the decoded sequence."""
+    dec = SEANetDecoder(channels=1, dimension=dimension, n_filters=n_filters, n_residual_layers=1, ratios=ratios,
+                        kernel_size=7, residual_kernel_size=3, last_kernel_size=3, causal=True, pad_mode="constant",
+                        true_skip=True, compress=2)
+    _init_weights(dec, torch.Generator().manual_seed(41))
+    dec = dec.to(DEV)
+    z = torch.rand(1, dimension, T).to(DEV)
+    full = dec(z)
+    hop = int(np.prod(ratios))
+    assert full.shape == (1, 1, T * hop)
+    for end in range(1, T + 1, max(1, T // 3)):
+        part = dec(z[..., :end].contiguous())
+        _close(part, full[..., :end * hop])
+
+
+def test_seanet_encoder_streaming_small():
+    enc = SEANetEncoder(channels=1, dimension=16, n_filters=4, n_residual_layers=1, ratios=[4, 2], kernel_size=7,
+                        residual_kernel_size=3, last_kernel_size=3, causal=True, pad_mode="constant", true_skip=True, compress=2)
+    _init_weights(enc, torch.Generator().manual_seed(41))
+    enc = enc.to(DEV)
+    x = torch.rand(2, 1, 64).to(DEV)
+    expected = enc(x)
+    outs = []
+    with enc.streaming(2):
+        for t in range(0, 64, 8):
+            outs.append(enc(x[..., t:t + 8].contiguous()))
+    _close(torch.cat(outs, -1), expected)
