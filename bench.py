@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print the per-launch GEMM table (shape, ms, TFLOP/s, GB/s) to stderr")
     ap.add_argument("--check", action="store_true", help="also report the code exact-match rate against the CPU oracle on a sample")
     return ap.parse_args()
 
@@ -120,6 +121,11 @@ def main():
         step()
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
+        if args.layers:
+            for i, (_, e0, e1, fl, nb, shp) in enumerate(recs):
+                ms = e0.elapsed_time(e1)
+                print(f"  gemm[{i:3d}] M={shp[0]:9d} N={shp[1]:5d} K={shp[2]:5d}  {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TFLOP/s  "
+                      f"{nb / ms / 1e6:8.1f} GB/s(min traffic)", file=sys.stderr)
         tot_ms = sum(e0.elapsed_time(e1) for _, e0, e1, *_ in recs)
         tot_flops = sum(r[3] for r in recs)
         t_step_ms = elapsed / args.steps * 1e3
