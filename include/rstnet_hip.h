@@ -66,6 +66,19 @@ int rst_convtr1d_causal_f32(const float* x, const float* hist, const float* w_pa
                             float* y, int B, int T_in, int Cin, int Cout, int Kw, int stride, int act_in,
                             rst_stream_t stream);
 
+/* Fused SEANetResnetBlock.forward (modules/seanet.py:92-94): y = x + conv_k1(ELU(conv_kKw(ELU(x)))), dilation 1, hidden
+ * H = C/2, one launch, hidden activation kept in LDS.   w1 [H][Kw*C] (tap-major, as rst_conv1d_causal_f32), w2 [C][H].
+ * Optional end fusions:  w0 != NULL ("pre"):  x is the mono audio [B][T] and the block input is computed on the fly as
+ *   the first encoder conv, Conv1d(1, C, K0) (encoder.model.0, modules/seanet.py:184-193), w0 [C][K0];
+ * wf != NULL ("post"): the block output goes through ELU + the last decoder conv, Conv1d(C, 1, Kf)
+ *   (decoder.model.14, modules/seanet.py:368-379), wf [Kf][C], bf [1], and y is the mono waveform [B][T].
+ * hist [B][Kw-1][C] (plain variant only) = streaming history of x.  rst_seanet_resblock_supported() tells whether a
+ * shape is covered (otherwise the caller composes the block from rst_conv1d_causal_f32 calls). */
+int rst_seanet_resblock_supported(int C, int H, int Kw, int pre, int post, int K0, int Kf);
+int rst_seanet_resblock_f32(const float* x, const float* hist, const float* w0, const float* b0, const float* w1,
+                            const float* b1, const float* w2, const float* b2, const float* wf, const float* bf,
+                            float* y, int B, int T, int C, int H, int Kw, int K0, int Kf, rst_stream_t stream);
+
 /* y[M][N] = epi(x[M][K] * w[N][K]^T + bias): F.linear call sites of modules/transformer.py:395,421,562 and the 1x1
  * Conv1d projections of quantization/vq.py:88-96. */
 int rst_linear_f32(const float* x, const float* w, const float* bias, const float* res, const float* scale, float* y,

@@ -82,6 +82,7 @@ class RawStreamingConv1d(StreamingModule[_StreamingConvState]):
         self.bias = nn.Parameter(torch.empty(out_channels, device=device, dtype=dtype)) if bias else None
         self.reset_parameters()
         self._packed = _PackedCache()
+        self._packed_aux = _PackedCache()   # layouts wanted by fused neighbours (first / last SEANet conv)
 
     def reset_parameters(self) -> None:
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))

@@ -39,9 +39,28 @@ def _activation(name: str, params: dict) -> nn.Module:
 
 
 def _run_fused(model: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
-    """Walk a SEANet ``Sequential`` channels-last, folding each ELU into the layer that follows it."""
+    """Walk a SEANet ``Sequential`` channels-last, folding each ELU into the layer that follows it, and the
+    first / last convolution into the neighbouring residual block where the fused kernel covers the shape."""
     pending = ops.ACT_NONE
-    for layer in model:
+    layers = list(model)
+    i = 0
+    while i < len(layers):
+        layer = layers[i]
+        i += 1
+        nxt = layers[i] if i < len(layers) else None
+        nxt2 = layers[i + 1] if i + 1 < len(layers) else None
+        # encoder.model.0 (Conv1d 1 -> C) + residual block: one launch, the conv output never leaves the chip
+        if (isinstance(layer, StreamingConv1d) and isinstance(nxt, SEANetResnetBlock) and pending == ops.ACT_NONE
+                and nxt.can_fuse(pre=layer)):
+            x = nxt.forward_nlc(x, pre=layer)
+            i += 1
+            continue
+        # residual block + ELU + decoder.model.14 (Conv1d C -> 1): only the waveform is written
+        if (isinstance(layer, SEANetResnetBlock) and isinstance(nxt, ELU) and isinstance(nxt2, StreamingConv1d)
+                and pending == ops.ACT_NONE and layer.can_fuse(post=nxt2)):
+            x = layer.forward_nlc(x, post=nxt2)
+            i += 2
+            continue
         if isinstance(layer, ELU):
             assert pending == ops.ACT_NONE
             pending = ops.ACT_ELU
@@ -56,6 +75,12 @@ def _run_fused(model: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     if pending != ops.ACT_NONE:
         x = ops.activation(x, "elu")
     return x
+
+
+def _plain_causal_conv(conv: StreamingConv1d) -> bool:
+    raw = conv.conv.conv
+    return (conv.causal and conv.pad_mode == "constant" and raw.stride[0] == 1 and raw.dilation[0] == 1
+            and raw.bias is not None and not conv.is_streaming)
 
 
 class SEANetResnetBlock(StreamingContainer):
@@ -83,7 +108,46 @@ class SEANetResnetBlock(StreamingContainer):
             self.shortcut = StreamingConv1d(dim, dim, kernel_size=1, norm=norm, norm_kwargs=norm_params, causal=causal,
                                             pad_mode=pad_mode)
 
-    def forward_nlc(self, x: torch.Tensor) -> torch.Tensor:
+    def can_fuse(self, pre: Optional[StreamingConv1d] = None, post: Optional[StreamingConv1d] = None) -> bool:
+        """True when rst_seanet_resblock_f32 covers this block (not streaming, identity skip, [k, 1] kernels, dilation 1)
+        and, if given, the neighbouring first (1 -> C) / last (C -> 1) convolution."""
+        convs = [m for m in self.block if isinstance(m, StreamingConv1d)]
+        if self.is_streaming or not isinstance(self.shortcut, nn.Identity) or len(convs) != 2:
+            return False
+        c1, c2 = convs
+        if not (_plain_causal_conv(c1) and _plain_causal_conv(c2) and c2.conv.conv.kernel_size[0] == 1):
+            return False
+        C, H, Kw = c2.conv.conv.out_channels, c1.conv.conv.out_channels, c1.conv.conv.kernel_size[0]
+        if c1.conv.conv.in_channels != C or c2.conv.conv.in_channels != H or c1.conv.conv.weight.dtype != torch.float32:
+            return False
+        K0 = Kf = 0
+        if pre is not None:
+            if not (_plain_causal_conv(pre) and pre.conv.conv.in_channels == 1 and pre.conv.conv.out_channels == C):
+                return False
+            K0 = pre.conv.conv.kernel_size[0]
+        if post is not None:
+            if not (_plain_causal_conv(post) and post.conv.conv.out_channels == 1 and post.conv.conv.in_channels == C):
+                return False
+            Kf = post.conv.conv.kernel_size[0]
+        return ops.resblock_supported(C, H, Kw, pre is not None, post is not None, K0, Kf)
+
+    def _fused(self, x: torch.Tensor, pre: Optional[StreamingConv1d], post: Optional[StreamingConv1d]) -> torch.Tensor:
+        c1, c2 = [m.conv.conv for m in self.block if isinstance(m, StreamingConv1d)]
+        pre_w = post_w = None
+        if pre is not None:
+            r = pre.conv.conv
+            pre_w = (r._packed_aux.get((r.weight,), lambda: r.weight.detach().float()[:, 0, :].contiguous()), r.bias)
+        if post is not None:
+            r = post.conv.conv
+            post_w = (r._packed_aux.get((r.weight,), lambda: r.weight.detach().float()[0].t().contiguous()), r.bias)
+        return ops.seanet_resblock(x, c1.packed_weight(), c1.bias, c2.packed_weight(), c2.bias, Kw=c1.kernel_size[0],
+                                   pre=pre_w, post=post_w)
+
+    def forward_nlc(self, x: torch.Tensor, pre: Optional[StreamingConv1d] = None,
+                    post: Optional[StreamingConv1d] = None) -> torch.Tensor:
+        if self.can_fuse(pre, post):
+            return self._fused(x, pre, post)
+        assert pre is None and post is None
         u = x if isinstance(self.shortcut, nn.Identity) else self.shortcut.forward_nlc(x)
         convs = [m for m in self.block if isinstance(m, StreamingConv1d)]
         h = x

@@ -65,6 +65,20 @@ int rst_linear_f32(const float* x, const float* w, const float* bias, const floa
                             act_out, stream);
 }
 
+int rst_seanet_resblock_supported(int C, int H, int Kw, int pre, int post, int K0, int Kf) {
+    return rst_resblock_supported(C, H, Kw, pre, post, K0, Kf) ? 1 : 0;
+}
+
+int rst_seanet_resblock_f32(const float* x, const float* hist, const float* w0, const float* b0, const float* w1,
+                            const float* b1, const float* w2, const float* b2, const float* wf, const float* bf,
+                            float* y, int B, int T, int C, int H, int Kw, int K0, int Kf, rst_stream_t stream) {
+    ResblockParams p;
+    p.x = x; p.hist = hist; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.wf = wf; p.bf = bf; p.y = y;
+    p.B = B; p.T = T; p.C = C; p.H = H; p.Kw = Kw; p.K0 = K0; p.Kf = Kf;
+    p.pre = w0 != nullptr; p.post = wf != nullptr;
+    return rst_launch_resblock(p, (hipStream_t)stream);
+}
+
 int rst_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int D, float eps,
                       rst_stream_t stream) {
     return rst_launch_layernorm(x, gamma, beta, y, rows, D, eps, (hipStream_t)stream);

@@ -24,6 +24,25 @@ struct GemmWinParams {
 };
 int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream);
 
+// ---- resblock.hip ---------------------------------------------------------------------------------
+struct ResblockParams {
+    const float* x;     // [B][T][C] block input, or (pre) the mono audio [B][T]
+    const float* hist;  // [B][Kw-1][C] streaming history of x (plain variant only) or nullptr
+    const float* w0;    // pre : first conv weight [C][K0], bias b0 [C]
+    const float* b0;
+    const float* w1;    // [H][Kw*C] (tap-major K), b1 [H]
+    const float* b1;
+    const float* w2;    // [C][H], b2 [C]
+    const float* b2;
+    const float* wf;    // post: last conv weight [Kf][C], bias bf [1]
+    const float* bf;
+    float* y;           // [B][T][C], or (post) the mono waveform [B][T]
+    int B, T, C, H, Kw, K0, Kf;
+    int pre, post;
+};
+bool rst_resblock_supported(int C, int H, int Kw, int pre, int post, int K0, int Kf);
+int rst_launch_resblock(const ResblockParams& p, hipStream_t stream);
+
 // ---- norm_elt.hip -----------------------------------------------------------------------------
 int rst_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D,
                          float eps, hipStream_t stream);

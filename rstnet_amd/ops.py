@@ -100,6 +100,47 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+def resblock_supported(C: int, H: int, Kw: int, pre: bool = False, post: bool = False, K0: int = 0, Kf: int = 0) -> bool:
+    return bool(_lib.lib().rst_seanet_resblock_supported(C, H, Kw, int(pre), int(post), K0, Kf))
+
+
+def seanet_resblock(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, *, Kw: int,
+                    hist: Optional[torch.Tensor] = None, pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                    post: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+    """Fused SEANet residual block (rst_seanet_resblock_f32).  ``x [B,T,C]`` -> ``[B,T,C]``;
+    ``pre=(w0 [C,K0], b0 [C])``: x is the mono audio ``[B,T,1]``; ``post=(wf [Kf,C], bf [1])``: returns ``[B,T,1]``."""
+    C, H = w2.shape
+    B, T = x.shape[0], x.shape[1]
+    tensors = [(x, "x"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2"), (hist, "hist")]
+    w0 = b0 = wf = bf = None
+    K0 = Kf = 0
+    if pre is not None:
+        w0, b0 = pre
+        K0 = w0.shape[1]
+        tensors += [(w0, "w0"), (b0, "b0")]
+        assert x.shape[2] == 1
+    else:
+        assert x.shape[2] == C
+    if post is not None:
+        wf, bf = post
+        Kf = wf.shape[0]
+        tensors += [(wf, "wf"), (bf, "bf")]
+    for t, n in tensors:
+        _chk(t, n)
+    out = torch.empty(B, T, 1 if post is not None else C, device=x.device, dtype=torch.float32)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.lib().rst_seanet_resblock_f32(_ptr(x), _ptr(hist), _ptr(w0), _ptr(b0), _ptr(w1), _ptr(b1), _ptr(w2),
+                                                  _ptr(b2), _ptr(wf), _ptr(bf), _ptr(out), B, T, C, H, Kw, K0, Kf, _stream()))
+    if prof is not None:
+        e1.record()
+        flops = 2.0 * B * T * (Kw * C * H + H * C) + (2.0 * B * T * C * K0) + (2.0 * B * T * C * Kf)
+        prof.append(("resblock", e0, e1, flops, 4 * (x.numel() + out.numel()), (B * T, C, Kw * C)))
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
     for t, n in ((x, "x"), (gamma, "gamma"), (beta, "beta")):
         _chk(t, n)

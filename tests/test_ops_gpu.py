@@ -89,6 +89,49 @@ def test_resblock(name):
     assert rel_err(ncl(y), gold) < TOL
 
 
+@pytest.mark.parametrize("C,B,T", [(64, 2, 300), (64, 1, 128), (64, 3, 129), (128, 2, 200), (128, 1, 63)])
+def test_fused_resblock(C, B, T):
+    """rst_seanet_resblock_f32 (plain) == the oracle's resnet_block."""
+    assert ops.resblock_supported(C, C // 2, 3)
+    name = f"fused{C}_{T}"
+    w1, b1, x = cases.layer_tensors(name + ".1", (C // 2, C, 3), C // 2, (B, C, T))
+    w2, b2, _ = cases.layer_tensors(name + ".3", (C, C // 2, 1), C, (1, 1, 1))
+    x = x * 2 - 1
+    sd = {"p.block.1.conv.conv.weight": w1, "p.block.1.conv.conv.bias": b1,
+          "p.block.3.conv.conv.weight": w2, "p.block.3.conv.conv.bias": b2}
+    y = ops.seanet_resblock(nlc(x), RF.pack_conv_weight(w1).to(DEV), b1.to(DEV), RF.pack_conv_weight(w2).to(DEV), b2.to(DEV), Kw=3)
+    assert rel_err(ncl(y), O.resnet_block(sd, "p", x)) < TOL
+
+
+@pytest.mark.parametrize("B,T", [(2, 500), (1, 126), (1, 127), (3, 253)])
+def test_fused_resblock_with_first_and_last_conv(B, T):
+    """pre: encoder.model.0 (Conv1d 1->64 k7) folded in;  post: ELU + decoder.model.14 (Conv1d 64->1 k3) folded in."""
+    C = 64
+    name = f"fusedpp_{T}"
+    w1, b1, _ = cases.layer_tensors(name + ".1", (C // 2, C, 3), C // 2, (1, 1, 1))
+    w2, b2, _ = cases.layer_tensors(name + ".3", (C, C // 2, 1), C, (1, 1, 1))
+    w0, b0, a = cases.layer_tensors(name + ".0", (C, 1, 7), C, (B, 1, T))
+    wf, bf, xin = cases.layer_tensors(name + ".f", (1, C, 3), 1, (B, C, T))
+    a, xin = a * 2 - 1, xin * 2 - 1
+    sd = {"p.block.1.conv.conv.weight": w1, "p.block.1.conv.conv.bias": b1,
+          "p.block.3.conv.conv.weight": w2, "p.block.3.conv.conv.bias": b2}
+    args = (RF.pack_conv_weight(w1).to(DEV), b1.to(DEV), RF.pack_conv_weight(w2).to(DEV), b2.to(DEV))
+    # pre
+    ref = O.resnet_block(sd, "p", O.causal_conv1d(a, w0, b0))
+    y = ops.seanet_resblock(a.view(B, T, 1).to(DEV), *args, Kw=3, pre=(w0[:, 0].contiguous().to(DEV), b0.to(DEV)))
+    assert rel_err(ncl(y), ref) < TOL
+    # post
+    ref = O.causal_conv1d(F.elu(O.resnet_block(sd, "p", xin)), wf, bf)
+    y = ops.seanet_resblock(nlc(xin), *args, Kw=3, post=(wf[0].t().contiguous().to(DEV), bf.to(DEV)))
+    assert y.shape == (B, T, 1)
+    assert rel_err(y.view(B, 1, T), ref) < TOL
+    # both
+    ref = O.causal_conv1d(F.elu(O.resnet_block(sd, "p", O.causal_conv1d(a, w0, b0))), wf, bf)
+    y = ops.seanet_resblock(a.view(B, T, 1).to(DEV), *args, Kw=3, pre=(w0[:, 0].contiguous().to(DEV), b0.to(DEV)),
+                            post=(wf[0].t().contiguous().to(DEV), bf.to(DEV)))
+    assert rel_err(y.view(B, 1, T), ref) < TOL
+
+
 @pytest.mark.parametrize("chunk", [1, 3, 7])
 @pytest.mark.parametrize("K,S", [(7, 1), (3, 1), (8, 4), (10, 5), (4, 2)])
 def test_conv1d_streaming_equals_batch(K, S, chunk):
