@@ -29,7 +29,9 @@ extern "C" {
 
 #define RST_ACT_NONE 0
 #define RST_ACT_ELU 1   /* act_in : ELU(alpha=1) applied to the input on load (nn.ELU before every SEANet conv) */
-#define RST_ACT_GELU 1  /* act_out: exact erf GELU (F.gelu, modules/transformer.py:551-569) */
+#define RST_ACT_GELU 1  /* act_out: exact erf GELU (F.gelu, modules/transformer.py:551-569), applied before the residual */
+#define RST_ACT_ELU_OUT 2 /* act_out: ELU applied last (after the residual): for outputs whose only consumer is ELU -> conv,
+                             so that the consumer needs no act_in (one ELU per element instead of one per window tap) */
 #define RST_PAD_ZERO 0
 #define RST_PAD_REPLICATE 1
 
@@ -54,7 +56,7 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
  *   res (optional, layout of y) is added to the result (SEANetResnetBlock skip, modules/seanet.py:92-94). */
 int rst_conv1d_causal_f32(const float* x, const float* hist, const float* w_packed, const float* bias,
                           const float* res, float* y, int B, int T_in, int T_out, int Cin, int Cout, int Kw_eff,
-                          int stride, int pad_mode, int act_in, rst_stream_t stream);
+                          int stride, int pad_mode, int act_in, int act_out, rst_stream_t stream);
 
 /* Causal ConvTranspose1d, right-trimmed (trim_right_ratio = 1).  Replaces F.conv_transpose1d in
  * RawStreamingConvTranspose1d.forward (modules/streaming.py:271-303) + the trim of StreamingConvTranspose1d.forward
@@ -63,7 +65,7 @@ int rst_conv1d_causal_f32(const float* x, const float* hist, const float* w_pack
  *   bias_tiled [stride*Cout] (bias repeated `stride` times) or NULL;   x [B][T_in][Cin] -> y [B][T_in*stride][Cout].
  *   hist [B][q-1][Cin] = the q-1 input steps preceding x (streaming) or NULL (zeros). */
 int rst_convtr1d_causal_f32(const float* x, const float* hist, const float* w_packed, const float* bias_tiled,
-                            float* y, int B, int T_in, int Cin, int Cout, int Kw, int stride, int act_in,
+                            float* y, int B, int T_in, int Cin, int Cout, int Kw, int stride, int act_in, int act_out,
                             rst_stream_t stream);
 
 /* Fused SEANetResnetBlock.forward (modules/seanet.py:92-94): y = x + conv_k1(ELU(conv_kKw(ELU(x)))), dilation 1, hidden
@@ -72,12 +74,14 @@ int rst_convtr1d_causal_f32(const float* x, const float* hist, const float* w_pa
  *   the first encoder conv, Conv1d(1, C, K0) (encoder.model.0, modules/seanet.py:184-193), w0 [C][K0];
  * wf != NULL ("post"): the block output goes through ELU + the last decoder conv, Conv1d(C, 1, Kf)
  *   (decoder.model.14, modules/seanet.py:368-379), wf [Kf][C], bf [1], and y is the mono waveform [B][T].
+ * elu_out != 0: y = ELU(y) (plain / pre variants) for a block whose only consumer is ELU -> conv.
  * hist [B][Kw-1][C] (plain variant only) = streaming history of x.  rst_seanet_resblock_supported() tells whether a
  * shape is covered (otherwise the caller composes the block from rst_conv1d_causal_f32 calls). */
 int rst_seanet_resblock_supported(int C, int H, int Kw, int pre, int post, int K0, int Kf);
 int rst_seanet_resblock_f32(const float* x, const float* hist, const float* w0, const float* b0, const float* w1,
                             const float* b1, const float* w2, const float* b2, const float* wf, const float* bf,
-                            float* y, int B, int T, int C, int H, int Kw, int K0, int Kf, rst_stream_t stream);
+                            float* y, int B, int T, int C, int H, int Kw, int K0, int Kf, int elu_out,
+                            rst_stream_t stream);
 
 /* y[M][N] = epi(x[M][K] * w[N][K]^T + bias): F.linear call sites of modules/transformer.py:395,421,562 and the 1x1
  * Conv1d projections of quantization/vq.py:88-96. */

@@ -20,10 +20,10 @@ _f = C.c_float
 # name -> argtypes (all functions return int); mirrors include/rstnet_hip.h one to one
 SIGNATURES = {
     "rst_gemm_win_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _i, _i, _p],
-    "rst_conv1d_causal_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
-    "rst_convtr1d_causal_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rst_conv1d_causal_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rst_convtr1d_causal_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rst_seanet_resblock_supported": [_i, _i, _i, _i, _i, _i, _i],
-    "rst_seanet_resblock_f32": [_p] * 11 + [_i] * 7 + [_p],
+    "rst_seanet_resblock_f32": [_p] * 11 + [_i] * 8 + [_p],
     "rst_linear_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p],
     "rst_layernorm_f32": [_p, _p, _p, _p, _l, _i, _f, _p],
     "rst_rope_split_f32": [_p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _f, _p],

@@ -101,7 +101,7 @@ class RawStreamingConv1d(StreamingModule[_StreamingConvState]):
         return _StreamingConvState()
 
     def forward_nlc(self, x: torch.Tensor, *, act_in: int = ops.ACT_NONE, res: Optional[torch.Tensor] = None,
-                    pad: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+                    pad: Optional[Tuple[int, int]] = None, act_out: int = ops.ACT_NONE) -> torch.Tensor:
         """x ``[B, T, Cin]``.  Not streaming: a plain valid convolution, optionally over a virtual padding
         ``pad = (left, pad_mode)`` (right side completed to a full last window).  Streaming: runs on
         concat(previous, x), emits the complete frames and keeps the rest (``modules/streaming.py:224-236``)."""
@@ -113,17 +113,17 @@ class RawStreamingConv1d(StreamingModule[_StreamingConvState]):
             if pad is None:
                 t_out = max(0, (T - k) // s + 1)
                 return ops.gemm_win(x, w, B=B, T_in=T, T_out=t_out, C_=C, S=s, P=0, N=self.out_channels, bias=bias, res=res,
-                                    act_in=act_in, out_shape=(B, t_out, self.out_channels))
+                                    act_in=act_in, act_out=act_out, out_shape=(B, t_out, self.out_channels))
             left, pad_mode = pad
             t_out = RF.conv_out_frames(T, k, s, False, left)
             return ops.gemm_win(x, w, B=B, T_in=T, T_out=t_out, C_=C, S=s, P=left, N=self.out_channels, bias=bias, res=res,
-                                pad_mode=pad_mode, act_in=act_in, out_shape=(B, t_out, self.out_channels))
+                                pad_mode=pad_mode, act_in=act_in, act_out=act_out, out_shape=(B, t_out, self.out_channels))
         prev = state.previous
         n_prev = prev.shape[1] if prev is not None else 0
         total = n_prev + T
         t_out = max(0, (total - k) // s + 1)
         y = ops.gemm_win(x, w, B=B, T_in=T, T_out=t_out, C_=C, S=s, P=n_prev, N=self.out_channels,
-                         hist=prev if n_prev > 0 else None, bias=bias, res=res, act_in=act_in,
+                         hist=prev if n_prev > 0 else None, bias=bias, res=res, act_in=act_in, act_out=act_out,
                          out_shape=(B, t_out, self.out_channels))
         state.previous = ops.hist_update(x, prev, total - t_out * s)
         return y
@@ -175,7 +175,8 @@ class RawStreamingConvTranspose1d(StreamingModule[_StreamingConvState]):
     def _init_streaming_state(self, batch_size: int) -> _StreamingConvState:
         return _StreamingConvState()
 
-    def forward_nlc(self, x: torch.Tensor, *, act_in: int = ops.ACT_NONE, trimmed: bool = False) -> torch.Tensor:
+    def forward_nlc(self, x: torch.Tensor, *, act_in: int = ops.ACT_NONE, trimmed: bool = False,
+                    act_out: int = ops.ACT_NONE) -> torch.Tensor:
         """x ``[B, T, Cin]`` -> ``[B, T*S (+ K-S when not streaming and not trimmed), Cout]``."""
         state = self._streaming_state
         B, T, C = x.shape
@@ -193,12 +194,12 @@ class RawStreamingConvTranspose1d(StreamingModule[_StreamingConvState]):
         if T == 0:
             return x.new_empty(B, 0, self.out_channels)
         if self.groups != 1:
-            assert act_in == ops.ACT_NONE
+            assert act_in == ops.ACT_NONE and act_out == ops.ACT_NONE
             y = ops.convtr_depthwise(x, w, S, hist=hist)
             if self.bias is not None:
                 raise NotImplementedError("depth-wise ConvTranspose1d with bias")
         else:
-            y = RF.convtr1d(x, w, bias_t, kernel=K, stride=S, act_in=act_in, hist=hist)
+            y = RF.convtr1d(x, w, bias_t, kernel=K, stride=S, act_in=act_in, hist=hist, act_out=act_out)
         if state is not None:
             state.previous = ops.hist_update(x, hist, q - 1)
         elif not trimmed and K > S:
@@ -277,12 +278,13 @@ class StreamingConv1d(StreamingModule[_StreamingConv1dState]):
         assert self.causal, "streaming is only supported for causal convs"
         return _StreamingConv1dState(self._padding_total, self._padding_total)
 
-    def forward_nlc(self, x: torch.Tensor, *, act_in: int = ops.ACT_NONE, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward_nlc(self, x: torch.Tensor, *, act_in: int = ops.ACT_NONE, res: Optional[torch.Tensor] = None,
+                    act_out: int = ops.ACT_NONE) -> torch.Tensor:
         raw = self.conv.conv
         state = self._streaming_state
         mode = ops.PAD_REPLICATE if self.pad_mode == "replicate" else ops.PAD_ZERO
         if state is None:
-            return raw.forward_nlc(x, act_in=act_in, res=res, pad=(self._padding_total, mode))
+            return raw.forward_nlc(x, act_in=act_in, res=res, pad=(self._padding_total, mode), act_out=act_out)
         if state.padding_to_add > 0 and x.shape[1] > 0:
             # the first chunk is left-padded (modules/conv.py:249-253): seed the raw layer's input history with it
             B, _, C = x.shape
@@ -294,7 +296,7 @@ class StreamingConv1d(StreamingModule[_StreamingConv1dState]):
             assert rs is not None, "StreamingConv1d is streaming but its raw conv is not"
             rs.previous = seed if rs.previous is None else torch.cat([rs.previous, seed], dim=1)
             state.padding_to_add = 0
-        return raw.forward_nlc(x, act_in=act_in, res=res)
+        return raw.forward_nlc(x, act_in=act_in, res=res, act_out=act_out)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return _to_ncl(self.forward_nlc(_to_nlc(x)))
@@ -324,8 +326,8 @@ class StreamingConvTranspose1d(StreamingModule[_StreamingConvTr1dState]):
         assert self.causal, "streaming is only supported for causal convtrs"
         return _StreamingConvTr1dState()
 
-    def forward_nlc(self, x: torch.Tensor, *, act_in: int = ops.ACT_NONE) -> torch.Tensor:
-        return self.convtr.convtr.forward_nlc(x, act_in=act_in, trimmed=True)
+    def forward_nlc(self, x: torch.Tensor, *, act_in: int = ops.ACT_NONE, act_out: int = ops.ACT_NONE) -> torch.Tensor:
+        return self.convtr.convtr.forward_nlc(x, act_in=act_in, trimmed=True, act_out=act_out)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return _to_ncl(self.forward_nlc(_to_nlc(x)))

@@ -48,7 +48,7 @@ def conv_out_frames(t_total: int, k_eff: int, stride: int, streaming: bool, pad_
 
 def conv1d(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, k_eff: int, stride: int = 1,
            pad_mode: int = ops.PAD_ZERO, act_in: int = ops.ACT_NONE, res: Optional[torch.Tensor] = None,
-           hist: Optional[torch.Tensor] = None) -> torch.Tensor:
+           hist: Optional[torch.Tensor] = None, act_out: int = ops.ACT_NONE) -> torch.Tensor:
     """Causal conv on ``x [B,T,Cin]``.  Without ``hist``: non-streaming (left pad k_eff-stride, right pad to a full
     last window).  With ``hist [B,P,Cin]``: the window runs over concat(hist, x) and only complete frames are produced."""
     B, T, cin = x.shape
@@ -60,14 +60,15 @@ def conv1d(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor]
         P = hist.shape[1]
         t_out = conv_out_frames(P + T, k_eff, stride, True, 0)
     return ops.gemm_win(x, w_packed, B=B, T_in=T, T_out=t_out, C_=cin, S=stride, P=P, N=cout, hist=hist if P > 0 else None,
-                        bias=bias, res=res, pad_mode=pad_mode, act_in=act_in, out_shape=(B, t_out, cout))
+                        bias=bias, res=res, pad_mode=pad_mode, act_in=act_in, act_out=act_out, out_shape=(B, t_out, cout))
 
 
 def convtr1d(x: torch.Tensor, w_packed: torch.Tensor, bias_tiled: Optional[torch.Tensor], *, kernel: int, stride: int,
-             act_in: int = ops.ACT_NONE, hist: Optional[torch.Tensor] = None) -> torch.Tensor:
+             act_in: int = ops.ACT_NONE, hist: Optional[torch.Tensor] = None, act_out: int = ops.ACT_NONE) -> torch.Tensor:
     """Causal transposed conv on ``x [B,T,Cin]`` -> ``[B,T*stride,Cout]``; ``hist [B,q-1,Cin]`` = previous input steps."""
     B, T, cin = x.shape
     q = -(-kernel // stride)
     cout = w_packed.shape[0] // stride
     return ops.gemm_win(x, w_packed, B=B, T_in=T, T_out=T, C_=cin, S=1, P=q - 1, N=stride * cout,
-                        hist=hist if q > 1 else None, bias=bias_tiled, act_in=act_in, out_shape=(B, T * stride, cout))
+                        hist=hist if q > 1 else None, bias=bias_tiled, act_in=act_in, act_out=act_out,
+                        out_shape=(B, T * stride, cout))

@@ -39,39 +39,49 @@ def _activation(name: str, params: dict) -> nn.Module:
 
 
 def _run_fused(model: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
-    """Walk a SEANet ``Sequential`` channels-last, folding each ELU into the layer that follows it, and the
-    first / last convolution into the neighbouring residual block where the fused kernel covers the shape."""
-    pending = ops.ACT_NONE
+    """Walk a SEANet ``Sequential`` channels-last with three fusions:
+    * an ELU whose input has no other consumer is applied ONCE, in the producer's epilogue (``act_out``), instead of on
+      every window tap of the consumer's operand load; otherwise it is folded into the consumer's load (``act_in``);
+    * the skip-add of a residual block lives in the epilogue of its 1x1 convolution (or the whole block is one launch);
+    * the first (1 -> C) / last (C -> 1) convolution is folded into the neighbouring residual block."""
     layers = list(model)
+    convs = (StreamingConv1d, StreamingConvTranspose1d)
+    pending = ops.ACT_NONE      # ELU still to be applied to x by its consumer
     i = 0
     while i < len(layers):
         layer = layers[i]
-        i += 1
-        nxt = layers[i] if i < len(layers) else None
-        nxt2 = layers[i + 1] if i + 1 < len(layers) else None
-        # encoder.model.0 (Conv1d 1 -> C) + residual block: one launch, the conv output never leaves the chip
-        if (isinstance(layer, StreamingConv1d) and isinstance(nxt, SEANetResnetBlock) and pending == ops.ACT_NONE
-                and nxt.can_fuse(pre=layer)):
-            x = nxt.forward_nlc(x, pre=layer)
+        nxt = layers[i + 1] if i + 1 < len(layers) else None
+        nxt2 = layers[i + 2] if i + 2 < len(layers) else None
+        if isinstance(layer, ELU):
+            assert pending == ops.ACT_NONE
+            pending = ops.ACT_ELU
             i += 1
             continue
         # residual block + ELU + decoder.model.14 (Conv1d C -> 1): only the waveform is written
         if (isinstance(layer, SEANetResnetBlock) and isinstance(nxt, ELU) and isinstance(nxt2, StreamingConv1d)
                 and pending == ops.ACT_NONE and layer.can_fuse(post=nxt2)):
             x = layer.forward_nlc(x, post=nxt2)
-            i += 2
+            i += 3
             continue
-        if isinstance(layer, ELU):
-            assert pending == ops.ACT_NONE
-            pending = ops.ACT_ELU
-        elif isinstance(layer, (StreamingConv1d, StreamingConvTranspose1d)):
-            x = layer.forward_nlc(x, act_in=pending)
+        # encoder.model.0 (Conv1d 1 -> C) + residual block: one launch, the conv output never leaves the chip
+        pre = None
+        if (isinstance(layer, StreamingConv1d) and isinstance(nxt, SEANetResnetBlock) and pending == ops.ACT_NONE
+                and nxt.can_fuse(pre=layer)):
+            pre, layer = layer, nxt
+            i += 1
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            nxt2 = layers[i + 2] if i + 2 < len(layers) else None
+        # this layer's output feeds only "ELU -> conv": apply that ELU here, once per element
+        elu_out = isinstance(nxt, ELU) and isinstance(nxt2, convs)
+        if isinstance(layer, convs):
+            x = layer.forward_nlc(x, act_in=pending, act_out=ops.ACT_ELU_OUT if elu_out else ops.ACT_NONE)
             pending = ops.ACT_NONE
         elif isinstance(layer, SEANetResnetBlock):
             assert pending == ops.ACT_NONE
-            x = layer.forward_nlc(x)
+            x = layer.forward_nlc(x, pre=pre, elu_out=elu_out)
         else:
             raise NotImplementedError(f"unexpected layer {type(layer).__name__} in SEANet")
+        i += 2 if elu_out else 1   # the ELU module after an elu_out producer is already done
     if pending != ops.ACT_NONE:
         x = ops.activation(x, "elu")
     return x
@@ -131,7 +141,8 @@ class SEANetResnetBlock(StreamingContainer):
             Kf = post.conv.conv.kernel_size[0]
         return ops.resblock_supported(C, H, Kw, pre is not None, post is not None, K0, Kf)
 
-    def _fused(self, x: torch.Tensor, pre: Optional[StreamingConv1d], post: Optional[StreamingConv1d]) -> torch.Tensor:
+    def _fused(self, x: torch.Tensor, pre: Optional[StreamingConv1d], post: Optional[StreamingConv1d],
+               elu_out: bool = False) -> torch.Tensor:
         c1, c2 = [m.conv.conv for m in self.block if isinstance(m, StreamingConv1d)]
         pre_w = post_w = None
         if pre is not None:
@@ -141,12 +152,13 @@ class SEANetResnetBlock(StreamingContainer):
             r = post.conv.conv
             post_w = (r._packed_aux.get((r.weight,), lambda: r.weight.detach().float()[0].t().contiguous()), r.bias)
         return ops.seanet_resblock(x, c1.packed_weight(), c1.bias, c2.packed_weight(), c2.bias, Kw=c1.kernel_size[0],
-                                   pre=pre_w, post=post_w)
+                                   pre=pre_w, post=post_w, elu_out=elu_out)
 
     def forward_nlc(self, x: torch.Tensor, pre: Optional[StreamingConv1d] = None,
-                    post: Optional[StreamingConv1d] = None) -> torch.Tensor:
+                    post: Optional[StreamingConv1d] = None, elu_out: bool = False) -> torch.Tensor:
+        """``elu_out``: return ELU(block(x)) (the caller's next layer is ``ELU -> conv``)."""
         if self.can_fuse(pre, post):
-            return self._fused(x, pre, post)
+            return self._fused(x, pre, post, elu_out)
         assert pre is None and post is None
         u = x if isinstance(self.shortcut, nn.Identity) else self.shortcut.forward_nlc(x)
         convs = [m for m in self.block if isinstance(m, StreamingConv1d)]
@@ -155,9 +167,11 @@ class SEANetResnetBlock(StreamingContainer):
             h = conv.forward_nlc(h, act_in=ops.ACT_ELU)
         last = convs[-1]
         if h.shape[1] == u.shape[1] and last._stride == 1 and last._effective_kernel_size == 1:
-            return last.forward_nlc(h, act_in=ops.ACT_ELU, res=u)  # skip-add fused into the epilogue
+            # skip-add (and the caller's ELU) fused into the epilogue
+            return last.forward_nlc(h, act_in=ops.ACT_ELU, res=u, act_out=ops.ACT_ELU_OUT if elu_out else ops.ACT_NONE)
         v = last.forward_nlc(h, act_in=ops.ACT_ELU)
-        return _to_nlc(self.add(_to_ncl(u), _to_ncl(v)))
+        y = _to_nlc(self.add(_to_ncl(u), _to_ncl(v)))
+        return ops.activation(y, "elu") if elu_out else y
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return _to_ncl(self.forward_nlc(_to_nlc(x)))

@@ -32,7 +32,7 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
                      int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, rst_stream_t stream) {
     RST_REQUIRE(ldy >= N, "gemm_win: ldy (%d) < N (%d)", ldy, N);
     RST_REQUIRE(act_in == 0 || act_in == 1, "gemm_win: unknown act_in %d", act_in);
-    RST_REQUIRE(act_out == 0 || act_out == 1, "gemm_win: unknown act_out %d", act_out);
+    RST_REQUIRE(act_out >= 0 && act_out <= 2, "gemm_win: unknown act_out %d", act_out);
     RST_REQUIRE(pad_mode == 0 || pad_mode == 1, "gemm_win: unknown pad_mode %d", pad_mode);
     GemmWinParams p;
     p.x = x; p.hist = hist; p.w = w; p.bias = bias; p.res = res; p.scale = scale; p.y = y;
@@ -43,19 +43,19 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
 
 int rst_conv1d_causal_f32(const float* x, const float* hist, const float* w_packed, const float* bias,
                           const float* res, float* y, int B, int T_in, int T_out, int Cin, int Cout, int Kw_eff,
-                          int stride, int pad_mode, int act_in, rst_stream_t stream) {
+                          int stride, int pad_mode, int act_in, int act_out, rst_stream_t stream) {
     RST_REQUIRE(Kw_eff >= stride && stride > 0, "conv1d: kernel (%d) must be >= stride (%d)", Kw_eff, stride);
     return rst_gemm_win_f32(x, hist, w_packed, bias, res, nullptr, y, B, T_in, T_out, Cin, Kw_eff * Cin, Cout, stride,
-                            Kw_eff - stride, pad_mode, (int64_t)T_in * Cin, Cout, act_in, 0, stream);
+                            Kw_eff - stride, pad_mode, (int64_t)T_in * Cin, Cout, act_in, act_out, stream);
 }
 
 int rst_convtr1d_causal_f32(const float* x, const float* hist, const float* w_packed, const float* bias_tiled,
-                            float* y, int B, int T_in, int Cin, int Cout, int Kw, int stride, int act_in,
+                            float* y, int B, int T_in, int Cin, int Cout, int Kw, int stride, int act_in, int act_out,
                             rst_stream_t stream) {
     RST_REQUIRE(Kw >= stride && stride > 0, "convtr1d: kernel (%d) must be >= stride (%d)", Kw, stride);
     const int q = (Kw + stride - 1) / stride;
     return rst_gemm_win_f32(x, hist, w_packed, bias_tiled, nullptr, nullptr, y, B, T_in, T_in, Cin, q * Cin,
-                            stride * Cout, 1, q - 1, 0, (int64_t)T_in * Cin, stride * Cout, act_in, 0, stream);
+                            stride * Cout, 1, q - 1, 0, (int64_t)T_in * Cin, stride * Cout, act_in, act_out, stream);
 }
 
 int rst_linear_f32(const float* x, const float* w, const float* bias, const float* res, const float* scale, float* y,
@@ -71,11 +71,13 @@ int rst_seanet_resblock_supported(int C, int H, int Kw, int pre, int post, int K
 
 int rst_seanet_resblock_f32(const float* x, const float* hist, const float* w0, const float* b0, const float* w1,
                             const float* b1, const float* w2, const float* b2, const float* wf, const float* bf,
-                            float* y, int B, int T, int C, int H, int Kw, int K0, int Kf, rst_stream_t stream) {
+                            float* y, int B, int T, int C, int H, int Kw, int K0, int Kf, int elu_out,
+                            rst_stream_t stream) {
     ResblockParams p;
     p.x = x; p.hist = hist; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.wf = wf; p.bf = bf; p.y = y;
     p.B = B; p.T = T; p.C = C; p.H = H; p.Kw = Kw; p.K0 = K0; p.Kf = Kf;
-    p.pre = w0 != nullptr; p.post = wf != nullptr;
+    p.pre = w0 != nullptr; p.post = wf != nullptr; p.elu_out = elu_out;
+    RST_REQUIRE(!(p.post && elu_out), "resblock: elu_out has no meaning with the fused last conv");
     return rst_launch_resblock(p, (hipStream_t)stream);
 }
 

@@ -22,7 +22,7 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;  // floats per LDS row
 
-template <int TM, int TN, int WM, int WN, bool VEC>
+template <int TM, int TN, int WM, int WN, bool VEC, bool ELU>
 __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
     long a_off[RA];                  // float offset of the batch inside x
     long h_off[RA];                  // float offset of the batch inside hist
     int a_f0[RA];                    // flat index of the window start inside the batch (may be < 0)
+    int a_klo[RA], a_khi[RA];        // k range served by a plain load from x (everything else: padding / history)
     bool a_ok[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
@@ -68,6 +69,8 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
         a_off[j] = (long)b * p.x_bstride;
         h_off[j] = (long)b * PC;
         a_f0[j] = (t * p.S - p.P) * p.C;
+        a_klo[j] = a_ok[j] ? max(0, -a_f0[j]) : 0x7fffffff;
+        a_khi[j] = a_ok[j] ? min(p.K, TC - a_f0[j]) : 0;
     }
 
     f32x4 ra[RA], rb[RB];
@@ -92,7 +95,9 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a_ok[j]) {
+            if (VEC && k >= a_klo[j] && k < a_khi[j]) {
+                v = *reinterpret_cast<const f32x4*>(p.x + a_off[j] + a_f0[j] + k);   // interior: the common case
+            } else if (a_ok[j]) {
                 if (VEC) {
                     if (k < p.K) {
                         const int f = a_f0[j] + k;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             f32x4 v = ra[j];
-            if (p.act_in == 1) {
+            if (ELU) {
                 v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]);
             }
             *reinterpret_cast<f32x4*>(a + (lrow + 32 * j) * LDS_LD + lk) = v;
@@ -171,6 +176,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
         if (kt + 1 < nk) load_tiles(kt + 1);
         const float* a = As + buf * BM * LDS_LD + (wm * TM * 32 + frag_row) * LDS_LD + frag_k;
         const float* b = Bs + buf * BN * LDS_LD + (wn * TN * 32 + frag_row) * LDS_LD + frag_k;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
             f32x4 fa[TM], fb[TN];
@@ -186,6 +192,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
     }
@@ -207,6 +214,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
                 if (p.act_out == 1) v = rst_gelu(v);
                 const long o = (long)m * p.ldy + n;
                 if (p.res) v = p.res[o] + scale * v;
+                if (p.act_out == 2) v = rst_elu(v);
                 p.y[o] = v;
             }
         }
@@ -224,18 +232,19 @@ int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
         return RST_ERR_UNSUPPORTED;
     }
     const size_t lds = 2 * (BM + BN) * LDS_LD * sizeof(float);
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_win_kernel<TM, TN, WM, WN, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_win_kernel<TM, TN, WM, WN, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    if (vec)
-        hipLaunchKernelGGL((gemm_win_kernel<TM, TN, WM, WN, true>), dim3((unsigned)tiles), dim3(256), lds, stream, p);
-    else
-        hipLaunchKernelGGL((gemm_win_kernel<TM, TN, WM, WN, false>), dim3((unsigned)tiles), dim3(256), lds, stream, p);
+    auto go = [&](auto kern) {
+        static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel instantiation
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+    };
+    const bool elu = p.act_in == 1;
+    if (vec && elu) go(gemm_win_kernel<TM, TN, WM, WN, true, true>);
+    else if (vec) go(gemm_win_kernel<TM, TN, WM, WN, true, false>);
+    else if (elu) go(gemm_win_kernel<TM, TN, WM, WN, false, true>);
+    else go(gemm_win_kernel<TM, TN, WM, WN, false, false>);
     return rst_check_launch("gemm_win");
 }
 

@@ -20,7 +20,30 @@ namespace {
 constexpr int BK = 32;
 constexpr int WLD = BK + 4;
 
-template <int C, int BM, int WM, int WN, bool PRE, bool POST>
+// LDS carve-up (floats), shared by kernel and launcher.  Region R0 holds the ELU'd input tile during GEMM1 and is
+// recycled afterwards (W2, and the hidden tile when it fits behind W2; POST: the output tile).
+template <int C, int BM, bool W1RES>
+struct Carve {
+    static constexpr int H = C / 2, XLD = C + 4, HLD = H + 4;
+    int r0, hs_off, w1_off, w1_ld, as_off, w0_off, wf_off, total;
+    __host__ __device__ Carve(int Kw, bool pre, bool post) {
+        const int xt = (BM + Kw - 1) * XLD, w2 = C * HLD, hs = BM * HLD;
+        const bool hs_in_r0 = xt >= w2 + hs;
+        r0 = xt > w2 ? xt : w2;
+        w1_ld = W1RES ? Kw * C + 4 : WLD;
+        const int w1 = W1RES ? H * w1_ld : 2 * H * WLD;
+        w1_off = r0;
+        // the hidden tile lives behind W2 inside R0 if there is room, else over the (dead) W1 stream ring, else on its own
+        hs_off = hs_in_r0 ? w2 : ((!W1RES && w1 >= hs) ? w1_off : r0 + w1);
+        const int end = (hs_in_r0 || (!W1RES && w1 >= hs)) ? r0 + w1 : r0 + w1 + hs;
+        as_off = end;
+        w0_off = as_off + (pre ? BM + 12 : 0);
+        wf_off = w0_off + (pre ? C * 9 : 0);
+        total = wf_off + (post ? 4 * C : 0);
+    }
+};
+
+template <int C, int BM, int WM, int WN, bool PRE, bool POST, bool W1RES>
 __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
     constexpr int H = C / 2;
     constexpr int XLD = C + 4, HLD = H + 4;
@@ -28,18 +51,19 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
     constexpr int NT2 = C / 32 / WN;      // GEMM2 column tiles per wave
     constexpr int W1CH = H * 8 / 256;     // float4 chunks of a W1 k-tile per thread
     constexpr int W2CH = C * H / 4 / 256; // float4 chunks of W2 per thread
-    constexpr int MAXKW = 4, MAXK0 = 8;
+    constexpr int MAXK0 = 8;
     static_assert(BM == 32 * WM && WM * WN == 4 && NT1 >= 1 && W1CH >= 1 && W2CH >= 1, "tile config");
     static_assert(!POST || BM == 128, "the fused last conv maps two lanes to each of the BM output rows");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int R0 = ((BM + MAXKW - 1) * XLD > C * HLD ? (BM + MAXKW - 1) * XLD : C * HLD);
-    float* Xs = smem;                    // [(BM+Kw-1)][XLD] ELU(x); later W2s [C][HLD]; later (POST) Ys [BM][XLD]
-    float* Hs = smem + R0;               // [BM][HLD]
-    float* W1s = Hs + BM * HLD;          // [2][H][WLD]
-    float* As = W1s + 2 * H * WLD;       // PRE: audio tile [BM + Kw-1 + K0-1] ; W0s [C][MAXK0+1]
-    float* W0s = As + (BM + MAXKW + MAXK0);   // [C][MAXK0+1]
-    float* Wfs = W0s + C * (MAXK0 + 1);       // POST: [Kf][C]
+    const Carve<C, BM, W1RES> cv(p.Kw, PRE, POST);
+    float* Xs = smem;                    // [(BM+Kw-1)][XLD] ELU(x); later W2s [C][HLD] (+ Hs); later (POST) Ys [BM][XLD]
+    float* Hs = smem + cv.hs_off;        // [BM][HLD]
+    float* W1s = smem + cv.w1_off;       // W1RES: [H][Kw*C+4] whole ; else ring [2][H][WLD]
+    float* As = smem + cv.as_off;        // PRE: audio tile [BM + Kw-1 + K0-1]
+    float* W0s = smem + cv.w0_off;       // PRE: [C][MAXK0+1]
+    float* Wfs = smem + cv.wf_off;       // POST: [Kf][C]
+    const int W1LD = cv.w1_ld;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -63,9 +87,9 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
     if (PRE) {
         const int K0 = p.K0;
         const int tA0 = t0 - (Kw - 1) - (K0 - 1);
-        for (int i = tid; i < XR + K0 - 1; i += 256) {
+        for (int i = tid; i < BM + 12; i += 256) {   // the whole carve (incl. the tail read with zero weights) is defined
             const int t = tA0 + i;
-            As[i] = (t >= 0 && t < T) ? p.x[b * T + t] : 0.f;
+            As[i] = (i < XR + K0 - 1 && t >= 0 && t < T) ? p.x[b * T + t] : 0.f;
         }
         for (int i = tid; i < C * K0; i += 256) W0s[(i / K0) * (MAXK0 + 1) + i % K0] = p.w0[i];
         __syncthreads();
@@ -81,65 +105,116 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
             Xs[rx * XLD + c] = v;
         }
     } else {
-        for (int idx = tid; idx < XR * (C / 4); idx += 256) {
+        // all global loads of the tile are issued before the first one is consumed (one exposed HBM latency, not nine)
+        constexpr int XCH = ((BM + 3) * (C / 4) + 255) / 256;
+        f32x4 xv[XCH];
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int idx = tid + 256 * i;
             const int rx = idx / (C / 4), c4 = (idx - rx * (C / 4)) * 4;
             const int t = t0 - (Kw - 1) + rx;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 0) {
-                if (t < T) v = *reinterpret_cast<const f32x4*>(p.x + (b * T + t) * C + c4);
-            } else if (p.hist && t >= -(Kw - 1)) {
-                v = *reinterpret_cast<const f32x4*>(p.hist + (b * (Kw - 1) + (Kw - 1) + t) * C + c4);
+            if (rx < XR) {
+                if (t >= 0) {
+                    if (t < T) v = *reinterpret_cast<const f32x4*>(p.x + (b * T + t) * C + c4);
+                } else if (p.hist && t >= -(Kw - 1)) {
+                    v = *reinterpret_cast<const f32x4*>(p.hist + (b * (Kw - 1) + (Kw - 1) + t) * C + c4);
+                }
             }
-            v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]);
-            *reinterpret_cast<f32x4*>(Xs + rx * XLD + c4) = v;
+            xv[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int idx = tid + 256 * i;
+            const int rx = idx / (C / 4), c4 = (idx - rx * (C / 4)) * 4;
+            if (rx < XR) {
+                f32x4 v = xv[i];
+                v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]);
+                *reinterpret_cast<f32x4*>(Xs + rx * XLD + c4) = v;
+            }
         }
     }
 
-    // ---- phase 1: GEMM1  acc1[BM x H] = Xwin[BM x Kw*C] * W1^T, W1 streamed through LDS
+    // ---- phase 1: GEMM1  acc1[BM x H] = Xwin[BM x Kw*C] * W1^T
     const int nk = Kw * C / BK;
-    f32x4 w1r[W1CH];
-    auto load_w1 = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < W1CH; ++i) {
-            const int ch = tid + 256 * i;   // row = ch / 8, k4 = ch % 8
-            w1r[i] = *reinterpret_cast<const f32x4*>(p.w1 + (size_t)(ch >> 3) * (Kw * C) + kt * BK + (ch & 7) * 4);
-        }
-    };
-    auto store_w1 = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < W1CH; ++i) {
-            const int ch = tid + 256 * i;
-            *reinterpret_cast<f32x4*>(W1s + buf * H * WLD + (ch >> 3) * WLD + (ch & 7) * 4) = w1r[i];
-        }
-    };
-    load_w1(0);
-    store_w1(0);
-    __syncthreads();
-
     f32x16 acc1[NT1];
 #pragma unroll
     for (int j = 0; j < NT1; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
     const int frow = lane & 31, fk = (lane >> 5) * 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_w1(kt + 1);
-        const int tap = (kt * BK) / C, ci0 = (kt * BK) % C;
-        const float* a = Xs + (wm * 32 + frow + tap) * XLD + ci0 + fk;
-        const float* bw = W1s + (kt & 1) * H * WLD + (wn * NT1 * 32 + frow) * WLD + fk;
+    if (W1RES) {
+        // whole W1 in LDS: one barrier, then an uninterrupted MFMA stream
+        const int KC = Kw * C;
+        constexpr int WCH = H * C / 256;   // chunks per thread at the maximum Kw = 4
+        f32x4 wv[WCH];
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            const f32x4 fa = *reinterpret_cast<const f32x4*>(a + ks * 8);
-            f32x4 fb[NT1];
-#pragma unroll
-            for (int j = 0; j < NT1; ++j) fb[j] = *reinterpret_cast<const f32x4*>(bw + j * 32 * WLD + ks * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int j = 0; j < NT1; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[j][e], acc1[j], 0, 0, 0);
+        for (int i = 0; i < WCH; ++i) {
+            const int idx = tid + 256 * i;
+            wv[i] = idx < H * (KC / 4) ? *reinterpret_cast<const f32x4*>(p.w1 + (size_t)idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (kt + 1 < nk) store_w1((kt + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / (KC / 4), k4 = (idx - row * (KC / 4)) * 4;
+            if (idx < H * (KC / 4)) *reinterpret_cast<f32x4*>(W1s + row * W1LD + k4) = wv[i];
+        }
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int tap = (kt * BK) / C, ci0 = (kt * BK) % C;
+            const float* a = Xs + (wm * 32 + frow + tap) * XLD + ci0 + fk;
+            const float* bw = W1s + (wn * NT1 * 32 + frow) * W1LD + kt * BK + fk;
+#pragma unroll
+            for (int ks = 0; ks < BK / 8; ++ks) {
+                const f32x4 fa = *reinterpret_cast<const f32x4*>(a + ks * 8);
+                f32x4 fb[NT1];
+#pragma unroll
+                for (int j = 0; j < NT1; ++j) fb[j] = *reinterpret_cast<const f32x4*>(bw + j * 32 * W1LD + ks * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < NT1; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[j][e], acc1[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    } else {
+        f32x4 w1r[W1CH];
+        auto load_w1 = [&](int kt) {
+#pragma unroll
+            for (int i = 0; i < W1CH; ++i) {
+                const int ch = tid + 256 * i;   // row = ch / 8, k4 = ch % 8
+                w1r[i] = *reinterpret_cast<const f32x4*>(p.w1 + (size_t)(ch >> 3) * (Kw * C) + kt * BK + (ch & 7) * 4);
+            }
+        };
+        auto store_w1 = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < W1CH; ++i) {
+                const int ch = tid + 256 * i;
+                *reinterpret_cast<f32x4*>(W1s + buf * H * WLD + (ch >> 3) * WLD + (ch & 7) * 4) = w1r[i];
+            }
+        };
+        load_w1(0);
+        store_w1(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_w1(kt + 1);
+            const int tap = (kt * BK) / C, ci0 = (kt * BK) % C;
+            const float* a = Xs + (wm * 32 + frow + tap) * XLD + ci0 + fk;
+            const float* bw = W1s + (kt & 1) * H * WLD + (wn * NT1 * 32 + frow) * WLD + fk;
+#pragma unroll
+            for (int ks = 0; ks < BK / 8; ++ks) {
+                const f32x4 fa = *reinterpret_cast<const f32x4*>(a + ks * 8);
+                f32x4 fb[NT1];
+#pragma unroll
+                for (int j = 0; j < NT1; ++j) fb[j] = *reinterpret_cast<const f32x4*>(bw + j * 32 * WLD + ks * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < NT1; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[j][e], acc1[j], 0, 0, 0);
+            }
+            if (kt + 1 < nk) store_w1((kt + 1) & 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue 1: Hs = ELU(acc1 + b1);  W2 registers -> LDS over the dead X tile
@@ -157,6 +232,20 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
         *reinterpret_cast<f32x4*>(W2s + (ch / (H / 4)) * HLD + (ch % (H / 4)) * 4) = w2r[i];
     }
     __syncthreads();
+
+    // skip-connection operand: issue the global loads now, they land under GEMM2's MFMAs
+    float xres[NT2][16];
+    if (!PRE) {
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) {
+            const int col = (wn * NT2 + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int t = t0 + wm * 32 + rst_mfma32_row(e, lane);
+                xres[j][e] = (t >= 0 && t < T) ? p.x[(b * T + t) * C + col] : 0.f;
+            }
+        }
+    }
 
     // ---- phase 2: GEMM2  acc2[BM x C] = Hs[BM x H] * W2^T
     f32x16 acc2[NT2];
@@ -198,21 +287,21 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
             const int r = wm * 32 + rst_mfma32_row(e, lane);
             const int t = t0 + r;
             const bool valid = t >= 0 && t < T;
-            float xres = 0.f;
-            if (valid) {
-                if (PRE) {
-                    xres = b0c;
+            float xr = 0.f;
+            if (PRE) {
+                if (valid) {
+                    xr = b0c;
 #pragma unroll
-                    for (int k = 0; k < MAXK0; ++k) xres = fmaf(w0c[k], As[r + (Kw - 1) + k], xres);
-                } else {
-                    xres = p.x[(b * T + t) * C + col];
+                    for (int k = 0; k < MAXK0; ++k) xr = fmaf(w0c[k], As[r + (Kw - 1) + k], xr);
                 }
+            } else {
+                xr = xres[j][e];
             }
-            const float yv = xres + (acc2[j][e] + bias);
+            const float yv = xr + (acc2[j][e] + bias);
             if (POST) {
                 Xs[r * XLD + col] = valid ? rst_elu(yv) : 0.f;
             } else if (valid) {
-                p.y[(b * T + t) * C + col] = yv;
+                p.y[(b * T + t) * C + col] = p.elu_out ? rst_elu(yv) : yv;
             }
         }
     }
@@ -228,7 +317,7 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
                 const float* wk = Wfs + k * C + half * (C / 2);
 #pragma unroll 8
                 for (int c = 0; c < C / 2; ++c) {
-                    const int cc = (c + (tid >> 1)) & (C / 2 - 1);   // rotate the start channel per row: conflict-free LDS reads
+                    const int cc = (c + (tid >> 1) + half * (C / 4)) & (C / 2 - 1);   // per-lane channel rotation: conflict-free LDS reads
                     s = fmaf(wk[cc], yr[cc], s);
                 }
             }
@@ -239,21 +328,20 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
     }
 }
 
-template <int C, int BM, int WM, int WN, bool PRE, bool POST>
+template <int C, int BM, int WM, int WN, bool PRE, bool POST, bool W1RES>
 int launch(const ResblockParams& p, hipStream_t stream) {
-    constexpr int H = C / 2;
-    constexpr int R0 = ((BM + 3) * (C + 4) > C * (H + 4) ? (BM + 3) * (C + 4) : C * (H + 4));
-    const size_t lds = (size_t)(R0 + BM * (H + 4) + 2 * H * WLD + (BM + 12) + C * 9 + 4 * C) * sizeof(float);
+    const Carve<C, BM, W1RES> cv(p.Kw, PRE, POST);
+    const size_t lds = (size_t)cv.total * sizeof(float);
     const int halo = POST ? p.Kf - 1 : 0;
     const long tiles = (long)p.B * ((p.T + (BM - halo) - 1) / (BM - halo));
     if (tiles > 0x7fffffffL) { rst_set_error("resblock: grid too large"); return RST_ERR_UNSUPPORTED; }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<C, BM, WM, WN, PRE, POST>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<C, BM, WM, WN, PRE, POST, W1RES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((resblock_kernel<C, BM, WM, WN, PRE, POST>), dim3((unsigned)tiles), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((resblock_kernel<C, BM, WM, WN, PRE, POST, W1RES>), dim3((unsigned)tiles), dim3(256), lds, stream, p);
     return rst_check_launch("resblock");
 }
 
@@ -278,10 +366,10 @@ int rst_launch_resblock(const ResblockParams& p, hipStream_t stream) {
     RST_REQUIRE(!p.post || (p.wf && p.bf), "resblock: POST needs wf/bf");
     RST_REQUIRE(!(p.hist && (p.pre || p.post)), "resblock: streaming history is only supported by the plain variant");
     if (p.C == 64) {
-        if (p.pre && p.post) return launch<64, 128, 4, 1, true, true>(p, stream);
-        if (p.pre) return launch<64, 128, 4, 1, true, false>(p, stream);
-        if (p.post) return launch<64, 128, 4, 1, false, true>(p, stream);
-        return launch<64, 128, 4, 1, false, false>(p, stream);
+        if (p.pre && p.post) return launch<64, 128, 4, 1, true, true, true>(p, stream);
+        if (p.pre) return launch<64, 128, 4, 1, true, false, true>(p, stream);
+        if (p.post) return launch<64, 128, 4, 1, false, true, true>(p, stream);
+        return launch<64, 128, 4, 1, false, false, true>(p, stream);
     }
-    return launch<128, 64, 2, 2, false, false>(p, stream);
+    return launch<128, 64, 2, 2, false, false, false>(p, stream);
 }

@@ -20,7 +20,7 @@ struct GemmWinParams {
     long x_bstride;      // floats between consecutive batches of x
     int ldy;             // floats between consecutive output rows (>= N)
     int act_in;          // 0: none, 1: ELU applied to A on load
-    int act_out;         // 0: none, 1: exact GELU
+    int act_out;         // 0: none, 1: exact GELU (before the residual), 2: ELU (applied last, after the residual)
 };
 int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream);
 
@@ -39,6 +39,7 @@ struct ResblockParams {
     float* y;           // [B][T][C], or (post) the mono waveform [B][T]
     int B, T, C, H, Kw, K0, Kf;
     int pre, post;
+    int elu_out;        // apply ELU to y before the store (the only consumer is an ELU -> conv), plain / pre variants
 };
 bool rst_resblock_supported(int C, int H, int Kw, int pre, int post, int K0, int Kf);
 int rst_launch_resblock(const ResblockParams& p, hipStream_t stream);

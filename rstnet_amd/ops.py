@@ -14,7 +14,8 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_ELU, ACT_GELU = 0, 1, 1
+ACT_NONE, ACT_ELU, ACT_GELU = 0, 1, 1   # act_in: 1 = ELU ; act_out: 1 = GELU
+ACT_ELU_OUT = 2                          # act_out: ELU applied last (after the residual)
 PAD_ZERO, PAD_REPLICATE = 0, 1
 
 
@@ -106,7 +107,7 @@ def resblock_supported(C: int, H: int, Kw: int, pre: bool = False, post: bool = 
 
 def seanet_resblock(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, *, Kw: int,
                     hist: Optional[torch.Tensor] = None, pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                    post: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+                    post: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, elu_out: bool = False) -> torch.Tensor:
     """Fused SEANet residual block (rst_seanet_resblock_f32).  ``x [B,T,C]`` -> ``[B,T,C]``;
     ``pre=(w0 [C,K0], b0 [C])``: x is the mono audio ``[B,T,1]``; ``post=(wf [Kf,C], bf [1])``: returns ``[B,T,1]``."""
     C, H = w2.shape
@@ -133,7 +134,8 @@ def seanet_resblock(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: tor
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.check(_lib.lib().rst_seanet_resblock_f32(_ptr(x), _ptr(hist), _ptr(w0), _ptr(b0), _ptr(w1), _ptr(b1), _ptr(w2),
-                                                  _ptr(b2), _ptr(wf), _ptr(bf), _ptr(out), B, T, C, H, Kw, K0, Kf, _stream()))
+                                                  _ptr(b2), _ptr(wf), _ptr(bf), _ptr(out), B, T, C, H, Kw, K0, Kf, int(elu_out),
+                                                  _stream()))
     if prof is not None:
         e1.record()
         flops = 2.0 * B * T * (Kw * C * H + H * C) + (2.0 * B * T * C * K0) + (2.0 * B * T * C * Kf)

@@ -1,0 +1,72 @@
+"""Micro-benchmarks of individual C-ABI kernels (HIP-event timing); also the workload for rocprofv3 --pmc passes.
+
+    python tools/bench_kernels.py [case ...]        cases: res64 res64pre res64post res128 gemm:<M>x<N>x<K>[:elu] ...
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from rstnet_amd import ops  # noqa: E402
+from rstnet_amd.codec import functional as RF  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def res_case(C, B, T, pre=False, post=False):
+    g = torch.Generator().manual_seed(0)
+    H = C // 2
+    w1 = (torch.randn(H, 3 * C, generator=g) * 0.05).to(DEV)
+    w2 = (torch.randn(C, H, generator=g) * 0.05).to(DEV)
+    b1, b2 = torch.zeros(H, device=DEV), torch.zeros(C, device=DEV)
+    x = torch.randn(B, T, 1 if pre else C, generator=g).to(DEV)
+    kw = {}
+    if pre:
+        kw["pre"] = ((torch.randn(C, 7, generator=g) * 0.3).to(DEV), torch.zeros(C, device=DEV))
+    if post:
+        kw["post"] = ((torch.randn(3, C, generator=g) * 0.1).to(DEV), torch.zeros(1, device=DEV))
+    ms = timeit(lambda: ops.seanet_resblock(x, w1, b1, w2, b2, Kw=3, **kw))
+    fl = 2.0 * B * T * (3 * C * H + H * C)
+    return ms, fl
+
+
+def gemm_case(M, N, K, elu=False, res=False):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    r = torch.randn(M, N, generator=g).to(DEV) if res else None
+    ms = timeit(lambda: ops.gemm_win(x, w, B=1, T_in=M, T_out=M, C_=K, S=1, P=0, N=N, res=r, act_in=int(elu)))
+    return ms, 2.0 * M * N * K
+
+
+def main():
+    cases = sys.argv[1:] or ["res64", "res64pre", "res64post", "res128", "gemm:3840000x128x512:elu", "gemm:16000x1024x8192",
+                             "gemm:128000x512x3072", "gemm:16000x512x512"]
+    B, T = 16, 240000
+    for c in cases:
+        if c.startswith("res"):
+            C = 128 if "128" in c else 64
+            ms, fl = res_case(C, B, T // (4 if C == 128 else 1), pre="pre" in c, post="post" in c)
+        else:
+            parts = c.split(":")
+            M, N, K = [int(v) for v in parts[1].split("x")]
+            ms, fl = gemm_case(M, N, K, elu="elu" in parts[2:], res="res" in parts[2:])
+        print(f"{c:32s} {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
