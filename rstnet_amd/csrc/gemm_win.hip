@@ -197,25 +197,31 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias -> activation -> (residual + scale *) -> store, 32 consecutive columns per half wave
+    // ---- epilogue: bias -> GELU? -> (residual + scale *) -> ELU? -> store; 32 consecutive columns per half wave.
+    // The residual loads of a tile are issued back to back (predicated, no branches) before any of them is consumed.
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.0f;
-        const float scale = p.scale ? p.scale[n] : 1.0f;
+        const bool n_ok = n < p.N;
+        const float bias = (p.bias && n_ok) ? p.bias[n] : 0.0f;
+        const float scale = (p.scale && n_ok) ? p.scale[n] : 1.0f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + (wm * TM + i) * 32;
+            float r[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * TM + i) * 32 + rst_mfma32_row(e, lane);
-                if (m >= M) continue;
+                const int m = mb + rst_mfma32_row(e, lane);
+                r[e] = (p.res && n_ok && m < M) ? p.res[(long)m * p.ldy + n] : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + rst_mfma32_row(e, lane);
                 float v = acc[i][j][e] + bias;
                 if (p.act_out == 1) v = rst_gelu(v);
-                const long o = (long)m * p.ldy + n;
-                if (p.res) v = p.res[o] + scale * v;
+                if (p.res) v = r[e] + scale * v;
                 if (p.act_out == 2) v = rst_elu(v);
-                p.y[o] = v;
+                if (n_ok && m < M) p.y[(long)m * p.ldy + n] = v;
             }
         }
     }

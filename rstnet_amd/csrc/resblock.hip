@@ -37,7 +37,7 @@ struct Carve {
         hs_off = hs_in_r0 ? w2 : ((!W1RES && w1 >= hs) ? w1_off : r0 + w1);
         const int end = (hs_in_r0 || (!W1RES && w1 >= hs)) ? r0 + w1 : r0 + w1 + hs;
         as_off = end;
-        w0_off = as_off + (pre ? BM + 12 : 0);
+        w0_off = as_off + (pre ? BM + 24 : 0);
         wf_off = w0_off + (pre ? C * 9 : 0);
         total = wf_off + (post ? 4 * C : 0);
     }
@@ -87,22 +87,34 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
     if (PRE) {
         const int K0 = p.K0;
         const int tA0 = t0 - (Kw - 1) - (K0 - 1);
-        for (int i = tid; i < BM + 12; i += 256) {   // the whole carve (incl. the tail read with zero weights) is defined
+        for (int i = tid; i < BM + 24; i += 256) {   // the whole carve (incl. the tail read with zero weights) is defined
             const int t = tA0 + i;
             As[i] = (i < XR + K0 - 1 && t >= 0 && t < T) ? p.x[b * T + t] : 0.f;
         }
         for (int i = tid; i < C * K0; i += 256) W0s[(i / K0) * (MAXK0 + 1) + i % K0] = p.w0[i];
         __syncthreads();
-        for (int idx = tid; idx < XR * C; idx += 256) {
-            const int rx = idx / C, c = idx - rx * C;
-            const int t = t0 - (Kw - 1) + rx;
-            float v = 0.f;
-            if (t >= 0 && t < T) {
-                v = p.b0[c];
-                for (int k = 0; k < K0; ++k) v = fmaf(W0s[c * (MAXK0 + 1) + k], As[rx + k], v);
-                v = rst_elu(v);
+        {   // conv0 + ELU: a thread owns one channel (weights in registers) and walks groups of 4 consecutive rows, so the
+            // 4 x K0 products need only K0+3 (wave-uniform, broadcast) LDS reads of the audio tile
+            constexpr int G = 256 / C;
+            const int c = tid & (C - 1), g = tid / C;
+            float w0r[MAXK0];
+#pragma unroll
+            for (int k = 0; k < MAXK0; ++k) w0r[k] = k < K0 ? W0s[c * (MAXK0 + 1) + k] : 0.f;
+            const float b0r = p.b0[c];
+            for (int rx0 = g * 4; rx0 < XR; rx0 += 4 * G) {
+                float av[MAXK0 + 3];
+#pragma unroll
+                for (int k = 0; k < MAXK0 + 3; ++k) av[k] = As[rx0 + k];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rx = rx0 + q;
+                    const int t = t0 - (Kw - 1) + rx;
+                    float v = b0r;
+#pragma unroll
+                    for (int k = 0; k < MAXK0; ++k) v = fmaf(w0r[k], av[q + k], v);
+                    if (rx < XR) Xs[rx * XLD + c] = (t >= 0 && t < T) ? rst_elu(v) : 0.f;
+                }
             }
-            Xs[rx * XLD + c] = v;
         }
     } else {
         // all global loads of the tile are issued before the first one is consumed (one exposed HBM latency, not nine)
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
     for (int j = 0; j < NT2; ++j) {
         const int col = (wn * NT2 + j) * 32 + (lane & 31);
         const float bias = p.b2[col];
-        float w0c[MAXK0];
+        float w0c[MAXK0], awin[MAXK0 + 3];
         float b0c = 0.f;
         if (PRE) {
             b0c = p.b0[col];
@@ -289,11 +301,14 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
             const bool valid = t >= 0 && t < T;
             float xr = 0.f;
             if (PRE) {
-                if (valid) {
-                    xr = b0c;
+                if ((e & 3) == 0) {   // rows e..e+3 of this lane are consecutive: one K0+3 window serves all four
 #pragma unroll
-                    for (int k = 0; k < MAXK0; ++k) xr = fmaf(w0c[k], As[r + (Kw - 1) + k], xr);
+                    for (int k = 0; k < MAXK0 + 3; ++k) awin[k] = As[r + (Kw - 1) + k];
                 }
+                xr = b0c;
+#pragma unroll
+                for (int k = 0; k < MAXK0; ++k) xr = fmaf(w0c[k], awin[(e & 3) + k], xr);
+                if (!valid) xr = 0.f;
             } else {
                 xr = xres[j][e];
             }
@@ -306,25 +321,33 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
         }
     }
     if (POST) {
-        // final Conv1d C -> 1, kernel Kf: out[t] = bf + sum_{k,c} wf[k][c] * ELU(y[t-Kf+1+k][c]); two lanes per output
+        // final Conv1d C -> 1, kernel Kf: out[t] = bf + sum_{k,c} wf[k][c] * ELU(y[t-Kf+1+k][c]).
+        // Four lanes per output row, each reducing C/4 channels with 16-byte LDS reads (conflict-free: 4 rows x 4 quarters
+        // of a 16-lane group fall into 16 distinct slots), two passes of 64 rows.
         __syncthreads();
         const int Kf = p.Kf;
-        const int r = halo + (tid >> 1), half = tid & 1;
-        float s = 0.f;
-        if (r < BM) {
-            for (int k = 0; k < Kf; ++k) {
-                const float* yr = Xs + (r - (Kf - 1) + k) * XLD + half * (C / 2);
-                const float* wk = Wfs + k * C + half * (C / 2);
-#pragma unroll 8
-                for (int c = 0; c < C / 2; ++c) {
-                    const int cc = (c + (tid >> 1) + half * (C / 4)) & (C / 2 - 1);   // per-lane channel rotation: conflict-free LDS reads
-                    s = fmaf(wk[cc], yr[cc], s);
+        const int q = tid & 3;
+#pragma unroll
+        for (int pass = 0; pass < BM / 64; ++pass) {
+            const int r = halo + pass * 64 + (tid >> 2);
+            float s = 0.f;
+            if (r < BM) {
+                for (int k = 0; k < Kf; ++k) {
+                    const float* yr = Xs + (r - (Kf - 1) + k) * XLD + q * (C / 4);
+                    const float* wk = Wfs + k * C + q * (C / 4);
+#pragma unroll
+                    for (int c4 = 0; c4 < C / 16; ++c4) {
+                        const f32x4 yv = *reinterpret_cast<const f32x4*>(yr + 4 * c4);
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wk + 4 * c4);
+                        s = fmaf(wv[0], yv[0], s); s = fmaf(wv[1], yv[1], s); s = fmaf(wv[2], yv[2], s); s = fmaf(wv[3], yv[3], s);
+                    }
                 }
             }
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            const int t = t0 + r;
+            if (q == 0 && r < BM && t >= 0 && t < T) p.y[b * T + t] = s + p.bf[0];
         }
-        s += __shfl_xor(s, 1);
-        const int t = t0 + r;
-        if (half == 0 && r < BM && t >= 0 && t < T) p.y[b * T + t] = s + p.bf[0];
     }
 }
 
