@@ -135,6 +135,45 @@ int rst_transpose_f32(const float* x, float* y, int B, int R, int C, rst_stream_
 int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, int B, int T_in, int P_in, int P_out,
                         int C, rst_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * RQ-Transformer decode step (T = 1 per call, small batch).  bf16 weights, fp32 activations / accumulation.
+ * Reference files below are relative to MLLM_v2/.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* y[b][n] = (res ? res[b][n] : 0) + sum_k P(x)[b][k] * w[n][k]  -- the F.linear call sites of one decode step:
+ * in_proj / out_proj (modules/transformer.py:391-395,418-421, incl. the per-step slices of multi_linear :155-179),
+ * gating linear_in / linear_out (modules/gating.py:12-22), depformer_in, text_linear, linears[k] (models/model.py:384,
+ * 411-425).  prologue P: 0 = identity; 1 = RMSNorm x*alpha*rsqrt(eps+mean(x^2)) (modules/transformer.py:34-46, eps 1e-8);
+ * 2 = SiLU gate: x is [B][2K] = [u ; v], P(x) = silu(u) * v.   w bf16 [N][K] row-major, K % 8 == 0, 1 <= B <= 4. */
+int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, float* y, int B, int N,
+                      int K, int ldx, int ldy, int prologue, float eps, rst_stream_t stream);
+
+/* out[b] = (add ? add[b] : 0) + sum_i table_i[tokens[b][tok_index[i]]]: the ScaledEmbedding sums of
+ * LMModel.forward_text / forward_depformer (models/model.py:67-91, 372-380, 413-419): id -1 -> zero row, ids clamped
+ * at 0, tables bf16 [rows][D], summed in table order in fp32.  `tables` / `tok_index` are HOST arrays (n_tables <= 24). */
+int rst_embed_sum_bf16(const int64_t* tokens, const uint16_t* const* tables, const int* tok_index, int n_tables,
+                       const float* add, float* out, int B, int D, int tok_stride, rst_stream_t stream);
+
+/* RMSNorm rows (rms_norm_f32, modules/transformer.py:34-46): out_norm of LMModel.forward_text. */
+int rst_rmsnorm_f32(const float* x, const float* alpha, float* y, int64_t rows, int D, float eps, rst_stream_t stream);
+
+/* One new step: split qkv [B][3*H*D], rotate q and k (interleaved RoPE, modules/rope.py) at position *pos_dev, write q
+ * [B][H*D] and append k, v to ring slot *pos_dev % cap of [B][H][cap][D] (RingKVCache.complete, transformer.py:255-262). */
+int rst_lm_rope_append_f32(const float* qkv, float* q, float* k, float* v, const int64_t* pos_dev, int B, int H, int D,
+                           int cap, int ldqkv, int rope, float rope_coef, rst_stream_t stream);
+
+/* Single-query attention over the ring (F.scaled_dot_product_attention with the mask of transformer.py:404-414 and the
+ * slot->position map of RingKVCache.complete incl. SURVEY Q1).  Split over `splits` workgroups per (b, h) + combine.
+ * ws: [B][H][splits][D+2] floats.  out [B][H*D]. */
+int rst_lm_attn_decode_f32(const float* q, const float* k, const float* v, float* ws, float* out, const int64_t* pos_dev,
+                           int B, int H, int D, int cap, int context, int splits, rst_stream_t stream);
+
+/* sample_token (utils/sampling.py:85-105): greedy argmax, or softmax(logits/temp) -> top-k (sorted descending) ->
+ * argmax_j p_j / noise_j with caller-provided Exp(1) noise [B][noise_stride] (the reference draws it with
+ * Tensor.exponential_, :44-46).  tokens[b * tok_stride] = result. */
+int rst_lm_sample_f32(const float* logits, const float* noise, int64_t* tokens, int B, int V, int ld, int top_k,
+                      int noise_stride, int tok_stride, int use_sampling, float temp, rst_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -155,4 +155,50 @@ int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, i
     return rst_launch_hist_update(x, hist_in, hist_out, B, T_in, P_in, P_out, C, (hipStream_t)stream);
 }
 
+// ---- LM decode step -------------------------------------------------------------------------------------------------
+int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, float* y, int B, int N,
+                      int K, int ldx, int ldy, int prologue, float eps, rst_stream_t stream) {
+    GemvParams p;
+    p.x = x; p.alpha = alpha; p.w = w; p.res = res; p.y = y; p.B = B; p.N = N; p.K = K; p.ldx = ldx; p.ldy = ldy;
+    p.prologue = prologue; p.eps = eps;
+    return rst_launch_gemv_bf16(p, (hipStream_t)stream);
+}
+
+int rst_embed_sum_bf16(const int64_t* tokens, const uint16_t* const* tables, const int* tok_index, int n_tables,
+                       const float* add, float* out, int B, int D, int tok_stride, rst_stream_t stream) {
+    RST_REQUIRE(n_tables >= 0 && n_tables <= RST_MAX_TABLES && (n_tables == 0 || (tables && tok_index)), "embed_sum: bad tables");
+    EmbedSumParams p;
+    p.tokens = (const long*)tokens; p.add = add; p.out = out; p.B = B; p.D = D; p.n_tables = n_tables; p.tok_stride = tok_stride;
+    for (int i = 0; i < n_tables; ++i) { p.tables[i] = tables[i]; p.tok_index[i] = tok_index[i]; }
+    return rst_launch_embed_sum(p, (hipStream_t)stream);
+}
+
+int rst_rmsnorm_f32(const float* x, const float* alpha, float* y, int64_t rows, int D, float eps, rst_stream_t stream) {
+    return rst_launch_rmsnorm(x, alpha, y, rows, D, eps, (hipStream_t)stream);
+}
+
+int rst_lm_rope_append_f32(const float* qkv, float* q, float* k, float* v, const int64_t* pos_dev, int B, int H, int D,
+                           int cap, int ldqkv, int rope, float rope_coef, rst_stream_t stream) {
+    LmRopeAppendParams p;
+    p.qkv = qkv; p.q = q; p.k = k; p.v = v; p.pos_dev = (const long*)pos_dev; p.B = B; p.H = H; p.D = D; p.cap = cap;
+    p.ldqkv = ldqkv; p.rope = rope; p.rope_coef = rope_coef;
+    return rst_launch_lm_rope_append(p, (hipStream_t)stream);
+}
+
+int rst_lm_attn_decode_f32(const float* q, const float* k, const float* v, float* ws, float* out, const int64_t* pos_dev,
+                           int B, int H, int D, int cap, int context, int splits, rst_stream_t stream) {
+    LmAttnParams p;
+    p.q = q; p.k = k; p.v = v; p.ws = ws; p.out = out; p.pos_dev = (const long*)pos_dev; p.B = B; p.H = H; p.D = D;
+    p.cap = cap; p.context = context; p.splits = splits;
+    return rst_launch_lm_attn(p, (hipStream_t)stream);
+}
+
+int rst_lm_sample_f32(const float* logits, const float* noise, int64_t* tokens, int B, int V, int ld, int top_k,
+                      int noise_stride, int tok_stride, int use_sampling, float temp, rst_stream_t stream) {
+    LmSampleParams p;
+    p.logits = logits; p.noise = noise; p.tokens = (long*)tokens; p.B = B; p.V = V; p.ld = ld; p.top_k = top_k;
+    p.noise_stride = noise_stride; p.tok_stride = tok_stride; p.use_sampling = use_sampling; p.temp = temp;
+    return rst_launch_lm_sample(p, (hipStream_t)stream);
+}
+
 }  // extern "C"

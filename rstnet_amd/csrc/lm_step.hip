@@ -1,0 +1,474 @@
+// Batch-1 (small-batch) decode step of the RQ-Transformer: every op of one temporal / depth transformer step at T = 1.
+//
+// At batch 1 the step is pure weight streaming (14.8 GB of bf16 weights per 80 ms frame for the Moshi-7B shape), so
+// the GEMV is built for HBM: 16-byte non-temporal weight loads, four rows per wave in flight, the (normalised /
+// gated) activation vector staged ONCE per workgroup in LDS as fp32, fp32 accumulation, wave-level reduction.
+// RMSNorm and the SiLU gate are prologues of the consuming GEMV and the residual add is its epilogue, so a
+// transformer layer is 7 launches: qkv GEMV | rope + KV append | attention partial | attention combine | out-proj
+// GEMV (+res) | ffn-in GEMV | ffn-out GEMV (+res).  Activations stay fp32 (>= the reference's bf16), weights bf16.
+#include "rst_common.h"
+#include "rst_kernels.h"
+#include <math.h>
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
+
+constexpr int GEMV_RPW = 4;      // rows per wave in flight
+constexpr int GEMV_WAVES = 4;
+
+// y[b][n] = (res ? res[b][n] : 0) + sum_k xs[b][k] * W[n][k],   xs = prologue(x)
+template <int B>
+__global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [B][K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K;
+
+    // ---- prologue: stage the activation vector(s) in LDS
+    if (p.prologue == 1) {           // RMSNorm: x * alpha * rsqrt(eps + mean(x^2))   (modules/transformer.py:34-46)
+        __shared__ float red[GEMV_WAVES];
+        for (int b = 0; b < B; ++b) {
+            float s = 0.f;
+            for (int k = tid; k < K; k += 64 * GEMV_WAVES) { const float v = p.x[(long)b * p.ldx + k]; s = fmaf(v, v, s); }
+            s = wave_sum(s);
+            __syncthreads();
+            if (lane == 0) red[wave] = s;
+            __syncthreads();
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < GEMV_WAVES; ++w) tot += red[w];
+            const float r = 1.0f / sqrtf(p.eps + tot / (float)K);
+            for (int k = tid; k < K; k += 64 * GEMV_WAVES) xs[b * K + k] = p.x[(long)b * p.ldx + k] * (p.alpha[k] * r);
+        }
+    } else if (p.prologue == 2) {    // SiLU gate: x holds [B][2K] = [u ; v], xs = silu(u) * v   (modules/gating.py:12-22)
+        for (int b = 0; b < B; ++b)
+            for (int k = tid; k < K; k += 64 * GEMV_WAVES)
+                xs[b * K + k] = silu(p.x[(long)b * p.ldx + k]) * p.x[(long)b * p.ldx + K + k];
+    } else {
+        for (int b = 0; b < B; ++b)
+            for (int k = tid; k < K; k += 64 * GEMV_WAVES) xs[b * K + k] = p.x[(long)b * p.ldx + k];
+    }
+    __syncthreads();
+
+    // ---- row groups, grid-strided: GEMV_RPW rows per wave, 8 bf16 (16 B) per lane per row per iteration
+    const int groups = (p.N + GEMV_RPW * GEMV_WAVES - 1) / (GEMV_RPW * GEMV_WAVES);
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int n0 = (grp * GEMV_WAVES + wave) * GEMV_RPW;
+        float acc[GEMV_RPW][B];
+#pragma unroll
+        for (int r = 0; r < GEMV_RPW; ++r)
+#pragma unroll
+            for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
+        const unsigned short* wrow[GEMV_RPW];
+#pragma unroll
+        for (int r = 0; r < GEMV_RPW; ++r) wrow[r] = p.w + (long)min(n0 + r, p.N - 1) * K;
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            u32x4 wv[GEMV_RPW];
+#pragma unroll
+            for (int r = 0; r < GEMV_RPW; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k));
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + b * K + k);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + b * K + k + 4);
+#pragma unroll
+                for (int r = 0; r < GEMV_RPW; ++r) {
+                    float a = acc[r][b];
+                    a = fmaf(bf16_lo(wv[r][0]), x0[0], a); a = fmaf(bf16_hi(wv[r][0]), x0[1], a);
+                    a = fmaf(bf16_lo(wv[r][1]), x0[2], a); a = fmaf(bf16_hi(wv[r][1]), x0[3], a);
+                    a = fmaf(bf16_lo(wv[r][2]), x1[0], a); a = fmaf(bf16_hi(wv[r][2]), x1[1], a);
+                    a = fmaf(bf16_lo(wv[r][3]), x1[2], a); a = fmaf(bf16_hi(wv[r][3]), x1[3], a);
+                    acc[r][b] = a;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < GEMV_RPW; ++r)
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const float s = wave_sum(acc[r][b]);
+                const int n = n0 + r;
+                if (lane == 0 && n < p.N) {
+                    const long o = (long)b * p.ldy + n;
+                    p.y[o] = p.res ? p.res[o] + s : s;
+                }
+            }
+    }
+}
+
+// x[b][:] = sum_i table_i[token[b][i]]  (bf16 tables, fp32 sum in table order; id -1 -> zero row, ids clamped at 0)
+__global__ __launch_bounds__(256) void embed_sum_kernel(const EmbedSumParams p) {
+    const int b = blockIdx.y;
+    for (int d = blockIdx.x * 256 + threadIdx.x; d < p.D; d += gridDim.x * 256) {
+        float s = p.add ? p.add[(long)b * p.D + d] : 0.f;
+        for (int i = 0; i < p.n_tables; ++i) {
+            const long tok = p.tokens[(long)b * p.tok_stride + p.tok_index[i]];
+            if (tok != -1) {
+                const long row = tok < 0 ? 0 : tok;
+                s += __uint_as_float((unsigned)p.tables[i][row * p.D + d] << 16);
+            }
+        }
+        p.out[(long)b * p.D + d] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                     float* __restrict__ y, int D, float eps) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xr = x + (long)blockIdx.x * D;
+    float s = 0.f;
+    for (int k = tid; k < D; k += 256) s = fmaf(xr[k], xr[k], s);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float r = 1.0f / sqrtf(eps + (red[0] + red[1] + red[2] + red[3]) / (float)D);
+    for (int k = tid; k < D; k += 256) y[(long)blockIdx.x * D + k] = xr[k] * (alpha[k] * r);
+}
+
+// qkv [B][3*H*D] (one new step) -> q_rot [B][H*D]; k (rotated) and v written into ring slot pos % cap of [B][H][cap][D]
+__global__ __launch_bounds__(256) void rope_append_kernel(const LmRopeAppendParams p) {
+    const int half = p.D / 2;
+    const long total = (long)p.B * p.H * half;
+    const long pos = *p.pos_dev;
+    const int slot = (int)(pos % p.cap);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int i = (int)(idx % half);
+        const int h = (int)((idx / half) % p.H);
+        const long b = idx / ((long)half * p.H);
+        const float* src = p.qkv + b * p.ldqkv + (long)h * p.D + 2 * i;
+        const long HD = (long)p.H * p.D;
+        float c = 1.f, s = 0.f;
+        if (p.rope) {
+            const float fr = expf((float)i * p.rope_coef);
+            const float ang = fr * ((float)pos + 0.0f);
+            c = cosf(ang);
+            s = sinf(ang);
+        }
+        const float qr = src[0], qi = src[1], kr = src[HD], ki = src[HD + 1];
+        float* qd = p.q + b * HD + (long)h * p.D + 2 * i;
+        float* kd = p.k + ((b * p.H + h) * p.cap + slot) * (long)p.D + 2 * i;
+        float* vd = p.v + ((b * p.H + h) * p.cap + slot) * (long)p.D + 2 * i;
+        qd[0] = qr * c - qi * s; qd[1] = qr * s + qi * c;
+        kd[0] = kr * c - ki * s; kd[1] = kr * s + ki * c;
+        vd[0] = src[2 * HD]; vd[1] = src[2 * HD + 1];
+    }
+}
+
+// One query per (b, h).  Slots are split over gridDim.x workgroups; each writes (m, l, o[D]) to the workspace.
+// Lane groups of D/16 lanes own one slot per iteration (each lane 16 contiguous floats of the K / V row: coalesced).
+template <int D>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) {
+    constexpr int LPS = D / 16;            // lanes per slot
+    constexpr int SPW = 64 / LPS;          // slots per wave iteration
+    __shared__ float sm_m[4], sm_l[4];
+    __shared__ __attribute__((aligned(16))) float sm_o[4][D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane % LPS, grp = lane / LPS;
+    const int split = blockIdx.x, h = blockIdx.y;
+    const long b = blockIdx.z;
+    const long pos = *p.pos_dev;                 // position of the query = index of the step just appended
+    const long end_offset = pos + 1;
+    const int end_index = (int)(end_offset % p.cap);
+    const float scale = 1.0f / sqrtf((float)D);
+
+    const float* qp = p.q + (b * p.H + h) * (long)D + sub * 16;
+    f32x4 q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const f32x4*>(qp + 4 * i);
+
+    const int per = (p.cap + gridDim.x - 1) / gridDim.x;
+    const int s_lo = split * per, s_hi = min(p.cap, s_lo + per);
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* kb = p.k + ((b * p.H + h) * p.cap) * (long)D + sub * 16;
+    const float* vb = p.v + ((b * p.H + h) * p.cap) * (long)D + sub * 16;
+
+    for (int s0 = s_lo + wave * SPW; s0 < s_hi; s0 += 4 * SPW) {
+        const int slot = s0 + grp;
+        // RingKVCache.complete slot -> position map incl. the `delta <= 0` quirk
+        const int delta = slot - end_index;
+        long pk = delta <= 0 ? end_offset + delta : end_offset + delta - p.cap;
+        if (slot >= end_offset) pk = -1;
+        const long dl = pos - pk;
+        bool ok = slot < s_hi && pk >= 0 && dl >= 0;
+        if (p.context > 0) ok = ok && dl < p.context;
+        f32x4 vv[4];
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(kb + (long)slot * D + 4 * i);
+                d = fmaf(kv[0], q[i][0], d); d = fmaf(kv[1], q[i][1], d); d = fmaf(kv[2], q[i][2], d); d = fmaf(kv[3], q[i][3], d);
+                vv[i] = *reinterpret_cast<const f32x4*>(vb + (long)slot * D + 4 * i);
+            }
+        }
+#pragma unroll
+        for (int off = LPS / 2; off > 0; off >>= 1) d += __shfl_xor(d, off);   // all lanes take part (ok is per group)
+        const float sc = ok ? d * scale : -INFINITY;
+        const float m_new = fmaxf(m_run, sc);
+        if (m_new != -INFINITY) {
+            const float alpha = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
+            const float pw = sc == -INFINITY ? 0.f : expf(sc - m_new);
+            l_run = l_run * alpha + pw;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = o[i] * alpha + pw * vv[i];
+            m_run = m_new;
+        }
+    }
+    // merge the lane groups of the wave (same `sub`), then the 4 waves, into one (m, l, o[D])
+    float m_w = m_run;
+#pragma unroll
+    for (int off = LPS; off < 64; off <<= 1) m_w = fmaxf(m_w, __shfl_xor(m_w, off));
+    const float f = (m_run == -INFINITY) ? 0.f : expf(m_run - m_w);
+    float l_w = l_run * f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] *= f;
+#pragma unroll
+    for (int off = LPS; off < 64; off <<= 1) {
+        l_w += __shfl_xor(l_w, off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[i][e] += __shfl_xor(o[i][e], off);
+    }
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&sm_o[wave][sub * 16 + 4 * i]) = o[i];
+        if (sub == 0) { sm_m[wave] = m_w; sm_l[wave] = l_w; }
+    }
+    __syncthreads();
+    if (tid < D) {
+        float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float fw = sm_m[w] == -INFINITY ? 0.f : expf(sm_m[w] - M);
+            L += sm_l[w] * fw;
+            O += sm_o[w][tid] * fw;
+        }
+        float* ws = p.ws + (((b * p.H + h) * gridDim.x) + split) * (long)(D + 2);
+        ws[2 + tid] = O;
+        if (tid == 0) { ws[0] = M; ws[1] = L; }
+    }
+}
+
+// out[b][h*D + j] = sum_s exp(m_s - M) o_s[j] / sum_s exp(m_s - M) l_s
+__global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ ws, float* __restrict__ out, int H, int D,
+                                                          int splits) {
+    const int h = blockIdx.x;
+    const long b = blockIdx.y;
+    const float* w0 = ws + ((b * H + h) * splits) * (long)(D + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < splits; ++s) M = fmaxf(M, w0[(long)s * (D + 2)]);
+    for (int j = threadIdx.x; j < D; j += 128) {
+        float L = 0.f, O = 0.f;
+        for (int s = 0; s < splits; ++s) {
+            const float* w = w0 + (long)s * (D + 2);
+            const float f = w[0] == -INFINITY ? 0.f : expf(w[0] - M);
+            L += w[1] * f;
+            O += w[2 + j] * f;
+        }
+        out[(b * H + h) * (long)D + j] = L > 0.f ? O / L : 0.f;
+    }
+}
+
+// One workgroup per batch row.  Greedy: argmax (lowest index on ties).  Sampling (utils/sampling.py:51-105):
+// probs = softmax(logits / temp); (p, idx) = top-k sorted descending; token = idx[argmax_j p_j / noise_j].
+__global__ __launch_bounds__(256) void sample_kernel(const LmSampleParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sv[];   // [V] scaled logits
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    __shared__ float best_v;
+    __shared__ int best_i;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long b = blockIdx.x;
+    const float* lg = p.logits + b * p.ld;
+    const bool sampling = p.use_sampling && p.temp > 0.f;
+    for (int i = tid; i < p.V; i += 256) sv[i] = sampling ? lg[i] / p.temp : lg[i];
+    __syncthreads();
+
+    auto block_argmax = [&]() {     // over sv[], lowest index wins ties; result in best_v / best_i
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < p.V; i += 256) {
+            const float v = sv[i];
+            if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = red_v[0];
+            int i = red_i[0];
+            for (int w = 1; w < 4; ++w)
+                if (red_v[w] > v || (red_v[w] == v && red_i[w] < i)) { v = red_v[w]; i = red_i[w]; }
+            best_v = v;
+            best_i = i;
+        }
+        __syncthreads();
+    };
+
+    block_argmax();
+    if (!sampling) {
+        if (tid == 0) p.tokens[b * p.tok_stride] = best_i;
+        return;
+    }
+    // softmax denominator (fp32, max-subtracted like torch.softmax)
+    const float mx = best_v;
+    float s = 0.f;
+    for (int i = tid; i < p.V; i += 256) s += expf(sv[i] - mx);
+    s = wave_sum(s);
+    __syncthreads();
+    if (lane == 0) red_v[wave] = s;
+    __syncthreads();
+    const float denom = red_v[0] + red_v[1] + red_v[2] + red_v[3];
+    const int k = min(p.top_k > 0 ? p.top_k : p.V, p.V);
+    float win = -INFINITY;
+    int win_tok = 0x7fffffff;
+    if (p.V <= 4096) {
+        // rank of every candidate by counting (descending, ties -> lowest index first = torch.topk order on sorted data);
+        // candidate of rank r < k is scored p_r / noise_r; the best score wins
+        for (int i = tid; i < p.V; i += 256) {
+            const float v = sv[i];
+            int rank = 0;
+            for (int j = 0; j < p.V; ++j) {
+                const float u = sv[j];
+                rank += (u > v || (u == v && j < i)) ? 1 : 0;
+            }
+            if (rank < k) {
+                const float sc = (expf(v - mx) / denom) / p.noise[b * p.noise_stride + rank];
+                if (sc > win || (sc == win && i < win_tok)) { win = sc; win_tok = i; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(win, o);
+            const int oi = __shfl_xor(win_tok, o);
+            if (ov > win || (ov == win && oi < win_tok)) { win = ov; win_tok = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { red_v[wave] = win; red_i[wave] = win_tok; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (red_v[w] > win || (red_v[w] == win && red_i[w] < win_tok)) { win = red_v[w]; win_tok = red_i[w]; }
+        }
+    } else {
+        // large vocabulary, small k (text head: V = 32000, k = 25): repeated extraction of the maximum
+        for (int j = 0; j < k; ++j) {
+            if (j > 0) block_argmax();
+            if (tid == 0) {
+                const float sc = (expf(best_v - mx) / denom) / p.noise[b * p.noise_stride + j];
+                if (sc > win) { win = sc; win_tok = best_i; }
+                sv[best_i] = -INFINITY;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) p.tokens[b * p.tok_stride] = win_tok;
+}
+
+inline unsigned cap_grid(long g, long cap) { return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g)); }
+
+}  // namespace
+
+int rst_launch_gemv_bf16(const GemvParams& p, hipStream_t stream) {
+    RST_REQUIRE(p.B >= 1 && p.B <= 4 && p.N > 0 && p.K > 0 && p.K % 8 == 0, "gemv_bf16: need 1 <= B <= 4 and K %% 8 == 0 (B=%d K=%d)", p.B, p.K);
+    RST_REQUIRE(p.x && p.w && p.y, "gemv_bf16: null pointer");
+    RST_REQUIRE(p.prologue >= 0 && p.prologue <= 2 && (p.prologue != 1 || p.alpha), "gemv_bf16: bad prologue");
+    RST_REQUIRE(((uintptr_t)p.w % 16) == 0 && ((uintptr_t)p.x % 16) == 0, "gemv_bf16: pointers must be 16-byte aligned");
+    const size_t lds = (size_t)p.B * p.K * sizeof(float);
+    RST_REQUIRE(lds <= 128 * 1024, "gemv_bf16: B*K = %d floats do not fit the activation stage (32768)", p.B * p.K);
+    const long groups = ((long)p.N + GEMV_RPW * GEMV_WAVES - 1) / (GEMV_RPW * GEMV_WAVES);
+    const unsigned grid = cap_grid(groups, lds > 64 * 1024 ? 256 : 512);
+    auto go = [&](auto kern) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GEMV_WAVES), lds, stream, p);
+    };
+    switch (p.B) {
+        case 1: go(gemv_bf16_kernel<1>); break;
+        case 2: go(gemv_bf16_kernel<2>); break;
+        case 3: go(gemv_bf16_kernel<3>); break;
+        default: go(gemv_bf16_kernel<4>); break;
+    }
+    return rst_check_launch("gemv_bf16");
+}
+
+int rst_launch_embed_sum(const EmbedSumParams& p, hipStream_t stream) {
+    RST_REQUIRE(p.B >= 1 && p.D > 0 && p.n_tables >= 0 && p.n_tables <= RST_MAX_TABLES && p.tokens && p.out, "embed_sum: bad arguments");
+    hipLaunchKernelGGL(embed_sum_kernel, dim3(cap_grid((p.D + 255) / 256, 64), p.B), dim3(256), 0, stream, p);
+    return rst_check_launch("embed_sum");
+}
+
+int rst_launch_rmsnorm(const float* x, const float* alpha, float* y, long rows, int D, float eps, hipStream_t stream) {
+    RST_REQUIRE(x && alpha && y && rows >= 0 && D > 0, "rmsnorm: bad arguments");
+    if (rows == 0) return RST_OK;
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, alpha, y, D, eps);
+    return rst_check_launch("rmsnorm");
+}
+
+int rst_launch_lm_rope_append(const LmRopeAppendParams& p, hipStream_t stream) {
+    RST_REQUIRE(p.qkv && p.q && p.k && p.v && p.pos_dev && p.B >= 1 && p.H > 0 && p.D > 0 && p.D % 2 == 0 && p.cap > 0,
+                "lm_rope_append: bad arguments");
+    const long total = (long)p.B * p.H * (p.D / 2);
+    hipLaunchKernelGGL(rope_append_kernel, dim3(cap_grid((total + 255) / 256, 1024)), dim3(256), 0, stream, p);
+    return rst_check_launch("lm_rope_append");
+}
+
+int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream) {
+    RST_REQUIRE(p.q && p.k && p.v && p.ws && p.out && p.pos_dev && p.B >= 1 && p.H > 0 && p.cap > 0 && p.splits >= 1,
+                "lm_attn: bad arguments");
+    RST_REQUIRE(p.B <= 65535 && p.H <= 65535, "lm_attn: grid too large");
+    const dim3 grid(p.splits, p.H, p.B);
+    switch (p.D) {
+        case 64: hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, stream, p); break;
+        case 128: hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, stream, p); break;
+        default:
+            rst_set_error("lm_attn: head dim %d unsupported (64, 128)", p.D);
+            return RST_ERR_UNSUPPORTED;
+    }
+    int rc = rst_check_launch("lm_attn");
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(p.H, p.B), dim3(128), 0, stream, p.ws, p.out, p.H, p.D, p.splits);
+    return rst_check_launch("lm_attn_combine");
+}
+
+int rst_launch_lm_sample(const LmSampleParams& p, hipStream_t stream) {
+    RST_REQUIRE(p.logits && p.tokens && p.B >= 1 && p.V > 0, "lm_sample: bad arguments");
+    RST_REQUIRE(!p.use_sampling || p.temp <= 0.f || p.noise, "lm_sample: sampling needs the exponential noise tensor");
+    const size_t lds = (size_t)p.V * sizeof(float);
+    RST_REQUIRE(lds <= 150 * 1024, "lm_sample: vocabulary %d too large for the LDS stage", p.V);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sample_kernel, dim3(p.B), dim3(256), lds, stream, p);
+    return rst_check_launch("lm_sample");
+}

@@ -109,3 +109,59 @@ struct RvqGatherParams {
     int group_count[2];
 };
 int rst_launch_rvq_gather(const RvqGatherParams& p, hipStream_t stream);
+
+// ---- lm_step.hip ------------------------------------------------------------------------------
+struct GemvParams {
+    const float* x;             // [B][ldx] fp32 activations (prologue 2: [B][2K] = [u ; v])
+    const float* alpha;         // prologue 1: RMSNorm gain [K]
+    const unsigned short* w;    // [N][K] bf16
+    const float* res;           // optional [B][ldy]
+    float* y;                   // [B][ldy]
+    int B, N, K, ldx, ldy;
+    int prologue;               // 0 none, 1 RMSNorm, 2 SiLU gate
+    float eps;
+};
+int rst_launch_gemv_bf16(const GemvParams& p, hipStream_t stream);
+
+#define RST_MAX_TABLES 24
+struct EmbedSumParams {
+    const long* tokens;                          // [B][tok_stride]
+    const unsigned short* tables[RST_MAX_TABLES];  // bf16 [rows][D]
+    int tok_index[RST_MAX_TABLES];               // token column feeding table i
+    const float* add;                            // optional fp32 [B][D] added first
+    float* out;                                  // [B][D]
+    int B, D, n_tables, tok_stride;
+};
+int rst_launch_embed_sum(const EmbedSumParams& p, hipStream_t stream);
+int rst_launch_rmsnorm(const float* x, const float* alpha, float* y, long rows, int D, float eps, hipStream_t stream);
+
+struct LmRopeAppendParams {
+    const float* qkv;     // [B][ldqkv], one step: [q | k | v] each H*D
+    float* q;             // [B][H*D]
+    float* k;             // [B][H][cap][D]
+    float* v;
+    const long* pos_dev;  // position of this step (device scalar; == steps already in the ring)
+    int B, H, D, cap, ldqkv, rope;
+    float rope_coef;
+};
+int rst_launch_lm_rope_append(const LmRopeAppendParams& p, hipStream_t stream);
+
+struct LmAttnParams {
+    const float* q;       // [B][H*D]
+    const float* k;       // [B][H][cap][D]
+    const float* v;
+    float* ws;            // [B][H][splits][D+2] workspace
+    float* out;           // [B][H*D]
+    const long* pos_dev;  // position of the query (the step just appended)
+    int B, H, D, cap, context, splits;
+};
+int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream);
+
+struct LmSampleParams {
+    const float* logits;  // [B][ld]
+    const float* noise;   // [B][noise_stride] Exp(1) draws (sampling only)
+    long* tokens;         // tokens[b * tok_stride]
+    int B, V, ld, top_k, noise_stride, tok_stride, use_sampling;
+    float temp;
+};
+int rst_launch_lm_sample(const LmSampleParams& p, hipStream_t stream);

@@ -1,0 +1,438 @@
+"""``LMModel`` / ``LMGen`` -- drop-in for the streaming generation half of ``MLLM_v2/models/model.py`` (Moshi-style
+RQ-Transformer: a temporal transformer over 17 token streams + a per-codebook depth transformer).
+
+Same constructor keywords, ``state_dict`` keys (``emb.{i}.weight``, ``transformer.layers.{l}.self_attn.in_proj_weight``,
+``...gating.linear_in.weight``, ``depformer.layers.{l}.gating.{k}.linear_out.weight``, ``linears.{k}.weight`` ...),
+``forward_text`` / ``forward_depformer`` signatures and ``LMGen.step`` semantics (delayed token ring cache, ``None`` for
+the first ``max_delay`` steps).  Training ``forward`` is out of scope.
+
+Execution: weights bf16 in HBM, activations fp32, one decode step (T = 1) per call through the kernels of
+``csrc/lm_step.hip``; the two per-frame halves (``forward_text`` and ``depformer_step``) are captured into HIP graphs
+after a warm-up exactly like the reference's ``CUDAGraphed`` wrappers (``MLLM_v2/utils/compile.py:189-277``), and the
+environment flag ``NO_CUDA_GRAPH`` disables that (``compile.py:168-174``).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..codec.conv import _PackedCache
+from ..codec.streaming import StreamingContainer, StreamingModule
+
+
+def _gating_hidden(dim: int, dim_feedforward: int) -> int:
+    """modules/gating.py:40-45."""
+    return (21 * dim) // 8 if dim_feedforward == 4 * dim else (2 * dim_feedforward) // 3
+
+
+class _Weight(nn.Module):
+    """Holder of a ``weight`` parameter (nn.Linear / nn.Embedding key layout); the arithmetic lives in the kernels."""
+
+    def __init__(self, *shape: int, device=None, dtype=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*shape, device=device, dtype=dtype), requires_grad=False)
+        nn.init.normal_(self.weight, std=0.02)
+
+
+class ScaledEmbedding(_Weight):
+    """models/model.py:67-91 -- lookup with id -1 -> zeros, executed by rst_embed_sum_bf16."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, zero_idx: int = -1, device=None, dtype=None, **_):
+        super().__init__(num_embeddings, embedding_dim, device=device, dtype=dtype)
+        self.zero_idx = zero_idx
+
+
+class RMSNorm(nn.Module):
+    """rms_norm_f32 (modules/transformer.py:49-65, eps 1e-8); key ``alpha`` [1,1,D]."""
+
+    def __init__(self, dim: int, eps: float = 1e-8, device=None, dtype=None):
+        super().__init__()
+        self.eps = eps
+        self.alpha = nn.Parameter(torch.ones(1, 1, dim, device=device, dtype=dtype), requires_grad=False)
+        self._f32 = _PackedCache()
+
+    def alpha_f32(self) -> torch.Tensor:
+        return self._f32.get((self.alpha,), lambda: self.alpha.detach().float().reshape(-1).contiguous())
+
+
+class ActivationGating(nn.Module):
+    """modules/gating.py:25-51 (SiLU): keys ``linear_in.weight`` [2*hidden, dim], ``linear_out.weight`` [dim, hidden]."""
+
+    def __init__(self, dim: int, dim_feedforward: int, device=None, dtype=None):
+        super().__init__()
+        hidden = _gating_hidden(dim, dim_feedforward)
+        self.linear_in = _Weight(2 * hidden, dim, device=device, dtype=dtype)
+        self.linear_out = _Weight(dim, hidden, device=device, dtype=dtype)
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim: int, mult: int, device=None, dtype=None):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(mult * 3 * dim, dim, device=device, dtype=dtype), requires_grad=False)
+        nn.init.normal_(self.in_proj_weight, std=0.02)
+        self.out_proj = _Weight(mult * dim, dim, device=device, dtype=dtype)
+
+
+class _Layer(nn.Module):
+    def __init__(self, dim: int, dim_feedforward: int, weights_per_step: int, device=None, dtype=None):
+        super().__init__()
+        fk = {"device": device, "dtype": dtype}
+        self.self_attn = _Attention(dim, weights_per_step or 1, **fk)
+        self.norm1 = RMSNorm(dim, **fk)
+        self.norm2 = RMSNorm(dim, **fk)
+        if weights_per_step:
+            self.gating = nn.ModuleList([ActivationGating(dim, dim_feedforward, **fk) for _ in range(weights_per_step)])
+        else:
+            self.gating = ActivationGating(dim, dim_feedforward, **fk)
+
+
+@dataclass
+class _StepState:
+    k: List[torch.Tensor]      # per layer [B, H, cap, D] fp32 ring
+    v: List[torch.Tensor]
+    pos: torch.Tensor          # int64 [1] on device: steps appended so far (= position of the next step)
+    offset_cpu: int = 0
+
+    def reset(self) -> None:
+        self.pos.zero_()
+        self.offset_cpu = 0
+
+
+class StreamingTransformer(StreamingModule[_StepState]):
+    """Decode-step executor with the parameter layout of modules/transformer.py:595-690 (norm rms_norm_f32, SiLU gating,
+    causal, rope or no positional embedding, optional per-step weights)."""
+
+    def __init__(self, d_model: int, num_heads: int, num_layers: int, dim_feedforward: int, context: Optional[int],
+                 positional_embedding: str, max_period: float = 10000.0, weights_per_step: int = 0, device=None, dtype=None):
+        super().__init__()
+        assert d_model % num_heads == 0
+        if positional_embedding not in ("rope", "none"):
+            raise NotImplementedError(f"positional_embedding={positional_embedding!r}")
+        self.d_model, self.num_heads, self.context = d_model, num_heads, context
+        self.rope, self.max_period, self.weights_per_step = positional_embedding == "rope", max_period, weights_per_step
+        self.layers = nn.ModuleList([_Layer(d_model, dim_feedforward, weights_per_step, device=device, dtype=dtype)
+                                     for _ in range(num_layers)])
+
+    def _init_streaming_state(self, batch_size: int) -> _StepState:
+        if self.context is None and not self.weights_per_step:
+            raise RuntimeError("Cannot create a streaming KVCache without a context to estimate capacity.")
+        cap = self.context if self.context is not None else self.weights_per_step
+        dev = self.layers[0].norm1.alpha.device
+        shape = (batch_size, self.num_heads, cap, self.d_model // self.num_heads)
+        return _StepState([torch.zeros(shape, device=dev) for _ in self.layers], [torch.zeros(shape, device=dev) for _ in self.layers],
+                          torch.zeros(1, device=dev, dtype=torch.long))
+
+    def step(self, x: torch.Tensor, step_index: Optional[int] = None) -> torch.Tensor:
+        """x fp32 ``[B, d_model]`` -> ``[B, d_model]``: one new time step through every layer (7 launches per layer)."""
+        st = self._streaming_state
+        if st is None:
+            raise RuntimeError("the decode-step transformer only runs in streaming mode")
+        E = self.d_model
+        k_idx = 0
+        if self.weights_per_step:
+            k_idx = st.offset_cpu if step_index is None else step_index
+        for l, layer in enumerate(self.layers):
+            att = layer.self_attn
+            if self.weights_per_step:
+                w_in = att.in_proj_weight.view(self.weights_per_step, 3 * E, E)[k_idx]
+                w_out = att.out_proj.weight.view(self.weights_per_step, E, E)[k_idx]
+                gate = layer.gating[k_idx]
+            else:
+                w_in, w_out, gate = att.in_proj_weight, att.out_proj.weight, layer.gating
+            qkv = ops.gemv_bf16(x, w_in, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm1.alpha_f32(), eps=layer.norm1.eps)
+            q = ops.lm_rope_append(qkv, st.k[l], st.v[l], st.pos, rope=self.rope, max_period=self.max_period)
+            a = ops.lm_attn_decode(q, st.k[l], st.v[l], st.pos, context=self.context)
+            x = ops.gemv_bf16(a, w_out, res=x)
+            h = ops.gemv_bf16(x, gate.linear_in.weight, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm2.alpha_f32(),
+                              eps=layer.norm2.eps)
+            x = ops.gemv_bf16(h, gate.linear_out.weight, prologue=ops.PROLOGUE_SILU_GATE, res=x)
+        st.pos.add_(1)
+        st.offset_cpu += 1
+        return x
+
+
+class ModelConfig:
+    def __init__(self, model_type):
+        self.model_type = model_type
+
+
+class LMModel(StreamingContainer):
+    """models/model.py:98-225 (constructor keywords identical; only the inference-relevant ones are interpreted)."""
+
+    def __init__(self, delays: List[int] = [0], n_q: int = 8, dep_q: int = 8, card: int = 1024, text_card: int = 32000,
+                 dim: int = 128, num_heads: int = 8, hidden_scale: float = 4, norm: str = "layer_norm", norm_emb: bool = False,
+                 bias_proj: bool = False, depformer_dim: int = 256, depformer_dim_feedforward=None,
+                 depformer_multi_linear: bool = False, depformer_weights_per_step: bool = False, depformer_pos_emb: str = "sin",
+                 existing_text_padding_id: Optional[int] = None, context: Optional[int] = None, device=None,
+                 dtype=torch.bfloat16, **kwargs):
+        super().__init__()
+        if norm != "rms_norm_f32" or norm_emb or bias_proj:
+            raise NotImplementedError("the decode path implements norm='rms_norm_f32', norm_emb=False, bias_proj=False")
+        if kwargs.get("gating", "silu") != "silu" or kwargs.get("depformer_gating", "silu") != "silu":
+            raise NotImplementedError("SiLU gating only")
+        if not (depformer_multi_linear and depformer_weights_per_step and depformer_pos_emb == "none"):
+            raise NotImplementedError("depth transformer: multi_linear + weights_per_step + pos_emb 'none' (the Moshi / RSTnet setup)")
+        if kwargs.get("layer_scale") is not None or kwargs.get("depformer_layer_scale") is not None:
+            raise NotImplementedError("layer_scale")
+        self.n_q, self.dep_q, self.card, self.text_card = n_q, dep_q, card, text_card
+        assert len(delays) == self.num_codebooks, "unexpected number of delays"
+        self.delays, self.dim, self.context = list(delays), dim, context
+        self.existing_text_padding_id = existing_text_padding_id
+        fk = {"device": device, "dtype": dtype}
+        self.emb = nn.ModuleList([ScaledEmbedding(card + 1, dim, **fk) for _ in range(n_q)])
+        self.text_emb = ScaledEmbedding(text_card + 1, dim, **fk)
+        self.text_linear = _Weight(text_card + (1 if existing_text_padding_id is None else 0), dim, **fk)
+        self.transformer = StreamingTransformer(dim, num_heads, kwargs["num_layers"], int(hidden_scale * dim), context,
+                                                kwargs.get("positional_embedding", "sin"), kwargs.get("max_period", 10000.0), **fk)
+        self.out_norm = RMSNorm(dim, **fk)
+        self.depformer_multi_linear = depformer_multi_linear
+        self.depformer_in = nn.ModuleList([_Weight(depformer_dim, dim, **fk) for _ in range(dep_q)])
+        self.depformer_emb = nn.ModuleList([ScaledEmbedding(card + 1, depformer_dim, **fk) for _ in range(dep_q - 1)])
+        self.depformer_text_emb = ScaledEmbedding(text_card + 1, depformer_dim, **fk)
+        if depformer_dim_feedforward is None:
+            depformer_dim_feedforward = int(hidden_scale * depformer_dim)
+        self.depformer = StreamingTransformer(depformer_dim, kwargs.get("depformer_num_heads", num_heads),
+                                              kwargs.get("depformer_num_layers", kwargs["num_layers"]), depformer_dim_feedforward,
+                                              None, "none", kwargs.get("depformer_max_period", 10000.0), weights_per_step=dep_q, **fk)
+        self.depformer.set_streaming_propagate(False)
+        self.linears = nn.ModuleList([_Weight(card, depformer_dim, **fk) for _ in range(dep_q)])
+        self.config = ModelConfig(model_type="lora")
+
+    # ---- token-id conventions (models/model.py:226-277)
+    @property
+    def initial_token_id(self) -> int:
+        return self.card
+
+    @property
+    def text_initial_token_id(self) -> int:
+        return self.text_card
+
+    @property
+    def text_padding_token_id(self) -> int:
+        return self.text_card if self.existing_text_padding_id is None else self.existing_text_padding_id
+
+    @property
+    def end_of_text_padding_id(self) -> int:
+        return 0
+
+    @property
+    def zero_token_id(self) -> int:
+        return -1
+
+    @property
+    def ungenerated_token_id(self) -> int:
+        return -2
+
+    @property
+    def device(self):
+        return next(iter(self.parameters())).device
+
+    @property
+    def num_codebooks(self) -> int:
+        return self.n_q + 1
+
+    @property
+    def num_audio_codebooks(self) -> int:
+        return self.n_q
+
+    @property
+    def audio_offset(self) -> int:
+        return 1
+
+    def _get_initial_token(self) -> torch.Tensor:
+        tok = torch.full([1, self.num_codebooks, 1], self.initial_token_id, device=self.device, dtype=torch.long)
+        tok[:, 0] = self.text_initial_token_id
+        return tok
+
+    def forward(self, sequence: torch.Tensor, masks: Optional[torch.Tensor] = None):
+        raise NotImplementedError("teacher-forced training forward is out of scope; use forward_text / forward_depformer")
+
+    # ---- decode step
+    def forward_text(self, sequence: torch.Tensor, masks: Optional[torch.Tensor] = None):
+        """sequence int64 ``[B, n_q+1, 1]`` -> (transformer_out fp32 ``[B,1,dim]``, text_logits fp32 ``[B,1,1,V]``)."""
+        B, K, S = sequence.shape
+        assert K == self.num_codebooks, f"Sequence shape {sequence.shape} must match the number of codebooks."
+        assert S == 1, "the streaming decode path takes one step at a time"
+        toks = sequence.reshape(B, K).contiguous()
+        tables = [e.weight for e in self.emb] + [self.text_emb.weight]
+        x = ops.embed_sum(toks, tables, list(range(1, K)) + [0])     # ((e_0 + e_1) + ...) + text, as the reference
+        x = self.transformer.step(x)
+        out = ops.rmsnorm(x, self.out_norm.alpha_f32(), self.out_norm.eps)
+        logits = ops.gemv_bf16(out, self.text_linear.weight)
+        return out.view(B, 1, self.dim), logits.view(B, 1, 1, -1)
+
+    def forward_depformer(self, depformer_cb_index: int, sequence: torch.Tensor, transformer_out: torch.Tensor) -> torch.Tensor:
+        """sequence int64 ``[B,1,1]`` (previous token), transformer_out fp32 ``[B,1,dim]`` -> logits fp32 ``[B,1,1,card]``."""
+        B, K, S = sequence.shape
+        assert K == 1, f"Codebooks for Depformer streaming should be passed 1 by 1, got {K}."
+        assert S == 1, f"Steps for Depformer streaming should be passed 1 by 1, got {S}."
+        assert transformer_out.shape[1] == 1, "Transformer out should be a for a single step."
+        k = depformer_cb_index
+        h = ops.gemv_bf16(transformer_out.reshape(B, self.dim).contiguous(), self.depformer_in[k].weight)
+        table = self.depformer_text_emb.weight if k == 0 else self.depformer_emb[k - 1].weight
+        x = ops.embed_sum(sequence.reshape(B, 1).contiguous(), [table], [0], add=h)
+        y = self.depformer.step(x)
+        logits = ops.gemv_bf16(y, self.linears[k].weight)
+        return logits.view(B, 1, 1, -1)
+
+    @classmethod
+    def from_state_dict(cls, sd: Dict[str, torch.Tensor], cfg: dict) -> "LMModel":
+        """Model for ``cfg`` (keys of ``rstnet_amd.synth.LM_*``) with weights taken from ``sd`` WITHOUT copying them
+        (a 7.7 B-parameter state dict stays a single 15 GB allocation)."""
+        model = cls(causal=True, layer_scale=None, gating="silu", norm="rms_norm_f32", positional_embedding="rope",
+                    depformer_causal=True, depformer_layer_scale=None, depformer_multi_linear=True, depformer_context=8,
+                    depformer_gating="silu", depformer_pos_emb="none", depformer_weights_per_step=True, device="meta", **cfg)
+        params = dict(model.named_parameters())
+        missing = [k for k in params if k not in sd]
+        unexpected = [k for k in sd if k not in params]
+        if missing or unexpected:
+            raise RuntimeError(f"state_dict mismatch: missing={missing[:5]} unexpected={unexpected[:5]}")
+        for name, tensor in sd.items():
+            mod = model
+            *path, leaf = name.split(".")
+            for part in path:
+                mod = getattr(mod, part) if not part.isdigit() else mod[int(part)]
+            assert tuple(getattr(mod, leaf).shape) == tuple(tensor.shape), name
+            setattr(mod, leaf, nn.Parameter(tensor, requires_grad=False))
+        return model.eval()
+
+
+class _Graphed:
+    """Capture-after-warm-up / replay wrapper over a function of static-shaped device tensors (the role of the
+    reference's CUDAGraphed, utils/compile.py:189-277).  Disabled on request or by NO_CUDA_GRAPH=1."""
+
+    def __init__(self, fn, warmup: int = 1, disable: bool = False):
+        self.fn, self.warmup, self.calls = fn, warmup, 0
+        self.disable = disable or os.environ.get("NO_CUDA_GRAPH", "") not in ("", "0")
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.static_in: List[torch.Tensor] = []
+        self.static_out = None
+
+    def reset(self) -> None:
+        self.graph, self.calls = None, 0
+
+    def __call__(self, *args: torch.Tensor):
+        if self.disable:
+            return self.fn(*args)
+        if self.graph is None:
+            self.calls += 1
+            if self.calls <= self.warmup:
+                return self.fn(*args)
+            self.static_in = [a.clone() for a in args]
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_out = self.fn(*self.static_in)
+            # the capture itself does not execute: replay below produces this call's result
+        for s, a in zip(self.static_in, args):
+            if s.shape != a.shape:
+                raise RuntimeError(f"graphed call with a different shape: {tuple(a.shape)} vs {tuple(s.shape)}")
+            s.copy_(a)
+        self.graph.replay()
+        return self.static_out
+
+
+@dataclass
+class _LMGenState:
+    cache: torch.Tensor
+    initial: torch.Tensor
+    graphed_main: _Graphed
+    graphed_depth: _Graphed
+    offset: int = 0
+
+    def reset(self) -> None:
+        self.offset = 0
+
+
+class LMGen(StreamingModule[_LMGenState]):
+    """models/model.py:443-597."""
+
+    def __init__(self, lm_model: LMModel, use_sampling: bool = True, temp: float = 0.8, temp_text: float = 0.7,
+                 top_k: int = 250, top_k_text: int = 25, check: bool = False):
+        assert not lm_model.training, "generation shouldn't be used in training mode."
+        super().__init__()
+        self.lm_model = lm_model
+        self.use_sampling, self.temp, self.temp_text = use_sampling, temp, temp_text
+        self.top_k, self.top_k_text, self.check = top_k, top_k_text, check
+        self.max_delay = max(lm_model.delays)
+        self.delays_cuda = torch.tensor(lm_model.delays, device=lm_model.device, dtype=torch.long)
+
+    def _init_streaming_state(self, batch_size: int) -> _LMGenState:
+        lm = self.lm_model
+        cache = torch.full((batch_size, lm.num_codebooks, self.max_delay + 2), lm.ungenerated_token_id, device=lm.device,
+                           dtype=torch.long)
+        disable = lm.device.type != "cuda"
+        return _LMGenState(cache, lm._get_initial_token(), _Graphed(self._main, disable=disable),
+                           _Graphed(self.depformer_step, disable=disable))
+
+    def _noise(self, B: int, k: int) -> Optional[torch.Tensor]:
+        if not self.use_sampling:
+            return None
+        return torch.empty(B, k, device=self.lm_model.device, dtype=torch.float32).exponential_(1)   # utils/sampling.py:44
+
+    def _main(self, input_: torch.Tensor):
+        out, text_logits = self.lm_model.forward_text(input_)
+        B = input_.shape[0]
+        text_token = ops.lm_sample(text_logits.view(B, -1), use_sampling=self.use_sampling, temp=self.temp_text,
+                                   top_k=self.top_k_text, noise=self._noise(B, self.top_k_text))
+        return out, text_token
+
+    @torch.no_grad()
+    def step(self, input_tokens: torch.Tensor) -> Optional[torch.Tensor]:
+        state = self._streaming_state
+        if state is None:
+            raise RuntimeError("You should wrap those calls with a `with lm_gen.streaming(): ...`.")
+        lm = self.lm_model
+        assert input_tokens.dim() == 3, "Shape should be [B, K, T]."
+        B, Ki, S = input_tokens.shape
+        assert S == 1, "Only support being given steps one by one."
+        needed = lm.num_codebooks - lm.dep_q - 1
+        assert Ki == needed, f"We expect {needed} tokens from the user stream, got {Ki}."
+        CT = state.cache.shape[2]
+        for q_other in range(Ki):
+            k = lm.dep_q + 1 + q_other
+            wp = (state.offset + lm.delays[k]) % CT
+            state.cache[:, k, wp:wp + 1] = input_tokens[:, q_other]
+        position = state.offset % CT
+        for k, delay in enumerate(lm.delays):
+            if state.offset <= delay:
+                state.cache[:, k, position] = state.initial[:, k, 0]
+        input_ = state.cache[:, :, position:position + 1].contiguous()
+        if self.check:
+            assert not (input_ == lm.ungenerated_token_id).any(), (state.offset, input_)
+            assert (input_[:, lm.audio_offset:] <= lm.card).all(), input_
+            assert (input_[:, :1] <= lm.text_card).all()
+        transformer_out, text_token = state.graphed_main(input_)
+        audio_tokens = state.graphed_depth(text_token, transformer_out)
+        state.offset += 1
+        position = state.offset % CT
+        state.cache[:, 0, position] = text_token
+        state.cache[:, 1:lm.dep_q + 1, position] = audio_tokens
+        if state.offset <= self.max_delay:
+            return None
+        gen_delays = self.delays_cuda[:lm.dep_q + 1]
+        index = ((state.offset - self.max_delay + gen_delays) % CT).view(1, -1, 1).expand(B, -1, 1)
+        return state.cache.gather(dim=2, index=index)
+
+    def depformer_step(self, text_token: torch.Tensor, transformer_out: torch.Tensor) -> torch.Tensor:
+        """8 sequential depth-transformer steps (models/model.py:564-597); the depth KV rings are persistent buffers whose
+        position counter is reset per frame (= the reference's fresh ``with depformer.streaming(B)`` context)."""
+        (B,) = text_token.shape
+        lm = self.lm_model
+        dep = lm.depformer
+        if dep._streaming_state is None or dep._streaming_state.k[0].shape[0] != B:
+            dep._streaming_state = dep._init_streaming_state(B)
+        dep._streaming_state.reset()
+        prev = text_token
+        out = torch.empty(B, lm.dep_q, device=text_token.device, dtype=torch.long)
+        for cb in range(lm.dep_q):
+            logits = lm.forward_depformer(cb, prev.view(B, 1, 1), transformer_out)
+            prev = ops.lm_sample(logits.view(B, -1), use_sampling=self.use_sampling, temp=self.temp, top_k=self.top_k,
+                                 noise=self._noise(B, self.top_k))
+            out[:, cb] = prev
+        return out

@@ -278,3 +278,99 @@ def hist_update(x: torch.Tensor, hist_in: Optional[torch.Tensor], P_out: int) ->
     out = torch.empty(B, P_out, Cc, device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().rst_hist_update_f32(_ptr(x), _ptr(hist_in), _ptr(out), B, T, P_in, P_out, Cc, _stream()))
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# RQ-Transformer decode step (T = 1, small batch): bf16 weights, fp32 activations
+# ----------------------------------------------------------------------------------------------------------------------
+PROLOGUE_NONE, PROLOGUE_RMSNORM, PROLOGUE_SILU_GATE = 0, 1, 2
+
+
+def gemv_bf16(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
+              eps: float = 1e-8, res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``y[B,N] = (res +) P(x) @ w.T`` with ``w`` bf16 ``[N,K]`` (rst_gemv_bf16_f32).  ``x`` is fp32 ``[B,K]``
+    (``[B,2K]`` for the SiLU-gate prologue)."""
+    _chk(x, "x")
+    _chk(w, "w", torch.bfloat16)
+    _chk(alpha, "alpha")
+    _chk(res, "res")
+    B = x.shape[0]
+    N, K = w.shape
+    assert x.shape[1] == (2 * K if prologue == PROLOGUE_SILU_GATE else K), (tuple(x.shape), N, K, prologue)
+    if out is None:
+        out = torch.empty(B, N, device=x.device, dtype=torch.float32)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.lib().rst_gemv_bf16_f32(_ptr(x), _ptr(alpha), _ptr(w), _ptr(res), _ptr(out), B, N, K, x.shape[1], N, prologue,
+                                           eps, _stream()))
+    if prof is not None:
+        e1.record()
+        prof.append(("gemv_bf16", e0, e1, 2.0 * B * N * K, 2 * N * K + 4 * (x.numel() + out.numel()), (B, N, K)))
+    return out
+
+
+def embed_sum(tokens: torch.Tensor, tables: Sequence[torch.Tensor], tok_index: Sequence[int],
+              add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out[b] = (add[b] +) sum_i tables[i][tokens[b, tok_index[i]]]``; tokens int64 ``[B, n]``, tables bf16 ``[rows, D]``."""
+    _chk(tokens, "tokens", torch.int64)
+    _chk(add, "add")
+    for t in tables:
+        _chk(t, "table", torch.bfloat16)
+    B, D = tokens.shape[0], tables[0].shape[1]
+    out = torch.empty(B, D, device=tokens.device, dtype=torch.float32)
+    tabs = (C.c_void_p * len(tables))(*[t.data_ptr() for t in tables])
+    _lib.check(_lib.lib().rst_embed_sum_bf16(_ptr(tokens), tabs, _int_array(list(tok_index)), len(tables), _ptr(add), _ptr(out), B, D,
+                                            tokens.shape[1], _stream()))
+    return out
+
+
+def rmsnorm(x: torch.Tensor, alpha: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    _chk(x, "x")
+    _chk(alpha, "alpha")
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().rst_rmsnorm_f32(_ptr(x), _ptr(alpha), _ptr(out), x.numel() // x.shape[-1], x.shape[-1], eps, _stream()))
+    return out
+
+
+def lm_rope_append(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos_dev: torch.Tensor, *, rope: bool,
+                   max_period: float = 10000.0) -> torch.Tensor:
+    """qkv ``[B, 3*H*D]`` (one step) -> rotated q ``[B, H*D]``; k/v appended to ring slot ``pos % cap`` of ``[B,H,cap,D]``."""
+    for t, n in ((qkv, "qkv"), (k_cache, "k_cache"), (v_cache, "v_cache")):
+        _chk(t, n)
+    _chk(pos_dev, "pos_dev", torch.int64)
+    B, H, cap, D = k_cache.shape
+    q = torch.empty(B, H * D, device=qkv.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_lm_rope_append_f32(_ptr(qkv), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(pos_dev), B, H, D, cap,
+                                                qkv.shape[1], int(rope), rope_coef(max_period, D), _stream()))
+    return q
+
+
+def lm_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos_dev: torch.Tensor, *,
+                   context: Optional[int], splits: Optional[int] = None) -> torch.Tensor:
+    """Single-query attention over the ring: q ``[B, H*D]`` -> ``[B, H*D]``."""
+    for t, n in ((q, "q"), (k_cache, "k_cache"), (v_cache, "v_cache")):
+        _chk(t, n)
+    _chk(pos_dev, "pos_dev", torch.int64)
+    B, H, cap, D = k_cache.shape
+    if splits is None:
+        splits = max(1, min(16, cap // 128, 512 // max(1, B * H)))
+    ws = torch.empty(B, H, splits, D + 2, device=q.device, dtype=torch.float32)
+    out = torch.empty(B, H * D, device=q.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_lm_attn_decode_f32(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(ws), _ptr(out), _ptr(pos_dev), B, H, D,
+                                                cap, int(context) if context else 0, splits, _stream()))
+    return out
+
+
+def lm_sample(logits: torch.Tensor, *, use_sampling: bool, temp: float, top_k: int, noise: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """logits fp32 ``[B, V]`` -> tokens int64 ``[B]`` (greedy, or top-k sampling with Exp(1) ``noise [B, top_k]``)."""
+    _chk(logits, "logits")
+    _chk(noise, "noise")
+    B, V = logits.shape
+    if out is None:
+        out = torch.empty(B, device=logits.device, dtype=torch.int64)
+    _lib.check(_lib.lib().rst_lm_sample_f32(_ptr(logits), _ptr(noise), _ptr(out), B, V, V, top_k, noise.shape[1] if noise is not None else 0,
+                                           1, int(use_sampling), float(temp), _stream()))
+    return out

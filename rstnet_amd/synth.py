@@ -149,3 +149,76 @@ def synth_audio(batch: int, samples: int, seed: int = 0) -> torch.Tensor:
     """0.1 * randn(B, 1, T) fp32 -- the synthetic 24 kHz mono input of BASELINE.md section 3."""
     g = torch.Generator().manual_seed(1000 + seed)
     return 0.1 * torch.randn(batch, 1, samples, generator=g)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# speech-text LM (LMModel of MLLM_v2/models/model.py:98-225, Moshi-style temporal + depth transformer)
+# ----------------------------------------------------------------------------------------------------------------------
+
+LM_MOSHI_7B = dict(dim=4096, text_card=32000, existing_text_padding_id=3, n_q=16, dep_q=8, card=2048, num_heads=32,
+                   num_layers=32, hidden_scale=4.125, context=3000, max_period=10000.0, depformer_dim=1024,
+                   depformer_dim_feedforward=4224, depformer_num_heads=16, depformer_num_layers=6,
+                   delays=[0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1])   # MLLM_v2/moshi/models/loaders.py:68-98
+
+# small config for parity fixtures (the imported reference runs it on CPU in seconds); head dims 64 / 64 like the
+# depth transformer of the real model, ring capacity 10 so that the temporal KV ring wraps within a short test
+LM_TINY = dict(dim=256, text_card=50, existing_text_padding_id=3, n_q=4, dep_q=2, card=32, num_heads=4, num_layers=2,
+               hidden_scale=4.125, context=10, max_period=10000.0, depformer_dim=128, depformer_dim_feedforward=528,
+               depformer_num_heads=2, depformer_num_layers=2, delays=[0, 0, 1, 0, 1])
+
+
+def _gating_hidden(dim: int, dim_feedforward: int) -> int:
+    return (21 * dim) // 8 if dim_feedforward == 4 * dim else (2 * dim_feedforward) // 3
+
+
+def lm_state_dict(cfg: dict, seed: int = 0, device: str = "cpu", dtype: torch.dtype = torch.bfloat16) -> Dict[str, torch.Tensor]:
+    """Random-init LMModel weights with the reference's ``state_dict`` keys.  Linear weights ~ U(+-sqrt(3/fan_in)),
+    embeddings ~ 0.5*N(0,1), norm gains 1 + 0.1*N(0,1); stored in ``dtype`` (bf16 like the released checkpoints).
+    On ``cpu`` the values are bit-reproducible across machines (parity fixtures); on ``cuda`` they are generated on the
+    device (the 7.7 B-parameter benchmark model never touches host memory)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(key: str, out_f: int, in_f: int):
+        b = math.sqrt(3.0 / in_f)
+        sd[key] = ((torch.rand(out_f, in_f, generator=g, device=device) * 2 - 1) * b).to(dtype)
+
+    def emb(key: str, n: int, d: int):
+        sd[key] = (0.5 * torch.randn(n, d, generator=g, device=device)).to(dtype)
+
+    def alpha(key: str, d: int):
+        sd[key] = (1.0 + 0.1 * torch.randn(1, 1, d, generator=g, device=device)).to(dtype)
+
+    dim, ddim, dep_q = cfg["dim"], cfg["depformer_dim"], cfg["dep_q"]
+    for i in range(cfg["n_q"]):
+        emb(f"emb.{i}.weight", cfg["card"] + 1, dim)
+    emb("text_emb.weight", cfg["text_card"] + 1, dim)
+    lin("text_linear.weight", cfg["text_card"] + (1 if cfg.get("existing_text_padding_id") is None else 0), dim)
+    hid = _gating_hidden(dim, int(cfg["hidden_scale"] * dim))
+    for l in range(cfg["num_layers"]):
+        p = f"transformer.layers.{l}"
+        lin(f"{p}.self_attn.in_proj_weight", 3 * dim, dim)
+        lin(f"{p}.self_attn.out_proj.weight", dim, dim)
+        alpha(f"{p}.norm1.alpha", dim)
+        alpha(f"{p}.norm2.alpha", dim)
+        lin(f"{p}.gating.linear_in.weight", 2 * hid, dim)
+        lin(f"{p}.gating.linear_out.weight", dim, hid)
+    alpha("out_norm.alpha", dim)
+    for k in range(dep_q):
+        lin(f"depformer_in.{k}.weight", ddim, dim)
+    for k in range(dep_q - 1):
+        emb(f"depformer_emb.{k}.weight", cfg["card"] + 1, ddim)
+    emb("depformer_text_emb.weight", cfg["text_card"] + 1, ddim)
+    dhid = _gating_hidden(ddim, cfg["depformer_dim_feedforward"])
+    for l in range(cfg["depformer_num_layers"]):
+        p = f"depformer.layers.{l}"
+        lin(f"{p}.self_attn.in_proj_weight", dep_q * 3 * ddim, ddim)
+        lin(f"{p}.self_attn.out_proj.weight", dep_q * ddim, ddim)
+        alpha(f"{p}.norm1.alpha", ddim)
+        alpha(f"{p}.norm2.alpha", ddim)
+        for k in range(dep_q):
+            lin(f"{p}.gating.{k}.linear_in.weight", 2 * dhid, ddim)
+            lin(f"{p}.gating.{k}.linear_out.weight", ddim, dhid)
+    for k in range(dep_q):
+        lin(f"linears.{k}.weight", cfg["card"], ddim)
+    return sd

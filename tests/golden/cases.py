@@ -78,3 +78,15 @@ def rvq_latent(sd, n_batch: int = 4, n_frames: int = 250):
 def transformer_input(batch: int = 1, frames: int = 300):
     g = torch.Generator().manual_seed(78)
     return torch.randn(batch, 512, frames, generator=g)
+
+
+# ---- LM (tiny config, CPU-feasible for the imported reference) ------------------------------------------------------
+LM_SEED = 3
+LM_STEPS = 14       # > context (10) so the temporal ring wraps, and > max_delay
+LM_BATCH = 2
+
+
+def lm_user_tokens(cfg: dict, steps: int = LM_STEPS, batch: int = LM_BATCH):
+    """Tokens of the "other" stream fed to LMGen.step: [steps][B, n_q - dep_q, 1]."""
+    g = torch.Generator().manual_seed(79)
+    return torch.randint(0, cfg["card"], (steps, batch, cfg["n_q"] - cfg["dep_q"], 1), generator=g)

@@ -117,7 +117,36 @@ def gen_layers():
     print("layers", len(out))
 
 
+@torch.no_grad()
+def gen_lm_tiny():
+    """F6 + F8: LMModel.forward_text / forward_depformer logits and the greedy LMGen.step token streams
+    (MLLM_v2/models/model.py:364-597) on the tiny config, fp32 arithmetic on bf16-rounded weights."""
+    from models.model import LMModel, LMGen
+    cfg = dict(synth.LM_TINY)
+    sd = {k: v.float() for k, v in synth.lm_state_dict(cfg, cases.LM_SEED).items()}
+    m = LMModel(causal=True, layer_scale=None, gating="silu", norm="rms_norm_f32", positional_embedding="rope",
+                depformer_causal=True, depformer_layer_scale=None, depformer_multi_linear=True, depformer_context=8,
+                depformer_max_period=10000, depformer_gating="silu", depformer_pos_emb="none",
+                depformer_weights_per_step=True, **cfg).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    gen = LMGen(m, use_sampling=False)
+    user = cases.lm_user_tokens(cfg)
+    outs, text_logits, dep_logits = [], [], []
+    # capture logits through forward hooks on the two heads
+    h1 = m.text_linear.register_forward_hook(lambda mod, i, o: text_logits.append(o.clone()))
+    hs = [l.register_forward_hook(lambda mod, i, o: dep_logits.append(o.clone())) for l in m.linears]
+    with gen.streaming(cases.LM_BATCH):
+        for s in range(cases.LM_STEPS):
+            o = gen.step(user[s])
+            outs.append(torch.full((cases.LM_BATCH, cfg["dep_q"] + 1, 1), -9, dtype=torch.long) if o is None else o)
+    h1.remove()
+    [h.remove() for h in hs]
+    np.savez(os.path.join(HERE, "lm_tiny.npz"), tokens=torch.cat(outs, -1).numpy().astype(np.int32),
+             text_logits=torch.stack(text_logits).numpy(), dep_logits=torch.stack(dep_logits).numpy())
+    print("lm_tiny", torch.cat(outs, -1).shape, torch.stack(text_logits).shape, torch.stack(dep_logits).shape)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e"]
+    which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e", "lm_tiny"]
     for w in which:
         globals()[f"gen_{w}"]()

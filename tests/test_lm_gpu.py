@@ -1,0 +1,163 @@
+"""GPU parity of the RQ-Transformer decode step (csrc/lm_step.hip + rstnet_amd/lm) against the CPU oracle
+(oracle/lm_oracle.py) and the reference-generated fixture tests/golden/lm_tiny.npz.
+
+bf16 weights are shared by both sides (the oracle up-casts them), activations are fp32 on both sides, so logits must
+agree to fp32 summation-order noise: tolerance 1e-3 relative (north star), observed ~1e-6.  Greedy tokens: exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import lm_oracle as L
+from rstnet_amd import ops, synth
+from rstnet_amd.lm.model import LMGen, LMModel
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("B,N,K", [(1, 12288, 4096), (1, 4096, 11264), (2, 1000, 1024), (3, 37, 2816), (4, 2048, 1024), (1, 5, 8)])
+def test_gemv_bf16_prologues(B, N, K):
+    g = torch.Generator().manual_seed(N + K)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    x = torch.randn(B, K, generator=g)
+    res = torch.randn(B, N, generator=g)
+    alpha = 1 + 0.1 * torch.randn(K, generator=g)
+    wf = w.float()
+    y = ops.gemv_bf16(x.to(DEV), w.to(DEV))
+    assert rel_err(y, x @ wf.t()) < 1e-5
+    y = ops.gemv_bf16(x.to(DEV), w.to(DEV), res=res.to(DEV))
+    assert rel_err(y, res + x @ wf.t()) < 1e-5
+    y = ops.gemv_bf16(x.to(DEV), w.to(DEV), prologue=ops.PROLOGUE_RMSNORM, alpha=alpha.to(DEV), eps=1e-8)
+    assert rel_err(y, L.rms_norm(x, alpha) @ wf.t()) < 1e-5
+    u = torch.randn(B, 2 * K, generator=g)
+    y = ops.gemv_bf16(u.to(DEV), w.to(DEV), prologue=ops.PROLOGUE_SILU_GATE)
+    assert rel_err(y, (F.silu(u[:, :K]) * u[:, K:]) @ wf.t()) < 1e-5
+
+
+def test_embed_sum_and_rmsnorm():
+    g = torch.Generator().manual_seed(1)
+    tabs = [(0.5 * torch.randn(33, 256, generator=g)).bfloat16() for _ in range(5)]
+    toks = torch.tensor([[3, -1, 32, 0, 7], [-1, -1, 5, 32, 1]])
+    out = ops.embed_sum(toks.to(DEV), [t.to(DEV) for t in tabs], [1, 2, 3, 4, 0])
+    ref = None
+    for i, col in enumerate([1, 2, 3, 4, 0]):
+        e = L.scaled_embedding(tabs[i], toks[:, col])
+        ref = e if ref is None else ref + e
+    assert torch.equal(out.cpu(), ref)
+    x = torch.randn(3, 1000, generator=g)
+    a = 1 + 0.1 * torch.randn(1000, generator=g)
+    assert rel_err(ops.rmsnorm(x.to(DEV), a.to(DEV), 1e-8), L.rms_norm(x, a)) < 1e-6
+
+
+@pytest.mark.parametrize("H,D,cap,context,steps,rope", [(4, 64, 8, None, 8, False), (2, 128, 10, 10, 25, True), (32, 128, 300, 300, 40, True)])
+def test_rope_append_and_ring_attention(H, D, cap, context, steps, rope):
+    """Step-by-step against the oracle's RingKV (slot->position map of RingKVCache.complete incl. SURVEY Q1)."""
+    g = torch.Generator().manual_seed(H * D)
+    B = 2
+    ring = L.RingKV(B, H, D, cap)
+    kc = torch.zeros(B, H, cap, D, device=DEV)
+    vc = torch.zeros(B, H, cap, D, device=DEV)
+    pos = torch.zeros(1, dtype=torch.long, device=DEV)
+    for s in range(steps):
+        qkv = torch.randn(B, 3 * H * D, generator=g)
+        q, k, v = qkv.view(B, 1, 3, H, D).permute(2, 0, 3, 1, 4)
+        if rope:
+            q, k = L.rope_interleaved_1(q, s, 10000.0), L.rope_interleaved_1(k, s, 10000.0)
+        keys, vals, pos_k = ring.complete(k, v)
+        delta = s - pos_k
+        mask = (pos_k >= 0) & (delta >= 0)
+        if context is not None:
+            mask = mask & (delta < context)
+        ref = F.scaled_dot_product_attention(q, keys, vals, mask.view(1, -1)).permute(0, 2, 1, 3).reshape(B, H * D)
+        qg = ops.lm_rope_append(qkv.to(DEV), kc, vc, pos, rope=rope)
+        out = ops.lm_attn_decode(qg, kc, vc, pos, context=context)
+        pos.add_(1)
+        assert rel_err(qg, q.permute(0, 2, 1, 3).reshape(B, H * D)) < 1e-5
+        assert rel_err(out, ref) < 1e-4, f"step {s}"
+    assert rel_err(kc, ring.k) < 1e-5
+
+
+@pytest.mark.parametrize("V,k", [(2048, 250), (32, 7), (32000, 25), (50, 25)])
+def test_sampling_matches_oracle(V, k):
+    g = torch.Generator().manual_seed(V)
+    B = 3
+    logits = torch.randn(B, V, generator=g) * 3
+    logits[0, 5] = logits[0, 3]  # an exact tie: lowest index first
+    noise = torch.empty(B, k).exponential_(1, generator=g)
+    assert torch.equal(ops.lm_sample(logits.to(DEV), use_sampling=False, temp=0.8, top_k=k).cpu(), logits.argmax(-1))
+    tok = ops.lm_sample(logits.to(DEV), use_sampling=True, temp=0.8, top_k=k, noise=noise.to(DEV))
+    ref = L.sample_token(logits, True, 0.8, k, noise)
+    assert torch.equal(tok.cpu(), ref)
+
+
+def _tiny():
+    cfg = dict(synth.LM_TINY)
+    sd = synth.lm_state_dict(cfg, cases.LM_SEED)
+    model = LMModel.from_state_dict({k: v.to(DEV) for k, v in sd.items()}, cfg)
+    return cfg, sd, model
+
+
+def test_lm_state_dict_keys():
+    cfg, sd, model = _tiny()
+    assert set(model.state_dict().keys()) == set(sd.keys())
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_lmgen_greedy_matches_reference_fixture(graphs, monkeypatch):
+    """LMGen.step token streams == the imported reference's (fixture), logits == oracle; with and without HIP graphs."""
+    monkeypatch.setenv("NO_CUDA_GRAPH", "0" if graphs else "1")
+    cfg, sd, model = _tiny()
+    gold = torch.from_numpy(np.load(os.path.join(G, "lm_tiny.npz"))["tokens"]).long()
+    user = cases.lm_user_tokens(cfg)
+    gen = LMGen(model, use_sampling=False)
+    outs = []
+    with gen.streaming(cases.LM_BATCH):
+        for s in range(cases.LM_STEPS):
+            o = gen.step(user[s].to(DEV))
+            outs.append(torch.full((cases.LM_BATCH, cfg["dep_q"] + 1, 1), -9, dtype=torch.long) if o is None else o.cpu())
+    got = torch.cat(outs, -1)
+    assert (got[..., 0] == -9).all() and (got[..., 1:] != -9).all()       # None exactly for the first max_delay steps (Q14)
+    assert torch.equal(got, gold)
+
+
+def test_forward_text_and_depformer_logits_match_oracle():
+    cfg, sd, model = _tiny()
+    g = np.load(os.path.join(G, "lm_tiny.npz"))
+    ocfg = L.LMConfig(**cfg)
+    sdf = {k: v.float() for k, v in sd.items()}
+    B = cases.LM_BATCH
+    gt = torch.Generator().manual_seed(5)
+    st = L.new_transformer_state(B, ocfg.num_layers, ocfg.num_heads, ocfg.dim // ocfg.num_heads, ocfg.context)
+    with model.streaming(B):
+        for s in range(13):     # crosses the ring capacity (10)
+            toks = torch.randint(0, cfg["card"], (B, cfg["n_q"] + 1, 1), generator=gt)
+            toks[0, 2, 0] = -1  # a zero-embedding token
+            ref_out, ref_logits = L.forward_text(sdf, ocfg, toks, st)
+            out, logits = model.forward_text(toks.to(DEV))
+            assert rel_err(out, ref_out) < 1e-3 and rel_err(logits, ref_logits) < 1e-3, f"step {s}"
+            dst = L.new_transformer_state(B, ocfg.depformer_num_layers, ocfg.depformer_num_heads,
+                                          ocfg.depformer_dim // ocfg.depformer_num_heads, ocfg.dep_q)
+            model.depformer._streaming_state = model.depformer._init_streaming_state(B)
+            prev = torch.randint(0, cfg["text_card"], (B, 1, 1), generator=gt)
+            for cb in range(cfg["dep_q"]):
+                rl = L.forward_depformer(sdf, ocfg, cb, prev, ref_out, dst)
+                gl = model.forward_depformer(cb, prev.to(DEV), out)
+                assert rel_err(gl, rl) < 1e-3, f"step {s} cb {cb}"
+                prev = torch.randint(0, cfg["card"], (B, 1, 1), generator=gt)
+
+
+def test_lmgen_requires_streaming():
+    cfg, sd, model = _tiny()
+    gen = LMGen(model, use_sampling=False)
+    with pytest.raises(RuntimeError):
+        gen.step(torch.zeros(1, cfg["n_q"] - cfg["dep_q"], 1, dtype=torch.long, device=DEV))

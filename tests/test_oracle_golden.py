@@ -92,3 +92,37 @@ def test_mimi_encode_decode_matches_reference(mimi_sd, name):
     assert rel_err(z, torch.from_numpy(g[f"{name}.latent"])) < 1e-5
     assert torch.equal(codes, ref_codes)
     assert rel_err(wav, torch.from_numpy(g[f"{name}.wav"])) < 1e-5
+
+
+def test_lm_oracle_matches_reference():
+    """oracle/lm_oracle.py vs the imported LMModel / LMGen (greedy) on the tiny config: logits 1e-5, tokens exact."""
+    from oracle import lm_oracle as L
+    cfg_d = dict(synth.LM_TINY)
+    sd = {k: v.float() for k, v in synth.lm_state_dict(cfg_d, cases.LM_SEED).items()}
+    cfg = L.LMConfig(**cfg_d)
+    g = np.load(os.path.join(G, "lm_tiny.npz"))
+    user = cases.lm_user_tokens(cfg_d)
+    gen = L.LMGenOracle(sd, cfg, cases.LM_BATCH)
+    text_logits, dep_logits, outs = [], [], []
+    ft, fd = L.forward_text, L.forward_depformer
+
+    def ft_hook(*a, **k):
+        r = ft(*a, **k)
+        text_logits.append(r[1][:, 0])
+        return r
+
+    def fd_hook(*a, **k):
+        r = fd(*a, **k)
+        dep_logits.append(r[:, 0])
+        return r
+    L.forward_text, L.forward_depformer = ft_hook, fd_hook
+    try:
+        with torch.no_grad():
+            for s in range(cases.LM_STEPS):
+                o = gen.step(user[s])
+                outs.append(torch.full((cases.LM_BATCH, cfg.dep_q + 1, 1), -9, dtype=torch.long) if o is None else o)
+    finally:
+        L.forward_text, L.forward_depformer = ft, fd
+    assert torch.equal(torch.cat(outs, -1), torch.from_numpy(g["tokens"]).long())
+    assert rel_err(torch.stack(text_logits), torch.from_numpy(g["text_logits"])) < 1e-5
+    assert rel_err(torch.stack(dep_logits), torch.from_numpy(g["dep_logits"])) < 1e-5
