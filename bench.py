@@ -35,6 +35,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--workload", choices=["codec", "lm"], default="codec",
+                    help="codec = BASELINE configs[1] (the default, headline); lm = configs[2]: Moshi-7B-shaped RQ-Transformer decode, batch 1")
+    ap.add_argument("--lm-config", choices=["moshi7b", "tiny"], default="moshi7b")
+    ap.add_argument("--greedy", action="store_true", help="lm: greedy decoding instead of temperature / top-k sampling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch GEMM table (shape, ms, TFLOP/s, GB/s) to stderr")
     ap.add_argument("--check", action="store_true", help="also report the code exact-match rate against the CPU oracle on a sample")
@@ -68,6 +72,107 @@ def cpu_baseline(sd, seconds_per_clip: float, batch: int = 4):
                       f"{os.cpu_count()} logical cores"}
 
 
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def lm_cpu_baseline(frames: int = 6):
+    """The LM oracle on this host at the depth-transformer's real shape with a Qwen-0.5B-sized temporal stack (BASELINE.md
+    section 3: the 7B temporal step is GPU-only -- a CPU step would take seconds and tells nothing)."""
+    from oracle import lm_oracle as L
+    from rstnet_amd import synth
+    cfg = dict(synth.LM_MOSHI_7B, dim=1024, num_heads=16, num_layers=24, context=3000)
+    sd = {k: v.float() for k, v in synth.lm_state_dict(cfg, 0).items()}
+    gen = L.LMGenOracle(sd, L.LMConfig(**cfg), 1)
+    user = torch.randint(0, cfg["card"], (frames + 1, 1, cfg["n_q"] - cfg["dep_q"], 1))
+    with torch.no_grad():
+        gen.step(user[0])
+        t0 = time.perf_counter()
+        for s in range(frames):
+            gen.step(user[s + 1])
+        dt = time.perf_counter() - t0
+    return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle LMGen greedy, {frames} frames, batch 1, fp32, temporal 24 x 1024 (Qwen-0.5B-sized) + the real "
+                      f"8-step depth transformer (6 x 1024); the 7B temporal stack is not run on CPU"}
+
+
+def bench_lm(args, rank, world, dev):
+    """BASELINE configs[2]: one step = one 80 ms frame of LMGen.step (temporal step + 8 depth steps + sampling), batch 1."""
+    from rstnet_amd import ops, synth
+    from rstnet_amd.lm.model import LMGen, LMModel
+    cfg = dict(synth.LM_MOSHI_7B if args.lm_config == "moshi7b" else synth.LM_TINY)
+    B = 1
+    sd = synth.lm_state_dict(cfg, seed=0, device=str(dev))     # generated on the device, bf16
+    n_params = sum(v.numel() for v in sd.values())
+    model = LMModel.from_state_dict(sd, cfg)
+    gen = LMGen(model, use_sampling=not args.greedy, temp=0.8, temp_text=0.7, top_k=250, top_k_text=25)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    user = torch.randint(0, cfg["card"], (args.warmup + args.steps + 1, B, cfg["n_q"] - cfg["dep_q"], 1), generator=g, device=dev)
+    torch.manual_seed(1234 + rank)
+    gen.streaming_forever(B)
+    for s in range(args.warmup):
+        gen.step(user[s])
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        gen.step(user[args.warmup + s])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    # roofline of the dominant kernel (weight-streaming GEMV): one extra frame, eager (no graph), HIP events per launch
+    os.environ["NO_CUDA_GRAPH"] = "1"
+    gen2 = LMGen(model, use_sampling=not args.greedy)
+    recs = []
+    with gen2.streaming(B):
+        gen2.step(user[0])
+        ops.PROFILE = recs
+        gen2.step(user[1])
+        torch.cuda.synchronize()
+        ops.PROFILE = None
+    os.environ["NO_CUDA_GRAPH"] = "0"
+    gemv = [r for r in recs if r[0] == "gemv_bf16"]
+    ms = sum(r[1].elapsed_time(r[2]) for r in gemv)
+    nbytes = sum(r[4] for r in gemv)
+    if args.layers:
+        agg = {}
+        for _, e0, e1, fl, nb, shp in gemv:
+            d = agg.setdefault(shp, [0, 0.0, 0])
+            d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += nb
+        for shp, (n, t, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print(f"  gemv B,N,K={shp}: {n:4d} launches {t:8.3f} ms  {nb / t / 1e6:8.1f} GB/s", file=sys.stderr)
+    ms_frame = elapsed / args.steps * 1e3
+    result = {
+        "metric": "codec+LM audio frames/sec (24 kHz, 12.5 Hz tokens) at batch=1 and batch=64; RVQ code-index exact-match",
+        "value": round(B * world * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_frame, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16 weights, f32 activations", "data": "synthetic",
+        "config": {"workload": f"LMGen.step (temporal + 8-step depth transformer + sampling), BASELINE.json configs[2], {args.lm_config}",
+                   "batch_per_gpu": B, "params": n_params, "context_frames": args.warmup + args.steps,
+                   "sampling": "greedy" if args.greedy else "temp 0.8/0.7 top-k 250/25", "hip_graphs": True,
+                   "parallelism": f"replica x{world}"},
+        "x_realtime_per_stream": round(args.steps / elapsed / 12.5, 2),
+        "roofline": {"bound": "hbm", "kernel": "gemv_bf16_kernel (bf16 weight streaming)", "achieved": round(nbytes / ms / 1e6, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "launches_per_step": len(gemv), "avg_launch_ms": round(ms / max(1, len(gemv)), 5),
+                     "kernel_ms_per_step": round(ms, 3), "algorithmic_gb_per_step": round(nbytes / 1e9, 3),
+                     "share_of_step_eager": round(ms / ms_frame, 3), "all_launches_per_step": None},
+    }
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = lm_cpu_baseline()
+    print(json.dumps(result), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -81,6 +186,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.workload == "lm":
+        bench_lm(args, rank, world, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from rstnet_amd import ops, synth
     from rstnet_amd.codec.mimi import MimiCodec

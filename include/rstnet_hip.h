@@ -143,8 +143,8 @@ int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, i
 /* y[b][n] = (res ? res[b][n] : 0) + sum_k P(x)[b][k] * w[n][k]  -- the F.linear call sites of one decode step:
  * in_proj / out_proj (modules/transformer.py:391-395,418-421, incl. the per-step slices of multi_linear :155-179),
  * gating linear_in / linear_out (modules/gating.py:12-22), depformer_in, text_linear, linears[k] (models/model.py:384,
- * 411-425).  prologue P: 0 = identity; 1 = RMSNorm x*alpha*rsqrt(eps+mean(x^2)) (modules/transformer.py:34-46, eps 1e-8);
- * 2 = SiLU gate: x is [B][2K] = [u ; v], P(x) = silu(u) * v.   w bf16 [N][K] row-major, K % 8 == 0, 1 <= B <= 4. */
+ * 411-425).  w bf16 [N][K] row-major, K % 8 == 0, 1 <= B <= 4.  prologue P: 0 identity; 1 RMSNorm
+ * x*alpha*rsqrt(eps+mean(x^2)) (modules/transformer.py:34-46, eps 1e-8); 2 SiLU gate: x is [B][2K] = [u ; v], P(x) = silu(u)*v. */
 int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, float* y, int B, int N,
                       int K, int ldx, int ldy, int prologue, float eps, rst_stream_t stream);
 
@@ -162,11 +162,15 @@ int rst_rmsnorm_f32(const float* x, const float* alpha, float* y, int64_t rows, 
 int rst_lm_rope_append_f32(const float* qkv, float* q, float* k, float* v, const int64_t* pos_dev, int B, int H, int D,
                            int cap, int ldqkv, int rope, float rope_coef, rst_stream_t stream);
 
-/* Single-query attention over the ring (F.scaled_dot_product_attention with the mask of transformer.py:404-414 and the
- * slot->position map of RingKVCache.complete incl. SURVEY Q1).  Split over `splits` workgroups per (b, h) + combine.
- * ws: [B][H][splits][D+2] floats.  out [B][H*D]. */
-int rst_lm_attn_decode_f32(const float* q, const float* k, const float* v, float* ws, float* out, const int64_t* pos_dev,
-                           int B, int H, int D, int cap, int context, int splits, rst_stream_t stream);
+/* Single-query attention over the ring, straight from the qkv row of the new step: interleaved RoPE on q and on the new key
+ * (modules/rope.py), append of k / v to ring slot *pos_dev % cap (RingKVCache.complete, transformer.py:255-262), masked
+ * softmax(q k^T / sqrt(D)) v with the mask of transformer.py:404-414 and the slot->position map incl. SURVEY Q1.
+ * out [B][H*D].  cap <= 64 with splits == 1 (the depth transformer): one wave per (b, h), no workspace.  Otherwise slots
+ * are split over `splits` workgroups per (b, h): ws [B][H][splits][D+2] floats, counters [B][H] uint32 zero-initialised
+ * once by the caller (the last-arriving workgroup combines and re-arms its counter; agent-scope release / acquire). */
+int rst_lm_attn_decode_f32(const float* qkv, float* k, float* v, float* ws, uint32_t* counters, float* out,
+                           const int64_t* pos_dev, int B, int H, int D, int cap, int context, int splits, int ldqkv, int rope,
+                           float rope_coef, rst_stream_t stream);
 
 /* sample_token (utils/sampling.py:85-105): greedy argmax, or softmax(logits/temp) -> top-k (sorted descending) ->
  * argmax_j p_j / noise_j with caller-provided Exp(1) noise [B][noise_stride] (the reference draws it with

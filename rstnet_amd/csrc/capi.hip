@@ -185,11 +185,13 @@ int rst_lm_rope_append_f32(const float* qkv, float* q, float* k, float* v, const
     return rst_launch_lm_rope_append(p, (hipStream_t)stream);
 }
 
-int rst_lm_attn_decode_f32(const float* q, const float* k, const float* v, float* ws, float* out, const int64_t* pos_dev,
-                           int B, int H, int D, int cap, int context, int splits, rst_stream_t stream) {
+int rst_lm_attn_decode_f32(const float* qkv, float* k, float* v, float* ws, uint32_t* counters, float* out,
+                           const int64_t* pos_dev, int B, int H, int D, int cap, int context, int splits, int ldqkv, int rope,
+                           float rope_coef, rst_stream_t stream) {
     LmAttnParams p;
-    p.q = q; p.k = k; p.v = v; p.ws = ws; p.out = out; p.pos_dev = (const long*)pos_dev; p.B = B; p.H = H; p.D = D;
-    p.cap = cap; p.context = context; p.splits = splits;
+    p.qkv = qkv; p.k = k; p.v = v; p.ws = ws; p.counters = counters; p.out = out; p.pos_dev = (const long*)pos_dev;
+    p.B = B; p.H = H; p.D = D; p.cap = cap; p.context = context; p.splits = splits; p.ldqkv = ldqkv; p.rope = rope;
+    p.rope_coef = rope_coef;
     return rst_launch_lm_attn(p, (hipStream_t)stream);
 }
 

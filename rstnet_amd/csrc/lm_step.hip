@@ -28,19 +28,32 @@ __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u 
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
 
-constexpr int GEMV_RPW = 4;      // rows per wave in flight
 constexpr int GEMV_WAVES = 4;
 
+// Ring slot -> position map of RingKVCache.complete (modules/transformer.py:254-278) incl. the `delta <= 0` quirk (Q1);
+// returns whether `slot` is visible to the query at position `pos` (= the step just appended).
+__device__ __forceinline__ bool ring_visible(int slot, long pos, int cap, int context) {
+    const long end_offset = pos + 1;
+    const int end_index = (int)(end_offset % cap);
+    const int delta = slot - end_index;
+    long pk = delta <= 0 ? end_offset + delta : end_offset + delta - cap;
+    if (slot >= end_offset) pk = -1;
+    const long dl = pos - pk;
+    bool ok = slot < cap && pk >= 0 && dl >= 0;
+    if (context > 0) ok = ok && dl < context;
+    return ok;
+}
+
 // y[b][n] = (res ? res[b][n] : 0) + sum_k xs[b][k] * W[n][k],   xs = prologue(x)
-template <int B>
+template <int B, int RPW>
 __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) float xs[];   // [B][K]
+    __shared__ float red[GEMV_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = p.K;
 
     // ---- prologue: stage the activation vector(s) in LDS
     if (p.prologue == 1) {           // RMSNorm: x * alpha * rsqrt(eps + mean(x^2))   (modules/transformer.py:34-46)
-        __shared__ float red[GEMV_WAVES];
         for (int b = 0; b < B; ++b) {
             float s = 0.f;
             for (int k = tid; k < K; k += 64 * GEMV_WAVES) { const float v = p.x[(long)b * p.ldx + k]; s = fmaf(v, v, s); }
@@ -64,28 +77,25 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvPa
     }
     __syncthreads();
 
-    // ---- row groups, grid-strided: GEMV_RPW rows per wave, 8 bf16 (16 B) per lane per row per iteration
-    const int groups = (p.N + GEMV_RPW * GEMV_WAVES - 1) / (GEMV_RPW * GEMV_WAVES);
+    // ---- row groups, grid-strided: RPW rows per wave, 8 bf16 (16 B) per lane per row per iteration, two iterations in flight
+    const int groups = (p.N + RPW * GEMV_WAVES - 1) / (RPW * GEMV_WAVES);
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-        const int n0 = (grp * GEMV_WAVES + wave) * GEMV_RPW;
-        float acc[GEMV_RPW][B];
+        const int n0 = (grp * GEMV_WAVES + wave) * RPW;
+        float acc[RPW][B];
 #pragma unroll
-        for (int r = 0; r < GEMV_RPW; ++r)
+        for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
-        const unsigned short* wrow[GEMV_RPW];
+        const unsigned short* wrow[RPW];
 #pragma unroll
-        for (int r = 0; r < GEMV_RPW; ++r) wrow[r] = p.w + (long)min(n0 + r, p.N - 1) * K;
-        for (int k = lane * 8; k < K; k += 64 * 8) {
-            u32x4 wv[GEMV_RPW];
-#pragma unroll
-            for (int r = 0; r < GEMV_RPW; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k));
+        for (int r = 0; r < RPW; ++r) wrow[r] = p.w + (long)min(n0 + r, p.N - 1) * K;
+        auto fma8 = [&](const u32x4 (&wv)[RPW], int k) {
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + b * K + k);
                 const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + b * K + k + 4);
 #pragma unroll
-                for (int r = 0; r < GEMV_RPW; ++r) {
+                for (int r = 0; r < RPW; ++r) {
                     float a = acc[r][b];
                     a = fmaf(bf16_lo(wv[r][0]), x0[0], a); a = fmaf(bf16_hi(wv[r][0]), x0[1], a);
                     a = fmaf(bf16_lo(wv[r][1]), x0[2], a); a = fmaf(bf16_hi(wv[r][1]), x0[3], a);
@@ -94,9 +104,26 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvPa
                     acc[r][b] = a;
                 }
             }
+        };
+        int k = lane * 8;
+        for (; k + 512 < K; k += 1024) {
+            u32x4 wa[RPW], wb[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                wa[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k));
+                wb[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k + 512));
+            }
+            fma8(wa, k);
+            fma8(wb, k + 512);
+        }
+        if (k < K) {
+            u32x4 wa[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) wa[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k));
+            fma8(wa, k);
         }
 #pragma unroll
-        for (int r = 0; r < GEMV_RPW; ++r)
+        for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 const float s = wave_sum(acc[r][b]);
@@ -168,7 +195,9 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const LmRopeAppendPara
     }
 }
 
-// One query per (b, h).  Slots are split over gridDim.x workgroups; each writes (m, l, o[D]) to the workspace.
+// One query per (b, h), read straight from the qkv vector of the new step: RoPE on q (every workgroup) and on the new
+// key (the workgroup whose slot range holds the ring slot of this step, which also appends k / v to the ring).
+// Slots are split over gridDim.x workgroups; each writes (m, l, o[D]) to the workspace and the last one to arrive combines.
 // Lane groups of D/16 lanes own one slot per iteration (each lane 16 contiguous floats of the K / V row: coalesced).
 template <int D>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) {
@@ -180,45 +209,65 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     const int sub = lane % LPS, grp = lane / LPS;
     const int split = blockIdx.x, h = blockIdx.y;
     const long b = blockIdx.z;
-    const long pos = *p.pos_dev;                 // position of the query = index of the step just appended
-    const long end_offset = pos + 1;
-    const int end_index = (int)(end_offset % p.cap);
+    const long pos = *p.pos_dev;                 // position of the query = index of the step being appended
+    const int slot_cur = (int)(pos % p.cap);
     const float scale = 1.0f / sqrtf((float)D);
+    const long HD = (long)p.H * D;
 
-    const float* qp = p.q + (b * p.H + h) * (long)D + sub * 16;
-    f32x4 q[4];
+    // rotation of this lane's 8 (real, imag) pairs at position `pos` (modules/rope.py:37-62)
+    float rc[8], rs[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const f32x4*>(qp + 4 * i);
+    for (int i = 0; i < 8; ++i) {
+        rc[i] = 1.f; rs[i] = 0.f;
+        if (p.rope) {
+            const float ang = expf((float)(sub * 8 + i) * p.rope_coef) * (float)pos;
+            rc[i] = cosf(ang); rs[i] = sinf(ang);
+        }
+    }
+    const float* qkv = p.qkv + b * p.ldqkv + (long)h * D + sub * 16;
+    float q[16], kcur[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float qr = qkv[2 * i], qi = qkv[2 * i + 1], kr = qkv[HD + 2 * i], ki = qkv[HD + 2 * i + 1];
+        q[2 * i] = qr * rc[i] - qi * rs[i]; q[2 * i + 1] = qr * rs[i] + qi * rc[i];
+        kcur[2 * i] = kr * rc[i] - ki * rs[i]; kcur[2 * i + 1] = kr * rs[i] + ki * rc[i];
+    }
 
     const int per = (p.cap + gridDim.x - 1) / gridDim.x;
     const int s_lo = split * per, s_hi = min(p.cap, s_lo + per);
     float m_run = -INFINITY, l_run = 0.f;
-    f32x4 o[4];
+    float o[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* kb = p.k + ((b * p.H + h) * p.cap) * (long)D + sub * 16;
-    const float* vb = p.v + ((b * p.H + h) * p.cap) * (long)D + sub * 16;
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+    float* kb = p.k + ((b * p.H + h) * p.cap) * (long)D + sub * 16;
+    float* vb = p.v + ((b * p.H + h) * p.cap) * (long)D + sub * 16;
 
     for (int s0 = s_lo + wave * SPW; s0 < s_hi; s0 += 4 * SPW) {
         const int slot = s0 + grp;
-        // RingKVCache.complete slot -> position map incl. the `delta <= 0` quirk
-        const int delta = slot - end_index;
-        long pk = delta <= 0 ? end_offset + delta : end_offset + delta - p.cap;
-        if (slot >= end_offset) pk = -1;
-        const long dl = pos - pk;
-        bool ok = slot < s_hi && pk >= 0 && dl >= 0;
-        if (p.context > 0) ok = ok && dl < p.context;
-        f32x4 vv[4];
-        float d = 0.f;
+        const bool ok = slot < s_hi && ring_visible(slot, pos, p.cap, p.context);
+        float kv[16], vv[16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            vv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                const f32x4 kv = *reinterpret_cast<const f32x4*>(kb + (long)slot * D + 4 * i);
-                d = fmaf(kv[0], q[i][0], d); d = fmaf(kv[1], q[i][1], d); d = fmaf(kv[2], q[i][2], d); d = fmaf(kv[3], q[i][3], d);
-                vv[i] = *reinterpret_cast<const f32x4*>(vb + (long)slot * D + 4 * i);
+        for (int i = 0; i < 16; ++i) { kv[i] = 0.f; vv[i] = 0.f; }
+        if (slot < s_hi && slot == slot_cur) {       // the new step: from qkv, and appended to the ring
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { kv[i] = kcur[i]; vv[i] = qkv[2 * HD + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x4*>(kb + (long)slot * D + 4 * i) = f32x4{kv[4 * i], kv[4 * i + 1], kv[4 * i + 2], kv[4 * i + 3]};
+                *reinterpret_cast<f32x4*>(vb + (long)slot * D + 4 * i) = f32x4{vv[4 * i], vv[4 * i + 1], vv[4 * i + 2], vv[4 * i + 3]};
+            }
+        } else if (ok) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 k4 = *reinterpret_cast<const f32x4*>(kb + (long)slot * D + 4 * i);
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(vb + (long)slot * D + 4 * i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { kv[4 * i + e] = k4[e]; vv[4 * i + e] = v4[e]; }
             }
         }
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d = fmaf(kv[i], q[i], d);
 #pragma unroll
         for (int off = LPS / 2; off > 0; off >>= 1) d += __shfl_xor(d, off);   // all lanes take part (ok is per group)
         const float sc = ok ? d * scale : -INFINITY;
@@ -228,7 +277,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
             const float pw = sc == -INFINITY ? 0.f : expf(sc - m_new);
             l_run = l_run * alpha + pw;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = o[i] * alpha + pw * vv[i];
+            for (int i = 0; i < 16; ++i) o[i] = o[i] * alpha + pw * vv[i];
             m_run = m_new;
         }
     }
@@ -239,18 +288,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     const float f = (m_run == -INFINITY) ? 0.f : expf(m_run - m_w);
     float l_w = l_run * f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] *= f;
+    for (int i = 0; i < 16; ++i) o[i] *= f;
 #pragma unroll
     for (int off = LPS; off < 64; off <<= 1) {
         l_w += __shfl_xor(l_w, off);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[i][e] += __shfl_xor(o[i][e], off);
+        for (int i = 0; i < 16; ++i) o[i] += __shfl_xor(o[i], off);
     }
     if (grp == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&sm_o[wave][sub * 16 + 4 * i]) = o[i];
+        for (int i = 0; i < 16; ++i) sm_o[wave][sub * 16 + i] = o[i];
         if (sub == 0) { sm_m[wave] = m_w; sm_l[wave] = l_w; }
     }
     __syncthreads();
@@ -263,29 +310,99 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
             L += sm_l[w] * fw;
             O += sm_o[w][tid] * fw;
         }
-        float* ws = p.ws + (((b * p.H + h) * gridDim.x) + split) * (long)(D + 2);
-        ws[2 + tid] = O;
-        if (tid == 0) { ws[0] = M; ws[1] = L; }
+        if (gridDim.x == 1) {                       // single split: finished
+            p.out[(b * p.H + h) * (long)D + tid] = L > 0.f ? O / L : 0.f;
+        } else {
+            float* ws = p.ws + (((b * p.H + h) * gridDim.x) + split) * (long)(D + 2);
+            ws[2 + tid] = O;
+            if (tid == 0) { ws[0] = M; ws[1] = L; }
+        }
+    }
+    if (gridDim.x == 1) return;
+    // In-launch reduction of the splits (cdna_hip_programming.md G16, counter form): every split publishes its partial with
+    // an agent-scope release, the LAST arriver of (b, h) acquires and combines; it also re-arms the counter for the next launch.
+    __shared__ int sm_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(p.counters + (b * p.H + h), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sm_last = prev == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!sm_last) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(p.counters + (b * p.H + h), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid < D) {
+        const float* w0 = p.ws + ((b * p.H + h) * gridDim.x) * (long)(D + 2);
+        float M = -INFINITY;
+        for (unsigned s2 = 0; s2 < gridDim.x; ++s2) M = fmaxf(M, w0[(long)s2 * (D + 2)]);
+        float L = 0.f, O = 0.f;
+        for (unsigned s2 = 0; s2 < gridDim.x; ++s2) {
+            const float* w = w0 + (long)s2 * (D + 2);
+            const float fw = w[0] == -INFINITY ? 0.f : expf(w[0] - M);
+            L = fmaf(w[1], fw, L);
+            O = fmaf(w[2 + tid], fw, O);
+        }
+        p.out[(b * p.H + h) * (long)D + tid] = L > 0.f ? O / L : 0.f;
     }
 }
 
-// out[b][h*D + j] = sum_s exp(m_s - M) o_s[j] / sum_s exp(m_s - M) l_s
-__global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ ws, float* __restrict__ out, int H, int D,
-                                                          int splits) {
-    const int h = blockIdx.x;
+// Short ring (capacity <= 64, e.g. the depth transformer's 8 steps): one wave per (b, h) does append + scores (lane = slot)
+// + softmax + PV (lane = output dim) with no split and no workspace.
+__global__ __launch_bounds__(64) void attn_small_kernel(const LmAttnParams p) {
+    const int lane = threadIdx.x, h = blockIdx.x;
     const long b = blockIdx.y;
-    const float* w0 = ws + ((b * H + h) * splits) * (long)(D + 2);
-    float M = -INFINITY;
-    for (int s = 0; s < splits; ++s) M = fmaxf(M, w0[(long)s * (D + 2)]);
-    for (int j = threadIdx.x; j < D; j += 128) {
-        float L = 0.f, O = 0.f;
-        for (int s = 0; s < splits; ++s) {
-            const float* w = w0 + (long)s * (D + 2);
-            const float f = w[0] == -INFINITY ? 0.f : expf(w[0] - M);
-            L += w[1] * f;
-            O += w[2 + j] * f;
+    const int D = p.D, cap = p.cap;
+    const long HD = (long)p.H * D;
+    const long pos = *p.pos_dev;
+    const int slot_cur = (int)(pos % cap);
+    const float* qkv = p.qkv + b * p.ldqkv + (long)h * D;
+    float* kc = p.k + ((b * p.H + h) * cap) * (long)D;
+    float* vc = p.v + ((b * p.H + h) * cap) * (long)D;
+    // append (RoPE optional: lane i rotates pair i)
+    for (int i = lane; i < D / 2; i += 64) {
+        float c = 1.f, sn = 0.f;
+        if (p.rope) { const float ang = expf((float)i * p.rope_coef) * (float)pos; c = cosf(ang); sn = sinf(ang); }
+        const float kr = qkv[HD + 2 * i], ki = qkv[HD + 2 * i + 1];
+        kc[(long)slot_cur * D + 2 * i] = kr * c - ki * sn;
+        kc[(long)slot_cur * D + 2 * i + 1] = kr * sn + ki * c;
+        vc[(long)slot_cur * D + 2 * i] = qkv[2 * HD + 2 * i];
+        vc[(long)slot_cur * D + 2 * i + 1] = qkv[2 * HD + 2 * i + 1];
+    }
+    // the new step is never re-read from memory: its key / value come from qkv
+    const bool ok = lane < cap && ring_visible(lane, pos, cap, p.context);
+    float sc = -INFINITY;
+    if (ok) {
+        float d = 0.f;
+        for (int i = 0; i < D / 2; ++i) {
+            float c = 1.f, sn = 0.f;
+            if (p.rope) { const float ang = expf((float)i * p.rope_coef) * (float)pos; c = cosf(ang); sn = sinf(ang); }
+            const float qr = qkv[2 * i], qi = qkv[2 * i + 1];
+            float k0, k1;
+            if (lane == slot_cur) {
+                const float kr = qkv[HD + 2 * i], ki = qkv[HD + 2 * i + 1];
+                k0 = kr * c - ki * sn; k1 = kr * sn + ki * c;
+            } else {
+                k0 = kc[(long)lane * D + 2 * i]; k1 = kc[(long)lane * D + 2 * i + 1];
+            }
+            d = fmaf(k0, qr * c - qi * sn, d);
+            d = fmaf(k1, qr * sn + qi * c, d);
         }
-        out[(b * H + h) * (long)D + j] = L > 0.f ? O / L : 0.f;
+        sc = d / sqrtf((float)D);
+    }
+    const float m = wave_max(sc);
+    const float pw = ok ? expf(sc - m) : 0.f;
+    const float l = wave_sum(pw);
+    for (int d0 = lane; d0 < D; d0 += 64) {
+        float o = 0.f;
+        for (int sl = 0; sl < cap; ++sl)
+            o = fmaf(__shfl(pw, sl), sl == slot_cur ? qkv[2 * HD + d0] : vc[(long)sl * D + d0], o);
+        p.out[(b * p.H + h) * (long)D + d0] = o / l;
     }
 }
 
@@ -348,32 +465,48 @@ __global__ __launch_bounds__(256) void sample_kernel(const LmSampleParams p) {
     float win = -INFINITY;
     int win_tok = 0x7fffffff;
     if (p.V <= 4096) {
-        // rank of every candidate by counting (descending, ties -> lowest index first = torch.topk order on sorted data);
-        // candidate of rank r < k is scored p_r / noise_r; the best score wins
-        for (int i = tid; i < p.V; i += 256) {
-            const float v = sv[i];
-            int rank = 0;
-            for (int j = 0; j < p.V; ++j) {
-                const float u = sv[j];
-                rank += (u > v || (u == v && j < i)) ? 1 : 0;
+        // bitonic sort of (value, index) in LDS: descending by value, ascending index on ties (the order torch.topk yields
+        // on distinct values); candidate j < k is scored p_j / noise_j and the best score wins (lowest j on score ties)
+        int NP = 1;
+        while (NP < p.V) NP <<= 1;
+        int* sidx = reinterpret_cast<int*>(sv + NP);
+        for (int i = tid; i < NP; i += 256) {
+            if (i >= p.V) sv[i] = -INFINITY;
+            sidx[i] = i;
+        }
+        __syncthreads();
+        for (int size = 2; size <= NP; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < NP / 2; t += 256) {
+                    const int lo = 2 * t - (t & (stride - 1));
+                    const int hi = lo + stride;
+                    const float a = sv[lo], c = sv[hi];
+                    const int ia = sidx[lo], ic = sidx[hi];
+                    const bool a_first = a > c || (a == c && ia < ic);
+                    const bool want_a_first = (lo & size) == 0;
+                    if (a_first != want_a_first) { sv[lo] = c; sv[hi] = a; sidx[lo] = ic; sidx[hi] = ia; }
+                }
+                __syncthreads();
             }
-            if (rank < k) {
-                const float sc = (expf(v - mx) / denom) / p.noise[b * p.noise_stride + rank];
-                if (sc > win || (sc == win && i < win_tok)) { win = sc; win_tok = i; }
-            }
+        }
+        int win_j = 0x7fffffff;
+        for (int j = tid; j < k; j += 256) {
+            const float sc = (expf(sv[j] - mx) / denom) / p.noise[b * p.noise_stride + j];
+            if (sc > win || (sc == win && j < win_j)) { win = sc; win_j = j; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(win, o);
-            const int oi = __shfl_xor(win_tok, o);
-            if (ov > win || (ov == win && oi < win_tok)) { win = ov; win_tok = oi; }
+            const int oj = __shfl_xor(win_j, o);
+            if (ov > win || (ov == win && oj < win_j)) { win = ov; win_j = oj; }
         }
         __syncthreads();
-        if (lane == 0) { red_v[wave] = win; red_i[wave] = win_tok; }
+        if (lane == 0) { red_v[wave] = win; red_i[wave] = win_j; }
         __syncthreads();
         if (tid == 0) {
             for (int w = 1; w < 4; ++w)
-                if (red_v[w] > win || (red_v[w] == win && red_i[w] < win_tok)) { win = red_v[w]; win_tok = red_i[w]; }
+                if (red_v[w] > win || (red_v[w] == win && red_i[w] < win_j)) { win = red_v[w]; win_j = red_i[w]; }
+            win_tok = sidx[win_j];
         }
     } else {
         // large vocabulary, small k (text head: V = 32000, k = 25): repeated extraction of the maximum
@@ -401,21 +534,30 @@ int rst_launch_gemv_bf16(const GemvParams& p, hipStream_t stream) {
     RST_REQUIRE(((uintptr_t)p.w % 16) == 0 && ((uintptr_t)p.x % 16) == 0, "gemv_bf16: pointers must be 16-byte aligned");
     const size_t lds = (size_t)p.B * p.K * sizeof(float);
     RST_REQUIRE(lds <= 128 * 1024, "gemv_bf16: B*K = %d floats do not fit the activation stage (32768)", p.B * p.K);
-    const long groups = ((long)p.N + GEMV_RPW * GEMV_WAVES - 1) / (GEMV_RPW * GEMV_WAVES);
-    const unsigned grid = cap_grid(groups, lds > 64 * 1024 ? 256 : 512);
+    // rows per wave: 4 when that still yields >= 2 workgroups per CU, else 2 (more workgroups -> more loads in flight)
+    const bool rpw4 = ((long)p.N + 15) / 16 >= 512;
+    const int rows_per_group = (rpw4 ? 4 : 2) * GEMV_WAVES;
+    const long groups = ((long)p.N + rows_per_group - 1) / rows_per_group;
+    const unsigned grid = cap_grid(groups, lds > 48 * 1024 ? 512 : 768);
     auto go = [&](auto kern) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            // static LDS (the 16-byte reduction scratch) counts against the 160 KiB budget: ask for what the check above allows
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipGetLastError();
             attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GEMV_WAVES), lds, stream, p);
     };
-    switch (p.B) {
-        case 1: go(gemv_bf16_kernel<1>); break;
-        case 2: go(gemv_bf16_kernel<2>); break;
-        case 3: go(gemv_bf16_kernel<3>); break;
-        default: go(gemv_bf16_kernel<4>); break;
+    switch (p.B * 2 + (rpw4 ? 1 : 0)) {
+        case 2: go(gemv_bf16_kernel<1, 2>); break;
+        case 3: go(gemv_bf16_kernel<1, 4>); break;
+        case 4: go(gemv_bf16_kernel<2, 2>); break;
+        case 5: go(gemv_bf16_kernel<2, 4>); break;
+        case 6: go(gemv_bf16_kernel<3, 2>); break;
+        case 7: go(gemv_bf16_kernel<3, 4>); break;
+        case 8: go(gemv_bf16_kernel<4, 2>); break;
+        default: go(gemv_bf16_kernel<4, 4>); break;
     }
     return rst_check_launch("gemv_bf16");
 }
@@ -442,31 +584,39 @@ int rst_launch_lm_rope_append(const LmRopeAppendParams& p, hipStream_t stream) {
 }
 
 int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream) {
-    RST_REQUIRE(p.q && p.k && p.v && p.ws && p.out && p.pos_dev && p.B >= 1 && p.H > 0 && p.cap > 0 && p.splits >= 1,
+    RST_REQUIRE(p.qkv && p.k && p.v && p.out && p.pos_dev && p.B >= 1 && p.H > 0 && p.cap > 0 && p.splits >= 1,
                 "lm_attn: bad arguments");
-    RST_REQUIRE(p.B <= 65535 && p.H <= 65535, "lm_attn: grid too large");
+    RST_REQUIRE(p.B <= 65535 && p.H <= 65535 && p.D % 2 == 0, "lm_attn: bad sizes");
+    if (p.cap <= 64 && p.splits == 1) {
+        hipLaunchKernelGGL(attn_small_kernel, dim3(p.H, p.B), dim3(64), 0, stream, p);
+        return rst_check_launch("lm_attn_small");
+    }
+    RST_REQUIRE(p.splits == 1 || (p.ws && p.counters), "lm_attn: splits > 1 need the workspace and the (zeroed) counters");
     const dim3 grid(p.splits, p.H, p.B);
     switch (p.D) {
         case 64: hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, stream, p); break;
         case 128: hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, stream, p); break;
         default:
-            rst_set_error("lm_attn: head dim %d unsupported (64, 128)", p.D);
+            rst_set_error("lm_attn: head dim %d unsupported for long rings (64, 128)", p.D);
             return RST_ERR_UNSUPPORTED;
     }
-    int rc = rst_check_launch("lm_attn");
-    if (rc) return rc;
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(p.H, p.B), dim3(128), 0, stream, p.ws, p.out, p.H, p.D, p.splits);
-    return rst_check_launch("lm_attn_combine");
+    return rst_check_launch("lm_attn");
 }
 
 int rst_launch_lm_sample(const LmSampleParams& p, hipStream_t stream) {
     RST_REQUIRE(p.logits && p.tokens && p.B >= 1 && p.V > 0, "lm_sample: bad arguments");
     RST_REQUIRE(!p.use_sampling || p.temp <= 0.f || p.noise, "lm_sample: sampling needs the exponential noise tensor");
-    const size_t lds = (size_t)p.V * sizeof(float);
+    size_t lds = (size_t)p.V * sizeof(float);
+    if (p.V <= 4096) {   // sort buffers: values padded to a power of two + indices
+        int np = 1;
+        while (np < p.V) np <<= 1;
+        lds = (size_t)np * 8;
+    }
     RST_REQUIRE(lds <= 150 * 1024, "lm_sample: vocabulary %d too large for the LDS stage", p.V);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipGetLastError();
         attr_set = true;
     }
     hipLaunchKernelGGL(sample_kernel, dim3(p.B), dim3(256), lds, stream, p);

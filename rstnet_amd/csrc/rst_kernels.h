@@ -147,13 +147,15 @@ struct LmRopeAppendParams {
 int rst_launch_lm_rope_append(const LmRopeAppendParams& p, hipStream_t stream);
 
 struct LmAttnParams {
-    const float* q;       // [B][H*D]
-    const float* k;       // [B][H][cap][D]
-    const float* v;
-    float* ws;            // [B][H][splits][D+2] workspace
+    const float* qkv;     // [B][ldqkv]: [q | k | v] of the new step, each H*D (un-rotated)
+    float* k;             // [B][H][cap][D] ring (the new step is appended)
+    float* v;
+    float* ws;            // [B][H][splits][D+2] workspace: (m, l, o[D]) per split (splits > 1)
+    unsigned* counters;   // [B][H] arrival counters, zero before the first launch (re-armed by the kernel)
     float* out;           // [B][H*D]
-    const long* pos_dev;  // position of the query (the step just appended)
-    int B, H, D, cap, context, splits;
+    const long* pos_dev;  // position of the new step
+    int B, H, D, cap, context, splits, ldqkv, rope;
+    float rope_coef;
 };
 int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream);
 

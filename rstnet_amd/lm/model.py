@@ -96,6 +96,7 @@ class _StepState:
     k: List[torch.Tensor]      # per layer [B, H, cap, D] fp32 ring
     v: List[torch.Tensor]
     pos: torch.Tensor          # int64 [1] on device: steps appended so far (= position of the next step)
+    scratch: Optional[tuple] = None   # (split workspace, arrival counters) of the long-ring attention kernel
     offset_cpu: int = 0
 
     def reset(self) -> None:
@@ -124,11 +125,17 @@ class StreamingTransformer(StreamingModule[_StepState]):
         cap = self.context if self.context is not None else self.weights_per_step
         dev = self.layers[0].norm1.alpha.device
         shape = (batch_size, self.num_heads, cap, self.d_model // self.num_heads)
+        scratch = None
+        if cap > 64:
+            splits = max(1, min(16, cap // 128, 1024 // max(1, batch_size * self.num_heads)))
+            scratch = (torch.empty(batch_size, self.num_heads, splits, shape[3] + 2, device=dev),
+                       torch.zeros(batch_size, self.num_heads, device=dev, dtype=torch.int32))
         return _StepState([torch.zeros(shape, device=dev) for _ in self.layers], [torch.zeros(shape, device=dev) for _ in self.layers],
-                          torch.zeros(1, device=dev, dtype=torch.long))
+                          torch.zeros(1, device=dev, dtype=torch.long), scratch)
 
     def step(self, x: torch.Tensor, step_index: Optional[int] = None) -> torch.Tensor:
-        """x fp32 ``[B, d_model]`` -> ``[B, d_model]``: one new time step through every layer (7 launches per layer)."""
+        """x fp32 ``[B, d_model]`` -> ``[B, d_model]``: one new time step through every layer (4 launches per layer for a short
+        ring, 5 otherwise)."""
         st = self._streaming_state
         if st is None:
             raise RuntimeError("the decode-step transformer only runs in streaming mode")
@@ -145,8 +152,8 @@ class StreamingTransformer(StreamingModule[_StepState]):
             else:
                 w_in, w_out, gate = att.in_proj_weight, att.out_proj.weight, layer.gating
             qkv = ops.gemv_bf16(x, w_in, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm1.alpha_f32(), eps=layer.norm1.eps)
-            q = ops.lm_rope_append(qkv, st.k[l], st.v[l], st.pos, rope=self.rope, max_period=self.max_period)
-            a = ops.lm_attn_decode(q, st.k[l], st.v[l], st.pos, context=self.context)
+            a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], st.pos, rope=self.rope, context=self.context,
+                                   max_period=self.max_period, scratch=st.scratch)
             x = ops.gemv_bf16(a, w_out, res=x)
             h = ops.gemv_bf16(x, gate.linear_in.weight, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm2.alpha_f32(),
                               eps=layer.norm2.eps)

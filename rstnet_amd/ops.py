@@ -347,19 +347,30 @@ def lm_rope_append(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     return q
 
 
-def lm_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos_dev: torch.Tensor, *,
-                   context: Optional[int], splits: Optional[int] = None) -> torch.Tensor:
-    """Single-query attention over the ring: q ``[B, H*D]`` -> ``[B, H*D]``."""
-    for t, n in ((q, "q"), (k_cache, "k_cache"), (v_cache, "v_cache")):
+def lm_attn_decode(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos_dev: torch.Tensor, *, rope: bool,
+                   context: Optional[int], max_period: float = 10000.0, splits: Optional[int] = None,
+                   scratch: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+    """Single-query attention of the new step given its qkv row ``[B, 3*H*D]`` (RoPE, ring append, attention and the
+    reduction over slot splits in ONE launch) -> ``[B, H*D]``.  ``scratch = (ws [B,H,splits,D+2] fp32, counters [B,H] int32
+    zeros)`` may be passed to reuse buffers (the counters re-arm themselves)."""
+    for t, n in ((qkv, "qkv"), (k_cache, "k_cache"), (v_cache, "v_cache")):
         _chk(t, n)
     _chk(pos_dev, "pos_dev", torch.int64)
     B, H, cap, D = k_cache.shape
     if splits is None:
-        splits = max(1, min(16, cap // 128, 512 // max(1, B * H)))
-    ws = torch.empty(B, H, splits, D + 2, device=q.device, dtype=torch.float32)
-    out = torch.empty(B, H * D, device=q.device, dtype=torch.float32)
-    _lib.check(_lib.lib().rst_lm_attn_decode_f32(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(ws), _ptr(out), _ptr(pos_dev), B, H, D,
-                                                cap, int(context) if context else 0, splits, _stream()))
+        splits = 1 if cap <= 64 else max(1, min(16, cap // 128, 1024 // max(1, B * H)))
+    ws = counters = None
+    if splits > 1:
+        if scratch is None:
+            scratch = (torch.empty(B, H, splits, D + 2, device=qkv.device, dtype=torch.float32),
+                       torch.zeros(B, H, device=qkv.device, dtype=torch.int32))
+        ws, counters = scratch
+        _chk(ws, "ws"); _chk(counters, "counters", torch.int32)
+        assert ws.numel() >= B * H * splits * (D + 2) and counters.numel() >= B * H
+    out = torch.empty(B, H * D, device=qkv.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_lm_attn_decode_f32(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(ws), _ptr(counters), _ptr(out),
+                                                _ptr(pos_dev), B, H, D, cap, int(context) if context else 0, splits, qkv.shape[1],
+                                                int(rope), rope_coef(max_period, D), _stream()))
     return out
 
 

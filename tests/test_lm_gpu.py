@@ -59,7 +59,8 @@ def test_embed_sum_and_rmsnorm():
     assert rel_err(ops.rmsnorm(x.to(DEV), a.to(DEV), 1e-8), L.rms_norm(x, a)) < 1e-6
 
 
-@pytest.mark.parametrize("H,D,cap,context,steps,rope", [(4, 64, 8, None, 8, False), (2, 128, 10, 10, 25, True), (32, 128, 300, 300, 40, True)])
+@pytest.mark.parametrize("H,D,cap,context,steps,rope", [(4, 64, 8, None, 8, False), (2, 128, 10, 10, 25, True), (32, 128, 300, 300, 40, True),
+                                                        (4, 64, 300, 250, 320, True), (16, 64, 8, None, 8, False)])
 def test_rope_append_and_ring_attention(H, D, cap, context, steps, rope):
     """Step-by-step against the oracle's RingKV (slot->position map of RingKVCache.complete incl. SURVEY Q1)."""
     g = torch.Generator().manual_seed(H * D)
@@ -79,12 +80,10 @@ def test_rope_append_and_ring_attention(H, D, cap, context, steps, rope):
         if context is not None:
             mask = mask & (delta < context)
         ref = F.scaled_dot_product_attention(q, keys, vals, mask.view(1, -1)).permute(0, 2, 1, 3).reshape(B, H * D)
-        qg = ops.lm_rope_append(qkv.to(DEV), kc, vc, pos, rope=rope)
-        out = ops.lm_attn_decode(qg, kc, vc, pos, context=context)
+        out = ops.lm_attn_decode(qkv.to(DEV), kc, vc, pos, rope=rope, context=context)
         pos.add_(1)
-        assert rel_err(qg, q.permute(0, 2, 1, 3).reshape(B, H * D)) < 1e-5
         assert rel_err(out, ref) < 1e-4, f"step {s}"
-    assert rel_err(kc, ring.k) < 1e-5
+    assert rel_err(kc, ring.k) < 1e-4   # rotated keys: fp32 sin/cos of angles up to ~300 rad
 
 
 @pytest.mark.parametrize("V,k", [(2048, 250), (32, 7), (32000, 25), (50, 25)])
