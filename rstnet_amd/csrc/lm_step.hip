@@ -52,11 +52,33 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvPa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = p.K;
 
+    // ---- the first weight chunk of this workgroup's first row group is requested BEFORE the activation prologue: the two
+    // dependent load chains (x -> norm -> LDS, and W) then overlap instead of adding up (small GEMVs are latency-bound)
+    const int groups = (p.N + RPW * GEMV_WAVES - 1) / (RPW * GEMV_WAVES);
+    u32x4 wpre[RPW];
+    {
+        const int n0 = (blockIdx.x * GEMV_WAVES + wave) * RPW;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            wpre[r] = u32x4{0u, 0u, 0u, 0u};
+            if (blockIdx.x < groups && lane * 8 < K)
+                wpre[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.w + (long)min(n0 + r, p.N - 1) * K + lane * 8));
+        }
+    }
+
     // ---- prologue: stage the activation vector(s) in LDS
     if (p.prologue == 1) {           // RMSNorm: x * alpha * rsqrt(eps + mean(x^2))   (modules/transformer.py:34-46)
         for (int b = 0; b < B; ++b) {
+            constexpr int XR = 16;   // elements kept in registers between the two passes (K <= 4096); the rest is re-read
+            float xr[XR];
             float s = 0.f;
-            for (int k = tid; k < K; k += 64 * GEMV_WAVES) { const float v = p.x[(long)b * p.ldx + k]; s = fmaf(v, v, s); }
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const int k = tid + i * 64 * GEMV_WAVES;
+                xr[i] = k < K ? p.x[(long)b * p.ldx + k] : 0.f;
+                s = fmaf(xr[i], xr[i], s);
+            }
+            for (int k = tid + XR * 64 * GEMV_WAVES; k < K; k += 64 * GEMV_WAVES) { const float v = p.x[(long)b * p.ldx + k]; s = fmaf(v, v, s); }
             s = wave_sum(s);
             __syncthreads();
             if (lane == 0) red[wave] = s;
@@ -65,7 +87,12 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvPa
 #pragma unroll
             for (int w = 0; w < GEMV_WAVES; ++w) tot += red[w];
             const float r = 1.0f / sqrtf(p.eps + tot / (float)K);
-            for (int k = tid; k < K; k += 64 * GEMV_WAVES) xs[b * K + k] = p.x[(long)b * p.ldx + k] * (p.alpha[k] * r);
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const int k = tid + i * 64 * GEMV_WAVES;
+                if (k < K) xs[b * K + k] = xr[i] * (p.alpha[k] * r);
+            }
+            for (int k = tid + XR * 64 * GEMV_WAVES; k < K; k += 64 * GEMV_WAVES) xs[b * K + k] = p.x[(long)b * p.ldx + k] * (p.alpha[k] * r);
         }
     } else if (p.prologue == 2) {    // SiLU gate: x holds [B][2K] = [u ; v], xs = silu(u) * v   (modules/gating.py:12-22)
         for (int b = 0; b < B; ++b)
@@ -78,7 +105,6 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvPa
     __syncthreads();
 
     // ---- row groups, grid-strided: RPW rows per wave, 8 bf16 (16 B) per lane per row per iteration, two iterations in flight
-    const int groups = (p.N + RPW * GEMV_WAVES - 1) / (RPW * GEMV_WAVES);
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int n0 = (grp * GEMV_WAVES + wave) * RPW;
         float acc[RPW][B];
@@ -106,6 +132,10 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvPa
             }
         };
         int k = lane * 8;
+        if (grp == (int)blockIdx.x && k < K) {   // the prefetched chunk
+            fma8(wpre, k);
+            k += 512;
+        }
         for (; k + 512 < K; k += 1024) {
             u32x4 wa[RPW], wb[RPW];
 #pragma unroll
@@ -233,8 +263,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
         kcur[2 * i] = kr * rc[i] - ki * rs[i]; kcur[2 * i + 1] = kr * rs[i] + ki * rc[i];
     }
 
-    const int per = (p.cap + gridDim.x - 1) / gridDim.x;
-    const int s_lo = split * per, s_hi = min(p.cap, s_lo + per);
+    const int n_used = (int)min((long)p.cap, pos + 1);          // slots >= end_offset are never visible
+    const int per = (n_used + gridDim.x - 1) / gridDim.x;
+    const int s_lo = split * per, s_hi = min(n_used, s_lo + per);
     float m_run = -INFINITY, l_run = 0.f;
     float o[16];
 #pragma unroll
@@ -477,6 +508,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const LmSampleParams p) {
         __syncthreads();
         for (int size = 2; size <= NP; size <<= 1) {
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll 4
                 for (int t = tid; t < NP / 2; t += 256) {
                     const int lo = 2 * t - (t & (stride - 1));
                     const int hi = lo + stride;
@@ -509,15 +541,45 @@ __global__ __launch_bounds__(256) void sample_kernel(const LmSampleParams p) {
             win_tok = sidx[win_j];
         }
     } else {
-        // large vocabulary, small k (text head: V = 32000, k = 25): repeated extraction of the maximum
+        // large vocabulary, small k (text head: V = 32000, k = 25): repeated extraction of the maximum.  Every thread caches
+        // the maximum of its own strided slice; a round is one block reduction over the 256 cached maxima plus a rescan of
+        // the single slice that lost its maximum.
+        auto local_max = [&](float& bv, int& bi) {
+            bv = -INFINITY;
+            bi = 0x7fffffff;
+#pragma unroll 8
+            for (int i = tid; i < p.V; i += 256) {
+                const float v = sv[i];
+                if (v > bv) { bv = v; bi = i; }     // ascending i: the lowest index of equal values is kept
+            }
+        };
+        float lv;
+        int li;
+        local_max(lv, li);
         for (int j = 0; j < k; ++j) {
-            if (j > 0) block_argmax();
-            if (tid == 0) {
-                const float sc = (expf(best_v - mx) / denom) / p.noise[b * p.noise_stride + j];
-                if (sc > win) { win = sc; win_tok = best_i; }
-                sv[best_i] = -INFINITY;
+            float bv = lv;
+            int bi = li;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o);
+                const int oi = __shfl_xor(bi, o);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
             }
             __syncthreads();
+            if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+            __syncthreads();
+            bv = red_v[0]; bi = red_i[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w)
+                if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) { bv = red_v[w]; bi = red_i[w]; }
+            if (tid == 0) {
+                const float sc = (expf(bv - mx) / denom) / p.noise[b * p.noise_stride + j];
+                if (sc > win) { win = sc; win_tok = bi; }
+            }
+            if ((bi & 255) == tid) {     // the owner of the extracted element drops it and refreshes its cached maximum
+                sv[bi] = -INFINITY;
+                local_max(lv, li);
+            }
         }
     }
     if (tid == 0) p.tokens[b * p.tok_stride] = win_tok;
