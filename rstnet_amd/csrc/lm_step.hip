@@ -264,7 +264,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     }
 
     const int n_used = (int)min((long)p.cap, pos + 1);          // slots >= end_offset are never visible
-    const int per = (n_used + gridDim.x - 1) / gridDim.x;
+    const int active = max(1, min((int)gridDim.x, (n_used + 63) / 64));   // splits that have work at this context length
+    if (split >= active) return;
+    const int per = (n_used + active - 1) / active;
     const int s_lo = split * per, s_hi = min(n_used, s_lo + per);
     float m_run = -INFINITY, l_run = 0.f;
     float o[16];
@@ -341,43 +343,43 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
             L += sm_l[w] * fw;
             O += sm_o[w][tid] * fw;
         }
-        if (gridDim.x == 1) {                       // single split: finished
+        if (active == 1) {                          // single split: finished
             p.out[(b * p.H + h) * (long)D + tid] = L > 0.f ? O / L : 0.f;
         } else {
+            // write-through (sc1) partials: visible at agent scope without an L2 write-back fence (cdna_hip_programming.md G16 R1)
             float* ws = p.ws + (((b * p.H + h) * gridDim.x) + split) * (long)(D + 2);
-            ws[2 + tid] = O;
-            if (tid == 0) { ws[0] = M; ws[1] = L; }
+            __hip_atomic_store(ws + 2 + tid, O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                __hip_atomic_store(ws, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ws + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
-    if (gridDim.x == 1) return;
-    // In-launch reduction of the splits (cdna_hip_programming.md G16, counter form): every split publishes its partial with
-    // an agent-scope release, the LAST arriver of (b, h) acquires and combines; it also re-arms the counter for the next launch.
+    if (active == 1) return;
+    // In-launch reduction of the splits: every storing wave drains its write-through stores, ONE lane bumps the arrival
+    // counter; the LAST arriver of (b, h) reads the partials with agent-scope (L1-bypassing) loads, combines, and re-arms the
+    // counter for the next launch.  No dispatch-order / placement assumption.
     __shared__ int sm_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned prev = __hip_atomic_fetch_add(p.counters + (b * p.H + h), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sm_last = prev == gridDim.x - 1;
+        sm_last = prev == (unsigned)active - 1;
+        if (sm_last) __hip_atomic_store(p.counters + (b * p.H + h), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!sm_last) return;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(p.counters + (b * p.H + h), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
     if (tid < D) {
         const float* w0 = p.ws + ((b * p.H + h) * gridDim.x) * (long)(D + 2);
         float M = -INFINITY;
-        for (unsigned s2 = 0; s2 < gridDim.x; ++s2) M = fmaxf(M, w0[(long)s2 * (D + 2)]);
+        for (int s2 = 0; s2 < active; ++s2) M = fmaxf(M, __hip_atomic_load(w0 + (long)s2 * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         float L = 0.f, O = 0.f;
-        for (unsigned s2 = 0; s2 < gridDim.x; ++s2) {
+        for (int s2 = 0; s2 < active; ++s2) {
             const float* w = w0 + (long)s2 * (D + 2);
-            const float fw = w[0] == -INFINITY ? 0.f : expf(w[0] - M);
-            L = fmaf(w[1], fw, L);
-            O = fmaf(w[2 + tid], fw, O);
+            const float ms = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float fw = ms == -INFINITY ? 0.f : expf(ms - M);
+            L = fmaf(__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fw, L);
+            O = fmaf(__hip_atomic_load(w + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fw, O);
         }
         p.out[(b * p.H + h) * (long)D + tid] = L > 0.f ? O / L : 0.f;
     }
