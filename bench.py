@@ -35,9 +35,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--workload", choices=["codec", "lm"], default="codec",
+    ap.add_argument("--workload", choices=["codec", "lm", "e2e"], default="codec",
                     help="codec = BASELINE configs[1] (the default, headline); lm = configs[2]: Moshi-7B-shaped RQ-Transformer decode, batch 1")
     ap.add_argument("--lm-config", choices=["moshi7b", "tiny"], default="moshi7b")
+    ap.add_argument("--lm-batch", type=int, default=1, help="lm / e2e: concurrent streams per GPU (<= 64)")
     ap.add_argument("--greedy", action="store_true", help="lm: greedy decoding instead of temperature / top-k sampling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch GEMM table (shape, ms, TFLOP/s, GB/s) to stderr")
@@ -100,7 +101,7 @@ def bench_lm(args, rank, world, dev):
     from rstnet_amd import ops, synth
     from rstnet_amd.lm.model import LMGen, LMModel
     cfg = dict(synth.LM_MOSHI_7B if args.lm_config == "moshi7b" else synth.LM_TINY)
-    B = 1
+    B = args.lm_batch
     sd = synth.lm_state_dict(cfg, seed=0, device=str(dev))     # generated on the device, bf16
     n_params = sum(v.numel() for v in sd.values())
     model = LMModel.from_state_dict(sd, cfg)
@@ -141,7 +142,7 @@ def bench_lm(args, rank, world, dev):
         torch.cuda.synchronize()
         ops.PROFILE = None
     os.environ["NO_CUDA_GRAPH"] = "0"
-    gemv = [r for r in recs if r[0] == "gemv_bf16"]
+    gemv = [r for r in recs if r[0] in ("gemv_bf16", "gemm_skinny")]
     ms = sum(r[1].elapsed_time(r[2]) for r in gemv)
     nbytes = sum(r[4] for r in gemv)
     if args.layers:
@@ -162,7 +163,8 @@ def bench_lm(args, rank, world, dev):
                    "sampling": "greedy" if args.greedy else "temp 0.8/0.7 top-k 250/25", "hip_graphs": True,
                    "parallelism": f"replica x{world}"},
         "x_realtime_per_stream": round(args.steps / elapsed / 12.5, 2),
-        "roofline": {"bound": "hbm", "kernel": "gemv_bf16_kernel (bf16 weight streaming)", "achieved": round(nbytes / ms / 1e6, 1),
+        "roofline": {"bound": "hbm", "kernel": ("gemv_bf16_kernel" if B <= 4 else "gemm_skinny_kernel") + " (bf16 weight streaming)",
+                     "achieved": round(nbytes / ms / 1e6, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
                      "launches_per_step": len(gemv), "avg_launch_ms": round(ms / max(1, len(gemv)), 5),
                      "kernel_ms_per_step": round(ms, 3), "algorithmic_gb_per_step": round(nbytes / 1e9, 3),
@@ -171,6 +173,51 @@ def bench_lm(args, rank, world, dev):
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = lm_cpu_baseline()
     print(json.dumps(result), flush=True)
+
+
+def bench_e2e(args, rank, world, dev):
+    """BASELINE configs[3] shape on one GPU: B concurrent streams, each frame = Mimi encode (1920 samples) -> LMGen.step ->
+    Mimi decode; value = B * frames / time."""
+    from rstnet_amd import synth
+    from rstnet_amd.codec.mimi import MimiCodec
+    from rstnet_amd.lm.model import LMGen, LMModel
+    from rstnet_amd.pipeline import StreamingPipeline
+    cfg = dict(synth.LM_MOSHI_7B if args.lm_config == "moshi7b" else synth.LM_TINY)
+    B = args.lm_batch
+    mimi = MimiCodec.from_state_dict(synth.mimi_state_dict(0)).to(dev)
+    model = LMModel.from_state_dict(synth.lm_state_dict(cfg, seed=0, device=str(dev)), cfg)
+    gen = LMGen(model, use_sampling=not args.greedy)
+    pcm = synth.synth_audio(B, 1920 * (args.warmup + args.steps), seed=200 + rank).to(dev)
+    torch.manual_seed(1234 + rank)
+    with StreamingPipeline(mimi, gen, B) as pipe:
+        for s in range(args.warmup):
+            pipe.step(pcm[:, :, s * 1920:(s + 1) * 1920].contiguous())
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(args.warmup, args.warmup + args.steps):
+            out = pipe.step(pcm[:, :, s * 1920:(s + 1) * 1920].contiguous())
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "codec+LM audio frames/sec (24 kHz, 12.5 Hz tokens) at batch=1 and batch=64; RVQ code-index exact-match",
+            "value": round(B * world * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "codec f32; LM bf16 weights, f32 activations", "data": "synthetic",
+            "config": {"workload": f"end-to-end streaming: Mimi encode -> LMGen.step -> Mimi decode, BASELINE.json configs[3] shape, {args.lm_config}",
+                       "streams_per_gpu": B, "parallelism": f"replica x{world}, streams sharded"},
+            "x_realtime_per_stream": round(args.steps / elapsed / 12.5, 2)}), flush=True)
 
 
 def main():
@@ -187,8 +234,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    if args.workload == "lm":
-        bench_lm(args, rank, world, dev)
+    if args.workload in ("lm", "e2e"):
+        (bench_lm if args.workload == "lm" else bench_e2e)(args, rank, world, dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

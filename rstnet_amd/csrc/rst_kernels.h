@@ -167,3 +167,15 @@ struct LmSampleParams {
     float temp;
 };
 int rst_launch_lm_sample(const LmSampleParams& p, hipStream_t stream);
+
+struct SkinnyParams {
+    const float* x;             // [B][ldx] fp32 (prologue 2: [B][2K])
+    const unsigned short* w;    // [N][K] bf16
+    const float* res;           // optional [B][ldy]
+    float* y;                   // [B][ldy]
+    float* ws;                  // split-K partials [splits][B][N]
+    unsigned* counters;         // [ceil(N/32)] arrival counters (zero before the first launch, self re-arming)
+    int B, N, K, ldx, ldy, prologue, k_slice;
+};
+int rst_skinny_plan(int B, int N, int K, int* k_slice, int* splits);
+int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream);

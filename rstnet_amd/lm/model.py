@@ -151,13 +151,13 @@ class StreamingTransformer(StreamingModule[_StepState]):
                 gate = layer.gating[k_idx]
             else:
                 w_in, w_out, gate = att.in_proj_weight, att.out_proj.weight, layer.gating
-            qkv = ops.gemv_bf16(x, w_in, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm1.alpha_f32(), eps=layer.norm1.eps)
+            qkv = ops.lm_linear(x, w_in, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm1.alpha_f32(), eps=layer.norm1.eps)
             a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], st.pos, rope=self.rope, context=self.context,
                                    max_period=self.max_period, scratch=st.scratch)
-            x = ops.gemv_bf16(a, w_out, res=x)
-            h = ops.gemv_bf16(x, gate.linear_in.weight, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm2.alpha_f32(),
+            x = ops.lm_linear(a, w_out, res=x)
+            h = ops.lm_linear(x, gate.linear_in.weight, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm2.alpha_f32(),
                               eps=layer.norm2.eps)
-            x = ops.gemv_bf16(h, gate.linear_out.weight, prologue=ops.PROLOGUE_SILU_GATE, res=x)
+            x = ops.lm_linear(h, gate.linear_out.weight, prologue=ops.PROLOGUE_SILU_GATE, res=x)
         st.pos.add_(1)
         st.offset_cpu += 1
         return x
@@ -270,7 +270,7 @@ class LMModel(StreamingContainer):
         x = ops.embed_sum(toks, tables, list(range(1, K)) + [0])     # ((e_0 + e_1) + ...) + text, as the reference
         x = self.transformer.step(x)
         out = ops.rmsnorm(x, self.out_norm.alpha_f32(), self.out_norm.eps)
-        logits = ops.gemv_bf16(out, self.text_linear.weight)
+        logits = ops.lm_linear(out, self.text_linear.weight)
         return out.view(B, 1, self.dim), logits.view(B, 1, 1, -1)
 
     def forward_depformer(self, depformer_cb_index: int, sequence: torch.Tensor, transformer_out: torch.Tensor) -> torch.Tensor:
@@ -280,11 +280,11 @@ class LMModel(StreamingContainer):
         assert S == 1, f"Steps for Depformer streaming should be passed 1 by 1, got {S}."
         assert transformer_out.shape[1] == 1, "Transformer out should be a for a single step."
         k = depformer_cb_index
-        h = ops.gemv_bf16(transformer_out.reshape(B, self.dim).contiguous(), self.depformer_in[k].weight)
+        h = ops.lm_linear(transformer_out.reshape(B, self.dim).contiguous(), self.depformer_in[k].weight)
         table = self.depformer_text_emb.weight if k == 0 else self.depformer_emb[k - 1].weight
         x = ops.embed_sum(sequence.reshape(B, 1).contiguous(), [table], [0], add=h)
         y = self.depformer.step(x)
-        logits = ops.gemv_bf16(y, self.linears[k].weight)
+        logits = ops.lm_linear(y, self.linears[k].weight)
         return logits.view(B, 1, 1, -1)
 
     @classmethod

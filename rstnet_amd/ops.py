@@ -311,6 +311,53 @@ def gemv_bf16(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE
     return out
 
 
+_skinny_scratch: dict = {}
+
+
+def gemm_skinny(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``y[B,N] = (res +) P(x) @ w.T`` for 4 < B <= 64 on the bf16 matrix cores (rst_gemm_skinny_bf16_f32); ``P`` is the
+    identity or the SiLU gate.  Split-K scratch (partials + self re-arming counters) is cached per shape: launches on one
+    stream are ordered, so layers of equal shape share it."""
+    _chk(x, "x")
+    _chk(w, "w", torch.bfloat16)
+    _chk(res, "res")
+    B = x.shape[0]
+    N, K = w.shape
+    assert x.shape[1] == (2 * K if prologue == PROLOGUE_SILU_GATE else K)
+    key = (x.device, B, N, K)
+    sc = _skinny_scratch.get(key)
+    if sc is None:
+        ks, sp = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().rst_gemm_skinny_plan(B, N, K, C.byref(ks), C.byref(sp)))
+        ws = torch.empty(sp.value, B, N, device=x.device, dtype=torch.float32) if sp.value > 1 else None
+        cnt = torch.zeros((N + 31) // 32, device=x.device, dtype=torch.int32) if sp.value > 1 else None
+        sc = _skinny_scratch[key] = (ks.value, ws, cnt)
+    k_slice, ws, cnt = sc
+    out = torch.empty(B, N, device=x.device, dtype=torch.float32)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.lib().rst_gemm_skinny_bf16_f32(_ptr(x), _ptr(w), _ptr(res), _ptr(out), _ptr(ws), _ptr(cnt), B, N, K, x.shape[1], N,
+                                                  prologue, k_slice, _stream()))
+    if prof is not None:
+        e1.record()
+        prof.append(("gemm_skinny", e0, e1, 2.0 * B * N * K, 2 * N * K + 4 * (x.numel() + out.numel()), (B, N, K)))
+    return out
+
+
+def lm_linear(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
+              eps: float = 1e-8, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Batch-size dispatch of one decode-step linear: weight-streaming GEMV for B <= 4, bf16-MFMA skinny GEMM above
+    (RMSNorm then runs as its own small kernel)."""
+    if x.shape[0] <= 4:
+        return gemv_bf16(x, w, prologue=prologue, alpha=alpha, eps=eps, res=res)
+    if prologue == PROLOGUE_RMSNORM:
+        x = rmsnorm(x, alpha, eps)
+        prologue = PROLOGUE_NONE
+    return gemm_skinny(x, w, prologue=prologue, res=res)
+
+
 def embed_sum(tokens: torch.Tensor, tables: Sequence[torch.Tensor], tok_index: Sequence[int],
               add: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``out[b] = (add[b] +) sum_i tables[i][tokens[b, tok_index[i]]]``; tokens int64 ``[B, n]``, tables bf16 ``[rows, D]``."""

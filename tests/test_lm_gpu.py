@@ -44,6 +44,53 @@ def test_gemv_bf16_prologues(B, N, K):
     assert rel_err(y, (F.silu(u[:, :K]) * u[:, K:]) @ wf.t()) < 1e-5
 
 
+@pytest.mark.parametrize("B,N,K", [(32, 4096, 4096), (5, 1000, 1024), (17, 37, 2816), (64, 2048, 1024), (33, 12288, 4096), (8, 96, 64)])
+def test_gemm_skinny_bf16(B, N, K):
+    """bf16-MFMA skinny GEMM with hi/lo-split activations: fp32-class accuracy against the fp32 oracle product."""
+    g = torch.Generator().manual_seed(B + N + K)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    x = torch.randn(B, K, generator=g)
+    res = torch.randn(B, N, generator=g)
+    wf = w.float()
+    ref = x.double() @ wf.double().t()
+    y = ops.gemm_skinny(x.to(DEV), w.to(DEV))
+    assert rel_err(y, ref) < 5e-5
+    y2 = ops.gemm_skinny(x.to(DEV), w.to(DEV))
+    assert torch.equal(y, y2), "split-K reduction must be deterministic"
+    y = ops.gemm_skinny(x.to(DEV), w.to(DEV), res=res.to(DEV))
+    assert rel_err(y, res.double() + ref) < 5e-5
+    u = torch.randn(B, 2 * K, generator=g)
+    y = ops.gemm_skinny(u.to(DEV), w.to(DEV), prologue=ops.PROLOGUE_SILU_GATE)
+    assert rel_err(y, (F.silu(u[:, :K]) * u[:, K:]).double() @ wf.double().t()) < 5e-5
+
+
+def test_lm_batch8_matches_oracle():
+    """The B > 4 path (rmsnorm + skinny GEMM) through forward_text / forward_depformer on the tiny config."""
+    cfg = dict(synth.LM_TINY)
+    sd = synth.lm_state_dict(cfg, cases.LM_SEED)
+    model = LMModel.from_state_dict({k: v.to(DEV) for k, v in sd.items()}, cfg)
+    ocfg = L.LMConfig(**cfg)
+    sdf = {k: v.float() for k, v in sd.items()}
+    B = 8
+    gt = torch.Generator().manual_seed(6)
+    st = L.new_transformer_state(B, ocfg.num_layers, ocfg.num_heads, ocfg.dim // ocfg.num_heads, ocfg.context)
+    with model.streaming(B):
+        for s in range(12):
+            toks = torch.randint(0, cfg["card"], (B, cfg["n_q"] + 1, 1), generator=gt)
+            ref_out, ref_logits = L.forward_text(sdf, ocfg, toks, st)
+            out, logits = model.forward_text(toks.to(DEV))
+            assert rel_err(out, ref_out) < 1e-3 and rel_err(logits, ref_logits) < 1e-3, f"step {s}"
+        dst = L.new_transformer_state(B, ocfg.depformer_num_layers, ocfg.depformer_num_heads,
+                                      ocfg.depformer_dim // ocfg.depformer_num_heads, ocfg.dep_q)
+        model.depformer._streaming_state = model.depformer._init_streaming_state(B)
+        prev = torch.randint(0, cfg["text_card"], (B, 1, 1), generator=gt)
+        for cb in range(cfg["dep_q"]):
+            rl = L.forward_depformer(sdf, ocfg, cb, prev, ref_out, dst)
+            gl = model.forward_depformer(cb, prev.to(DEV), out)
+            assert rel_err(gl, rl) < 1e-3
+            prev = torch.randint(0, cfg["card"], (B, 1, 1), generator=gt)
+
+
 def test_embed_sum_and_rmsnorm():
     g = torch.Generator().manual_seed(1)
     tabs = [(0.5 * torch.randn(33, 256, generator=g)).bfloat16() for _ in range(5)]
