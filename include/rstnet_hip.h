@@ -44,10 +44,16 @@ const char* rst_last_error(void);
  *   y[b*T_out + t][n] = epi( sum_{k<K} act_in(A(b,t,k)) * w[n][k] + bias[n] ),  A(b,t,k) = xflat_b[(t*S - P)*C + k]
  *   epi(v) = res ? res + (scale ? scale[n] : 1) * act_out(v) : act_out(v)
  * Elements before the start of a batch item come from hist ([B][P][C]) if given, else are zero / replicated;
- * elements past the end are zero.  All three named wrappers below are thin fronts for it. */
+ * elements past the end are zero.  All three named wrappers below are thin fronts for it.
+ * split_k > 1 (only for B*T_out <= 32 rows, N > 64: the per-frame streaming steps, which are weight-bandwidth bound):
+ * K is split over split_k workgroups per N tile; ws [split_k][B*T_out][N] floats and counters [ceil(N/128)] uint32
+ * (zeroed once by the caller, self re-arming) carry the deterministic in-launch reduction.
+ * rst_gemm_win_split_plan(M, N, K) returns the recommended split_k (1 = no split). */
+int rst_gemm_win_split_plan(int64_t M, int N, int K);
 int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const float* bias, const float* res,
                      const float* scale, float* y, int B, int T_in, int T_out, int C, int K, int N, int S, int P,
-                     int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, rst_stream_t stream);
+                     int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, int split_k, float* ws,
+                     uint32_t* counters, rst_stream_t stream);
 
 /* Causal Conv1d.  Replaces F.conv1d in RawStreamingConv1d.forward (modules/streaming.py:216-244) together with the
  * padding logic of StreamingConv1d.forward (modules/conv.py:232-254).
@@ -110,9 +116,12 @@ int rst_rvq_pack_f32(const float* emb, float* packed, float* e2, int n_codes, in
 /* Residual VQ nearest-codeword search, all levels fused: EuclideanCodebook._quantize + the residual loop of
  * ResidualVectorQuantization.encode (quantization/core_vq.py:179-185, 365-376).  x [M][ldx] holds the projected
  * latents of group g in columns [g*D, (g+1)*D); group g runs levels [group_begin[g], +group_count[g]).
- * codes [B][L][F] int64 with M = B*F.  dist (optional) [L][M] = winning score |e|^2 - 2 x.e. */
+ * codes [B][L][F] int64 with M = B*F.  dist (optional) [L][M] = winning score |e|^2 - 2 x.e.
+ * keys == NULL: one launch, a workgroup per 32 frames runs all levels (thousands of frames).  keys != NULL ([L][M] uint64,
+ * all-ones before the first call, re-armed by the call): the few-frame streaming form -- codes are spread over workgroups,
+ * one launch per level, winners published with a 64-bit atomicMin; decisions are bit-identical to the fused form. */
 int rst_rvq_search_f32(const float* x, const float* emb, const float* packed, const float* e2, int64_t* codes,
-                       float* dist, int M, int F, int ldx, int D, int n_codes, int L, int n_groups,
+                       float* dist, uint64_t* keys, int M, int F, int ldx, int D, int n_codes, int L, int n_groups,
                        const int* group_begin, const int* group_count, rst_stream_t stream);
 
 /* Sum of codebook rows per group = ResidualVectorQuantization.decode (core_vq.py:378-384): out [M][n_groups*D]. */
@@ -180,6 +189,14 @@ int rst_lm_rope_append_f32(const float* qkv, float* q, float* k, float* v, const
 int rst_lm_attn_decode_f32(const float* qkv, float* k, float* v, float* ws, uint32_t* counters, float* out,
                            const int64_t* pos_dev, int B, int H, int D, int cap, int context, int splits, int ldqkv, int rope,
                            float rope_coef, rst_stream_t stream);
+
+/* The few-query form of rst_attention_f32(ring = 1) for streaming steps of the codec transformers (T <= a few new steps per
+ * call): q [B][H][T][D] already rotated and k / v already appended by rst_rope_split_f32; every (b, t, h) query is split
+ * over the occupied ring slots like rst_lm_attn_decode_f32 (same mask / slot map with end_offset = *pos_dev + T).
+ * out [B][T][H*D].  ws [B*T][H][splits][D+2], counters [B*T][H] (needed when splits > 1). */
+int rst_attn_decode_multi_f32(const float* q, const float* k, const float* v, float* ws, uint32_t* counters, float* out,
+                              const int64_t* pos_dev, int B, int T, int H, int D, int cap, int context, int splits,
+                              rst_stream_t stream);
 
 /* sample_token (utils/sampling.py:85-105): greedy argmax, or softmax(logits/temp) -> top-k (sorted descending) ->
  * argmax_j p_j / noise_j with caller-provided Exp(1) noise [B][noise_stride] (the reference draws it with

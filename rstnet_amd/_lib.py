@@ -19,7 +19,8 @@ _f = C.c_float
 
 # name -> argtypes (all functions return int); mirrors include/rstnet_hip.h one to one
 SIGNATURES = {
-    "rst_gemm_win_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _i, _i, _p],
+    "rst_gemm_win_split_plan": [_l, _i, _i],
+    "rst_gemm_win_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _i, _i, _i, _p, _p, _p],
     "rst_conv1d_causal_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rst_convtr1d_causal_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rst_seanet_resblock_supported": [_i, _i, _i, _i, _i, _i, _i],
@@ -29,7 +30,7 @@ SIGNATURES = {
     "rst_rope_split_f32": [_p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "rst_attention_f32": [_p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "rst_rvq_pack_f32": [_p, _p, _p, _i, _i, _p],
-    "rst_rvq_search_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _p],
+    "rst_rvq_search_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _p],
     "rst_rvq_gather_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _p],
     "rst_convtr_depthwise_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "rst_act_f32": [_p, _p, _l, _i, _p],
@@ -42,6 +43,7 @@ SIGNATURES = {
     "rst_rmsnorm_f32": [_p, _p, _p, _l, _i, _f, _p],
     "rst_lm_rope_append_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p],
     "rst_lm_attn_decode_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "rst_attn_decode_multi_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rst_lm_sample_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
 }
 

@@ -18,10 +18,24 @@ from . import transformer as Stransformer
 from .quantization import SplitResidualVectorQuantizer
 from .resample import ConvDownsample1d, ConvTrUpsample1d
 from .seanet import SEANetDecoder, SEANetEncoder
-from .streaming import StreamingContainer
+from dataclasses import dataclass, field
+
+from ..graphs import Graphed
+from .streaming import StreamingModule
 
 
-class MimiCodec(StreamingContainer):
+@dataclass
+class _MimiState:
+    """Per-streaming-session graph wrappers (one per input shape) of the encode / decode step."""
+    enc: dict = field(default_factory=dict)
+    dec: dict = field(default_factory=dict)
+
+    def reset(self) -> None:
+        self.enc.clear()
+        self.dec.clear()
+
+
+class MimiCodec(StreamingModule[_MimiState]):
     def __init__(self, sample_rate: int = 24000, n_filters: int = 64, encoder_rates: List[int] = [4, 5, 6, 8],
                  compress: int = 2, causal: bool = True, latent_dim: int = 512, codebook_size: int = 4096,
                  codebook_dim: int = 32, rvq_layers: int = 8, num_heads: int = 8, num_layers: int = 8,
@@ -56,6 +70,9 @@ class MimiCodec(StreamingContainer):
         self.quantizer = SplitResidualVectorQuantizer(**quantizer_kwargs)
         self.frame_hop = self.hop_length * stride  # samples per code frame (1920 for Mimi)
 
+    def _init_streaming_state(self, batch_size: int) -> _MimiState:
+        return _MimiState()
+
     # ------------------------------------------------------------------ reference API
     def forward(self, audio_data: torch.Tensor, semantic_features: torch.Tensor):
         raise NotImplementedError("the GAN / distillation training forward is out of scope of the inference hot path")
@@ -72,11 +89,27 @@ class MimiCodec(StreamingContainer):
     @torch.no_grad()
     def encode(self, audio_data: torch.Tensor) -> torch.Tensor:
         """``[B, 1, T]`` fp32 -> ``[B, K, ceil(T / 1920)]`` int64 (streaming: floor, remainder kept in the conv states)."""
-        return self.quantizer.encode_nlc(self.encode_latent(audio_data))
+        state = self._streaming_state
+        if state is None or not audio_data.is_cuda:
+            return self.quantizer.encode_nlc(self.encode_latent(audio_data))
+        # streaming: after two eager frames every step has the same shapes and buffer addresses -> replay a HIP graph
+        g = state.enc.get(tuple(audio_data.shape))
+        if g is None:
+            g = state.enc[tuple(audio_data.shape)] = Graphed(lambda a: self.quantizer.encode_nlc(self.encode_latent(a)), warmup=2)
+        return g(audio_data.contiguous()).clone()
 
     @torch.no_grad()
     def decode(self, codes: torch.Tensor) -> torch.Tensor:
         """``[B, K, F]`` int64 -> ``[B, 1, F * 1920]`` fp32 (not trimmed, as in the reference)."""
+        state = self._streaming_state
+        if state is None or not codes.is_cuda:
+            return self._decode(codes)
+        g = state.dec.get(tuple(codes.shape))
+        if g is None:
+            g = state.dec[tuple(codes.shape)] = Graphed(self._decode, warmup=2)
+        return g(codes.contiguous()).clone()
+
+    def _decode(self, codes: torch.Tensor) -> torch.Tensor:
         z = self.quantizer.decode_nlc(codes.contiguous())
         z = self.upsample.forward_nlc(z)
         z = self.decoder_transformer.forward_nlc(z)[0]

@@ -146,9 +146,10 @@ class StreamingMultiheadAttention(StreamingModule[_MHAState]):
             q, k, v = ops.rope_split(qkv, H, pos0=0, rope=use_rope, max_period=period)
             a = ops.attention(q, k, v, pos0=0, ring=False, context=self.context)
         else:
-            q, k, v = ops.rope_split(qkv, H, k=state.k_cache, v=state.v_cache, pos0=offset, ring=True, rope=use_rope,
-                                     max_period=period)
-            a = ops.attention(q, k, v, pos0=offset, ring=True, context=self.context)
+            # position from the device-side counter (graph-replay safe), mirrored on the host in offset_cpu
+            q, k, v = ops.rope_split(qkv, H, k=state.k_cache, v=state.v_cache, pos0=offset, pos_dev=state.offset, ring=True,
+                                     rope=use_rope, max_period=period)
+            a = ops.attention(q, k, v, pos0=offset, pos_dev=state.offset, ring=True, context=self.context)
         out = self._project(self.out_proj.weight, a, offset, res=res, scale=scale)
         if state is not None:
             state.offset.add_(T)

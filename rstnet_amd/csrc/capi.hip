@@ -29,7 +29,8 @@ const char* rst_last_error(void) { return g_err; }
 
 int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const float* bias, const float* res,
                      const float* scale, float* y, int B, int T_in, int T_out, int C, int K, int N, int S, int P,
-                     int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, rst_stream_t stream) {
+                     int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, int split_k, float* ws,
+                     uint32_t* counters, rst_stream_t stream) {
     RST_REQUIRE(ldy >= N, "gemm_win: ldy (%d) < N (%d)", ldy, N);
     RST_REQUIRE(act_in == 0 || act_in == 1, "gemm_win: unknown act_in %d", act_in);
     RST_REQUIRE(act_out >= 0 && act_out <= 2, "gemm_win: unknown act_out %d", act_out);
@@ -38,15 +39,19 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
     p.x = x; p.hist = hist; p.w = w; p.bias = bias; p.res = res; p.scale = scale; p.y = y;
     p.B = B; p.T_in = T_in; p.T_out = T_out; p.C = C; p.K = K; p.N = N; p.S = S; p.P = P;
     p.pad_mode = pad_mode; p.x_bstride = x_bstride; p.ldy = ldy; p.act_in = act_in; p.act_out = act_out;
+    p.split_k = split_k; p.ws = ws; p.counters = counters;
+    RST_REQUIRE(split_k <= 1 || ldy == N, "gemm_win: split-K needs ldy == N");
     return rst_launch_gemm_win(p, (hipStream_t)stream);
 }
+
+int rst_gemm_win_split_plan(int64_t M, int N, int K) { return rst_gemm_win_split_plan((long)M, N, K); }
 
 int rst_conv1d_causal_f32(const float* x, const float* hist, const float* w_packed, const float* bias,
                           const float* res, float* y, int B, int T_in, int T_out, int Cin, int Cout, int Kw_eff,
                           int stride, int pad_mode, int act_in, int act_out, rst_stream_t stream) {
     RST_REQUIRE(Kw_eff >= stride && stride > 0, "conv1d: kernel (%d) must be >= stride (%d)", Kw_eff, stride);
     return rst_gemm_win_f32(x, hist, w_packed, bias, res, nullptr, y, B, T_in, T_out, Cin, Kw_eff * Cin, Cout, stride,
-                            Kw_eff - stride, pad_mode, (int64_t)T_in * Cin, Cout, act_in, act_out, stream);
+                            Kw_eff - stride, pad_mode, (int64_t)T_in * Cin, Cout, act_in, act_out, 1, nullptr, nullptr, stream);
 }
 
 int rst_convtr1d_causal_f32(const float* x, const float* hist, const float* w_packed, const float* bias_tiled,
@@ -55,14 +60,15 @@ int rst_convtr1d_causal_f32(const float* x, const float* hist, const float* w_pa
     RST_REQUIRE(Kw >= stride && stride > 0, "convtr1d: kernel (%d) must be >= stride (%d)", Kw, stride);
     const int q = (Kw + stride - 1) / stride;
     return rst_gemm_win_f32(x, hist, w_packed, bias_tiled, nullptr, nullptr, y, B, T_in, T_in, Cin, q * Cin,
-                            stride * Cout, 1, q - 1, 0, (int64_t)T_in * Cin, stride * Cout, act_in, act_out, stream);
+                            stride * Cout, 1, q - 1, 0, (int64_t)T_in * Cin, stride * Cout, act_in, act_out, 1, nullptr, nullptr,
+                            stream);
 }
 
 int rst_linear_f32(const float* x, const float* w, const float* bias, const float* res, const float* scale, float* y,
                    int64_t M, int K, int N, int act_out, rst_stream_t stream) {
     RST_REQUIRE(M >= 0 && M < 0x7fffffffLL, "linear: M out of range");
     return rst_gemm_win_f32(x, nullptr, w, bias, res, scale, y, 1, (int)M, (int)M, K, K, N, 1, 0, 0, M * K, N, 0,
-                            act_out, stream);
+                            act_out, 1, nullptr, nullptr, stream);
 }
 
 int rst_seanet_resblock_supported(int C, int H, int Kw, int pre, int post, int K0, int Kf) {
@@ -107,7 +113,7 @@ int rst_rvq_pack_f32(const float* emb, float* packed, float* e2, int n_codes, in
 }
 
 int rst_rvq_search_f32(const float* x, const float* emb, const float* packed, const float* e2, int64_t* codes,
-                       float* dist, int M, int F, int ldx, int D, int n_codes, int L, int n_groups,
+                       float* dist, uint64_t* keys, int M, int F, int ldx, int D, int n_codes, int L, int n_groups,
                        const int* group_begin, const int* group_count, rst_stream_t stream) {
     RST_REQUIRE(n_groups >= 1 && n_groups <= 2 && group_begin && group_count, "rvq_search: bad groups");
     RvqSearchParams p;
@@ -119,6 +125,7 @@ int rst_rvq_search_f32(const float* x, const float* emb, const float* packed, co
         RST_REQUIRE(p.group_begin[g] >= 0 && p.group_count[g] >= 0 && p.group_begin[g] + p.group_count[g] <= L,
                     "rvq_search: group %d out of range", g);
     }
+    if (keys) return rst_launch_rvq_search_small(p, (unsigned long long*)keys, (hipStream_t)stream);
     return rst_launch_rvq_search(p, (hipStream_t)stream);
 }
 
@@ -202,9 +209,20 @@ int rst_lm_attn_decode_f32(const float* qkv, float* k, float* v, float* ws, uint
                            const int64_t* pos_dev, int B, int H, int D, int cap, int context, int splits, int ldqkv, int rope,
                            float rope_coef, rst_stream_t stream) {
     LmAttnParams p;
+    p.q_pre = nullptr; p.T = 1;
     p.qkv = qkv; p.k = k; p.v = v; p.ws = ws; p.counters = counters; p.out = out; p.pos_dev = (const long*)pos_dev;
     p.B = B; p.H = H; p.D = D; p.cap = cap; p.context = context; p.splits = splits; p.ldqkv = ldqkv; p.rope = rope;
     p.rope_coef = rope_coef;
+    return rst_launch_lm_attn(p, (hipStream_t)stream);
+}
+
+int rst_attn_decode_multi_f32(const float* q, const float* k, const float* v, float* ws, uint32_t* counters, float* out,
+                              const int64_t* pos_dev, int B, int T, int H, int D, int cap, int context, int splits,
+                              rst_stream_t stream) {
+    LmAttnParams p;
+    p.qkv = nullptr; p.q_pre = q; p.T = T; p.k = const_cast<float*>(k); p.v = const_cast<float*>(v); p.ws = ws; p.counters = counters;
+    p.out = out; p.pos_dev = (const long*)pos_dev; p.B = B; p.H = H; p.D = D; p.cap = cap; p.context = context; p.splits = splits;
+    p.ldqkv = 0; p.rope = 0; p.rope_coef = 0.f;
     return rst_launch_lm_attn(p, (hipStream_t)stream);
 }
 

@@ -163,15 +163,21 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    const int nk = (p.K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
+    // split-K (few-row streaming steps): workgroup blockIdx.y owns k-tiles [kt0, kt1)
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int per_split = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kt0 = blockIdx.y * per_split;
+    const int nk = min(nk_all, kt0 + per_split);
+    if (kt0 < nk) {
+        load_tiles(kt0);
+        store_tiles(kt0 & 1);
+    }
     __syncthreads();
 
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tiles(kt + 1);
         const float* a = As + buf * BM * LDS_LD + (wm * TM * 32 + frag_row) * LDS_LD + frag_k;
@@ -195,6 +201,49 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
         __builtin_amdgcn_s_setprio(0);
         if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
+    }
+
+    // ---- split-K reduction: write-through partials + arrival counter; the last workgroup of the tile sums them in a
+    // fixed order (deterministic) and runs the epilogue (cdna_hip_programming.md G16, counter form)
+    if (gridDim.y > 1) {
+        __shared__ int sm_last;
+        float* wsb = p.ws + (long)blockIdx.y * M * p.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + (wm * TM + i) * 32 + rst_mfma32_row(e, lane);
+                    if (n < p.N && m < M)
+                        __hip_atomic_store(wsb + (long)m * p.N + n, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sm_last = prev == gridDim.y - 1;
+            if (sm_last) __hip_atomic_store(p.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!sm_last) return;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + (wm * TM + i) * 32 + rst_mfma32_row(e, lane);
+                    float s = 0.f;
+                    if (n < p.N && m < M)
+                        for (unsigned ks = 0; ks < gridDim.y; ++ks)
+                            s += __hip_atomic_load(p.ws + ((long)ks * M + m) * p.N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc[i][j][e] = s;
+                }
+        }
     }
 
     // ---- epilogue: bias -> GELU? -> (residual + scale *) -> ELU? -> store; 32 consecutive columns per half wave.
@@ -241,10 +290,12 @@ int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
     auto go = [&](auto kern) {
         static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel instantiation
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            // the kernel also has a few bytes of static LDS: stay below the 160 KiB total (the largest tile needs 83 KiB)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipGetLastError();
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)(p.split_k > 1 ? p.split_k : 1)), dim3(256), lds, stream, p);
     };
     const bool elu = p.act_in == 1;
     if (vec && elu) go(gemm_win_kernel<TM, TN, WM, WN, true, true>);
@@ -255,6 +306,16 @@ int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
 }
 
 }  // namespace
+
+int rst_gemm_win_split_plan(long M, int N, int K) {
+    // few-row calls (streaming steps) are weight-bandwidth bound: spread K over enough workgroups to fill the chip
+    if (M > 32 || N <= 64) return 1;
+    const int tiles = (N + 127) / 128;
+    const int nk = (K + BK - 1) / BK;
+    int s = 1;
+    while (tiles * s < 256 && nk / (2 * s) >= 2 && s < 64) s *= 2;
+    return s;
+}
 
 int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B >= 0 && p.T_in >= 0 && p.T_out >= 0 && p.C > 0 && p.K > 0 && p.N > 0 && p.S > 0 && p.P >= 0,
@@ -268,6 +329,7 @@ int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
                      ((uintptr_t)p.x % 16 == 0) && ((uintptr_t)p.w % 16 == 0) &&
                      (!p.hist || (uintptr_t)p.hist % 16 == 0);
     const long M = (long)p.B * p.T_out;
+    RST_REQUIRE(p.split_k <= 1 || (p.ws && p.counters && M <= 32 && p.N > 64), "gemm_win: split-K needs M <= 32, N > 64 and the scratch buffers");
     if (p.N > 64 && M > 64) return launch_cfg<2, 2, 2, 2>(p, vec, stream);   // 128 x 128
     if (p.N > 64) return launch_cfg<1, 1, 1, 4>(p, vec, stream);             // 32 x 128 (few rows: streaming steps)
     if (p.N > 32) return launch_cfg<1, 2, 4, 1>(p, vec, stream);             // 128 x 64

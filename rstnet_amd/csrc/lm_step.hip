@@ -32,8 +32,7 @@ constexpr int GEMV_WAVES = 4;
 
 // Ring slot -> position map of RingKVCache.complete (modules/transformer.py:254-278) incl. the `delta <= 0` quirk (Q1);
 // returns whether `slot` is visible to the query at position `pos` (= the step just appended).
-__device__ __forceinline__ bool ring_visible(int slot, long pos, int cap, int context) {
-    const long end_offset = pos + 1;
+__device__ __forceinline__ bool ring_visible(int slot, long pos, int cap, int context, long end_offset) {
     const int end_index = (int)(end_offset % cap);
     const int delta = slot - end_index;
     long pk = delta <= 0 ? end_offset + delta : end_offset + delta - cap;
@@ -238,9 +237,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane % LPS, grp = lane / LPS;
     const int split = blockIdx.x, h = blockIdx.y;
-    const long b = blockIdx.z;
-    const long pos = *p.pos_dev;                 // position of the query = index of the step being appended
-    const int slot_cur = (int)(pos % p.cap);
+    const int T = p.q_pre ? p.T : 1;
+    const long b = blockIdx.z / T;
+    const int tq = blockIdx.z % T;
+    const long pos = *p.pos_dev;                 // position of the first new step
+    const long pos_q = pos + tq;                 // position of this query
+    const long end_offset = pos + T;             // RingKVCache.end_offset after the append of all T new steps
+    const int slot_cur = p.q_pre ? -1 : (int)(pos % p.cap);   // fused mode: the slot this launch appends
     const float scale = 1.0f / sqrtf((float)D);
     const long HD = (long)p.H * D;
 
@@ -254,16 +257,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
             rc[i] = cosf(ang); rs[i] = sinf(ang);
         }
     }
-    const float* qkv = p.qkv + b * p.ldqkv + (long)h * D + sub * 16;
+    const float* qkv = p.q_pre ? nullptr : p.qkv + b * p.ldqkv + (long)h * D + sub * 16;
     float q[16], kcur[16];
+    if (p.q_pre) {      // queries already rotated, keys already in the ring (codec transformer: rst_rope_split_f32 ran before)
+        const float* qp = p.q_pre + (((b * p.H + h) * T) + tq) * (long)D + sub * 16;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float qr = qkv[2 * i], qi = qkv[2 * i + 1], kr = qkv[HD + 2 * i], ki = qkv[HD + 2 * i + 1];
-        q[2 * i] = qr * rc[i] - qi * rs[i]; q[2 * i + 1] = qr * rs[i] + qi * rc[i];
-        kcur[2 * i] = kr * rc[i] - ki * rs[i]; kcur[2 * i + 1] = kr * rs[i] + ki * rc[i];
+        for (int i = 0; i < 16; ++i) { q[i] = qp[i]; kcur[i] = 0.f; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float qr = qkv[2 * i], qi = qkv[2 * i + 1], kr = qkv[HD + 2 * i], ki = qkv[HD + 2 * i + 1];
+            q[2 * i] = qr * rc[i] - qi * rs[i]; q[2 * i + 1] = qr * rs[i] + qi * rc[i];
+            kcur[2 * i] = kr * rc[i] - ki * rs[i]; kcur[2 * i + 1] = kr * rs[i] + ki * rc[i];
+        }
     }
 
-    const int n_used = (int)min((long)p.cap, pos + 1);          // slots >= end_offset are never visible
+    const int n_used = (int)min((long)p.cap, end_offset);       // slots >= end_offset are never visible
     const int active = max(1, min((int)gridDim.x, (n_used + 63) / 64));   // splits that have work at this context length
     if (split >= active) return;
     const int per = (n_used + active - 1) / active;
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
 
     for (int s0 = s_lo + wave * SPW; s0 < s_hi; s0 += 4 * SPW) {
         const int slot = s0 + grp;
-        const bool ok = slot < s_hi && ring_visible(slot, pos, p.cap, p.context);
+        const bool ok = slot < s_hi && ring_visible(slot, pos_q, p.cap, p.context, end_offset);
         float kv[16], vv[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { kv[i] = 0.f; vv[i] = 0.f; }
@@ -344,10 +353,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
             O += sm_o[w][tid] * fw;
         }
         if (active == 1) {                          // single split: finished
-            p.out[(b * p.H + h) * (long)D + tid] = L > 0.f ? O / L : 0.f;
+            p.out[((b * T + tq) * p.H + h) * (long)D + tid] = L > 0.f ? O / L : 0.f;
         } else {
             // write-through (sc1) partials: visible at agent scope without an L2 write-back fence (cdna_hip_programming.md G16 R1)
-            float* ws = p.ws + (((b * p.H + h) * gridDim.x) + split) * (long)(D + 2);
+            float* ws = p.ws + ((((long)blockIdx.z * p.H + h) * gridDim.x) + split) * (long)(D + 2);
             __hip_atomic_store(ws + 2 + tid, O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tid == 0) {
                 __hip_atomic_store(ws, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -363,14 +372,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(p.counters + (b * p.H + h), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned* cnt = p.counters + ((long)blockIdx.z * p.H + h);
+        const unsigned prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sm_last = prev == (unsigned)active - 1;
-        if (sm_last) __hip_atomic_store(p.counters + (b * p.H + h), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sm_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!sm_last) return;
     if (tid < D) {
-        const float* w0 = p.ws + ((b * p.H + h) * gridDim.x) * (long)(D + 2);
+        const float* w0 = p.ws + (((long)blockIdx.z * p.H + h) * gridDim.x) * (long)(D + 2);
         float M = -INFINITY;
         for (int s2 = 0; s2 < active; ++s2) M = fmaxf(M, __hip_atomic_load(w0 + (long)s2 * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         float L = 0.f, O = 0.f;
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
             L = fmaf(__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fw, L);
             O = fmaf(__hip_atomic_load(w + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fw, O);
         }
-        p.out[(b * p.H + h) * (long)D + tid] = L > 0.f ? O / L : 0.f;
+        p.out[((b * T + tq) * p.H + h) * (long)D + tid] = L > 0.f ? O / L : 0.f;
     }
 }
 
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(64) void attn_small_kernel(const LmAttnParams p) {
         vc[(long)slot_cur * D + 2 * i + 1] = qkv[2 * HD + 2 * i + 1];
     }
     // the new step is never re-read from memory: its key / value come from qkv
-    const bool ok = lane < cap && ring_visible(lane, pos, cap, p.context);
+    const bool ok = lane < cap && ring_visible(lane, pos, cap, p.context, pos + 1);
     float sc = -INFINITY;
     if (ok) {
         float d = 0.f;
@@ -648,15 +658,16 @@ int rst_launch_lm_rope_append(const LmRopeAppendParams& p, hipStream_t stream) {
 }
 
 int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream) {
-    RST_REQUIRE(p.qkv && p.k && p.v && p.out && p.pos_dev && p.B >= 1 && p.H > 0 && p.cap > 0 && p.splits >= 1,
+    RST_REQUIRE((p.qkv || p.q_pre) && p.k && p.v && p.out && p.pos_dev && p.B >= 1 && p.H > 0 && p.cap > 0 && p.splits >= 1,
                 "lm_attn: bad arguments");
-    RST_REQUIRE(p.B <= 65535 && p.H <= 65535 && p.D % 2 == 0, "lm_attn: bad sizes");
-    if (p.cap <= 64 && p.splits == 1) {
+    const int T = p.q_pre ? p.T : 1;
+    RST_REQUIRE(T >= 1 && (long)p.B * T <= 65535 && p.H <= 65535 && p.D % 2 == 0, "lm_attn: bad sizes");
+    if (!p.q_pre && p.cap <= 64 && p.splits == 1) {
         hipLaunchKernelGGL(attn_small_kernel, dim3(p.H, p.B), dim3(64), 0, stream, p);
         return rst_check_launch("lm_attn_small");
     }
     RST_REQUIRE(p.splits == 1 || (p.ws && p.counters), "lm_attn: splits > 1 need the workspace and the (zeroed) counters");
-    const dim3 grid(p.splits, p.H, p.B);
+    const dim3 grid(p.splits, p.H, p.B * T);
     switch (p.D) {
         case 64: hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, stream, p); break;
         case 128: hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, stream, p); break;

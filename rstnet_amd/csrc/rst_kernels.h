@@ -21,8 +21,12 @@ struct GemmWinParams {
     int ldy;             // floats between consecutive output rows (>= N)
     int act_in;          // 0: none, 1: ELU applied to A on load
     int act_out;         // 0: none, 1: exact GELU (before the residual), 2: ELU (applied last, after the residual)
+    int split_k;         // > 1: K split over gridDim.y workgroups (M <= 32 only), partials in ws, counters per N tile
+    float* ws;           // [split_k][M][N]
+    unsigned* counters;  // [ceil(N/128)], zero before the first launch (self re-arming)
 };
 int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream);
+int rst_gemm_win_split_plan(long M, int N, int K);
 
 // ---- resblock.hip ---------------------------------------------------------------------------------
 struct ResblockParams {
@@ -100,6 +104,8 @@ struct RvqSearchParams {
     int group_count[2];
 };
 int rst_launch_rvq_search(const RvqSearchParams& p, hipStream_t stream);
+// few-frame variant: codes spread over workgroups, one launch per level; keys [L][M] uint64, all-ones before the first call
+int rst_launch_rvq_search_small(const RvqSearchParams& p, unsigned long long* keys, hipStream_t stream);
 struct RvqGatherParams {
     const long* codes;     // [B][L][F]
     const float* emb;      // [L][n_codes][D]
@@ -147,7 +153,9 @@ struct LmRopeAppendParams {
 int rst_launch_lm_rope_append(const LmRopeAppendParams& p, hipStream_t stream);
 
 struct LmAttnParams {
-    const float* qkv;     // [B][ldqkv]: [q | k | v] of the new step, each H*D (un-rotated)
+    const float* qkv;     // [B][ldqkv]: [q | k | v] of the new step, each H*D (un-rotated); or nullptr with q_pre
+    const float* q_pre;   // optional [B][H][T][D]: rotated queries of T new steps whose keys are already in the ring
+    int T;
     float* k;             // [B][H][cap][D] ring (the new step is appended)
     float* v;
     float* ws;            // [B][H][splits][D+2] workspace: (m, l, o[D]) per split (splits > 1)

@@ -124,6 +124,97 @@ __global__ __launch_bounds__(64 * NW) void rvq_search_kernel(const RvqSearchPara
     }
 }
 
+// ---- few-frame path (streaming steps: M <= a few dozen frames) ------------------------------------------------------
+// The big kernel serialises 2048 codes x 7 levels inside one workgroup, which is the right shape for thousands of frames
+// but ~1 ms of latency for one.  Here the CODES are spread over workgroups instead: one launch per residual level, every
+// workgroup re-derives the level's residual from x and the winners of the previous levels (exact, sequential
+// subtractions), scores its 128 codes with the SAME k-ordered MFMA chain, and publishes (score, index) with a 64-bit
+// atomicMin on an order-preserving key -- lowest score, then lowest index: bit-identical decisions to the big kernel.
+__device__ __forceinline__ unsigned long long rvq_key(float score, int code) {
+    unsigned u = __float_as_uint(score);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // monotonic float -> uint
+    return ((unsigned long long)u << 32) | (unsigned)code;
+}
+
+__global__ __launch_bounds__(256) void rvq_level_kernel(const RvqSearchParams p, unsigned long long* __restrict__ keys, int step) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int D = p.D, LD = D + 4;
+    float* r_pk = smem;                       // [FR][LD]
+    int* prev = reinterpret_cast<int*>(r_pk + FR * LD);   // [FR] winner of the previous level
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int g = blockIdx.y;
+    if (step >= p.group_count[g]) return;
+    const int lvl = p.group_begin[g] + step;
+    const int m0 = blockIdx.z * FR;
+    // residual of this level: ((x - e_0[c_0]) - e_1[c_1]) - ...   in level order, exactly as the fused kernel does
+    for (int idx = tid; idx < FR * D; idx += 256) {
+        const int f = idx / D, k = idx - f * D;
+        const int m = m0 + f;
+        r_pk[f * LD + pk_off(k)] = m < p.M ? p.x[(long)m * p.ldx + g * D + k] : 0.f;
+    }
+    for (int s = 0; s < step; ++s) {
+        const int lv = p.group_begin[g] + s;
+        __syncthreads();
+        if (tid < FR) prev[tid] = (m0 + tid < p.M) ? (int)(keys[(long)lv * p.M + m0 + tid] & 0xffffffffu) : 0;
+        __syncthreads();
+        const float* emb = p.emb + (long)lv * p.n_codes * D;
+        for (int idx = tid; idx < FR * D; idx += 256) {
+            const int f = idx / D, k = idx - f * D;
+            r_pk[f * LD + pk_off(k)] -= emb[(long)prev[f] * D + k];
+        }
+    }
+    __syncthreads();
+    const int c0 = (blockIdx.x * 4 + wave) * 32;
+    if (c0 >= p.n_codes) return;
+    const float* packed = p.packed + (long)lvl * p.n_codes * D;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const float* ap = packed + (long)(c0 + j) * 8 + h * 4;
+    const float* rrow = r_pk + j * LD + h * 4;
+    for (int kq = 0; kq < D / 8; ++kq) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + (long)kq * p.n_codes * 8);
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(rrow + kq * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bq[e], acc, 0, 0, 0);
+    }
+    float best = INFINITY;
+    int bidx = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int code = c0 + rst_mfma32_row(r, lane);
+        const float sc = fmaf(-2.0f, acc[r], p.e2[(long)lvl * p.n_codes + code]);
+        if (sc < best) { best = sc; bidx = code; }
+    }
+    const float ob = __shfl_xor(best, 32);
+    const int oi = __shfl_xor(bidx, 32);
+    if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    if (h == 0 && m0 + j < p.M) atomicMin(keys + (long)lvl * p.M + m0 + j, rvq_key(best, bidx));
+}
+
+__global__ __launch_bounds__(256) void rvq_finalize_kernel(const RvqSearchParams p, unsigned long long* __restrict__ keys) {
+    const long total = (long)p.L * p.M;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int lvl = (int)(idx / p.M);
+        const int m = (int)(idx - (long)lvl * p.M);
+        bool used = false;
+        for (int g = 0; g < p.n_groups; ++g) used = used || (lvl >= p.group_begin[g] && lvl < p.group_begin[g] + p.group_count[g]);
+        const unsigned long long kv = keys[idx];
+        keys[idx] = ~0ull;                                   // re-arm for the next call
+        if (!used) continue;
+        const int b = m / p.F, f = m - b * p.F;
+        int code = (int)(kv & 0xffffffffu);
+        if (code < 0 || code >= p.n_codes) code = 0;        // only reachable with NaN inputs
+        p.codes[((long)b * p.L + lvl) * p.F + f] = code;
+        if (p.dist) {
+            unsigned u = (unsigned)(kv >> 32);
+            u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+            p.dist[idx] = __uint_as_float(u);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void rvq_gather_kernel(const RvqGatherParams p) {
     const int ND = p.n_groups * p.D;
     const long total = (long)p.M * ND;
@@ -171,6 +262,26 @@ int rst_launch_rvq_search(const RvqSearchParams& p, hipStream_t stream) {
     }
     hipLaunchKernelGGL(rvq_search_kernel, dim3((p.M + FR - 1) / FR, p.n_groups), dim3(64 * NW), lds, stream, p);
     return rst_check_launch("rvq_search");
+}
+
+int rst_launch_rvq_search_small(const RvqSearchParams& p, unsigned long long* keys, hipStream_t stream) {
+    if (p.M == 0) return RST_OK;
+    RST_REQUIRE(p.x && p.emb && p.packed && p.e2 && p.codes && keys, "rvq_search_small: null pointer");
+    RST_REQUIRE(p.F > 0 && p.D > 0 && p.D % 8 == 0 && p.n_codes > 0 && p.n_codes % 32 == 0 && p.M % p.F == 0 &&
+                    p.n_groups >= 1 && p.n_groups <= 2,
+                "rvq_search_small: need D %% 8 == 0 and n_codes %% 32 == 0 (D=%d n_codes=%d)", p.D, p.n_codes);
+    const size_t lds = ((size_t)FR * (p.D + 4) + FR) * sizeof(float);
+    int steps = 0;
+    for (int g = 0; g < p.n_groups; ++g) steps = p.group_count[g] > steps ? p.group_count[g] : steps;
+    const dim3 grid((p.n_codes + 127) / 128, p.n_groups, (p.M + FR - 1) / FR);
+    for (int s = 0; s < steps; ++s) {
+        hipLaunchKernelGGL(rvq_level_kernel, grid, dim3(256), lds, stream, p, keys, s);
+        const int rc = rst_check_launch("rvq_level");
+        if (rc) return rc;
+    }
+    long g = ((long)p.L * p.M + 255) / 256;
+    hipLaunchKernelGGL(rvq_finalize_kernel, dim3((unsigned)(g > 64 ? 64 : g)), dim3(256), 0, stream, p, keys);
+    return rst_check_launch("rvq_finalize");
 }
 
 int rst_launch_rvq_gather(const RvqGatherParams& p, hipStream_t stream) {

@@ -45,6 +45,27 @@ def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32) -> None:
         raise ValueError(f"rstnet_amd.ops: `{name}` must be contiguous")
 
 
+_gemm_scratch: dict = {}
+
+
+def _gemm_split_scratch(device, M: int, N: int, K: int):
+    """Split-K plan + scratch of the few-row (streaming step) GEMMs, cached per shape; launches on one stream are ordered
+    and the counters re-arm themselves, so layers of equal shape share the buffers."""
+    if M > 32 or M == 0:
+        return 1, None, None
+    key = (device, M, N, K)
+    sc = _gemm_scratch.get(key)
+    if sc is None:
+        sk = int(_lib.lib().rst_gemm_win_split_plan(M, N, K))
+        if sk > 1:
+            sc = (sk, torch.empty(sk, M, N, device=device, dtype=torch.float32),
+                  torch.zeros((N + 127) // 128, device=device, dtype=torch.int32))
+        else:
+            sc = (1, None, None)
+        _gemm_scratch[key] = sc
+    return sc
+
+
 def gemm_win(x: torch.Tensor, w: torch.Tensor, *, B: int, T_in: int, T_out: int, C_: int, S: int, P: int, N: int,
              hist: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
              res: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, pad_mode: int = PAD_ZERO,
@@ -64,13 +85,14 @@ def gemm_win(x: torch.Tensor, w: torch.Tensor, *, B: int, T_in: int, T_out: int,
         assert res.numel() == out.numel()
     if hist is not None:
         assert hist.numel() == B * P * C_, (tuple(hist.shape), B, P, C_)
+    split_k, ws, cnt = _gemm_split_scratch(x.device, B * T_out, N, K)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.check(_lib.lib().rst_gemm_win_f32(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out),
                                            B, T_in, T_out, C_, K, N, S, P, pad_mode, T_in * C_, N, act_in, act_out,
-                                           _stream()))
+                                           split_k, _ptr(ws), _ptr(cnt), _stream()))
     if prof is not None:
         e1.record()
         nbytes = 4 * (x.numel() + w.numel() + out.numel() + (res.numel() if res is not None else 0))
@@ -88,12 +110,17 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     assert w.shape[1] == K
     M = x.numel() // K if K else 0
     out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    split_k, ws, cnt = _gemm_split_scratch(x.device, M, N, K)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.lib().rst_linear_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, K, N,
-                                         act_out, _stream()))
+    if split_k > 1:
+        _lib.check(_lib.lib().rst_gemm_win_f32(_ptr(x), None, _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), 1, M, M, K, K, N,
+                                               1, 0, 0, M * K, N, 0, act_out, split_k, _ptr(ws), _ptr(cnt), _stream()))
+    else:
+        _lib.check(_lib.lib().rst_linear_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, K, N,
+                                             act_out, _stream()))
     if prof is not None:
         e1.record()
         nbytes = 4 * (x.numel() + w.numel() + out.numel() + (res.numel() if res is not None else 0))
@@ -180,6 +207,9 @@ def rope_split(qkv: torch.Tensor, H: int, *, q: Optional[torch.Tensor] = None, k
     return q, k, v
 
 
+_attn_scratch: dict = {}
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, pos0: int = 0, pos_dev: Optional[torch.Tensor] = None,
               ring: bool = False, context: Optional[int] = None) -> torch.Tensor:
     """q ``[B,H,T,D]``, k/v ``[B,H,cap,D]`` -> ``[B,T,H*D]``."""
@@ -190,6 +220,18 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, pos0: int = 
     out = torch.empty(B, T, H * D, device=q.device, dtype=torch.float32)
     if pos_dev is not None:
         _chk(pos_dev, "pos_dev", torch.int64)
+    if ring and pos_dev is not None and T <= 8 and D in (64, 128):
+        # streaming step with a handful of new queries: split every query over the occupied ring slots instead of walking
+        # the ring tile by tile with one wave per head
+        splits = max(1, min(4, cap // 64))
+        key = (q.device, B * T, H, splits, D)
+        sc = _attn_scratch.get(key)
+        if sc is None:
+            sc = _attn_scratch[key] = (torch.empty(B * T, H, splits, D + 2, device=q.device, dtype=torch.float32),
+                                       torch.zeros(B * T, H, device=q.device, dtype=torch.int32))
+        _lib.check(_lib.lib().rst_attn_decode_multi_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(sc[0]), _ptr(sc[1]), _ptr(out), _ptr(pos_dev),
+                                                       B, T, H, D, cap, int(context) if context else 0, splits, _stream()))
+        return out
     _lib.check(_lib.lib().rst_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(pos_dev), pos0, B, T, H, D, cap,
                                             int(ring), int(context) if context else 0, _stream()))
     return out
@@ -210,6 +252,9 @@ def _int_array(vals: Sequence[int]):
     return (C.c_int * len(vals))(*vals)
 
 
+_rvq_keys: dict = {}
+
+
 def rvq_search(x: torch.Tensor, emb: torch.Tensor, packed: torch.Tensor, e2: torch.Tensor, B: int, F: int,
                groups: Sequence[Tuple[int, int]], return_dist: bool = False):
     """x ``[B*F, n_groups*D]`` projected latents -> codes ``[B, L, F]`` int64 (levels outside ``groups`` untouched)."""
@@ -220,7 +265,13 @@ def rvq_search(x: torch.Tensor, emb: torch.Tensor, packed: torch.Tensor, e2: tor
     assert x.shape == (M, len(groups) * D), (tuple(x.shape), M, len(groups), D)
     codes = torch.zeros(B, L, F, device=x.device, dtype=torch.int64)
     dist = torch.zeros(L, M, device=x.device, dtype=torch.float32) if return_dist else None
-    _lib.check(_lib.lib().rst_rvq_search_f32(_ptr(x), _ptr(emb), _ptr(packed), _ptr(e2), _ptr(codes), _ptr(dist), M, max(F, 1),
+    keys = None
+    if 0 < M <= 64:     # streaming step: the few-frame form (codes spread over workgroups)
+        kk = (x.device, L, M)
+        keys = _rvq_keys.get(kk)
+        if keys is None:
+            keys = _rvq_keys[kk] = torch.full((L, M), -1, device=x.device, dtype=torch.int64)
+    _lib.check(_lib.lib().rst_rvq_search_f32(_ptr(x), _ptr(emb), _ptr(packed), _ptr(e2), _ptr(codes), _ptr(dist), _ptr(keys), M, max(F, 1),
                                              x.shape[1], D, n_codes, L, len(groups), _int_array([g[0] for g in groups]),
                                              _int_array([g[1] for g in groups]), _stream()))
     return (codes, dist) if return_dist else codes

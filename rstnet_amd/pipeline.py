@@ -24,31 +24,24 @@ class StreamingPipeline:
         self._dec = None
 
     def __enter__(self):
-        import copy
-        # two independent streaming states of the codec: one for the incoming stream, one for the generated one
-        self._enc_ctx = self.mimi.streaming(self.batch_size)
-        self._enc_ctx.__enter__()
-        self._enc_state = self.mimi.get_streaming_state()
-        self.mimi._stop_streaming()
-        self.mimi._start_streaming(self.batch_size)
-        self._dec_state = self.mimi.get_streaming_state()
+        # encode touches only the encoder-side modules' states and decode only the decoder-side ones: one context serves both
+        self._mimi_ctx = self.mimi.streaming(self.batch_size)
+        self._mimi_ctx.__enter__()
         self._lm_ctx = self.lm_gen.streaming(self.batch_size)
         self._lm_ctx.__enter__()
         return self
 
     def __exit__(self, *exc):
         self._lm_ctx.__exit__(*exc)
-        self.mimi._stop_streaming()
+        self._mimi_ctx.__exit__(*exc)
         return False
 
     @torch.no_grad()
     def step(self, pcm: torch.Tensor) -> Optional[torch.Tensor]:
         """pcm fp32 ``[B, 1, 1920]`` -> generated pcm ``[B, 1, 1920]`` (or ``None`` during the first ``max_delay`` frames)."""
         assert pcm.shape == (self.batch_size, 1, self.frame_size), tuple(pcm.shape)
-        self.mimi.set_streaming_state(self._enc_state)
         codes = self.mimi.encode(pcm)                                   # [B, 8, 1]
         tokens = self.lm_gen.step(codes[:, :self.n_user].contiguous())  # [B, 1 + dep_q, 1] or None
         if tokens is None:
             return None
-        self.mimi.set_streaming_state(self._dec_state)
         return self.mimi.decode(tokens[:, 1:].contiguous())
