@@ -44,7 +44,7 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
     return rst_launch_gemm_win(p, (hipStream_t)stream);
 }
 
-int rst_gemm_win_split_plan(int64_t M, int N, int K) { return rst_gemm_win_split_plan((long)M, N, K); }
+int rst_gemm_win_split_plan(int64_t M, int N, int K) { return rst_gemm_split_plan_impl((long)M, N, K); }
 
 int rst_conv1d_causal_f32(const float* x, const float* hist, const float* w_packed, const float* bias,
                           const float* res, float* y, int B, int T_in, int T_out, int Cin, int Cout, int Kw_eff,
@@ -173,7 +173,7 @@ int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, con
 
 int rst_gemm_skinny_plan(int B, int N, int K, int* k_slice, int* splits) {
     RST_REQUIRE(k_slice && splits && B >= 1 && N > 0 && K > 0, "gemm_skinny_plan: bad arguments");
-    return rst_skinny_plan(B, N, K, k_slice, splits);
+    return rst_skinny_plan_impl(B, N, K, k_slice, splits);
 }
 
 int rst_gemm_skinny_bf16_f32(const float* x, const uint16_t* w, const float* res, float* y, float* ws, uint32_t* counters,

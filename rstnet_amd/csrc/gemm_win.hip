@@ -307,7 +307,7 @@ int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
 
 }  // namespace
 
-int rst_gemm_win_split_plan(long M, int N, int K) {
+int rst_gemm_split_plan_impl(long M, int N, int K) {
     // few-row calls (streaming steps) are weight-bandwidth bound: spread K over enough workgroups to fill the chip
     if (M > 32 || N <= 64) return 1;
     const int tiles = (N + 127) / 128;

@@ -449,152 +449,168 @@ __global__ __launch_bounds__(64) void attn_small_kernel(const LmAttnParams p) {
     }
 }
 
-// One workgroup per batch row.  Greedy: argmax (lowest index on ties).  Sampling (utils/sampling.py:51-105):
-// probs = softmax(logits / temp); (p, idx) = top-k sorted descending; token = idx[argmax_j p_j / noise_j].
-__global__ __launch_bounds__(256) void sample_kernel(const LmSampleParams p) {
-    extern __shared__ __attribute__((aligned(16))) float sv[];   // [V] scaled logits
-    __shared__ float red_v[4];
-    __shared__ int red_i[4];
-    __shared__ float best_v;
-    __shared__ int best_i;
+// One workgroup per batch row (256 threads for V <= 4096, 1024 above).  Greedy: argmax (lowest index on ties).
+// Sampling (utils/sampling.py:51-105): probs = softmax(logits / temp); (p, idx) = top-k in descending order (ties: lowest
+// index first); token = idx[argmax_j p_j / noise_j].  Exact top-k WITHOUT sorting, register resident: each thread keeps
+// EPT order-preserving uint keys of the scaled logits; a bit-wise binary search on the key (block-wide counts, early exit
+// as soon as exactly k keys lie above the probe) finds the k-th largest key, ties at that value are resolved by a search
+// on the index, the exactly-k candidates are compacted into LDS as 64-bit (key, ~index) composites and each computes its
+// rank by counting the larger composites.
+template <int NT, int EPT>
+__global__ __launch_bounds__(NT) void sample_kernel(const LmSampleParams p) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned long long comp[];   // [k rounded up to 8] candidates
+    __shared__ float red_v[NW];
+    __shared__ int red_i[NW], red_j[NW];
+    __shared__ int cnt[40];
+    __shared__ int n_cand;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long b = blockIdx.x;
     const float* lg = p.logits + b * p.ld;
     const bool sampling = p.use_sampling && p.temp > 0.f;
-    for (int i = tid; i < p.V; i += 256) sv[i] = sampling ? lg[i] / p.temp : lg[i];
-    __syncthreads();
+    const int V = p.V;
 
-    auto block_argmax = [&]() {     // over sv[], lowest index wins ties; result in best_v / best_i
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int i = tid; i < p.V; i += 256) {
-            const float v = sv[i];
-            if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
-        }
+    auto to_key = [](float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+    auto from_key = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); };
+    int slot = 0;                                  // every block-wide count uses a fresh (pre-zeroed) LDS counter
+    auto block_sum_i = [&](int c) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o);
-            const int oi = __shfl_xor(bi, o);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) atomicAdd(&cnt[slot], c);
         __syncthreads();
-        if (tid == 0) {
-            float v = red_v[0];
-            int i = red_i[0];
-            for (int w = 1; w < 4; ++w)
-                if (red_v[w] > v || (red_v[w] == v && red_i[w] < i)) { v = red_v[w]; i = red_i[w]; }
-            best_v = v;
-            best_i = i;
-        }
-        __syncthreads();
+        return cnt[slot++];
     };
 
-    block_argmax();
+    if (tid < 40) cnt[tid] = 0;
+    if (tid == 0) n_cand = 0;
+    // keys of the (scaled) logits, element j of this thread is index j * NT + tid; key 0 (below every real key) pads the tail
+    unsigned key[EPT];
+    unsigned bk = 0u;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = j * NT + tid;
+        float f = i < V ? lg[i] : 0.f;
+        if (sampling) f = f / p.temp;
+        key[j] = i < V ? to_key(f) : 0u;
+        if (key[j] > bk) { bk = key[j]; bi = i; }          // ascending i: the first maximum is kept
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned ok = __shfl_xor(bk, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ok > bk || (ok == bk && oi < bi)) { bk = ok; bi = oi; }
+    }
+    if (lane == 0) { red_j[wave] = (int)bk; red_i[wave] = bi; }
+    __syncthreads();
+    bk = (unsigned)red_j[0]; bi = red_i[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w)
+        if ((unsigned)red_j[w] > bk || ((unsigned)red_j[w] == bk && red_i[w] < bi)) { bk = (unsigned)red_j[w]; bi = red_i[w]; }
     if (!sampling) {
-        if (tid == 0) p.tokens[b * p.tok_stride] = best_i;
+        if (tid == 0) p.tokens[b * p.tok_stride] = bi;
         return;
     }
     // softmax denominator (fp32, max-subtracted like torch.softmax)
-    const float mx = best_v;
+    const float mx = from_key(bk);
     float s = 0.f;
-    for (int i = tid; i < p.V; i += 256) s += expf(sv[i] - mx);
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) s += key[j] ? expf(from_key(key[j]) - mx) : 0.f;
     s = wave_sum(s);
-    __syncthreads();
     if (lane == 0) red_v[wave] = s;
     __syncthreads();
-    const float denom = red_v[0] + red_v[1] + red_v[2] + red_v[3];
-    const int k = min(p.top_k > 0 ? p.top_k : p.V, p.V);
-    float win = -INFINITY;
-    int win_tok = 0x7fffffff;
-    if (p.V <= 4096) {
-        // bitonic sort of (value, index) in LDS: descending by value, ascending index on ties (the order torch.topk yields
-        // on distinct values); candidate j < k is scored p_j / noise_j and the best score wins (lowest j on score ties)
-        int NP = 1;
-        while (NP < p.V) NP <<= 1;
-        int* sidx = reinterpret_cast<int*>(sv + NP);
-        for (int i = tid; i < NP; i += 256) {
-            if (i >= p.V) sv[i] = -INFINITY;
-            sidx[i] = i;
-        }
-        __syncthreads();
-        for (int size = 2; size <= NP; size <<= 1) {
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-#pragma unroll 4
-                for (int t = tid; t < NP / 2; t += 256) {
-                    const int lo = 2 * t - (t & (stride - 1));
-                    const int hi = lo + stride;
-                    const float a = sv[lo], c = sv[hi];
-                    const int ia = sidx[lo], ic = sidx[hi];
-                    const bool a_first = a > c || (a == c && ia < ic);
-                    const bool want_a_first = (lo & size) == 0;
-                    if (a_first != want_a_first) { sv[lo] = c; sv[hi] = a; sidx[lo] = ic; sidx[hi] = ia; }
-                }
-                __syncthreads();
-            }
-        }
-        int win_j = 0x7fffffff;
-        for (int j = tid; j < k; j += 256) {
-            const float sc = (expf(sv[j] - mx) / denom) / p.noise[b * p.noise_stride + j];
-            if (sc > win || (sc == win && j < win_j)) { win = sc; win_j = j; }
-        }
+    float denom = 0.f;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(win, o);
-            const int oj = __shfl_xor(win_j, o);
-            if (ov > win || (ov == win && oj < win_j)) { win = ov; win_j = oj; }
-        }
-        __syncthreads();
-        if (lane == 0) { red_v[wave] = win; red_i[wave] = win_j; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
-                if (red_v[w] > win || (red_v[w] == win && red_i[w] < win_j)) { win = red_v[w]; win_j = red_i[w]; }
-            win_tok = sidx[win_j];
-        }
-    } else {
-        // large vocabulary, small k (text head: V = 32000, k = 25): repeated extraction of the maximum.  Every thread caches
-        // the maximum of its own strided slice; a round is one block reduction over the 256 cached maxima plus a rescan of
-        // the single slice that lost its maximum.
-        auto local_max = [&](float& bv, int& bi) {
-            bv = -INFINITY;
-            bi = 0x7fffffff;
-#pragma unroll 8
-            for (int i = tid; i < p.V; i += 256) {
-                const float v = sv[i];
-                if (v > bv) { bv = v; bi = i; }     // ascending i: the lowest index of equal values is kept
-            }
-        };
-        float lv;
-        int li;
-        local_max(lv, li);
-        for (int j = 0; j < k; ++j) {
-            float bv = lv;
-            int bi = li;
+    for (int w = 0; w < NW; ++w) denom += red_v[w];
+
+    // k-th largest key: binary search from the top bit down; stop as soon as a probe isolates exactly k keys
+    const int k = min(p.top_k > 0 ? p.top_k : V, V);
+    unsigned thr = 0u;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = thr | (1u << bit);
+        int c = 0;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o);
-                const int oi = __shfl_xor(bi, o);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            __syncthreads();
-            if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
-            __syncthreads();
-            bv = red_v[0]; bi = red_i[0];
-#pragma unroll
-            for (int w = 1; w < 4; ++w)
-                if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) { bv = red_v[w]; bi = red_i[w]; }
-            if (tid == 0) {
-                const float sc = (expf(bv - mx) / denom) / p.noise[b * p.noise_stride + j];
-                if (sc > win) { win = sc; win_tok = bi; }
-            }
-            if ((bi & 255) == tid) {     // the owner of the extracted element drops it and refreshes its cached maximum
-                sv[bi] = -INFINITY;
-                local_max(lv, li);
-            }
-        }
+        for (int j = 0; j < EPT; ++j) c += key[j] >= cand ? 1 : 0;
+        const int n = block_sum_i(c);
+        if (n >= k) thr = cand;
+        if (n == k) break;
     }
-    if (tid == 0) p.tokens[b * p.tok_stride] = win_tok;
+    int c_gt = 0, c_eq = 0;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) { c_gt += key[j] > thr ? 1 : 0; c_eq += key[j] == thr ? 1 : 0; }
+    const int n_gt = block_sum_i(c_gt);
+    const int n_eq = block_sum_i(c_eq);
+    // of the n_eq elements equal to the threshold only the need = k - n_gt with the LOWEST indices belong to the top-k
+    const int need = k - n_gt;
+    int idx_lim = 0x7fffffff;            // ties with index <= idx_lim are taken
+    if (need < n_eq) {
+        int lim = 0;                     // largest L with count(ties, idx < L) < need, built bit by bit
+        for (int bit = 16; bit >= 0; --bit) {
+            const int cand = lim | (1 << bit);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) c += (key[j] == thr && j * NT + tid < cand) ? 1 : 0;
+            __syncthreads();
+            if (tid == 0) cnt[39] = 0;
+            __syncthreads();
+            slot = 39;
+            if (block_sum_i(c) < need) lim = cand;
+        }
+        idx_lim = lim;
+    }
+    // compact the exactly-k candidates (any order: ranks come from comparisons)
+    const int kpad = (k + 7) & ~7;
+    for (int i = k + tid; i < kpad; i += NT) comp[i] = 0ull;
+    int mine_n = 0;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) mine_n += (key[j] > thr || (key[j] == thr && j * NT + tid <= idx_lim)) ? 1 : 0;
+    int incl = mine_n;                   // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    int base = 0;
+    if (lane == 63) base = atomicAdd(&n_cand, incl);
+    int at = __shfl(base, 63) + incl - mine_n;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (key[j] > thr || (key[j] == thr && j * NT + tid <= idx_lim)) {
+            if (at < k) comp[at] = ((unsigned long long)key[j] << 32) | (unsigned)(0x7fffffff - (j * NT + tid));
+            ++at;
+        }
+    __syncthreads();
+    float win = -INFINITY;
+    int win_rank = 0x7fffffff, win_tok = 0;
+    for (int c = tid; c < k; c += NT) {
+        const unsigned long long mine = comp[c];
+        int rank = 0;
+        for (int j0 = 0; j0 < kpad; j0 += 8) {
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = comp[j0 + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += v[u] > mine ? 1 : 0;
+        }
+        const float sc = (expf(from_key((unsigned)(mine >> 32)) - mx) / denom) / p.noise[b * p.noise_stride + rank];
+        if (sc > win || (sc == win && rank < win_rank)) { win = sc; win_rank = rank; win_tok = 0x7fffffff - (int)(unsigned)mine; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(win, o);
+        const int orank = __shfl_xor(win_rank, o);
+        const int ot = __shfl_xor(win_tok, o);
+        if (ov > win || (ov == win && orank < win_rank)) { win = ov; win_rank = orank; win_tok = ot; }
+    }
+    __syncthreads();
+    if (lane == 0) { red_v[wave] = win; red_i[wave] = win_rank; red_j[wave] = win_tok; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < NW; ++w)
+            if (red_v[w] > win || (red_v[w] == win && red_i[w] < win_rank)) { win = red_v[w]; win_rank = red_i[w]; win_tok = red_j[w]; }
+        p.tokens[b * p.tok_stride] = win_tok;
+    }
 }
 
 inline unsigned cap_grid(long g, long cap) { return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g)); }
@@ -679,22 +695,15 @@ int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream) {
 }
 
 int rst_launch_lm_sample(const LmSampleParams& p, hipStream_t stream) {
-    RST_REQUIRE(p.logits && p.tokens && p.B >= 1 && p.V > 0, "lm_sample: bad arguments");
+    RST_REQUIRE(p.logits && p.tokens && p.B >= 1 && p.V > 0 && p.V <= 65536, "lm_sample: bad arguments");
     RST_REQUIRE(!p.use_sampling || p.temp <= 0.f || p.noise, "lm_sample: sampling needs the exponential noise tensor");
-    size_t lds = (size_t)p.V * sizeof(float);
-    if (p.V <= 4096) {   // sort buffers: values padded to a power of two + indices
-        int np = 1;
-        while (np < p.V) np <<= 1;
-        lds = (size_t)np * 8;
-    }
-    RST_REQUIRE(lds <= 150 * 1024, "lm_sample: vocabulary %d too large for the LDS stage", p.V);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipGetLastError();
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(sample_kernel, dim3(p.B), dim3(256), lds, stream, p);
+    const int k = p.top_k > 0 && p.top_k < p.V ? p.top_k : p.V;
+    RST_REQUIRE(!p.use_sampling || p.temp <= 0.f || k <= 8192, "lm_sample: top-k %d exceeds the 8192 candidate stage", k);
+    const size_t lds = (size_t)((k + 7) & ~7) * 8;
+    if (p.V <= 2048) hipLaunchKernelGGL((sample_kernel<256, 8>), dim3(p.B), dim3(256), lds, stream, p);
+    else if (p.V <= 4096) hipLaunchKernelGGL((sample_kernel<256, 16>), dim3(p.B), dim3(256), lds, stream, p);
+    else if (p.V <= 32768) hipLaunchKernelGGL((sample_kernel<1024, 32>), dim3(p.B), dim3(1024), lds, stream, p);
+    else hipLaunchKernelGGL((sample_kernel<1024, 64>), dim3(p.B), dim3(1024), lds, stream, p);
     return rst_check_launch("lm_sample");
 }
 
@@ -833,7 +842,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
 
 }  // namespace
 
-int rst_skinny_plan(int B, int N, int K, int* k_slice, int* splits) {
+int rst_skinny_plan_impl(int B, int N, int K, int* k_slice, int* splits) {
     // K slice per workgroup: hi+lo bf16 stage of 32 (64) batch rows must fit ~64 KiB; enough workgroups to fill 256 CUs
     const int nb = B <= 32 ? 1 : 2;
     int ks = nb == 1 ? 512 : 256;

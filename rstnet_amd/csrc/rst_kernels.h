@@ -26,7 +26,7 @@ struct GemmWinParams {
     unsigned* counters;  // [ceil(N/128)], zero before the first launch (self re-arming)
 };
 int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream);
-int rst_gemm_win_split_plan(long M, int N, int K);
+int rst_gemm_split_plan_impl(long M, int N, int K);
 
 // ---- resblock.hip ---------------------------------------------------------------------------------
 struct ResblockParams {
@@ -185,5 +185,5 @@ struct SkinnyParams {
     unsigned* counters;         // [ceil(N/32)] arrival counters (zero before the first launch, self re-arming)
     int B, N, K, ldx, ldy, prologue, k_slice;
 };
-int rst_skinny_plan(int B, int N, int K, int* k_slice, int* splits);
+int rst_skinny_plan_impl(int B, int N, int K, int* k_slice, int* splits);
 int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream);

@@ -53,11 +53,25 @@ def gemm_case(M, N, K, elu=False, res=False):
     return ms, 2.0 * M * N * K
 
 
+def sample_case(V, k, sampling=True):
+    g = torch.Generator().manual_seed(0)
+    logits = (torch.randn(1, V, generator=g) * 3).to(DEV)
+    noise = torch.empty(1, k).exponential_(1, generator=g).to(DEV)
+    out = torch.empty(1, dtype=torch.long, device=DEV)
+    ms = timeit(lambda: ops.lm_sample(logits, use_sampling=sampling, temp=0.8, top_k=k, noise=noise, out=out), iters=50, warm=5)
+    return ms, 1.0
+
+
 def main():
     cases = sys.argv[1:] or ["res64", "res64pre", "res64post", "res128", "gemm:3840000x128x512:elu", "gemm:16000x1024x8192",
                              "gemm:128000x512x3072", "gemm:16000x512x512"]
     B, T = 16, 240000
     for c in cases:
+        if c.startswith("sample"):
+            parts = c.split(":")
+            ms, fl = sample_case(int(parts[1]), int(parts[2]), sampling="greedy" not in parts)
+            print(f"{c:32s} {ms * 1e3:8.1f} us", flush=True)
+            continue
         if c.startswith("res"):
             C = 128 if "128" in c else 64
             ms, fl = res_case(C, B, T // (4 if C == 128 else 1), pre="pre" in c, post="post" in c)
