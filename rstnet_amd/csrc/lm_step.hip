@@ -395,57 +395,104 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     }
 }
 
-// Short ring (capacity <= 64, e.g. the depth transformer's 8 steps): one wave per (b, h) does append + scores (lane = slot)
-// + softmax + PV (lane = output dim) with no split and no workspace.
+// Short ring (capacity <= 64, e.g. the depth transformer's 8 steps): one wave per (b, h), no split and no workspace.
+// Lane = (slot group g = lane / 8, dim chunk c = lane % 8): a pass covers 8 ring slots, each lane holding D/8 contiguous
+// dims of its slot's key and value (coalesced 16-byte loads issued before the position is even known); scores reduce
+// over the 8 chunk lanes, the softmax and P.V over the 8 slot groups.  The new step's key / value come straight from qkv
+// (and are appended to the ring by the lanes that own its slot).
+template <int D>
 __global__ __launch_bounds__(64) void attn_small_kernel(const LmAttnParams p) {
-    const int lane = threadIdx.x, h = blockIdx.x;
+    constexpr int DPL = D / 8;                   // dims per lane
+    constexpr int MAXP = 8;                      // passes of 8 slots (cap <= 64)
+    const int lane = threadIdx.x, g = lane >> 3, c = lane & 7, h = blockIdx.x;
     const long b = blockIdx.y;
-    const int D = p.D, cap = p.cap;
+    const int cap = p.cap;
     const long HD = (long)p.H * D;
+    const float* qkv = p.qkv + b * p.ldqkv + (long)h * D + c * DPL;
+    float* kc = p.k + ((b * p.H + h) * cap) * (long)D + c * DPL;
+    float* vc = p.v + ((b * p.H + h) * cap) * (long)D + c * DPL;
+    const int npass = (cap + 7) >> 3;
+    float q[DPL], kn[DPL], vn[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; i += 4) {
+        *reinterpret_cast<f32x4*>(q + i) = *reinterpret_cast<const f32x4*>(qkv + i);
+        *reinterpret_cast<f32x4*>(kn + i) = *reinterpret_cast<const f32x4*>(qkv + HD + i);
+        *reinterpret_cast<f32x4*>(vn + i) = *reinterpret_cast<const f32x4*>(qkv + 2 * HD + i);
+    }
     const long pos = *p.pos_dev;
     const int slot_cur = (int)(pos % cap);
-    const float* qkv = p.qkv + b * p.ldqkv + (long)h * D;
-    float* kc = p.k + ((b * p.H + h) * cap) * (long)D;
-    float* vc = p.v + ((b * p.H + h) * cap) * (long)D;
-    // append (RoPE optional: lane i rotates pair i)
-    for (int i = lane; i < D / 2; i += 64) {
-        float c = 1.f, sn = 0.f;
-        if (p.rope) { const float ang = expf((float)i * p.rope_coef) * (float)pos; c = cosf(ang); sn = sinf(ang); }
-        const float kr = qkv[HD + 2 * i], ki = qkv[HD + 2 * i + 1];
-        kc[(long)slot_cur * D + 2 * i] = kr * c - ki * sn;
-        kc[(long)slot_cur * D + 2 * i + 1] = kr * sn + ki * c;
-        vc[(long)slot_cur * D + 2 * i] = qkv[2 * HD + 2 * i];
-        vc[(long)slot_cur * D + 2 * i + 1] = qkv[2 * HD + 2 * i + 1];
-    }
-    // the new step is never re-read from memory: its key / value come from qkv
-    const bool ok = lane < cap && ring_visible(lane, pos, cap, p.context, pos + 1);
-    float sc = -INFINITY;
-    if (ok) {
-        float d = 0.f;
-        for (int i = 0; i < D / 2; ++i) {
-            float c = 1.f, sn = 0.f;
-            if (p.rope) { const float ang = expf((float)i * p.rope_coef) * (float)pos; c = cosf(ang); sn = sinf(ang); }
-            const float qr = qkv[2 * i], qi = qkv[2 * i + 1];
-            float k0, k1;
-            if (lane == slot_cur) {
-                const float kr = qkv[HD + 2 * i], ki = qkv[HD + 2 * i + 1];
-                k0 = kr * c - ki * sn; k1 = kr * sn + ki * c;
-            } else {
-                k0 = kc[(long)lane * D + 2 * i]; k1 = kc[(long)lane * D + 2 * i + 1];
-            }
-            d = fmaf(k0, qr * c - qi * sn, d);
-            d = fmaf(k1, qr * sn + qi * c, d);
+    if (p.rope) {
+#pragma unroll
+        for (int i = 0; i < DPL; i += 2) {
+            const float ang = expf((float)((c * DPL + i) >> 1) * p.rope_coef) * (float)pos;
+            const float cs = cosf(ang), sn = sinf(ang);
+            const float qr = q[i], qi = q[i + 1], kr = kn[i], ki = kn[i + 1];
+            q[i] = qr * cs - qi * sn; q[i + 1] = qr * sn + qi * cs;
+            kn[i] = kr * cs - ki * sn; kn[i + 1] = kr * sn + ki * cs;
         }
-        sc = d / sqrtf((float)D);
     }
-    const float m = wave_max(sc);
-    const float pw = ok ? expf(sc - m) : 0.f;
-    const float l = wave_sum(pw);
-    for (int d0 = lane; d0 < D; d0 += 64) {
-        float o = 0.f;
-        for (int sl = 0; sl < cap; ++sl)
-            o = fmaf(__shfl(pw, sl), sl == slot_cur ? qkv[2 * HD + d0] : vc[(long)sl * D + d0], o);
-        p.out[(b * p.H + h) * (long)D + d0] = o / l;
+    float sc[MAXP];
+    float m = -INFINITY;
+#pragma unroll
+    for (int ps = 0; ps < MAXP; ++ps) {
+        sc[ps] = -INFINITY;
+        if (ps < npass) {
+            const int slot = ps * 8 + g;
+            const bool cur = slot == slot_cur;
+            const bool ok = slot < cap && ring_visible(slot, pos, cap, p.context, pos + 1);
+            float kk[DPL];
+            if (cur) {
+#pragma unroll
+                for (int i = 0; i < DPL; i += 4) {
+                    *reinterpret_cast<f32x4*>(kc + (long)slot * D + i) = *reinterpret_cast<const f32x4*>(kn + i);
+                    *reinterpret_cast<f32x4*>(vc + (long)slot * D + i) = *reinterpret_cast<const f32x4*>(vn + i);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < DPL; i += 4) {
+                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok && !cur) t = *reinterpret_cast<const f32x4*>(kc + (long)slot * D + i);
+                *reinterpret_cast<f32x4*>(kk + i) = t;
+            }
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) d = fmaf(cur ? kn[i] : kk[i], q[i], d);
+            d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+            if (ok) sc[ps] = d / sqrtf((float)D);
+            m = fmaxf(m, sc[ps]);
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f, o[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) o[i] = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < MAXP; ++ps) {
+        if (ps < npass) {
+            const int slot = ps * 8 + g;
+            const bool cur = slot == slot_cur;
+            const float pw = sc[ps] == -INFINITY ? 0.f : expf(sc[ps] - m);
+            l += pw;
+#pragma unroll
+            for (int i = 0; i < DPL; i += 4) {
+                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (cur) t = *reinterpret_cast<const f32x4*>(vn + i);
+                else if (pw != 0.f) t = *reinterpret_cast<const f32x4*>(vc + (long)slot * D + i);
+                o[i] = fmaf(pw, t[0], o[i]); o[i + 1] = fmaf(pw, t[1], o[i + 1]);
+                o[i + 2] = fmaf(pw, t[2], o[i + 2]); o[i + 3] = fmaf(pw, t[3], o[i + 3]);
+            }
+        }
+    }
+    l += __shfl_xor(l, 8); l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        o[i] += __shfl_xor(o[i], 8); o[i] += __shfl_xor(o[i], 16); o[i] += __shfl_xor(o[i], 32);
+        o[i] = o[i] / l;
+    }
+    if (g == 0) {
+        float* out = p.out + (b * p.H + h) * (long)D + c * DPL;
+#pragma unroll
+        for (int i = 0; i < DPL; i += 4) *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(o + i);
     }
 }
 
@@ -462,7 +509,7 @@ __global__ __launch_bounds__(NT) void sample_kernel(const LmSampleParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long comp[];   // [k rounded up to 8] candidates
     __shared__ float red_v[NW];
     __shared__ int red_i[NW], red_j[NW];
-    __shared__ int cnt[40];
+    __shared__ int cnt[52 * NW];
     __shared__ int n_cand;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long b = blockIdx.x;
@@ -472,19 +519,25 @@ __global__ __launch_bounds__(NT) void sample_kernel(const LmSampleParams p) {
 
     auto to_key = [](float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
     auto from_key = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); };
-    int slot = 0;                                  // every block-wide count uses a fresh (pre-zeroed) LDS counter
-    auto block_sum_i = [&](int c) {
+    unsigned key[EPT];
+    int slot = 0;                                  // every block-wide count uses a fresh row of per-wave LDS cells
+    // number of elements in the block satisfying pred(j) (j = the thread's element slot): ballots + scalar popcounts per
+    // wave, one LDS cell per wave, one barrier
+    auto block_count = [&](auto pred) {
+        int c = 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if (lane == 0) atomicAdd(&cnt[slot], c);
+        for (int j = 0; j < EPT; ++j) c += __popcll(__ballot(pred(j)));
+        if (lane == 0) cnt[slot * NW + wave] = c;
         __syncthreads();
-        return cnt[slot++];
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += cnt[slot * NW + w];
+        ++slot;
+        return t;
     };
 
-    if (tid < 40) cnt[tid] = 0;
     if (tid == 0) n_cand = 0;
     // keys of the (scaled) logits, element j of this thread is index j * NT + tid; key 0 (below every real key) pads the tail
-    unsigned key[EPT];
     unsigned bk = 0u;
     int bi = 0x7fffffff;
 #pragma unroll
@@ -526,60 +579,47 @@ __global__ __launch_bounds__(NT) void sample_kernel(const LmSampleParams p) {
     // k-th largest key: binary search from the top bit down; stop as soon as a probe isolates exactly k keys
     const int k = min(p.top_k > 0 ? p.top_k : V, V);
     unsigned thr = 0u;
+    bool exact = false;
 #pragma unroll 1
     for (int bit = 31; bit >= 0; --bit) {
         const unsigned cand = thr | (1u << bit);
-        int c = 0;
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) c += key[j] >= cand ? 1 : 0;
-        const int n = block_sum_i(c);
+        const int n = block_count([&](int j) { return key[j] >= cand; });
         if (n >= k) thr = cand;
-        if (n == k) break;
+        if (n == k) { exact = true; break; }
     }
-    int c_gt = 0, c_eq = 0;
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) { c_gt += key[j] > thr ? 1 : 0; c_eq += key[j] == thr ? 1 : 0; }
-    const int n_gt = block_sum_i(c_gt);
-    const int n_eq = block_sum_i(c_eq);
-    // of the n_eq elements equal to the threshold only the need = k - n_gt with the LOWEST indices belong to the top-k
-    const int need = k - n_gt;
-    int idx_lim = 0x7fffffff;            // ties with index <= idx_lim are taken
-    if (need < n_eq) {
-        int lim = 0;                     // largest L with count(ties, idx < L) < need, built bit by bit
-        for (int bit = 16; bit >= 0; --bit) {
-            const int cand = lim | (1 << bit);
-            int c = 0;
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) c += (key[j] == thr && j * NT + tid < cand) ? 1 : 0;
-            __syncthreads();
-            if (tid == 0) cnt[39] = 0;
-            __syncthreads();
-            slot = 39;
-            if (block_sum_i(c) < need) lim = cand;
+    int idx_lim = 0x7fffffff;            // ties (key == thr) with index <= idx_lim are taken
+    if (!exact) {
+        const int n_gt = block_count([&](int j) { return key[j] > thr; });
+        const int n_eq = block_count([&](int j) { return key[j] == thr; });
+        // of the n_eq elements equal to the threshold only the need = k - n_gt with the LOWEST indices belong to the top-k
+        const int need = k - n_gt;
+        if (need < n_eq) {
+            int lim = 0;                 // largest L with count(ties, idx < L) < need, built bit by bit
+            for (int bit = 16; bit >= 0; --bit) {
+                const int cand = lim | (1 << bit);
+                if (block_count([&](int j) { return key[j] == thr && j * NT + tid < cand; }) < need) lim = cand;
+            }
+            idx_lim = lim;
         }
-        idx_lim = lim;
     }
     // compact the exactly-k candidates (any order: ranks come from comparisons)
     const int kpad = (k + 7) & ~7;
     for (int i = k + tid; i < kpad; i += NT) comp[i] = 0ull;
-    int mine_n = 0;
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) mine_n += (key[j] > thr || (key[j] == thr && j * NT + tid <= idx_lim)) ? 1 : 0;
-    int incl = mine_n;                   // inclusive scan over the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    int base = 0;
-    if (lane == 63) base = atomicAdd(&n_cand, incl);
-    int at = __shfl(base, 63) + incl - mine_n;
+    int wave_total = 0;
 #pragma unroll
     for (int j = 0; j < EPT; ++j)
-        if (key[j] > thr || (key[j] == thr && j * NT + tid <= idx_lim)) {
-            if (at < k) comp[at] = ((unsigned long long)key[j] << 32) | (unsigned)(0x7fffffff - (j * NT + tid));
-            ++at;
-        }
+        wave_total += __popcll(__ballot(key[j] > thr || (key[j] == thr && j * NT + tid <= idx_lim)));
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&n_cand, wave_total);
+    base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const bool take = key[j] > thr || (key[j] == thr && j * NT + tid <= idx_lim);
+        const unsigned long long mk = __ballot(take);
+        const int at = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+        if (take && at < k) comp[at] = ((unsigned long long)key[j] << 32) | (unsigned)(0x7fffffff - (j * NT + tid));
+        base += __popcll(mk);
+    }
     __syncthreads();
     float win = -INFINITY;
     int win_rank = 0x7fffffff, win_tok = 0;
@@ -679,7 +719,14 @@ int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream) {
     const int T = p.q_pre ? p.T : 1;
     RST_REQUIRE(T >= 1 && (long)p.B * T <= 65535 && p.H <= 65535 && p.D % 2 == 0, "lm_attn: bad sizes");
     if (!p.q_pre && p.cap <= 64 && p.splits == 1) {
-        hipLaunchKernelGGL(attn_small_kernel, dim3(p.H, p.B), dim3(64), 0, stream, p);
+        switch (p.D) {
+            case 32: hipLaunchKernelGGL(attn_small_kernel<32>, dim3(p.H, p.B), dim3(64), 0, stream, p); break;
+            case 64: hipLaunchKernelGGL(attn_small_kernel<64>, dim3(p.H, p.B), dim3(64), 0, stream, p); break;
+            case 128: hipLaunchKernelGGL(attn_small_kernel<128>, dim3(p.H, p.B), dim3(64), 0, stream, p); break;
+            default:
+                rst_set_error("lm_attn: head dim %d unsupported for short rings (32, 64, 128)", p.D);
+                return RST_ERR_UNSUPPORTED;
+        }
         return rst_check_launch("lm_attn_small");
     }
     RST_REQUIRE(p.splits == 1 || (p.ws && p.counters), "lm_attn: splits > 1 need the workspace and the (zeroed) counters");
