@@ -152,10 +152,13 @@ int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, i
 /* y[b][n] = (res ? res[b][n] : 0) + sum_k P(x)[b][k] * w[n][k]  -- the F.linear call sites of one decode step:
  * in_proj / out_proj (modules/transformer.py:391-395,418-421, incl. the per-step slices of multi_linear :155-179),
  * gating linear_in / linear_out (modules/gating.py:12-22), depformer_in, text_linear, linears[k] (models/model.py:384,
- * 411-425).  w bf16 [N][K] row-major, K % 8 == 0, 1 <= B <= 4.  prologue P: 0 identity; 1 RMSNorm
- * x*alpha*rsqrt(eps+mean(x^2)) (modules/transformer.py:34-46, eps 1e-8); 2 SiLU gate: x is [B][2K] = [u ; v], P(x) = silu(u)*v. */
-int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, float* y, int B, int N,
-                      int K, int ldx, int ldy, int prologue, float eps, rst_stream_t stream);
+ * 411-425), and of the litgpt backbone: LoRAQKVLinear / LoRALinear after merge (models/llama_streaming.py:113-143,368-371),
+ * LLaMAMLP fc_1|fc_2 / proj (models/lit_model.py:399-403), lm_head.  w bf16 [N][K] row-major, K % 8 == 0, 1 <= B <= 4;
+ * bias optional fp32 [N] (config.bias / lm_head_bias).  prologue P: 0 identity; 1 RMSNorm x*alpha*rsqrt(eps+mean(x^2))
+ * (modules/transformer.py:34-46 eps 1e-8; lit_model.py:693-717 with weight as alpha); 2 SiLU gate: x is [B][2K] = [u ; v],
+ * P(x) = silu(u)*v. */
+int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, const float* bias, float* y,
+                      int B, int N, int K, int ldx, int ldy, int prologue, float eps, rst_stream_t stream);
 
 /* The same contraction for 4 < B <= 64 on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16): weights streamed once,
  * fp32 activations split into bf16 hi + lo (fp32-class accuracy), split-K over K / k_slice workgroups reduced in a fixed
@@ -163,8 +166,9 @@ int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, con
  * rst_gemm_skinny_plan picks k_slice / the split count; ws [splits][B][N] floats and counters [ceil(N/32)] uint32 (zeroed
  * once) are needed when splits > 1. */
 int rst_gemm_skinny_plan(int B, int N, int K, int* k_slice, int* splits);
-int rst_gemm_skinny_bf16_f32(const float* x, const uint16_t* w, const float* res, float* y, float* ws, uint32_t* counters,
-                             int B, int N, int K, int ldx, int ldy, int prologue, int k_slice, rst_stream_t stream);
+int rst_gemm_skinny_bf16_f32(const float* x, const uint16_t* w, const float* res, const float* bias, float* y, float* ws,
+                             uint32_t* counters, int B, int N, int K, int ldx, int ldy, int prologue, int k_slice,
+                             rst_stream_t stream);
 
 /* out[b] = (add ? add[b] : 0) + sum_i table_i[tokens[b][tok_index[i]]]: the ScaledEmbedding sums of
  * LMModel.forward_text / forward_depformer (models/model.py:67-91, 372-380, 413-419): id -1 -> zero row, ids clamped
@@ -175,28 +179,36 @@ int rst_embed_sum_bf16(const int64_t* tokens, const uint16_t* const* tables, con
 /* RMSNorm rows (rms_norm_f32, modules/transformer.py:34-46): out_norm of LMModel.forward_text. */
 int rst_rmsnorm_f32(const float* x, const float* alpha, float* y, int64_t rows, int D, float eps, rst_stream_t stream);
 
-/* One new step: split qkv [B][3*H*D], rotate q and k (interleaved RoPE, modules/rope.py) at position *pos_dev, write q
- * [B][H*D] and append k, v to ring slot *pos_dev % cap of [B][H][cap][D] (RingKVCache.complete, transformer.py:255-262). */
-int rst_lm_rope_append_f32(const float* qkv, float* q, float* k, float* v, const int64_t* pos_dev, int B, int H, int D,
-                           int cap, int ldqkv, int rope, float rope_coef, rst_stream_t stream);
+/* T new steps (prompt prefill): split qkv [B][T][ldqkv] = [q (H*D) | k (G*D) | v (G*D)], rotate q and k (interleaved RoPE on
+ * the leading rope_dims head dims, modules/rope.py; rotate-half checkpoints -- lit_model.py:560-573 -- are served by
+ * permuting the q / k weight rows at load time) at positions *pos_dev + t, write q [B][H][T][D] and append k, v to ring
+ * slots (*pos_dev + t) % cap of [B][G][cap][D] (RingKVCache.complete, transformer.py:255-262 / lit_model.py RingKVCache).
+ * kv_heads = G (0 -> H), rope_dims 0 -> D.  Follow with rst_attn_decode_multi_f32. */
+int rst_lm_rope_append_f32(const float* qkv, float* q, float* k, float* v, const int64_t* pos_dev, int B, int T, int H,
+                           int kv_heads, int D, int cap, int ldqkv, int rope, float rope_coef, int rope_dims,
+                           rst_stream_t stream);
 
 /* Single-query attention over the ring, straight from the qkv row of the new step: interleaved RoPE on q and on the new key
  * (modules/rope.py), append of k / v to ring slot *pos_dev % cap (RingKVCache.complete, transformer.py:255-262), masked
  * softmax(q k^T / sqrt(D)) v with the mask of transformer.py:404-414 and the slot->position map incl. SURVEY Q1.
  * out [B][H*D].  cap <= 64 with splits == 1 (the depth transformer): one wave per (b, h), no workspace.  Otherwise slots
  * are split over `splits` workgroups per (b, h): ws [B][H][splits][D+2] floats, counters [B][H] uint32 zero-initialised
- * once by the caller (the last-arriving workgroup combines and re-arms its counter; agent-scope release / acquire). */
+ * once by the caller (the last-arriving workgroup combines and re-arms its counter; agent-scope release / acquire).
+ * Grouped-query attention (CausalSelfAttention, models/llama_streaming.py:935-998): qkv = [q (H*D) | k (G*D) | v (G*D)],
+ * ring [B][G][cap][D] with G = kv_heads (0 -> H) -- the reference caches keys expanded to H heads (:965-971), the grouped
+ * ring holds the same values once.  rope_dims: leading head dims that rotate (config.rope_n_elem; 0 -> D). */
 int rst_lm_attn_decode_f32(const float* qkv, float* k, float* v, float* ws, uint32_t* counters, float* out,
                            const int64_t* pos_dev, int B, int H, int D, int cap, int context, int splits, int ldqkv, int rope,
-                           float rope_coef, rst_stream_t stream);
+                           float rope_coef, int kv_heads, int rope_dims, rst_stream_t stream);
 
 /* The few-query form of rst_attention_f32(ring = 1) for streaming steps of the codec transformers (T <= a few new steps per
  * call): q [B][H][T][D] already rotated and k / v already appended by rst_rope_split_f32; every (b, t, h) query is split
  * over the occupied ring slots like rst_lm_attn_decode_f32 (same mask / slot map with end_offset = *pos_dev + T).
- * out [B][T][H*D].  ws [B*T][H][splits][D+2], counters [B*T][H] (needed when splits > 1). */
+ * out [B][T][H*D].  ws [B*T][H][splits][D+2], counters [B*T][H] (needed when splits > 1).  k / v [B][G][cap][D] with
+ * G = kv_heads (0 -> H). */
 int rst_attn_decode_multi_f32(const float* q, const float* k, const float* v, float* ws, uint32_t* counters, float* out,
                               const int64_t* pos_dev, int B, int T, int H, int D, int cap, int context, int splits,
-                              rst_stream_t stream);
+                              int kv_heads, rst_stream_t stream);
 
 /* sample_token (utils/sampling.py:85-105): greedy argmax, or softmax(logits/temp) -> top-k (sorted descending) ->
  * argmax_j p_j / noise_j with caller-provided Exp(1) noise [B][noise_stride] (the reference draws it with

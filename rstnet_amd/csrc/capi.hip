@@ -163,10 +163,10 @@ int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, i
 }
 
 // ---- LM decode step -------------------------------------------------------------------------------------------------
-int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, float* y, int B, int N,
-                      int K, int ldx, int ldy, int prologue, float eps, rst_stream_t stream) {
+int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, const float* bias, float* y,
+                      int B, int N, int K, int ldx, int ldy, int prologue, float eps, rst_stream_t stream) {
     GemvParams p;
-    p.x = x; p.alpha = alpha; p.w = w; p.res = res; p.y = y; p.B = B; p.N = N; p.K = K; p.ldx = ldx; p.ldy = ldy;
+    p.x = x; p.alpha = alpha; p.w = w; p.res = res; p.bias = bias; p.y = y; p.B = B; p.N = N; p.K = K; p.ldx = ldx; p.ldy = ldy;
     p.prologue = prologue; p.eps = eps;
     return rst_launch_gemv_bf16(p, (hipStream_t)stream);
 }
@@ -176,10 +176,11 @@ int rst_gemm_skinny_plan(int B, int N, int K, int* k_slice, int* splits) {
     return rst_skinny_plan_impl(B, N, K, k_slice, splits);
 }
 
-int rst_gemm_skinny_bf16_f32(const float* x, const uint16_t* w, const float* res, float* y, float* ws, uint32_t* counters,
-                             int B, int N, int K, int ldx, int ldy, int prologue, int k_slice, rst_stream_t stream) {
+int rst_gemm_skinny_bf16_f32(const float* x, const uint16_t* w, const float* res, const float* bias, float* y, float* ws,
+                             uint32_t* counters, int B, int N, int K, int ldx, int ldy, int prologue, int k_slice,
+                             rst_stream_t stream) {
     SkinnyParams p;
-    p.x = x; p.w = w; p.res = res; p.y = y; p.ws = ws; p.counters = counters; p.B = B; p.N = N; p.K = K; p.ldx = ldx;
+    p.x = x; p.w = w; p.res = res; p.bias = bias; p.y = y; p.ws = ws; p.counters = counters; p.B = B; p.N = N; p.K = K; p.ldx = ldx;
     p.ldy = ldy; p.prologue = prologue; p.k_slice = k_slice;
     return rst_launch_gemm_skinny(p, (hipStream_t)stream);
 }
@@ -197,19 +198,21 @@ int rst_rmsnorm_f32(const float* x, const float* alpha, float* y, int64_t rows, 
     return rst_launch_rmsnorm(x, alpha, y, rows, D, eps, (hipStream_t)stream);
 }
 
-int rst_lm_rope_append_f32(const float* qkv, float* q, float* k, float* v, const int64_t* pos_dev, int B, int H, int D,
-                           int cap, int ldqkv, int rope, float rope_coef, rst_stream_t stream) {
+int rst_lm_rope_append_f32(const float* qkv, float* q, float* k, float* v, const int64_t* pos_dev, int B, int T, int H,
+                           int kv_heads, int D, int cap, int ldqkv, int rope, float rope_coef, int rope_dims,
+                           rst_stream_t stream) {
     LmRopeAppendParams p;
-    p.qkv = qkv; p.q = q; p.k = k; p.v = v; p.pos_dev = (const long*)pos_dev; p.B = B; p.H = H; p.D = D; p.cap = cap;
-    p.ldqkv = ldqkv; p.rope = rope; p.rope_coef = rope_coef;
+    p.qkv = qkv; p.q = q; p.k = k; p.v = v; p.pos_dev = (const long*)pos_dev; p.B = B; p.T = T; p.H = H;
+    p.G = kv_heads > 0 ? kv_heads : H; p.D = D; p.cap = cap;
+    p.ldqkv = ldqkv; p.rope = rope; p.rope_coef = rope_coef; p.rope_dims = rope_dims > 0 ? rope_dims : D;
     return rst_launch_lm_rope_append(p, (hipStream_t)stream);
 }
 
 int rst_lm_attn_decode_f32(const float* qkv, float* k, float* v, float* ws, uint32_t* counters, float* out,
                            const int64_t* pos_dev, int B, int H, int D, int cap, int context, int splits, int ldqkv, int rope,
-                           float rope_coef, rst_stream_t stream) {
+                           float rope_coef, int kv_heads, int rope_dims, rst_stream_t stream) {
     LmAttnParams p;
-    p.q_pre = nullptr; p.T = 1;
+    p.q_pre = nullptr; p.T = 1; p.G = kv_heads > 0 ? kv_heads : H; p.rope_dims = rope_dims > 0 ? rope_dims : D;
     p.qkv = qkv; p.k = k; p.v = v; p.ws = ws; p.counters = counters; p.out = out; p.pos_dev = (const long*)pos_dev;
     p.B = B; p.H = H; p.D = D; p.cap = cap; p.context = context; p.splits = splits; p.ldqkv = ldqkv; p.rope = rope;
     p.rope_coef = rope_coef;
@@ -218,8 +221,9 @@ int rst_lm_attn_decode_f32(const float* qkv, float* k, float* v, float* ws, uint
 
 int rst_attn_decode_multi_f32(const float* q, const float* k, const float* v, float* ws, uint32_t* counters, float* out,
                               const int64_t* pos_dev, int B, int T, int H, int D, int cap, int context, int splits,
-                              rst_stream_t stream) {
+                              int kv_heads, rst_stream_t stream) {
     LmAttnParams p;
+    p.G = kv_heads > 0 ? kv_heads : H; p.rope_dims = D;
     p.qkv = nullptr; p.q_pre = q; p.T = T; p.k = const_cast<float*>(k); p.v = const_cast<float*>(v); p.ws = ws; p.counters = counters;
     p.out = out; p.pos_dev = (const long*)pos_dev; p.B = B; p.H = H; p.D = D; p.cap = cap; p.context = context; p.splits = splits;
     p.ldqkv = 0; p.rope = 0; p.rope_coef = 0.f;

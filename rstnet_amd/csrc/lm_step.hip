@@ -159,7 +159,8 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvPa
                 const int n = n0 + r;
                 if (lane == 0 && n < p.N) {
                     const long o = (long)b * p.ldy + n;
-                    p.y[o] = p.res ? p.res[o] + s : s;
+                    const float sb = p.bias ? s + p.bias[n] : s;
+                    p.y[o] = p.res ? p.res[o] + sb : sb;
                 }
             }
     }
@@ -195,32 +196,40 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     for (int k = tid; k < D; k += 256) y[(long)blockIdx.x * D + k] = xr[k] * (alpha[k] * r);
 }
 
-// qkv [B][3*H*D] (one new step) -> q_rot [B][H*D]; k (rotated) and v written into ring slot pos % cap of [B][H][cap][D]
+// qkv [B][T][ldqkv] (T new steps, [q | k | v] with H / G / G heads) -> q_rot [B][H][T][D]; k (rotated) and v written into
+// ring slots (pos + t) % cap of [B][G][cap][D].  Work item = one (real, imag) pair of one q head or one k/v head.
 __global__ __launch_bounds__(256) void rope_append_kernel(const LmRopeAppendParams p) {
     const int half = p.D / 2;
-    const long total = (long)p.B * p.H * half;
-    const long pos = *p.pos_dev;
-    const int slot = (int)(pos % p.cap);
+    const int HG = p.H + p.G;
+    const long total = (long)p.B * p.T * HG * half;
+    const long pos0 = *p.pos_dev;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int i = (int)(idx % half);
-        const int h = (int)((idx / half) % p.H);
-        const long b = idx / ((long)half * p.H);
-        const float* src = p.qkv + b * p.ldqkv + (long)h * p.D + 2 * i;
-        const long HD = (long)p.H * p.D;
+        const int hh = (int)((idx / half) % HG);
+        const int t = (int)((idx / ((long)half * HG)) % p.T);
+        const long b = idx / ((long)half * HG * p.T);
+        const long pos = pos0 + t;
+        const float* row = p.qkv + (b * p.T + t) * (long)p.ldqkv;
         float c = 1.f, s = 0.f;
-        if (p.rope) {
-            const float fr = expf((float)i * p.rope_coef);
-            const float ang = fr * ((float)pos + 0.0f);
+        if (p.rope && 2 * i < p.rope_dims) {
+            const float ang = expf((float)i * p.rope_coef) * (float)pos;
             c = cosf(ang);
             s = sinf(ang);
         }
-        const float qr = src[0], qi = src[1], kr = src[HD], ki = src[HD + 1];
-        float* qd = p.q + b * HD + (long)h * p.D + 2 * i;
-        float* kd = p.k + ((b * p.H + h) * p.cap + slot) * (long)p.D + 2 * i;
-        float* vd = p.v + ((b * p.H + h) * p.cap + slot) * (long)p.D + 2 * i;
-        qd[0] = qr * c - qi * s; qd[1] = qr * s + qi * c;
-        kd[0] = kr * c - ki * s; kd[1] = kr * s + ki * c;
-        vd[0] = src[2 * HD]; vd[1] = src[2 * HD + 1];
+        if (hh < p.H) {
+            const float qr = row[(long)hh * p.D + 2 * i], qi = row[(long)hh * p.D + 2 * i + 1];
+            float* qd = p.q + ((b * p.H + hh) * p.T + t) * (long)p.D + 2 * i;
+            qd[0] = qr * c - qi * s; qd[1] = qr * s + qi * c;
+        } else {
+            const int g = hh - p.H;
+            const int slot = (int)(pos % p.cap);
+            const float* ks = row + (long)p.H * p.D + (long)g * p.D + 2 * i;
+            const float* vs = ks + (long)p.G * p.D;
+            float* kd = p.k + ((b * p.G + g) * p.cap + slot) * (long)p.D + 2 * i;
+            float* vd = p.v + ((b * p.G + g) * p.cap + slot) * (long)p.D + 2 * i;
+            kd[0] = ks[0] * c - ks[1] * s; kd[1] = ks[0] * s + ks[1] * c;
+            vd[0] = vs[0]; vd[1] = vs[1];
+        }
     }
 }
 
@@ -245,19 +254,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     const long end_offset = pos + T;             // RingKVCache.end_offset after the append of all T new steps
     const int slot_cur = p.q_pre ? -1 : (int)(pos % p.cap);   // fused mode: the slot this launch appends
     const float scale = 1.0f / sqrtf((float)D);
-    const long HD = (long)p.H * D;
+    const int qpk = p.H / p.G, g = h / qpk;      // grouped-query attention: kv head of this query head
+    const bool appender = h % qpk == 0;          // one query head per group writes the new step into the ring
 
     // rotation of this lane's 8 (real, imag) pairs at position `pos` (modules/rope.py:37-62)
     float rc[8], rs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         rc[i] = 1.f; rs[i] = 0.f;
-        if (p.rope) {
+        if (p.rope && 2 * (sub * 8 + i) < p.rope_dims) {
             const float ang = expf((float)(sub * 8 + i) * p.rope_coef) * (float)pos;
             rc[i] = cosf(ang); rs[i] = sinf(ang);
         }
     }
     const float* qkv = p.q_pre ? nullptr : p.qkv + b * p.ldqkv + (long)h * D + sub * 16;
+    const float* kn = p.q_pre ? nullptr : p.qkv + b * p.ldqkv + ((long)p.H + g) * D + sub * 16;
+    const float* vn = p.q_pre ? nullptr : kn + (long)p.G * D;
     float q[16], kcur[16];
     if (p.q_pre) {      // queries already rotated, keys already in the ring (codec transformer: rst_rope_split_f32 ran before)
         const float* qp = p.q_pre + (((b * p.H + h) * T) + tq) * (long)D + sub * 16;
@@ -266,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float qr = qkv[2 * i], qi = qkv[2 * i + 1], kr = qkv[HD + 2 * i], ki = qkv[HD + 2 * i + 1];
+            const float qr = qkv[2 * i], qi = qkv[2 * i + 1], kr = kn[2 * i], ki = kn[2 * i + 1];
             q[2 * i] = qr * rc[i] - qi * rs[i]; q[2 * i + 1] = qr * rs[i] + qi * rc[i];
             kcur[2 * i] = kr * rc[i] - ki * rs[i]; kcur[2 * i + 1] = kr * rs[i] + ki * rc[i];
         }
@@ -281,8 +293,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     float o[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = 0.f;
-    float* kb = p.k + ((b * p.H + h) * p.cap) * (long)D + sub * 16;
-    float* vb = p.v + ((b * p.H + h) * p.cap) * (long)D + sub * 16;
+    float* kb = p.k + ((b * p.G + g) * p.cap) * (long)D + sub * 16;
+    float* vb = p.v + ((b * p.G + g) * p.cap) * (long)D + sub * 16;
 
     for (int s0 = s_lo + wave * SPW; s0 < s_hi; s0 += 4 * SPW) {
         const int slot = s0 + grp;
@@ -292,11 +304,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
         for (int i = 0; i < 16; ++i) { kv[i] = 0.f; vv[i] = 0.f; }
         if (slot < s_hi && slot == slot_cur) {       // the new step: from qkv, and appended to the ring
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { kv[i] = kcur[i]; vv[i] = qkv[2 * HD + i]; }
+            for (int i = 0; i < 16; ++i) { kv[i] = kcur[i]; vv[i] = vn[i]; }
+            if (appender) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<f32x4*>(kb + (long)slot * D + 4 * i) = f32x4{kv[4 * i], kv[4 * i + 1], kv[4 * i + 2], kv[4 * i + 3]};
-                *reinterpret_cast<f32x4*>(vb + (long)slot * D + 4 * i) = f32x4{vv[4 * i], vv[4 * i + 1], vv[4 * i + 2], vv[4 * i + 3]};
+                for (int i = 0; i < 4; ++i) {
+                    *reinterpret_cast<f32x4*>(kb + (long)slot * D + 4 * i) = f32x4{kv[4 * i], kv[4 * i + 1], kv[4 * i + 2], kv[4 * i + 3]};
+                    *reinterpret_cast<f32x4*>(vb + (long)slot * D + 4 * i) = f32x4{vv[4 * i], vv[4 * i + 1], vv[4 * i + 2], vv[4 * i + 3]};
+                }
             }
         } else if (ok) {
 #pragma unroll
@@ -407,23 +421,27 @@ __global__ __launch_bounds__(64) void attn_small_kernel(const LmAttnParams p) {
     const int lane = threadIdx.x, g = lane >> 3, c = lane & 7, h = blockIdx.x;
     const long b = blockIdx.y;
     const int cap = p.cap;
-    const long HD = (long)p.H * D;
+    const int qpk = p.H / p.G, kvh = h / qpk;    // grouped-query attention: kv head of this query head
+    const bool appender = h % qpk == 0;
     const float* qkv = p.qkv + b * p.ldqkv + (long)h * D + c * DPL;
-    float* kc = p.k + ((b * p.H + h) * cap) * (long)D + c * DPL;
-    float* vc = p.v + ((b * p.H + h) * cap) * (long)D + c * DPL;
+    const float* knp = p.qkv + b * p.ldqkv + ((long)p.H + kvh) * D + c * DPL;
+    const float* vnp = knp + (long)p.G * D;
+    float* kc = p.k + ((b * p.G + kvh) * cap) * (long)D + c * DPL;
+    float* vc = p.v + ((b * p.G + kvh) * cap) * (long)D + c * DPL;
     const int npass = (cap + 7) >> 3;
     float q[DPL], kn[DPL], vn[DPL];
 #pragma unroll
     for (int i = 0; i < DPL; i += 4) {
         *reinterpret_cast<f32x4*>(q + i) = *reinterpret_cast<const f32x4*>(qkv + i);
-        *reinterpret_cast<f32x4*>(kn + i) = *reinterpret_cast<const f32x4*>(qkv + HD + i);
-        *reinterpret_cast<f32x4*>(vn + i) = *reinterpret_cast<const f32x4*>(qkv + 2 * HD + i);
+        *reinterpret_cast<f32x4*>(kn + i) = *reinterpret_cast<const f32x4*>(knp + i);
+        *reinterpret_cast<f32x4*>(vn + i) = *reinterpret_cast<const f32x4*>(vnp + i);
     }
     const long pos = *p.pos_dev;
     const int slot_cur = (int)(pos % cap);
     if (p.rope) {
 #pragma unroll
         for (int i = 0; i < DPL; i += 2) {
+            if (c * DPL + i >= p.rope_dims) continue;
             const float ang = expf((float)((c * DPL + i) >> 1) * p.rope_coef) * (float)pos;
             const float cs = cosf(ang), sn = sinf(ang);
             const float qr = q[i], qi = q[i + 1], kr = kn[i], ki = kn[i + 1];
@@ -441,7 +459,7 @@ __global__ __launch_bounds__(64) void attn_small_kernel(const LmAttnParams p) {
             const bool cur = slot == slot_cur;
             const bool ok = slot < cap && ring_visible(slot, pos, cap, p.context, pos + 1);
             float kk[DPL];
-            if (cur) {
+            if (cur && appender) {
 #pragma unroll
                 for (int i = 0; i < DPL; i += 4) {
                     *reinterpret_cast<f32x4*>(kc + (long)slot * D + i) = *reinterpret_cast<const f32x4*>(kn + i);
@@ -706,9 +724,12 @@ int rst_launch_rmsnorm(const float* x, const float* alpha, float* y, long rows, 
 }
 
 int rst_launch_lm_rope_append(const LmRopeAppendParams& p, hipStream_t stream) {
-    RST_REQUIRE(p.qkv && p.q && p.k && p.v && p.pos_dev && p.B >= 1 && p.H > 0 && p.D > 0 && p.D % 2 == 0 && p.cap > 0,
+    RST_REQUIRE(p.qkv && p.q && p.k && p.v && p.pos_dev && p.B >= 1 && p.T >= 1 && p.H > 0 && p.D > 0 && p.D % 2 == 0 && p.cap > 0,
                 "lm_rope_append: bad arguments");
-    const long total = (long)p.B * p.H * (p.D / 2);
+    RST_REQUIRE(p.G >= 1 && p.H % p.G == 0 && p.T <= p.cap && p.rope_dims >= 0 && p.rope_dims <= p.D && p.rope_dims % 2 == 0,
+                "lm_rope_append: bad kv head count %d for %d heads, %d steps for capacity %d, or rope_dims %d", p.G, p.H, p.T, p.cap,
+                p.rope_dims);
+    const long total = (long)p.B * p.T * (p.H + p.G) * (p.D / 2);
     hipLaunchKernelGGL(rope_append_kernel, dim3(cap_grid((total + 255) / 256, 1024)), dim3(256), 0, stream, p);
     return rst_check_launch("lm_rope_append");
 }
@@ -718,6 +739,8 @@ int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream) {
                 "lm_attn: bad arguments");
     const int T = p.q_pre ? p.T : 1;
     RST_REQUIRE(T >= 1 && (long)p.B * T <= 65535 && p.H <= 65535 && p.D % 2 == 0, "lm_attn: bad sizes");
+    RST_REQUIRE(p.G >= 1 && p.H % p.G == 0 && p.rope_dims >= 0 && p.rope_dims <= p.D && p.rope_dims % 2 == 0,
+                "lm_attn: bad kv head count %d for %d heads or rope_dims %d", p.G, p.H, p.rope_dims);
     if (!p.q_pre && p.cap <= 64 && p.splits == 1) {
         switch (p.D) {
             case 32: hipLaunchKernelGGL(attn_small_kernel<32>, dim3(p.H, p.B), dim3(64), 0, stream, p); break;
@@ -858,6 +881,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
         if (b < p.B && n < p.N) {
             if (SK == 1) {
                 const long o = (long)b * p.ldy + n;
+                if (p.bias) s += p.bias[n];
                 p.y[o] = p.res ? p.res[o] + s : s;
             } else {
                 __hip_atomic_store(p.ws + ((long)blockIdx.y * p.B + b) * p.N + n, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -882,6 +906,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
             for (int sk = 0; sk < SK; ++sk)
                 s += __hip_atomic_load(p.ws + ((long)sk * p.B + b) * p.N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const long o = (long)b * p.ldy + n;
+            if (p.bias) s += p.bias[n];
             p.y[o] = p.res ? p.res[o] + s : s;
         }
     }

@@ -122,6 +122,7 @@ struct GemvParams {
     const float* alpha;         // prologue 1: RMSNorm gain [K]
     const unsigned short* w;    // [N][K] bf16
     const float* res;           // optional [B][ldy]
+    const float* bias;          // optional [N]
     float* y;                   // [B][ldy]
     int B, N, K, ldx, ldy;
     int prologue;               // 0 none, 1 RMSNorm, 2 SiLU gate
@@ -142,21 +143,21 @@ int rst_launch_embed_sum(const EmbedSumParams& p, hipStream_t stream);
 int rst_launch_rmsnorm(const float* x, const float* alpha, float* y, long rows, int D, float eps, hipStream_t stream);
 
 struct LmRopeAppendParams {
-    const float* qkv;     // [B][ldqkv], one step: [q | k | v] each H*D
-    float* q;             // [B][H*D]
-    float* k;             // [B][H][cap][D]
+    const float* qkv;     // [B][T][ldqkv], T new steps: [q (H*D) | k (G*D) | v (G*D)]
+    float* q;             // [B][H][T][D] rotated queries
+    float* k;             // [B][G][cap][D]
     float* v;
-    const long* pos_dev;  // position of this step (device scalar; == steps already in the ring)
-    int B, H, D, cap, ldqkv, rope;
+    const long* pos_dev;  // position of the first new step (device scalar; == steps already in the ring)
+    int B, T, H, G, D, cap, ldqkv, rope, rope_dims;
     float rope_coef;
 };
 int rst_launch_lm_rope_append(const LmRopeAppendParams& p, hipStream_t stream);
 
 struct LmAttnParams {
-    const float* qkv;     // [B][ldqkv]: [q | k | v] of the new step, each H*D (un-rotated); or nullptr with q_pre
+    const float* qkv;     // [B][ldqkv]: [q (H*D) | k (G*D) | v (G*D)] of the new step (un-rotated); or nullptr with q_pre
     const float* q_pre;   // optional [B][H][T][D]: rotated queries of T new steps whose keys are already in the ring
     int T;
-    float* k;             // [B][H][cap][D] ring (the new step is appended)
+    float* k;             // [B][G][cap][D] ring (the new step is appended)
     float* v;
     float* ws;            // [B][H][splits][D+2] workspace: (m, l, o[D]) per split (splits > 1)
     unsigned* counters;   // [B][H] arrival counters, zero before the first launch (re-armed by the kernel)
@@ -164,6 +165,8 @@ struct LmAttnParams {
     const long* pos_dev;  // position of the new step
     int B, H, D, cap, context, splits, ldqkv, rope;
     float rope_coef;
+    int G;                // key/value heads (grouped-query attention: query head h reads kv head h / (H/G)); G == H for MHA
+    int rope_dims;        // leading head dims that rotate (pairs (2i, 2i+1), i < rope_dims/2); D = all
 };
 int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream);
 
@@ -180,6 +183,7 @@ struct SkinnyParams {
     const float* x;             // [B][ldx] fp32 (prologue 2: [B][2K])
     const unsigned short* w;    // [N][K] bf16
     const float* res;           // optional [B][ldy]
+    const float* bias;          // optional [N]
     float* y;                   // [B][ldy]
     float* ws;                  // split-K partials [splits][B][N]
     unsigned* counters;         // [ceil(N/32)] arrival counters (zero before the first launch, self re-arming)

@@ -212,15 +212,17 @@ _attn_scratch: dict = {}
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, pos0: int = 0, pos_dev: Optional[torch.Tensor] = None,
               ring: bool = False, context: Optional[int] = None) -> torch.Tensor:
-    """q ``[B,H,T,D]``, k/v ``[B,H,cap,D]`` -> ``[B,T,H*D]``."""
+    """q ``[B,H,T,D]``, k/v ``[B,G,cap,D]`` (G = H, or fewer key/value heads on the few-query ring path) -> ``[B,T,H*D]``."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk(t, n)
     B, H, T, D = q.shape
-    cap = k.shape[2]
+    G, cap = k.shape[1], k.shape[2]
     out = torch.empty(B, T, H * D, device=q.device, dtype=torch.float32)
     if pos_dev is not None:
         _chk(pos_dev, "pos_dev", torch.int64)
-    if ring and pos_dev is not None and T <= 8 and D in (64, 128):
+    if G != H and not (ring and pos_dev is not None and D in (64, 128)):
+        raise NotImplementedError("grouped key/value heads are served by the ring decode path only (head dim 64 / 128)")
+    if ring and pos_dev is not None and (T <= 8 or G != H) and D in (64, 128):
         # streaming step with a handful of new queries: split every query over the occupied ring slots instead of walking
         # the ring tile by tile with one wave per head
         splits = max(1, min(4, cap // 64))
@@ -230,7 +232,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, pos0: int = 
             sc = _attn_scratch[key] = (torch.empty(B * T, H, splits, D + 2, device=q.device, dtype=torch.float32),
                                        torch.zeros(B * T, H, device=q.device, dtype=torch.int32))
         _lib.check(_lib.lib().rst_attn_decode_multi_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(sc[0]), _ptr(sc[1]), _ptr(out), _ptr(pos_dev),
-                                                       B, T, H, D, cap, int(context) if context else 0, splits, _stream()))
+                                                       B, T, H, D, cap, int(context) if context else 0, splits, G, _stream()))
         return out
     _lib.check(_lib.lib().rst_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(pos_dev), pos0, B, T, H, D, cap,
                                             int(ring), int(context) if context else 0, _stream()))
@@ -338,13 +340,15 @@ PROLOGUE_NONE, PROLOGUE_RMSNORM, PROLOGUE_SILU_GATE = 0, 1, 2
 
 
 def gemv_bf16(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
-              eps: float = 1e-8, res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``y[B,N] = (res +) P(x) @ w.T`` with ``w`` bf16 ``[N,K]`` (rst_gemv_bf16_f32).  ``x`` is fp32 ``[B,K]``
+              eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``y[B,N] = (res +) (bias +) P(x) @ w.T`` with ``w`` bf16 ``[N,K]`` (rst_gemv_bf16_f32).  ``x`` is fp32 ``[B,K]``
     (``[B,2K]`` for the SiLU-gate prologue)."""
     _chk(x, "x")
     _chk(w, "w", torch.bfloat16)
     _chk(alpha, "alpha")
     _chk(res, "res")
+    _chk(bias, "bias")
     B = x.shape[0]
     N, K = w.shape
     assert x.shape[1] == (2 * K if prologue == PROLOGUE_SILU_GATE else K), (tuple(x.shape), N, K, prologue)
@@ -354,8 +358,8 @@ def gemv_bf16(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.lib().rst_gemv_bf16_f32(_ptr(x), _ptr(alpha), _ptr(w), _ptr(res), _ptr(out), B, N, K, x.shape[1], N, prologue,
-                                           eps, _stream()))
+    _lib.check(_lib.lib().rst_gemv_bf16_f32(_ptr(x), _ptr(alpha), _ptr(w), _ptr(res), _ptr(bias), _ptr(out), B, N, K, x.shape[1], N,
+                                           prologue, eps, _stream()))
     if prof is not None:
         e1.record()
         prof.append(("gemv_bf16", e0, e1, 2.0 * B * N * K, 2 * N * K + 4 * (x.numel() + out.numel()), (B, N, K)))
@@ -365,13 +369,15 @@ def gemv_bf16(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE
 _skinny_scratch: dict = {}
 
 
-def gemm_skinny(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_skinny(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, res: Optional[torch.Tensor] = None,
+                bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``y[B,N] = (res +) P(x) @ w.T`` for 4 < B <= 64 on the bf16 matrix cores (rst_gemm_skinny_bf16_f32); ``P`` is the
     identity or the SiLU gate.  Split-K scratch (partials + self re-arming counters) is cached per shape: launches on one
     stream are ordered, so layers of equal shape share it."""
     _chk(x, "x")
     _chk(w, "w", torch.bfloat16)
     _chk(res, "res")
+    _chk(bias, "bias")
     B = x.shape[0]
     N, K = w.shape
     assert x.shape[1] == (2 * K if prologue == PROLOGUE_SILU_GATE else K)
@@ -389,8 +395,8 @@ def gemm_skinny(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NO
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.lib().rst_gemm_skinny_bf16_f32(_ptr(x), _ptr(w), _ptr(res), _ptr(out), _ptr(ws), _ptr(cnt), B, N, K, x.shape[1], N,
-                                                  prologue, k_slice, _stream()))
+    _lib.check(_lib.lib().rst_gemm_skinny_bf16_f32(_ptr(x), _ptr(w), _ptr(res), _ptr(bias), _ptr(out), _ptr(ws), _ptr(cnt), B, N, K,
+                                                  x.shape[1], N, prologue, k_slice, _stream()))
     if prof is not None:
         e1.record()
         prof.append(("gemm_skinny", e0, e1, 2.0 * B * N * K, 2 * N * K + 4 * (x.numel() + out.numel()), (B, N, K)))
@@ -398,15 +404,19 @@ def gemm_skinny(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NO
 
 
 def lm_linear(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
-              eps: float = 1e-8, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+              eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Batch-size dispatch of one decode-step linear: weight-streaming GEMV for B <= 4, bf16-MFMA skinny GEMM above
     (RMSNorm then runs as its own small kernel)."""
     if x.shape[0] <= 4:
-        return gemv_bf16(x, w, prologue=prologue, alpha=alpha, eps=eps, res=res)
+        return gemv_bf16(x, w, prologue=prologue, alpha=alpha, eps=eps, res=res, bias=bias)
     if prologue == PROLOGUE_RMSNORM:
         x = rmsnorm(x, alpha, eps)
         prologue = PROLOGUE_NONE
-    return gemm_skinny(x, w, prologue=prologue, res=res)
+    if x.shape[0] <= 64:
+        return gemm_skinny(x, w, prologue=prologue, res=res, bias=bias)
+    # more rows than one skinny tile set (prompt prefill): chunks of 64 rows, each streaming the weights once
+    return torch.cat([gemm_skinny(x[i:i + 64], w, prologue=prologue, res=None if res is None else res[i:i + 64], bias=bias)
+                      for i in range(0, x.shape[0], 64)])
 
 
 def embed_sum(tokens: torch.Tensor, tables: Sequence[torch.Tensor], tok_index: Sequence[int],
@@ -432,29 +442,36 @@ def rmsnorm(x: torch.Tensor, alpha: torch.Tensor, eps: float = 1e-8) -> torch.Te
     return out
 
 
-def lm_rope_append(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos_dev: torch.Tensor, *, rope: bool,
-                   max_period: float = 10000.0) -> torch.Tensor:
-    """qkv ``[B, 3*H*D]`` (one step) -> rotated q ``[B, H*D]``; k/v appended to ring slot ``pos % cap`` of ``[B,H,cap,D]``."""
+def lm_rope_append(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos_dev: torch.Tensor, *, heads: int, rope: bool,
+                   max_period: float = 10000.0, rope_dims: int = 0) -> torch.Tensor:
+    """qkv ``[B, T, (H+2G)*D]`` (T new steps) -> rotated q ``[B, H, T, D]``; k/v appended to ring slots ``(pos+t) % cap`` of
+    ``[B,G,cap,D]``.  ``rope_dims``: leading head dims that rotate (0 = all)."""
     for t, n in ((qkv, "qkv"), (k_cache, "k_cache"), (v_cache, "v_cache")):
         _chk(t, n)
     _chk(pos_dev, "pos_dev", torch.int64)
-    B, H, cap, D = k_cache.shape
-    q = torch.empty(B, H * D, device=qkv.device, dtype=torch.float32)
-    _lib.check(_lib.lib().rst_lm_rope_append_f32(_ptr(qkv), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(pos_dev), B, H, D, cap,
-                                                qkv.shape[1], int(rope), rope_coef(max_period, D), _stream()))
+    B, G, cap, D = k_cache.shape
+    T = qkv.shape[1]
+    assert qkv.dim() == 3 and qkv.shape[2] == (heads + 2 * G) * D, (tuple(qkv.shape), heads, G, D)
+    q = torch.empty(B, heads, T, D, device=qkv.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_lm_rope_append_f32(_ptr(qkv), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(pos_dev), B, T, heads, G, D, cap,
+                                                qkv.shape[2], int(rope), rope_coef(max_period, rope_dims or D), rope_dims, _stream()))
     return q
 
 
 def lm_attn_decode(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos_dev: torch.Tensor, *, rope: bool,
                    context: Optional[int], max_period: float = 10000.0, splits: Optional[int] = None,
-                   scratch: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
-    """Single-query attention of the new step given its qkv row ``[B, 3*H*D]`` (RoPE, ring append, attention and the
-    reduction over slot splits in ONE launch) -> ``[B, H*D]``.  ``scratch = (ws [B,H,splits,D+2] fp32, counters [B,H] int32
-    zeros)`` may be passed to reuse buffers (the counters re-arm themselves)."""
+                   scratch: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, heads: Optional[int] = None,
+                   rope_dims: int = 0) -> torch.Tensor:
+    """Single-query attention of the new step given its qkv row ``[B, (H+2G)*D]`` (RoPE, ring append, attention and the
+    reduction over slot splits in ONE launch) -> ``[B, H*D]``; the ring is ``[B,G,cap,D]`` (``heads`` = H when G < H).
+    ``scratch = (ws [B,H,splits,D+2] fp32, counters [B,H] int32 zeros)`` may be passed to reuse buffers (the counters re-arm
+    themselves).  ``rope_dims``: leading head dims that rotate (0 = all; the frequencies then span ``rope_dims``)."""
     for t, n in ((qkv, "qkv"), (k_cache, "k_cache"), (v_cache, "v_cache")):
         _chk(t, n)
     _chk(pos_dev, "pos_dev", torch.int64)
-    B, H, cap, D = k_cache.shape
+    B, G, cap, D = k_cache.shape
+    H = heads or G
+    assert qkv.shape[1] == (H + 2 * G) * D, (tuple(qkv.shape), H, G, D)
     if splits is None:
         splits = 1 if cap <= 64 else max(1, min(16, cap // 128, 1024 // max(1, B * H)))
     ws = counters = None
@@ -468,7 +485,7 @@ def lm_attn_decode(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     out = torch.empty(B, H * D, device=qkv.device, dtype=torch.float32)
     _lib.check(_lib.lib().rst_lm_attn_decode_f32(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(ws), _ptr(counters), _ptr(out),
                                                 _ptr(pos_dev), B, H, D, cap, int(context) if context else 0, splits, qkv.shape[1],
-                                                int(rope), rope_coef(max_period, D), _stream()))
+                                                int(rope), rope_coef(max_period, rope_dims or D), G, rope_dims, _stream()))
     return out
 
 

@@ -222,3 +222,101 @@ def lm_state_dict(cfg: dict, seed: int = 0, device: str = "cpu", dtype: torch.dt
     for k in range(dep_q):
         lin(f"linears.{k}.weight", cfg["card"], ddim)
     return sd
+
+
+# ---- litgpt-style backbone (MLLM_v2/models/llama_streaming.py) -------------------------------------------------------
+# Keys = fields of models/config.py:Config + models/llama_streaming.py:Config (:447-489).
+# BASELINE.json configs[4]: Qwen-1.5-0.5B-shaped backbone + LoRA r=32 alpha=16 on q,k,v,proj,mlp,head (egs recipe run.sh),
+# codecformer 1024 / 16 heads / 6 layers / ff 4224.
+GPT_QWEN_0_5B = dict(block_size=4096, n_layer=24, n_embd=1024, n_head=16, n_query_groups=16, padded_vocab_size=151936,
+                     rotary_percentage=1.0, rope_base=1000000, norm_class_name="RMSNorm", norm_eps=1e-6, bias=False,
+                     lm_head_bias=False, parallel_residual=False, mlp_class_name="LLaMAMLP", intermediate_size=2816,
+                     lora_r=32, lora_alpha=16, lora_query=True, lora_key=True, lora_value=True, lora_projection=True,
+                     lora_mlp=True, lora_head=True, audio_card=2050, codecformer_dim=1024, n_q=8, dep_q=8,
+                     codecformer_heads=16, codecformer_layers=6, codecformer_dim_feedforward=4224, context=3000)
+# grouped-query attention, partial RoPE, LoRA on q and v only (exercises the lora_ind scatter), no biases
+GPT_TINY_GQA = dict(block_size=64, n_layer=2, n_embd=256, n_head=4, n_query_groups=2, padded_vocab_size=320,
+                    rotary_percentage=0.5, rope_base=10000, norm_class_name="RMSNorm", norm_eps=1e-5, bias=False,
+                    lm_head_bias=False, parallel_residual=False, mlp_class_name="LLaMAMLP", intermediate_size=384,
+                    lora_r=4, lora_alpha=8, lora_query=True, lora_key=False, lora_value=True, lora_projection=True,
+                    lora_mlp=True, lora_head=True, audio_card=32, codecformer_dim=128, n_q=4, dep_q=3,
+                    codecformer_heads=2, codecformer_layers=2, codecformer_dim_feedforward=528, context=10)
+# multi-head attention, full RoPE, LoRA on q, k and v (the zero_pad early-return quirk), biases everywhere
+GPT_TINY_MHA = dict(block_size=64, n_layer=2, n_embd=256, n_head=4, n_query_groups=4, padded_vocab_size=320,
+                    rotary_percentage=1.0, rope_base=10000, norm_class_name="RMSNorm", norm_eps=1e-5, bias=True,
+                    lm_head_bias=True, parallel_residual=False, mlp_class_name="LLaMAMLP", intermediate_size=384,
+                    lora_r=4, lora_alpha=8, lora_query=True, lora_key=True, lora_value=True, lora_projection=False,
+                    lora_mlp=False, lora_head=False, audio_card=32, codecformer_dim=128, n_q=4, dep_q=3,
+                    codecformer_heads=2, codecformer_layers=2, codecformer_dim_feedforward=528, context=10,
+                    codecformer_bias_proj=True)
+
+
+def gpt_state_dict(cfg: dict, seed: int = 0, device: str = "cpu", dtype: torch.dtype = torch.bfloat16,
+                   lora: bool = True) -> Dict[str, torch.Tensor]:
+    """Random-init weights with the ``state_dict`` keys of ``models.llama_streaming.GPT`` (same distributions as
+    ``lm_state_dict``; LoRA A ~ U(+-sqrt(3/in)), B ~ U(+-sqrt(3/r)) -- non-zero so that the adapters matter).  ``lora=False``
+    leaves the adapters out (a checkpoint that was merged before saving)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(key: str, out_f: int, in_f: int, bias: bool = False, scale: float = 1.0):
+        b = math.sqrt(3.0 / in_f) * scale
+        sd[f"{key}.weight" if not key.endswith(("lora_A", "lora_B")) else key] = \
+            ((torch.rand(out_f, in_f, generator=g, device=device) * 2 - 1) * b).to(dtype)
+        if bias:
+            sd[f"{key}.bias"] = (0.1 * torch.randn(out_f, generator=g, device=device)).to(dtype)
+
+    def emb(key: str, n: int, d: int):
+        sd[key] = (0.5 * torch.randn(n, d, generator=g, device=device)).to(dtype)
+
+    def gain(key: str, shape):
+        sd[key] = (1.0 + 0.1 * torch.randn(*shape, generator=g, device=device)).to(dtype)
+
+    E, H, G = cfg["n_embd"], cfg["n_head"], cfg["n_query_groups"]
+    hs = cfg.get("head_size") or E // H
+    r = cfg.get("lora_r", 0) if lora else 0
+    V, I = cfg["padded_vocab_size"], cfg["intermediate_size"]
+
+    def lora_linear(key: str, out_f: int, in_f: int, bias: bool, enabled: bool):
+        lin(f"{key}.linear", out_f, in_f, bias)
+        if r > 0 and enabled:
+            lin(f"{key}.lora_A", r, in_f)
+            lin(f"{key}.lora_B", out_f, r, scale=0.5)
+
+    lora_linear("lm_head", V, E, cfg.get("lm_head_bias", False), cfg.get("lora_head", False))
+    emb("transformer.wte.weight", V, E)
+    for l in range(cfg["n_layer"]):
+        p = f"transformer.h.{l}"
+        gain(f"{p}.norm_1.weight", (E,))
+        lin(f"{p}.attn.attn.linear", (H + 2 * G) * hs, E, cfg.get("bias", False))
+        en = (cfg.get("lora_query", False), cfg.get("lora_key", False), cfg.get("lora_value", False))
+        if r > 0 and any(en):
+            lin(f"{p}.attn.attn.lora_A", r * sum(en), E)
+            lin(f"{p}.attn.attn.lora_B", hs * (H * en[0] + G * en[1] + G * en[2]), r, scale=0.5)
+        lora_linear(f"{p}.attn.proj", E, hs * H, cfg.get("bias", False), cfg.get("lora_projection", False))
+        gain(f"{p}.norm_2.weight", (E,))
+        for name, (o, i) in (("fc_1", (I, E)), ("fc_2", (I, E)), ("proj", (E, I))):
+            lora_linear(f"{p}.mlp.{name}", o, i, cfg.get("bias", False), cfg.get("lora_mlp", False))
+    gain("transformer.ln_f.weight", (E,))
+    card, ddim, dep_q = cfg["audio_card"], cfg["codecformer_dim"], cfg["dep_q"]
+    for k in range(cfg["n_q"]):
+        emb(f"input_emb.{k}.weight", card + 1, E)
+    for k in range(dep_q):
+        lin(f"codecformer_in.{k}", ddim, E)
+    for k in range(dep_q - 1):
+        emb(f"codecformer_emb.{k}.weight", card + 1, ddim)
+    emb("codecformer_text_emb.weight", V, ddim)
+    dhid = _gating_hidden(ddim, cfg["codecformer_dim_feedforward"])
+    for l in range(cfg["codecformer_layers"]):
+        p = f"codecformer.layers.{l}"
+        sd[f"{p}.self_attn.in_proj_weight"] = ((torch.rand(dep_q * 3 * ddim, ddim, generator=g, device=device) * 2 - 1)
+                                               * math.sqrt(3.0 / ddim)).to(dtype)
+        lin(f"{p}.self_attn.out_proj", dep_q * ddim, ddim)
+        gain(f"{p}.norm1.alpha", (1, 1, ddim))
+        gain(f"{p}.norm2.alpha", (1, 1, ddim))
+        for k in range(dep_q):
+            lin(f"{p}.gating.{k}.linear_in", 2 * dhid, ddim)
+            lin(f"{p}.gating.{k}.linear_out", ddim, dhid)
+    for k in range(dep_q):
+        lin(f"audio_linears.{k}", card, ddim, cfg.get("codecformer_bias_proj", False))
+    return sd

@@ -90,3 +90,19 @@ def lm_user_tokens(cfg: dict, steps: int = LM_STEPS, batch: int = LM_BATCH):
     """Tokens of the "other" stream fed to LMGen.step: [steps][B, n_q - dep_q, 1]."""
     g = torch.Generator().manual_seed(79)
     return torch.randint(0, cfg["card"], (steps, batch, cfg["n_q"] - cfg["dep_q"], 1), generator=g)
+
+
+# ---- litgpt-style backbone (tiny configs) ---------------------------------------------------------------------------
+GPT_SEED = 5
+GPT_STEPS = 14      # > context (10): the ring wraps
+GPT_BATCH = 2
+GPT_T_FULL = 9      # non-streaming forward_global length (< context, so the context mask is also exercised by GPT_STEPS only)
+
+
+def gpt_tokens(cfg: dict, steps: int = GPT_STEPS, batch: int = GPT_BATCH):
+    """Input frames [B, n_q + 1, steps]: row 0 text ids, rows 1.. audio ids (one column is the -1 'no input' id)."""
+    g = torch.Generator().manual_seed(80)
+    text = torch.randint(0, cfg["padded_vocab_size"], (batch, 1, steps), generator=g)
+    audio = torch.randint(0, cfg["audio_card"] + 1, (batch, cfg["n_q"], steps), generator=g)
+    audio[0, 1, 2] = -1
+    return torch.cat([text, audio], 1)

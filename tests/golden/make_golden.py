@@ -146,7 +146,46 @@ def gen_lm_tiny():
     print("lm_tiny", torch.cat(outs, -1).shape, torch.stack(text_logits).shape, torch.stack(dep_logits).shape)
 
 
+@torch.no_grad()
+def gen_gpt_tiny():
+    """F6 + F7: models.llama_streaming.GPT on the two tiny configs -- non-streaming forward_global (LoRA unmerged and after
+    merge_lora_weights), streamed T = 1 forward_global steps across the ring wrap, forward_codecformer steps and the
+    teacher-forced forward_local.  fp32 arithmetic on bf16-rounded weights."""
+    from models.llama_streaming import GPT, Config, merge_lora_weights
+    out = {}
+    for name, cfg in (("gqa", synth.GPT_TINY_GQA), ("mha", synth.GPT_TINY_MHA)):
+        sd = {k: v.float() for k, v in synth.gpt_state_dict(cfg, cases.GPT_SEED).items()}
+        m = GPT(Config(name=name, **cfg)).eval()
+        missing, unexpected = m.load_state_dict(sd, strict=True)
+        toks = cases.gpt_tokens(cfg)
+        B, dep_q = cases.GPT_BATCH, cfg["dep_q"]
+        h_full, logits_full = m.forward_global(toks[:, :, :cases.GPT_T_FULL])
+        out[f"{name}.full.h"], out[f"{name}.full.logits"] = h_full.numpy(), logits_full.numpy()
+        hs, ls, dep = [], [], []
+        with m.streaming(B):
+            for t in range(cases.GPT_STEPS):
+                h, lg = m.forward_global(toks[:, :, t:t + 1])
+                hs.append(h)
+                ls.append(lg)
+                with m.codecformer.streaming(B):
+                    for k in range(dep_q):
+                        prev = toks[:, 0:1, t:t + 1] if k == 0 else toks[:, k:k + 1, t:t + 1]
+                        dep.append(m.forward_codecformer(k, prev, h))
+        out[f"{name}.stream.h"], out[f"{name}.stream.logits"] = torch.cat(hs, 1).numpy(), torch.cat(ls, 1).numpy()
+        out[f"{name}.stream.dep_logits"] = torch.stack(dep).view(cases.GPT_STEPS, dep_q, B, -1).numpy()
+        T = cases.GPT_T_FULL
+        local = m.forward_local(m.codecformer_text_emb(toks[:, 0, :T]), toks[:, 1:dep_q + 1, :T], h_full)
+        out[f"{name}.local.logits"] = local.numpy()
+        merge_lora_weights(m)
+        h_m, logits_m = m.forward_global(toks[:, :, :T])
+        out[f"{name}.merged.logits"] = logits_m.numpy()
+        out[f"{name}.merged.qkv0"] = m.transformer.h[0].attn.attn.linear.weight.detach().numpy()
+        print("gpt_tiny", name, logits_full.shape, out[f"{name}.stream.dep_logits"].shape, local.shape,
+              float((logits_m - logits_full).abs().max()))
+    np.savez(os.path.join(HERE, "gpt_tiny.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e", "lm_tiny"]
+    which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e", "lm_tiny", "gpt_tiny"]
     for w in which:
         globals()[f"gen_{w}"]()

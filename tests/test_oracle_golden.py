@@ -126,3 +126,46 @@ def test_lm_oracle_matches_reference():
     assert torch.equal(torch.cat(outs, -1), torch.from_numpy(g["tokens"]).long())
     assert rel_err(torch.stack(text_logits), torch.from_numpy(g["text_logits"])) < 1e-5
     assert rel_err(torch.stack(dep_logits), torch.from_numpy(g["dep_logits"])) < 1e-5
+
+
+def _gpt_cfg(cfg_d):
+    from oracle import gpt_oracle as Gp
+    keep = {f for f in Gp.GPTConfig.__dataclass_fields__}
+    return Gp.GPTConfig(**{k: v for k, v in cfg_d.items() if k in keep})
+
+
+@pytest.mark.parametrize("name", ["gqa", "mha"])
+def test_gpt_oracle_matches_reference(name):
+    """oracle/gpt_oracle.py vs the imported models.llama_streaming.GPT on the tiny configs (fixture gpt_tiny.npz):
+    non-streaming forward_global with unmerged LoRA, the merged weights, streamed T = 1 steps across the ring wrap,
+    forward_codecformer steps and the teacher-forced forward_local -- all within 2e-5 relative."""
+    from oracle import gpt_oracle as Gp
+    cfg_d = synth.GPT_TINY_GQA if name == "gqa" else synth.GPT_TINY_MHA
+    cfg = _gpt_cfg(cfg_d)
+    sd = {k: v.float() for k, v in synth.gpt_state_dict(cfg_d, cases.GPT_SEED).items()}
+    g = np.load(os.path.join(G, "gpt_tiny.npz"))
+    toks = cases.gpt_tokens(cfg_d)
+    T, B = cases.GPT_T_FULL, cases.GPT_BATCH
+    with torch.no_grad():
+        h_full, lg_full = Gp.forward_global(sd, cfg, toks[:, :, :T])
+        assert rel_err(h_full, torch.from_numpy(g[f"{name}.full.h"])) < 2e-5
+        assert rel_err(lg_full, torch.from_numpy(g[f"{name}.full.logits"])) < 2e-5
+        msd = Gp.merged_state(sd, cfg)
+        assert rel_err(msd["transformer.h.0.attn.attn.linear.weight"], torch.from_numpy(g[f"{name}.merged.qkv0"])) < 1e-6
+        _, lg_m = Gp.forward_global(msd, cfg, toks[:, :, :T], merged=True)
+        assert rel_err(lg_m, torch.from_numpy(g[f"{name}.merged.logits"])) < 2e-5
+        st = Gp.new_global_state(cfg, B)
+        hs, ls, dep = [], [], []
+        for t in range(cases.GPT_STEPS):
+            h, lg = Gp.forward_global(msd, cfg, toks[:, :, t:t + 1], st, merged=True)
+            hs.append(h)
+            ls.append(lg)
+            cst = Gp.new_codecformer_state(cfg, B)
+            for k in range(cfg.dep_q):
+                prev = toks[:, 0:1, t:t + 1] if k == 0 else toks[:, k:k + 1, t:t + 1]
+                dep.append(Gp.forward_codecformer(msd, cfg, k, prev, h, cst))
+        assert rel_err(torch.cat(hs, 1), torch.from_numpy(g[f"{name}.stream.h"])) < 2e-5
+        assert rel_err(torch.cat(ls, 1), torch.from_numpy(g[f"{name}.stream.logits"])) < 2e-5
+        assert rel_err(torch.stack(dep).view(cases.GPT_STEPS, cfg.dep_q, B, -1), torch.from_numpy(g[f"{name}.stream.dep_logits"])) < 2e-5
+        local = Gp.forward_local(sd, cfg, toks[:, 0, :T], toks[:, 1:cfg.dep_q + 1, :T], h_full)
+        assert rel_err(local, torch.from_numpy(g[f"{name}.local.logits"])) < 2e-5
