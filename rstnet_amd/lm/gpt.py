@@ -1,0 +1,584 @@
+"""``GPT`` -- drop-in for the inference half of ``MLLM_v2/models/llama_streaming.py``: the litgpt-style speech-text backbone
+(global transformer with fused grouped-query QKV, partial rotate-half RoPE, SiLU-gated MLP, optional LoRA adapters) plus the
+per-codebook "codecformer" depth transformer.
+
+Same ``Config`` field names, ``state_dict`` keys (``transformer.h.{l}.attn.attn.linear.weight``, ``...mlp.fc_1.linear.weight``,
+``lm_head.linear.weight``, ``input_emb.{k}.weight``, ``codecformer.layers.{l}.gating.{k}.linear_in.weight``, ... incl. the
+legacy remaps of llama_streaming.py:762-766,1000-1009,1034-1088), method signatures (``forward_global``,
+``forward_codecformer``, ``forward_local``, ``forward``, ``_get_initial_token``, token-id properties) and streaming protocol
+(``with gpt.streaming(B)``, ``with gpt.codecformer.streaming(B)``).
+
+Execution (csrc/lm_step.hip): bf16 weights, fp32 activations.
+  * LoRA adapters are merged into the dense weights when a state dict is loaded (what the reference's ``merge_lora_weights``
+    does before inference, :1120-), including the reference's zero_pad behaviour when q, k and v are all adapted.
+  * The fused QKV rows are re-ordered once from the GQA-interleaved ``[group: q.. k v]`` layout to ``[Q | K | V]`` and, inside
+    every q / k head, from rotate-half pairing ``(i, i + n/2)`` to interleaved pairing ``(2i, 2i+1)`` -- a permutation applied to
+    q and k alike leaves q.k unchanged -- so the ring-attention kernels of the Moshi path serve this model too.
+  * The KV ring stores the n_query_groups key/value heads once (the reference expands them to n_head before caching, :965-971).
+  * One decode step = 5 launches per layer for batch <= 4 (RMSNorm fused into the GEMVs); longer inputs (prompt prefill, batch
+    > 4) use the bf16-MFMA skinny GEMM over all rows + the multi-query ring attention.  T = 1 steps are graph-captured.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, fields
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..codec.conv import _PackedCache
+from ..codec.streaming import StreamingModule
+from ..graphs import Graphed as _Graphed
+from .model import RMSNorm as _AlphaNorm  # noqa: F401  (key layout of the codecformer norms)
+from .model import ScaledEmbedding, StreamingTransformer, _StepState, _Weight
+
+
+@dataclass
+class Config:
+    """models/config.py:Config + models/llama_streaming.py:Config (:447-489).  Fields that select code paths this build does
+    not implement are validated in ``__post_init__`` (NotImplementedError) instead of being silently ignored."""
+    name: str = ""
+    block_size: int = 4096
+    n_layer: int = 16
+    n_embd: int = 4096
+    vocab_size: int = 50254
+    padding_multiple: int = 512
+    padded_vocab_size: Optional[int] = None
+    norm_class_name: str = "LayerNorm"
+    norm_eps: float = 1e-5
+    norm_qk: bool = False
+    post_attention_norm: bool = False
+    post_mlp_norm: bool = False
+    parallel_residual: bool = True
+    shared_attention_norm: bool = False
+    n_head: int = 32
+    head_size: Optional[int] = None
+    n_query_groups: Optional[int] = None
+    attention_scores_scalar: Optional[int] = None
+    sliding_window_size: Optional[int] = None
+    attention_logit_softcapping: Optional[float] = None
+    rope_base: int = 10000
+    rotary_percentage: float = 0.25
+    rope_condense_ratio: int = 1
+    rope_adjustments: Optional[dict] = None
+    intermediate_size: Optional[int] = None
+    bias: bool = True
+    mlp_class_name: str = "GptNeoxMLP"
+    scale_embeddings: bool = False
+    lm_head_bias: bool = False
+    final_logit_softcapping: Optional[float] = None
+    # lora
+    lora_r: int = 0
+    lora_alpha: int = 1
+    lora_dropout: float = 0.0
+    lora_query: bool = False
+    lora_key: bool = False
+    lora_value: bool = False
+    lora_projection: bool = False
+    lora_mlp: bool = False
+    lora_head: bool = False
+    # local transformer
+    audio_card: int = 2048
+    codecformer_dim: int = 1024
+    n_q: int = 9
+    dep_q: int = 8
+    codecformer_heads: int = 32
+    codecformer_layers: int = 6
+    codecformer_hidden_scale: float = 4.5
+    causal: bool = True
+    codecformer_multi_linear: bool = True
+    codecformer_weights_per_step: bool = True
+    codecformer_dim_feedforward: int = 1024
+    codecfomer_norm: str = "rms_norm_f32"
+    codecformer_bias_proj: bool = False
+    codecfomer_norm_emb: bool = False
+    context: int = 3000
+
+    def __post_init__(self):
+        if self.head_size is None:
+            assert self.n_embd % self.n_head == 0
+            self.head_size = self.n_embd // self.n_head
+        if self.padded_vocab_size is None:
+            m = self.padding_multiple
+            self.padded_vocab_size = self.vocab_size if self.vocab_size % m == 0 else self.vocab_size + m - self.vocab_size % m
+        else:
+            self.vocab_size = min(self.vocab_size, self.padded_vocab_size)
+        if self.n_query_groups is None:
+            self.n_query_groups = self.n_head
+        assert self.n_head % self.n_query_groups == 0
+        if self.intermediate_size is None:
+            if self.mlp_class_name == "LLaMAMLP":
+                raise ValueError(f"The config {self.name!r}, needs to set the `intermediate_size`")
+            self.intermediate_size = 4 * self.n_embd
+        self.rope_n_elem = int(self.rotary_percentage * self.head_size)
+        unsupported = {
+            "norm_class_name": self.norm_class_name != "RMSNorm", "mlp_class_name": self.mlp_class_name != "LLaMAMLP",
+            "parallel_residual": self.parallel_residual, "shared_attention_norm": self.shared_attention_norm,
+            "norm_qk": self.norm_qk, "post_attention_norm": self.post_attention_norm, "post_mlp_norm": self.post_mlp_norm,
+            "attention_scores_scalar": self.attention_scores_scalar is not None,
+            "sliding_window_size": self.sliding_window_size is not None,
+            "attention_logit_softcapping": self.attention_logit_softcapping is not None,
+            "final_logit_softcapping": self.final_logit_softcapping is not None,
+            "rope_condense_ratio": self.rope_condense_ratio != 1, "rope_adjustments": self.rope_adjustments is not None,
+            "scale_embeddings": self.scale_embeddings, "n_query_groups == 1 (the reference's ring cannot hold MQA either)":
+                self.n_query_groups == 1 and self.n_head != 1,
+            "codecformer options": not (self.codecformer_multi_linear and self.codecformer_weights_per_step and self.causal
+                                        and self.codecfomer_norm == "rms_norm_f32" and not self.codecfomer_norm_emb),
+            "rope_n_elem": self.rope_n_elem % 2 != 0 or self.rope_n_elem == 0,
+        }
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"Config options outside the MI355X decode path: {bad} (supported: RMSNorm, LLaMAMLP, "
+                                      "sequential residual, plain RoPE, MHA / GQA)")
+
+    @classmethod
+    def from_dict(cls, d: Dict[str, Any]) -> "Config":
+        known = {f.name for f in fields(cls)}
+        return cls(**{k: v for k, v in d.items() if k in known})
+
+
+# ---------------------------------------------------------------------------------------------------------------- loading
+_LEGACY = (("lm_head.weight", "lm_head.linear.weight"), ("lm_head.bias", "lm_head.linear.bias"))
+_LEGACY_SUFFIX = tuple((f".{m}.{p}", f".{m}.linear.{p}") for m in ("attn.attn", "attn.proj", "mlp.fc_1", "mlp.fc_2", "mlp.proj")
+                       for p in ("weight", "bias"))
+
+
+def _remap_legacy(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Base-checkpoint key names -> LoRA-wrapped names (llama_streaming.py:762-766, 1000-1009, 1076-1088)."""
+    out = {}
+    for k, v in sd.items():
+        for old, new in _LEGACY:
+            if k == old:
+                k = new
+        for old, new in _LEGACY_SUFFIX:
+            if k.endswith(old) and not k.endswith(new):
+                k = k[: -len(old)] + new
+        out[k] = v
+    return out
+
+
+def _qkv_lora_rows(cfg: Config, enable: Tuple[bool, bool, bool]) -> Optional[torch.Tensor]:
+    """Destination rows (in the GQA-interleaved fused-QKV output) of the adapter rows, which come ordered [q heads | k heads |
+    v heads] over the enabled projections.  None = 'as is': the reference adds the update unscattered when all three
+    projections are adapted (zero_pad, llama_streaming.py:307-308)."""
+    if all(enable):
+        return None
+    hs, G = cfg.head_size, cfg.n_query_groups
+    qpk = cfg.n_head // G
+    d = torch.arange(hs)
+    grp = torch.arange(G).view(G, 1, 1) * (qpk + 2)
+    rows = []
+    if enable[0]:
+        rows.append(((grp + torch.arange(qpk).view(1, qpk, 1)) * hs + d).reshape(-1))
+    if enable[1]:
+        rows.append(((grp + qpk) * hs + d).reshape(-1))
+    if enable[2]:
+        rows.append(((grp + qpk + 1) * hs + d).reshape(-1))
+    return torch.cat(rows)
+
+
+def merge_lora_state_dict(sd: Dict[str, torch.Tensor], cfg: Config) -> Dict[str, torch.Tensor]:
+    """``merge_lora_weights`` (llama_streaming.py:1120-) on a state dict: W += (B A) * alpha / r for every adapted linear
+    (fp32 accumulate, stored back in W's dtype), adapter tensors dropped."""
+    out = {k: v for k, v in sd.items() if not k.endswith((".lora_A", ".lora_B"))}
+    scale = cfg.lora_alpha / cfg.lora_r if cfg.lora_r else 0.0
+    for key in [k for k in sd if k.endswith(".lora_A")]:
+        base = key[: -len(".lora_A")]
+        A, Bm = sd[key].float(), sd[base + ".lora_B"].float()
+        W = sd[base + ".linear.weight"]
+        if base.endswith(".attn.attn"):
+            enable = (cfg.lora_query, cfg.lora_key, cfg.lora_value)
+            sizes = [n for n, e in zip((cfg.head_size * cfg.n_head, cfg.head_size * cfg.n_query_groups,
+                                        cfg.head_size * cfg.n_query_groups), enable) if e]
+            r = cfg.lora_r
+            upd, row = [], 0
+            for i, n in enumerate(sizes):      # every adapted projection owns r rows of A and its block of B rows
+                upd.append(Bm[row:row + n] @ A[i * r:(i + 1) * r])
+                row += n
+            upd = torch.cat(upd) * scale
+            rows = _qkv_lora_rows(cfg, enable)
+            Wf = W.float()
+            if rows is None:
+                Wf = Wf + upd
+            else:
+                Wf = Wf.index_add(0, rows.to(Wf.device), upd)
+        else:
+            Wf = W.float() + (Bm @ A) * scale
+        out[base + ".linear.weight"] = Wf.to(W.dtype)
+    return out
+
+
+def merge_lora_weights(model: "GPT") -> None:
+    """API parity with llama_streaming.py:1120-: adapters are already merged when a ``GPT`` is built from a state dict."""
+    return None
+
+
+def _qkv_row_order(cfg: Config) -> torch.Tensor:
+    """Row permutation of the fused QKV weight: GQA-interleaved [group: q_0..q_{qpk-1}, k, v] -> [Q heads | K heads | V heads],
+    and within each q / k head the rotary dims from rotate-half order to interleaved pairs:
+    new dim 2i <- old dim i, new dim 2i+1 <- old dim i + n/2 (i < n/2); dims >= n keep their place."""
+    hs, H, G, n = cfg.head_size, cfg.n_head, cfg.n_query_groups, cfg.rope_n_elem
+    qpk = H // G
+    inner = torch.arange(hs)
+    half = n // 2
+    inner[0:n:2] = torch.arange(half)
+    inner[1:n:2] = torch.arange(half) + half
+    plain = torch.arange(hs)
+    order = []
+    for h in range(H):
+        g, j = divmod(h, qpk)
+        order.append((g * (qpk + 2) + j) * hs + inner)
+    for g in range(G):
+        order.append((g * (qpk + 2) + qpk) * hs + inner)
+    for g in range(G):
+        order.append((g * (qpk + 2) + qpk + 1) * hs + plain)
+    return torch.cat(order)
+
+
+# ----------------------------------------------------------------------------------------------------------------- modules
+class _Linear(nn.Module):
+    """``<name>.linear.{weight,bias}`` holder (a merged LoRALinear)."""
+
+    def __init__(self, in_f: int, out_f: int, bias: bool, device=None, dtype=None):
+        super().__init__()
+        self.linear = nn.Module()
+        self.linear.weight = nn.Parameter(torch.empty(out_f, in_f, device=device, dtype=dtype), requires_grad=False)
+        self.linear.bias = nn.Parameter(torch.zeros(out_f, device=device, dtype=dtype), requires_grad=False) if bias else None
+        self._b32 = _PackedCache()
+
+    @property
+    def weight(self) -> torch.Tensor:
+        return self.linear.weight
+
+    def bias_f32(self) -> Optional[torch.Tensor]:
+        if self.linear.bias is None:
+            return None
+        return self._b32.get((self.linear.bias,), lambda: self.linear.bias.detach().float().contiguous())
+
+
+class _PlainLinear(_Weight):
+    """nn.Linear key layout (``weight`` / ``bias``) for codecformer_in / audio_linears."""
+
+    def __init__(self, out_f: int, in_f: int, bias: bool = False, device=None, dtype=None):
+        super().__init__(out_f, in_f, device=device, dtype=dtype)
+        self.bias = nn.Parameter(torch.zeros(out_f, device=device, dtype=dtype), requires_grad=False) if bias else None
+        self._b32 = _PackedCache()
+
+    def bias_f32(self) -> Optional[torch.Tensor]:
+        if self.bias is None:
+            return None
+        return self._b32.get((self.bias,), lambda: self.bias.detach().float().contiguous())
+
+
+class _LitNorm(nn.Module):
+    """lit_model.RMSNorm (:693-717): key ``weight`` [D]."""
+
+    def __init__(self, dim: int, eps: float, device=None, dtype=None):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim, device=device, dtype=dtype), requires_grad=False)
+        self._f32 = _PackedCache()
+
+    def gain_f32(self) -> torch.Tensor:
+        return self._f32.get((self.weight,), lambda: self.weight.detach().float().contiguous())
+
+
+class CausalSelfAttention(nn.Module):
+    """Weights of llama_streaming.py:867-998 (``attn`` fused QKV, ``proj``) + their kernel-side packing."""
+
+    def __init__(self, config: Config, device=None, dtype=None):
+        super().__init__()
+        self.config = config
+        fk = {"device": device, "dtype": dtype}
+        self.attn = _Linear(config.n_embd, (config.n_head + 2 * config.n_query_groups) * config.head_size, config.bias, **fk)
+        self.proj = _Linear(config.head_size * config.n_head, config.n_embd, config.bias, **fk)
+        self._packed = _PackedCache()
+
+    def packed_qkv(self) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """(weight, bias) with rows in [Q | K | V] order and interleaved rotary pairs (see the module docstring)."""
+        w, b = self.attn.linear.weight, self.attn.linear.bias
+
+        def build():
+            order = _qkv_row_order(self.config).to(w.device)
+            return (w.detach().index_select(0, order).contiguous(),
+                    None if b is None else b.detach().float().index_select(0, order).contiguous())
+        return self._packed.get((w,) if b is None else (w, b), build)
+
+
+class LLaMAMLP(nn.Module):
+    """Weights of llama_streaming.py:1046-1088 / lit_model.py:391-403; fc_1 | fc_2 are stacked for the gated GEMV."""
+
+    def __init__(self, config: Config, device=None, dtype=None):
+        super().__init__()
+        fk = {"device": device, "dtype": dtype}
+        self.fc_1 = _Linear(config.n_embd, config.intermediate_size, config.bias, **fk)
+        self.fc_2 = _Linear(config.n_embd, config.intermediate_size, config.bias, **fk)
+        self.proj = _Linear(config.intermediate_size, config.n_embd, config.bias, **fk)
+        self._packed = _PackedCache()
+
+    def packed_fc(self) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        w1, w2, b1, b2 = self.fc_1.linear.weight, self.fc_2.linear.weight, self.fc_1.linear.bias, self.fc_2.linear.bias
+
+        def build():
+            return (torch.cat([w1.detach(), w2.detach()]).contiguous(),
+                    None if b1 is None else torch.cat([b1.detach().float(), b2.detach().float()]).contiguous())
+        return self._packed.get((w1, w2) if b1 is None else (w1, w2, b1, b2), build)
+
+
+class Block(nn.Module):
+    """llama_streaming.py:810-853 (sequential residual)."""
+
+    def __init__(self, config: Config, device=None, dtype=None):
+        super().__init__()
+        fk = {"device": device, "dtype": dtype}
+        self.norm_1 = _LitNorm(config.n_embd, config.norm_eps, **fk)
+        self.attn = CausalSelfAttention(config, **fk)
+        self.norm_2 = _LitNorm(config.n_embd, config.norm_eps, **fk)
+        self.mlp = LLaMAMLP(config, **fk)
+
+
+class LLAMAStreamingTransformer(StreamingModule[_StepState]):
+    """llama_streaming.py:775-800: ``wte`` + blocks + ``ln_f``; the streaming state holds the grouped KV rings."""
+
+    def __init__(self, config: Config, device=None, dtype=None):
+        super().__init__()
+        self.config = config
+        fk = {"device": device, "dtype": dtype}
+        self.wte = _Weight(config.padded_vocab_size, config.n_embd, **fk)
+        self.h = nn.ModuleList([Block(config, **fk) for _ in range(config.n_layer)])
+        self.ln_f = _LitNorm(config.n_embd, config.norm_eps, **fk)
+
+    def _make_state(self, batch_size: int, capacity: int) -> _StepState:
+        c = self.config
+        dev = self.ln_f.weight.device
+        shape = (batch_size, c.n_query_groups, capacity, c.head_size)
+        scratch = None
+        if capacity > 64:
+            splits = max(1, min(16, capacity // 128, 1024 // max(1, batch_size * c.n_head)))
+            scratch = (torch.empty(batch_size, c.n_head, splits, c.head_size + 2, device=dev),
+                       torch.zeros(batch_size, c.n_head, device=dev, dtype=torch.int32))
+        return _StepState([torch.zeros(shape, device=dev) for _ in self.h], [torch.zeros(shape, device=dev) for _ in self.h],
+                          torch.zeros(1, device=dev, dtype=torch.long), scratch)
+
+    def _init_streaming_state(self, batch_size: int) -> _StepState:
+        if self.config.context is None:
+            raise RuntimeError("Cannot create a streaming KVCache without a context to estimate capacity.")
+        return self._make_state(batch_size, self.config.context)
+
+    def run(self, x: torch.Tensor, B: int, T: int, st: _StepState) -> torch.Tensor:
+        """x fp32 ``[B*T, n_embd]`` (T new positions per stream) -> final-normed hidden ``[B*T, n_embd]``."""
+        c = self.config
+        H, G, hs, n = c.n_head, c.n_query_groups, c.head_size, c.rope_n_elem
+        for l, blk in enumerate(self.h):
+            wqkv, bqkv = blk.attn.packed_qkv()
+            qkv = ops.lm_linear(x, wqkv, prologue=ops.PROLOGUE_RMSNORM, alpha=blk.norm_1.gain_f32(), eps=blk.norm_1.eps, bias=bqkv)
+            if T == 1:
+                a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], st.pos, rope=True, context=c.context, max_period=float(c.rope_base),
+                                       scratch=st.scratch, heads=H, rope_dims=n)
+            else:
+                q = ops.lm_rope_append(qkv.view(B, T, -1), st.k[l], st.v[l], st.pos, heads=H, rope=True,
+                                       max_period=float(c.rope_base), rope_dims=n)
+                a = ops.attention(q, st.k[l], st.v[l], pos_dev=st.pos, ring=True, context=c.context).view(B * T, H * hs)
+            x = ops.lm_linear(a, blk.attn.proj.weight, res=x, bias=blk.attn.proj.bias_f32())
+            wfc, bfc = blk.mlp.packed_fc()
+            u = ops.lm_linear(x, wfc, prologue=ops.PROLOGUE_RMSNORM, alpha=blk.norm_2.gain_f32(), eps=blk.norm_2.eps, bias=bfc)
+            x = ops.lm_linear(u, blk.mlp.proj.weight, prologue=ops.PROLOGUE_SILU_GATE, res=x, bias=blk.mlp.proj.bias_f32())
+        st.pos.add_(T)
+        st.offset_cpu += T
+        return ops.rmsnorm(x, self.ln_f.gain_f32(), self.ln_f.eps)
+
+
+@dataclass
+class _GPTState:
+    graphed_global: _Graphed
+    graphed_depth: Optional[_Graphed] = None
+
+    def reset(self) -> None:
+        pass
+
+
+class GPT(StreamingModule[_GPTState]):
+    """The audio-text LLM of llama_streaming.py:520-767 (inference)."""
+
+    def __init__(self, config: Config, device=None, dtype=torch.bfloat16):
+        super().__init__()
+        assert config.padded_vocab_size is not None
+        self.config = config
+        fk = {"device": device, "dtype": dtype}
+        self.lm_head = _Linear(config.n_embd, config.padded_vocab_size, config.lm_head_bias, **fk)
+        self.dep_q = config.dep_q
+        self.transformer = LLAMAStreamingTransformer(config, **fk)
+        self.max_seq_length = config.block_size
+        self.input_emb = nn.ModuleList([ScaledEmbedding(config.audio_card + 1, config.n_embd, **fk) for _ in range(config.n_q)])
+        self.codecformer_in = nn.ModuleList([_PlainLinear(config.codecformer_dim, config.n_embd, **fk) for _ in range(config.dep_q)])
+        self.codecformer_emb = nn.ModuleList([ScaledEmbedding(config.audio_card + 1, config.codecformer_dim, **fk)
+                                              for _ in range(config.dep_q - 1)])
+        self.codecformer_text_emb = ScaledEmbedding(config.padded_vocab_size, config.codecformer_dim, **fk)
+        self.codecformer = StreamingTransformer(config.codecformer_dim, config.codecformer_heads, config.codecformer_layers,
+                                                config.codecformer_dim_feedforward, None, "none", 10000.0,
+                                                weights_per_step=config.dep_q, **fk)
+        self.codecformer.set_streaming_propagate(False)
+        self.audio_linears = nn.ModuleList([_PlainLinear(config.audio_card, config.codecformer_dim, config.codecformer_bias_proj, **fk)
+                                            for _ in range(config.dep_q)])
+
+    # ---- token-id conventions (llama_streaming.py:591-649)
+    @property
+    def zero_token_id(self) -> int:
+        return -1
+
+    @property
+    def text_initial_token_id(self) -> int:
+        return 151655
+
+    @property
+    def initial_token_id(self) -> int:
+        return self.config.audio_card
+
+    @property
+    def num_codebooks(self) -> int:
+        return self.config.n_q + 1
+
+    @property
+    def num_audio_codebooks(self) -> int:
+        return self.config.n_q
+
+    @property
+    def audio_offset(self) -> int:
+        return 1
+
+    @property
+    def ungenerated_token_id(self) -> int:
+        return -2
+
+    @property
+    def device(self):
+        return next(iter(self.parameters())).device
+
+    def _get_initial_token(self) -> torch.Tensor:
+        tok = torch.full([1, self.num_codebooks, 1], self.initial_token_id, device=self.device, dtype=torch.long)
+        tok[:, 0] = self.text_initial_token_id
+        return tok
+
+    # ---- streaming state
+    def _init_streaming_state(self, batch_size: int) -> _GPTState:
+        disable = self.device.type != "cuda"
+        return _GPTState(_Graphed(self._global_step, disable=disable))
+
+    # ---- global transformer
+    def _embed(self, toks: torch.Tensor) -> torch.Tensor:
+        K = toks.shape[1]
+        tables = [e.weight for e in self.input_emb] + [self.transformer.wte.weight]
+        return ops.embed_sum(toks, tables, list(range(1, K)) + [0])       # audio streams first, then text, as :680-686
+
+    def _global_step(self, toks: torch.Tensor):
+        """One streamed position: toks int64 ``[B, n_q+1]`` -> (hidden ``[B, n_embd]``, text logits ``[B, V]``)."""
+        st = self.transformer._streaming_state
+        h = self.transformer.run(self._embed(toks), toks.shape[0], 1, st)
+        return h, ops.lm_linear(h, self.lm_head.weight, bias=self.lm_head.bias_f32())
+
+    @torch.no_grad()
+    def forward_global(self, sequence: torch.Tensor):
+        """sequence int64 ``[B, n_q+1, T]`` -> (transformer_out fp32 ``[B,T,n_embd]``, text_logits fp32 ``[B,T,V]``).
+        Outside ``streaming()`` the T positions are 0..T-1 (plain causal + context mask, no ring effects); inside, they follow
+        the positions already streamed (T = 1 steps replay a captured graph)."""
+        B, K, T = sequence.shape
+        assert K == self.num_codebooks, f"Sequence shape {sequence.shape} must match the number of codebooks."
+        if self.max_seq_length < T:
+            raise ValueError(f"Cannot forward sequence of length {T}, max seq length is only {self.max_seq_length}.")
+        c = self.config
+        st = self.transformer._streaming_state
+        if st is not None and T == 1 and self._streaming_state is not None:
+            h, logits = self._streaming_state.graphed_global(sequence.reshape(B, K).contiguous())
+            return h.view(B, 1, c.n_embd), logits.view(B, 1, -1)
+        if st is None:
+            st = self.transformer._make_state(B, T + 1)      # a ring that never fills: positions 0..T-1 all addressable
+        toks = sequence.permute(0, 2, 1).reshape(B * T, K).contiguous()
+        h = self.transformer.run(self._embed(toks), B, T, st)
+        logits = ops.lm_linear(h, self.lm_head.weight, bias=self.lm_head.bias_f32())
+        return h.view(B, T, c.n_embd), logits.view(B, T, -1)
+
+    # ---- local (depth) transformer
+    def _codec_in(self, k: int, prev: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+        """codecformer_in[k](h) + embedding of the previous token (text embedding for k = 0): prev int64 [N], h fp32 [N, n_embd]."""
+        x = ops.lm_linear(h, self.codecformer_in[k].weight)
+        table = self.codecformer_text_emb.weight if k == 0 else self.codecformer_emb[k - 1].weight
+        return ops.embed_sum(prev.reshape(-1, 1).contiguous(), [table], [0], add=x)
+
+    @torch.no_grad()
+    def forward_codecformer(self, codecformer_cb_index: int, sequence: torch.Tensor, transformer_out: torch.Tensor) -> torch.Tensor:
+        """sequence int64 ``[B,1,1]`` (previous token), transformer_out fp32 ``[B,1,n_embd]`` -> logits fp32 ``[B,1,1,card]``;
+        the caller holds ``with gpt.codecformer.streaming(B)`` for the dep_q steps of a frame, as with the reference."""
+        B, K, S = sequence.shape
+        assert K == 1, f"Codebooks for Depformer streaming should be passed 1 by 1, got {K}."
+        assert S == 1, f"Steps for Depformer streaming should be passed 1 by 1, got {S}."
+        assert transformer_out.shape[1] == 1, "Transformer out should be a for a single step."
+        k = codecformer_cb_index
+        x = self._codec_in(k, sequence.reshape(B), transformer_out.reshape(B, -1).float().contiguous())
+        y = self.codecformer.step(x)
+        head = self.audio_linears[k]
+        return ops.lm_linear(y, head.weight, bias=head.bias_f32()).view(B, 1, 1, -1)
+
+    @torch.no_grad()
+    def forward_local(self, local_start_token: torch.Tensor, sequence: torch.Tensor, transformer_out: torch.Tensor) -> torch.Tensor:
+        """Teacher-forced depth logits (llama_streaming.py:694-725).  ``local_start_token``: the ``codecformer_text_emb``
+        embedding of the text ids, float ``[B,T,D]`` as in the reference, or the int64 ids ``[B,T]`` themselves (the lookup then
+        stays inside the kernel); ``sequence`` int64 ``[B,dep_q,T]``, ``transformer_out`` fp32 ``[B,T,n_embd]`` ->
+        ``[B,T,dep_q,card]``.  Runs dep_q steps over B*T rows on a ring that never fills (the non-streaming reference path has
+        no ring, hence no Q1 slot quirk at the last codebook)."""
+        B, K, T = sequence.shape
+        assert K == self.config.dep_q, f"Sequence shape {sequence.shape} must match the moshi stream output."
+        dep, N = self.codecformer, B * T
+        saved = dep._streaming_state
+        dep._streaming_state = dep._init_streaming_state(N, capacity=self.config.dep_q + 1)
+        try:
+            h = transformer_out.reshape(N, -1).float().contiguous()
+            outs = []
+            for k in range(K):
+                if k == 0 and local_start_token.dtype != torch.long:
+                    x = ops.lm_linear(h, self.codecformer_in[0].weight, res=local_start_token.reshape(N, -1).float().contiguous())
+                else:
+                    x = self._codec_in(k, local_start_token.reshape(N) if k == 0 else sequence[:, k - 1].reshape(N), h)
+                y = dep.step(x)
+                head = self.audio_linears[k]
+                outs.append(ops.lm_linear(y, head.weight, bias=head.bias_f32()).view(B, T, 1, -1))
+        finally:
+            dep._streaming_state = saved
+        return torch.cat(outs, dim=2)
+
+    @torch.no_grad()
+    def forward(self, sequence: torch.Tensor, input_pos: Optional[torch.Tensor] = None, lm_head_chunk_size: int = 0):
+        """llama_streaming.py:651-663 (inference only): sequence ``[B, n_q+1, S]`` -> (audio_logits ``[B,S,dep_q,card]``,
+        text_logits ``[B,S,V]``), the global input being the sequence shifted right behind the initial frame."""
+        B, K, S = sequence.shape
+        start = self._get_initial_token().repeat(B, 1, 1)
+        transformer_out, text_logits = self.forward_global(torch.cat([start, sequence[:, :, :-1]], dim=2))
+        audio_logits = self.forward_local(sequence[:, 0, :], sequence[:, 1:self.config.dep_q + 1, :], transformer_out)
+        return audio_logits, text_logits
+
+    # ---- loading
+    @classmethod
+    def from_state_dict(cls, sd: Dict[str, torch.Tensor], config: Config) -> "GPT":
+        """Model for ``config`` with weights taken from ``sd`` (reference key names, legacy base-checkpoint names accepted,
+        LoRA adapters merged) without copying the dense tensors."""
+        sd = _remap_legacy(dict(sd))
+        sd = {k: v for k, v in sd.items() if not k.endswith(("cos", "sin", "_lora_ind"))}
+        if any(k.endswith(".lora_A") for k in sd):
+            if config.lora_r <= 0:
+                raise RuntimeError("state dict carries LoRA adapters but config.lora_r == 0")
+            sd = merge_lora_state_dict(sd, config)
+        model = cls(config, device="meta")
+        params = dict(model.named_parameters())
+        missing = [k for k in params if k not in sd]
+        unexpected = [k for k in sd if k not in params]
+        if missing or unexpected:
+            raise RuntimeError(f"state_dict mismatch: missing={missing[:5]} unexpected={unexpected[:5]}")
+        for name, tensor in sd.items():
+            mod = model
+            *path, leaf = name.split(".")
+            for part in path:
+                mod = getattr(mod, part) if not part.isdigit() else mod[int(part)]
+            assert tuple(getattr(mod, leaf).shape) == tuple(tensor.shape), name
+            setattr(mod, leaf, nn.Parameter(tensor, requires_grad=False))
+        return model.eval()

@@ -47,6 +47,11 @@ class ScaledEmbedding(_Weight):
         super().__init__(num_embeddings, embedding_dim, device=device, dtype=dtype)
         self.zero_idx = zero_idx
 
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        """ids int64 ``[...]`` -> fp32 ``[..., D]`` (callers that look a table up directly, e.g. infer_no_streaming.py:258)."""
+        flat = input.reshape(-1, 1).contiguous()
+        return ops.embed_sum(flat, [self.weight], [0]).view(*input.shape, self.weight.shape[1])
+
 
 class RMSNorm(nn.Module):
     """rms_norm_f32 (modules/transformer.py:49-65, eps 1e-8); key ``alpha`` [1,1,D]."""
@@ -120,10 +125,16 @@ class StreamingTransformer(StreamingModule[_StepState]):
         self.layers = nn.ModuleList([_Layer(d_model, dim_feedforward, weights_per_step, device=device, dtype=dtype)
                                      for _ in range(num_layers)])
 
-    def _init_streaming_state(self, batch_size: int) -> _StepState:
+    def _apply_named_streaming(self, fn) -> None:
+        """As the ROOT of a walk this module is always visited: the reference skips a propagate=False root but still visits
+        its layers (modules/streaming.py:67-84, relied on by ``with lm.depformer.streaming(B)``), and the per-layer states of
+        the reference live in this module's single state."""
+        fn("", self)
+
+    def _init_streaming_state(self, batch_size: int, capacity: Optional[int] = None) -> _StepState:
         if self.context is None and not self.weights_per_step:
             raise RuntimeError("Cannot create a streaming KVCache without a context to estimate capacity.")
-        cap = self.context if self.context is not None else self.weights_per_step
+        cap = capacity or (self.context if self.context is not None else self.weights_per_step)
         dev = self.layers[0].norm1.alpha.device
         shape = (batch_size, self.num_heads, cap, self.d_model // self.num_heads)
         scratch = None

@@ -1,0 +1,82 @@
+"""Host-side logic of rstnet_amd.lm.gpt that needs no GPU: LoRA merge, legacy key remaps, config validation, the QKV row
+permutation.  The oracle (pinned to the reference by gpt_tiny.npz) is the checker."""
+import pytest
+import torch
+
+from oracle import gpt_oracle as Gp
+from rstnet_amd import synth
+from rstnet_amd.lm import gpt as G
+from tests.golden import cases
+
+
+def _cfgs(cfg_d):
+    keep = set(Gp.GPTConfig.__dataclass_fields__)
+    return G.Config.from_dict(cfg_d), Gp.GPTConfig(**{k: v for k, v in cfg_d.items() if k in keep})
+
+
+@pytest.mark.parametrize("cfg_d", [synth.GPT_TINY_GQA, synth.GPT_TINY_MHA], ids=["gqa", "mha"])
+def test_lora_merge_matches_oracle(cfg_d):
+    cfg, ocfg = _cfgs(cfg_d)
+    sd = {k: v.float() for k, v in synth.gpt_state_dict(cfg_d, cases.GPT_SEED).items()}
+    mine = G.merge_lora_state_dict(sd, cfg)
+    ref = Gp.merged_state(sd, ocfg)
+    assert set(mine) == set(ref)
+    for k in ref:
+        assert torch.allclose(mine[k].float(), ref[k].float(), rtol=0, atol=1e-6), k
+
+
+def test_legacy_keys_and_missing_adapter_config():
+    cfg_d = dict(synth.GPT_TINY_GQA)
+    sd = synth.gpt_state_dict(cfg_d, 1, lora=False)
+    old = {}
+    for k, v in sd.items():
+        if ".linear." in k and (k.startswith("lm_head") or ".attn." in k or ".mlp." in k):
+            k = k.replace(".linear.", ".")
+        old[k] = v
+    assert "lm_head.weight" in old and "transformer.h.0.attn.attn.weight" in old and "transformer.h.1.mlp.fc_2.weight" in old
+    assert set(G._remap_legacy(old)) == set(sd)
+    with pytest.raises(RuntimeError):
+        G.GPT.from_state_dict(synth.gpt_state_dict(cfg_d, 1), G.Config.from_dict({**cfg_d, "lora_r": 0}))
+
+
+def test_config_rejects_unimplemented_paths():
+    ok = dict(synth.GPT_TINY_MHA)
+    G.Config.from_dict(ok)
+    for bad in ({"norm_class_name": "LayerNorm"}, {"mlp_class_name": "GptNeoxMLP", "intermediate_size": 8}, {"parallel_residual": True},
+                {"rope_condense_ratio": 2}, {"attention_logit_softcapping": 30.0}, {"n_query_groups": 1}):
+        with pytest.raises(NotImplementedError):
+            G.Config.from_dict({**ok, **bad})
+
+
+@pytest.mark.parametrize("cfg_d", [synth.GPT_TINY_GQA, synth.GPT_TINY_MHA], ids=["gqa", "mha"])
+def test_qkv_row_order_is_the_rotate_half_to_interleaved_permutation(cfg_d):
+    """Attention scores computed from the permuted rows with INTERLEAVED RoPE equal the reference formulation (interleaved
+    GQA layout + rotate-half RoPE), and the value rows are only regrouped."""
+    cfg, ocfg = _cfgs(cfg_d)
+    order = G._qkv_row_order(cfg)
+    H, Gq, hs, n = cfg.n_head, cfg.n_query_groups, cfg.head_size, cfg.rope_n_elem
+    assert sorted(order.tolist()) == list(range((H + 2 * Gq) * hs))
+    g = torch.Generator().manual_seed(0)
+    qkv = torch.randn((H + 2 * Gq) * hs, generator=g)
+    pos = 7
+    # reference side
+    qpk = H // Gq
+    ref = qkv.view(Gq, qpk + 2, hs)
+    q_ref, k_ref, v_ref = ref[:, :qpk].reshape(H, hs), ref[:, qpk], ref[:, qpk + 1]
+    cos, sin = Gp.build_rope_cache(16, n, cfg.rope_base)
+    rot = lambda x: torch.cat((Gp.apply_rope_half(x[..., :n], cos[pos], sin[pos]), x[..., n:]), -1)
+    s_ref = (rot(q_ref).view(Gq, qpk, hs) * rot(k_ref)[:, None]).sum(-1)
+    # permuted side: interleaved rotation of the leading n dims
+    p = qkv[order]
+    q, k, v = p[:H * hs].view(H, hs), p[H * hs:(H + Gq) * hs].view(Gq, hs), p[(H + Gq) * hs:].view(Gq, hs)
+    theta = torch.exp(torch.arange(n // 2).float() * (-torch.log(torch.tensor(float(cfg.rope_base))) * 2 / n)) * pos
+
+    def rot_i(x):
+        xr, xi = x[..., 0:n:2], x[..., 1:n:2]
+        out = x.clone()
+        out[..., 0:n:2] = xr * torch.cos(theta) - xi * torch.sin(theta)
+        out[..., 1:n:2] = xr * torch.sin(theta) + xi * torch.cos(theta)
+        return out
+    s = (rot_i(q).view(Gq, qpk, hs) * rot_i(k)[:, None]).sum(-1)
+    assert torch.allclose(s, s_ref, rtol=1e-5, atol=1e-5)
+    assert torch.equal(v, v_ref)
