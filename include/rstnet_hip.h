@@ -212,9 +212,12 @@ int rst_attn_decode_multi_f32(const float* q, const float* k, const float* v, fl
 
 /* sample_token (utils/sampling.py:85-105): greedy argmax, or softmax(logits/temp) -> top-k (sorted descending) ->
  * argmax_j p_j / noise_j with caller-provided Exp(1) noise [B][noise_stride] (the reference draws it with
- * Tensor.exponential_, :44-46).  tokens[b * tok_stride] = result. */
+ * Tensor.exponential_, :44-46).  tokens[b * tok_stride] = result.  v_limit (0 = V; v_limit_dev, when given, is a device
+ * int32 that overrides it): ids >= limit are never drawn -- the probability blanking of sample_token_audio (2049) and
+ * sample_token_audio_2048 (2048), utils/sampling.py:107-158, applied after the softmax like there; greedy ignores it. */
 int rst_lm_sample_f32(const float* logits, const float* noise, int64_t* tokens, int B, int V, int ld, int top_k,
-                      int noise_stride, int tok_stride, int use_sampling, float temp, rst_stream_t stream);
+                      int noise_stride, int tok_stride, int use_sampling, float temp, int v_limit, const int32_t* v_limit_dev,
+                      rst_stream_t stream);
 
 #ifdef __cplusplus
 }

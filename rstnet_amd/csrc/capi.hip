@@ -231,8 +231,10 @@ int rst_attn_decode_multi_f32(const float* q, const float* k, const float* v, fl
 }
 
 int rst_lm_sample_f32(const float* logits, const float* noise, int64_t* tokens, int B, int V, int ld, int top_k,
-                      int noise_stride, int tok_stride, int use_sampling, float temp, rst_stream_t stream) {
+                      int noise_stride, int tok_stride, int use_sampling, float temp, int v_limit, const int32_t* v_limit_dev,
+                      rst_stream_t stream) {
     LmSampleParams p;
+    p.v_limit = v_limit; p.v_limit_dev = v_limit_dev;
     p.logits = logits; p.noise = noise; p.tokens = (long*)tokens; p.B = B; p.V = V; p.ld = ld; p.top_k = top_k;
     p.noise_stride = noise_stride; p.tok_stride = tok_stride; p.use_sampling = use_sampling; p.temp = temp;
     return rst_launch_lm_sample(p, (hipStream_t)stream);

@@ -594,8 +594,16 @@ __global__ __launch_bounds__(NT) void sample_kernel(const LmSampleParams p) {
 #pragma unroll
     for (int w = 0; w < NW; ++w) denom += red_v[w];
 
+    // id blanking of sample_token_audio / sample_token_audio_2048 (utils/sampling.py:107-158): the probabilities of ids >= limit
+    // are overwritten after the softmax over ALL ids, so the denominator above is untouched and the ids just leave the race
+    int limit = p.v_limit_dev ? *p.v_limit_dev : p.v_limit;
+    limit = limit > 0 && limit < V ? limit : V;
+    if (limit < V) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) key[j] = j * NT + tid < limit ? key[j] : 0u;
+    }
     // k-th largest key: binary search from the top bit down; stop as soon as a probe isolates exactly k keys
-    const int k = min(p.top_k > 0 ? p.top_k : V, V);
+    const int k = min(p.top_k > 0 ? p.top_k : V, limit);
     unsigned thr = 0u;
     bool exact = false;
 #pragma unroll 1

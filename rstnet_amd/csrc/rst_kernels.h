@@ -176,6 +176,8 @@ struct LmSampleParams {
     long* tokens;         // tokens[b * tok_stride]
     int B, V, ld, top_k, noise_stride, tok_stride, use_sampling;
     float temp;
+    int v_limit;               // sampling only: ids >= v_limit are never drawn (probabilities blanked AFTER the softmax); 0 = V
+    const int* v_limit_dev;    // optional device scalar overriding v_limit (lets one captured graph serve changing limits)
 };
 int rst_launch_lm_sample(const LmSampleParams& p, hipStream_t stream);
 

@@ -490,13 +490,15 @@ def lm_attn_decode(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
 
 
 def lm_sample(logits: torch.Tensor, *, use_sampling: bool, temp: float, top_k: int, noise: Optional[torch.Tensor] = None,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """logits fp32 ``[B, V]`` -> tokens int64 ``[B]`` (greedy, or top-k sampling with Exp(1) ``noise [B, top_k]``)."""
+              out: Optional[torch.Tensor] = None, limit: int = 0, limit_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """logits fp32 ``[B, V]`` -> tokens int64 ``[B]`` (greedy, or top-k sampling with Exp(1) ``noise [B, top_k]``).  ``limit``
+    (or the int32 device scalar ``limit_dev``): ids >= limit are never drawn when sampling."""
     _chk(logits, "logits")
     _chk(noise, "noise")
+    _chk(limit_dev, "limit_dev", torch.int32)
     B, V = logits.shape
     if out is None:
         out = torch.empty(B, device=logits.device, dtype=torch.int64)
     _lib.check(_lib.lib().rst_lm_sample_f32(_ptr(logits), _ptr(noise), _ptr(out), B, V, V, top_k, noise.shape[1] if noise is not None else 0,
-                                           1, int(use_sampling), float(temp), _stream()))
+                                           1, int(use_sampling), float(temp), int(limit), _ptr(limit_dev), _stream()))
     return out

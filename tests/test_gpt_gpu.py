@@ -167,3 +167,78 @@ def test_gqa_partial_rope_decode_attention(D, H, G, n, cap, context):
         assert rel_err(out, ref) < 1e-4, t
         pos += 1
     assert rel_err(kc[:, :, :steps], kh) < 1e-4 and rel_err(vc[:, :, :steps], vh) == 0.0
+
+
+# ---- streaming generation vs the O(T^2) restatement of infer_no_streaming.py ------------------------------------------------
+def _tts_prompt(cfg_d, L=16, n_text=5, n_pad=2, seed=0):
+    """A [K, L] utterance in the reference's TTS layout: text ids then `text_empty` on row 0, audio rows, trailing padding."""
+    g = torch.Generator().manual_seed(seed)
+    K = cfg_d["n_q"] + 1
+    seq = torch.randint(0, 30, (K, L), generator=g)
+    seq[0, :n_text] = torch.randint(0, 300, (n_text,), generator=g)
+    seq[0, n_text:] = 318
+    seq[1:, L - n_pad:] = 31
+    return seq
+
+
+def _noise_fn(k_text, k_audio):
+    def fn(kind, g_idx, l_idx):
+        g = torch.Generator().manual_seed(1000 * g_idx + 10 * l_idx + (kind == "text"))
+        k = k_text if kind == "text" else k_audio
+        return -torch.log(torch.rand(1, k, generator=g).clamp_min(1e-9))
+    return fn
+
+
+@pytest.mark.parametrize("name", ["gqa", "mha"])
+@pytest.mark.parametrize("task,use_sampling", [("TTS", False), ("TTS", True), ("audio_only", True), ("ASR", False)])
+def test_streaming_generate_matches_offline_loop(name, task, use_sampling):
+    from oracle import gpt_generate_oracle as GG
+    from rstnet_amd.lm.generate import GenIds, InferenceImp
+    model, ocfg, osd, cfg_d = build(name)
+    seq = _tts_prompt(cfg_d)
+    if task == "ASR":
+        seq[0, :4] = 318          # ASR layout: leading `text_empty` frames
+        seq[0, 4:] = torch.arange(seq.shape[1] - 4) % 300
+        seq[0, -2:] = 319         # text padding
+    ids = dict(text_pad_token=319, text_empty_token=318, semantic_pad_token=31, n_audio_codes=30)
+    noise = _noise_fn(5, 8)
+    kw = dict(use_sampling=use_sampling, temp=0.8, top_k=8, temp_text=0.7, top_k_text=5)
+    ref = GG.generate(osd, ocfg, seq, task, ids=GG.GenIds(text_initial_token_id=model.text_initial_token_id % 320, **ids),
+                      noise=lambda kind, g, l: noise(kind, g, l).view(1, 1, -1) if kind == "text" else noise(kind, g, l).view(1, 1, 1, -1),
+                      **kw)
+    imp = InferenceImp(None, model, "sample", kw["temp_text"], kw["top_k_text"], kw["temp"], kw["top_k"], task,
+                       use_sampling=use_sampling, ids=GenIds(text_initial_token_id=model.text_initial_token_id % 320, **ids),
+                       noise=noise)
+    out = imp.generate(seq)
+    assert out["frames"].shape == ref["frames"].shape and out["frames"].shape[0] > 0
+    assert torch.equal(out["frames"].cpu(), ref["frames"])
+    assert torch.equal(out["text"].cpu(), ref["text"])
+
+
+def test_streaming_generate_graphed_greedy_equals_eager():
+    """The production configuration (captured graphs, device-side Exp(1) draws) in greedy mode reproduces the eager loop."""
+    from rstnet_amd.lm.generate import GenIds, InferenceImp
+    model, ocfg, osd, cfg_d = build("gqa")
+    seq = _tts_prompt(cfg_d, L=20)
+    ids = GenIds(text_pad_token=319, text_empty_token=318, semantic_pad_token=31, n_audio_codes=30, text_initial_token_id=7)
+    a = InferenceImp(None, model, "sample", 0.7, 5, 0.8, 8, "TTS", use_sampling=False, ids=ids).generate(seq)
+    b = InferenceImp(None, model, "sample", 0.7, 5, 0.8, 8, "TTS", use_sampling=False, ids=ids, noise=lambda *a: torch.ones(1, 8)).generate(seq)
+    assert torch.equal(a["frames"], b["frames"]) and torch.equal(a["text"], b["text"])
+    c = InferenceImp(None, model, "sample", 0.7, 5, 0.8, 8, "TTS", use_sampling=True, ids=ids).generate(seq)
+    assert c["frames"].shape == a["frames"].shape and int(c["frames"][1:, 0].max()) < 30      # blanked ids never sampled at l = 0
+
+
+def test_sampler_id_blanking():
+    from oracle.gpt_generate_oracle import sample_token
+    torch.manual_seed(3)
+    B, V, k = 3, 2050, 250
+    logits = torch.randn(B, V) * 3
+    logits[:, 2048:] += 6.0          # the blanked ids would otherwise dominate
+    noise = -torch.log(torch.rand(B, k).clamp_min(1e-9))
+    for limit in (2048, 2049, 0):
+        ref = sample_token(logits.view(B, 1, 1, V), True, 0.8, k, noise.view(B, 1, 1, k), limit)[:, 0, 0]
+        got = ops.lm_sample(logits.to(DEV), use_sampling=True, temp=0.8, top_k=k, noise=noise.to(DEV), limit=limit)
+        assert torch.equal(got.cpu(), ref), limit
+        lim_dev = torch.tensor([limit], dtype=torch.int32, device=DEV)
+        got = ops.lm_sample(logits.to(DEV), use_sampling=True, temp=0.8, top_k=k, noise=noise.to(DEV), limit_dev=lim_dev)
+        assert torch.equal(got.cpu(), ref), limit
