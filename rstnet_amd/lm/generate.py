@@ -45,6 +45,98 @@ class GenIds:
     text_initial_token_id: Optional[int] = None      # None = model.text_initial_token_id (151655)
 
 
+class GPTGen:
+    """Frame-by-frame generator over a ``GPT`` for B concurrent streams (the counterpart of ``LMGen`` for the litgpt-style
+    backbone): ``prefill`` pushes a prompt through the global transformer, ``frame`` draws the text token and the dep_q audio
+    tokens of the next frame (one captured graph), ``advance`` feeds the completed frame back (one captured graph).
+    Rings: capacity context + 1 (global) and dep_q + 1 (depth) -- see the module docstring."""
+
+    def __init__(self, model: GPT, use_sampling: bool = True, temp: float = 0.8, temp_text: float = 0.7, top_k: int = 250,
+                 top_k_text: int = 25, n_audio_codes: int = 2048,
+                 noise: Optional[Callable[[str, int, int], torch.Tensor]] = None):
+        self.model = model
+        self.use_sampling, self.temp, self.temp_text, self.top_k, self.top_k_text = use_sampling, temp, temp_text, top_k, top_k_text
+        self.n_audio_codes = n_audio_codes
+        self.noise = noise           # test hook: Exp(1) draws (kind, g_idx, l_idx) -> [B, k]; disables graph capture
+        self._saved = None
+        self._limits: Optional[torch.Tensor] = None
+        self._depth: Optional[_Graphed] = None
+        self._regime = None
+        self.B = 0
+
+    def begin(self, batch_size: int) -> None:
+        m = self.model
+        cfg, dev = m.config, m.device
+        eager = self.noise is not None or dev.type != "cuda"
+        self._saved = (m.transformer._streaming_state, m._streaming_state, m.codecformer._streaming_state)
+        m.transformer._streaming_state = m.transformer._make_state(batch_size, cfg.context + 1)
+        m._streaming_state = _GPTState(_Graphed(m._global_step, disable=eager))
+        m.codecformer._streaming_state = m.codecformer._init_streaming_state(batch_size, capacity=cfg.dep_q + 1)
+        self._limits = torch.full((cfg.dep_q,), self.n_audio_codes + 1, device=dev, dtype=torch.int32)
+        self._depth = _Graphed(self._depth_frame, disable=eager)
+        self._regime, self.B, self._eager = None, batch_size, eager
+
+    def end(self) -> None:
+        m = self.model
+        m.transformer._streaming_state, m._streaming_state, m.codecformer._streaming_state = self._saved
+        self._saved = None
+
+    def _exp_noise(self, kind: str, g_idx: int, l_idx: int, B: int, k: int) -> Optional[torch.Tensor]:
+        if not self.use_sampling:
+            return None
+        if self.noise is not None:
+            return self.noise(kind, g_idx, l_idx).reshape(B, k).to(self.model.device, torch.float32).contiguous()
+        return torch.empty(B, k, device=self.model.device, dtype=torch.float32).exponential_(1)    # utils/sampling.py:44-46
+
+    def _depth_frame(self, text_token: torch.Tensor, h: torch.Tensor, g_idx: int = 0) -> torch.Tensor:
+        """dep_q depth-transformer steps + sampling: text_token int64 [B], h fp32 [B, n_embd] -> tokens int64 [B, dep_q]."""
+        m = self.model
+        dep, cfg = m.codecformer, m.config
+        (B,) = text_token.shape
+        dep._streaming_state.reset()
+        out = torch.empty(B, cfg.dep_q, device=text_token.device, dtype=torch.long)
+        prev = text_token
+        k_eff = min(self.top_k, cfg.audio_card)
+        for l_idx in range(cfg.dep_q):
+            y = dep.step(m._codec_in(l_idx, prev, h))
+            head = m.audio_linears[l_idx]
+            logits = ops.lm_linear(y, head.weight, bias=head.bias_f32())
+            prev = ops.lm_sample(logits, use_sampling=self.use_sampling, temp=self.temp, top_k=k_eff,
+                                 noise=self._exp_noise("audio", g_idx, l_idx, B, k_eff), limit_dev=self._limits[l_idx:l_idx + 1])
+            out[:, l_idx] = prev
+        return out
+
+    def set_blanking(self, wide: list) -> None:
+        """Per-codebook id limit of the next frames: n_audio_codes + 1 where ``wide`` (sample_token_audio) else n_audio_codes
+        (sample_token_audio_2048)."""
+        n = self.n_audio_codes
+        self._limits.copy_(torch.tensor([n + 1 if w else n for w in wide], dtype=torch.int32))
+
+    def prefill(self, tokens: torch.Tensor):
+        """tokens int64 [B, K, T] -> (h [B, n_embd], logits [B, V]) of the LAST position."""
+        h, logits = self.model.forward_global(tokens)
+        return h[:, -1].contiguous(), logits[:, -1].contiguous()
+
+    def frame(self, h: torch.Tensor, logits: torch.Tensor, g_idx: int = 0):
+        """(h, logits) of the last position -> (text token [B], audio tokens [B, dep_q]) of the next frame."""
+        B = h.shape[0]
+        k_text = min(self.top_k_text, self.model.config.padded_vocab_size)
+        text = ops.lm_sample(logits, use_sampling=self.use_sampling, temp=self.temp_text, top_k=k_text,
+                             noise=self._exp_noise("text", g_idx, 0, B, k_text))
+        audio = self._depth_frame(text, h, g_idx) if self._eager else self._depth(text, h)
+        return text, audio
+
+    def advance(self, text: torch.Tensor, audio: torch.Tensor):
+        """Feed the completed frame (rows beyond dep_q carry the initial-token pad, infer_no_streaming.py:243-244)."""
+        m = self.model
+        cfg = m.config
+        col = torch.full((text.shape[0], cfg.n_q + 1, 1), m.initial_token_id, device=text.device, dtype=torch.long)
+        col[:, 0, 0] = text
+        col[:, 1:cfg.dep_q + 1, 0] = audio
+        h, logits = m.forward_global(col)
+        return h[:, 0], logits[:, 0]
+
+
 class InferenceImp:
     """Same constructor and call convention as infer_no_streaming.py:168-190 (``args`` is kept for signature parity and unused).
     ``__call__(seq [K, L], mask)`` returns what the reference returns for task 'TTS' (``reverse_delay`` of the generated
@@ -58,8 +150,6 @@ class InferenceImp:
         self.use_sampling, self.temp_text, self.top_k_text, self.temp, self.top_k = use_sampling, temp_text, top_k_text, temp, top_k
         self.ids = ids or GenIds()
         self.noise = noise           # test hook: Exp(1) draws (kind, g_idx, l_idx) -> [1, k]; disables graph capture
-        self._depth: Optional[_Graphed] = None
-        self._limits: Optional[torch.Tensor] = None
 
     # ---- prompt handling (:190-230)
     def split_prompt(self, seq: torch.Tensor):
@@ -83,31 +173,6 @@ class InferenceImp:
             return seq[:, :, :n_prefix + 1], seq.shape[2] - n_prefix + 13, seq.shape[2] - n_prefix - 13
         raise NotImplementedError
 
-    # ---- one frame of the depth transformer: dep_q steps + sampling, tokens [B, dep_q]
-    def _exp_noise(self, kind: str, g_idx: int, l_idx: int, B: int, k: int) -> Optional[torch.Tensor]:
-        if not self.use_sampling:
-            return None
-        if self.noise is not None:
-            return self.noise(kind, g_idx, l_idx).reshape(B, k).to(self.model.device, torch.float32).contiguous()
-        return torch.empty(B, k, device=self.model.device, dtype=torch.float32).exponential_(1)    # utils/sampling.py:44-46
-
-    def _depth_frame(self, text_token: torch.Tensor, h: torch.Tensor, g_idx: int = 0) -> torch.Tensor:
-        m = self.model
-        dep, cfg = m.codecformer, m.config
-        (B,) = text_token.shape
-        dep._streaming_state.reset()
-        out = torch.empty(B, cfg.dep_q, device=text_token.device, dtype=torch.long)
-        prev = text_token
-        k_eff = min(self.top_k, cfg.audio_card)
-        for l_idx in range(cfg.dep_q):
-            y = dep.step(m._codec_in(l_idx, prev, h))
-            head = m.audio_linears[l_idx]
-            logits = ops.lm_linear(y, head.weight, bias=head.bias_f32())
-            prev = ops.lm_sample(logits, use_sampling=self.use_sampling, temp=self.temp, top_k=k_eff,
-                                 noise=self._exp_noise("audio", g_idx, l_idx, B, k_eff), limit_dev=self._limits[l_idx:l_idx + 1])
-            out[:, l_idx] = prev
-        return out
-
     @torch.no_grad()
     def generate(self, seq: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """seq int64 ``[K, L]`` -> {'frames': [n, dep_q], 'text': [n]} (+ 'codes' = reverse_delay(frames) for task 'TTS' with
@@ -116,54 +181,36 @@ class InferenceImp:
         cfg, dev = m.config, m.device
         seq = seq.to(dev).unsqueeze(0)
         prefix, maxlen, minlen = self.split_prompt(seq)
-        B, K = 1, cfg.n_q + 1
         init = m._get_initial_token()
         if ids.text_initial_token_id is not None:
             init[:, 0] = ids.text_initial_token_id
         pre_gen_len = prefix.shape[2]
         n_codes = ids.n_audio_codes
-        eager = self.noise is not None or dev.type != "cuda"
-        saved = (m.transformer._streaming_state, m._streaming_state, m.codecformer._streaming_state)
-        m.transformer._streaming_state = m.transformer._make_state(B, cfg.context + 1)
-        m._streaming_state = _GPTState(_Graphed(m._global_step, disable=eager))
-        m.codecformer._streaming_state = m.codecformer._init_streaming_state(B, capacity=cfg.dep_q + 1)
-        self._limits = torch.zeros(cfg.dep_q, device=dev, dtype=torch.int32)
-        depth = _Graphed(self._depth_frame, disable=eager)
-        k_text = min(self.top_k_text, cfg.padded_vocab_size)
+        gen = GPTGen(m, self.use_sampling, self.temp, self.temp_text, self.top_k, self.top_k_text, n_codes, self.noise)
+        gen.begin(1)
         frames, texts = [], []
         try:
-            h, logits = m.forward_global(torch.cat([init, prefix], dim=-1))      # prefill: positions 0 .. pre_gen_len
-            h, logits = h[:, -1], logits[:, -1]
+            h, logits = gen.prefill(torch.cat([init, prefix], dim=-1))      # positions 0 .. pre_gen_len
             regime = None
             for g_idx in range(maxlen):
                 g_len = pre_gen_len + g_idx
-                text_token = ops.lm_sample(logits.contiguous(), use_sampling=self.use_sampling, temp=self.temp_text, top_k=k_text,
-                                           noise=self._exp_noise("text", g_idx, 0, B, k_text))
                 # blanking regime of this frame (:264-283): first frame -> 2049 everywhere; later l = 0 -> 2048,
                 # l > 0 -> 2049 once g_len > minlen else 2048
                 new_regime = 0 if g_len == pre_gen_len else (1 if g_len > minlen else 2)
                 if new_regime != regime:
-                    wide = [True] * cfg.dep_q if new_regime == 0 else [l > 0 and new_regime == 1 for l in range(cfg.dep_q)]
-                    self._limits.copy_(torch.tensor([n_codes + 1 if w else n_codes for w in wide], dtype=torch.int32))
+                    gen.set_blanking([True] * cfg.dep_q if new_regime == 0 else [l > 0 and new_regime == 1 for l in range(cfg.dep_q)])
                     regime = new_regime
-                if eager:
-                    audio = self._depth_frame(text_token, h.contiguous(), g_idx)
-                else:
-                    audio = depth(text_token, h.contiguous())
+                text, audio = gen.frame(h.contiguous(), logits.contiguous(), g_idx)
                 audio_host = audio[0].tolist()
                 if g_idx > minlen and any(t >= n_codes for t in audio_host[3:]):     # the stop rule of :286-288
                     break
                 frames.append(audio[0].clone())
-                texts.append(text_token[0].clone())
+                texts.append(text[0].clone())
                 if g_idx + 1 == maxlen:
                     break
-                col = torch.full((B, K, 1), m.initial_token_id, device=dev, dtype=torch.long)
-                col[:, 0, 0] = text_token
-                col[:, 1:cfg.dep_q + 1, 0] = audio
-                h, logits = m.forward_global(col)
-                h, logits = h[:, 0], logits[:, 0]
+                h, logits = gen.advance(text, audio)
         finally:
-            m.transformer._streaming_state, m._streaming_state, m.codecformer._streaming_state = saved
+            gen.end()
         out = {"frames": torch.stack(frames) if frames else torch.zeros(0, cfg.dep_q, dtype=torch.long, device=dev),
                "text": torch.stack(texts) if texts else torch.zeros(0, dtype=torch.long, device=dev)}
         if self.task_name == "TTS" and frames and cfg.dep_q == 8:

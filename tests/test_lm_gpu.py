@@ -133,7 +133,7 @@ def test_rope_append_and_ring_attention(H, D, cap, context, steps, rope):
     assert rel_err(kc, ring.k) < 1e-4   # rotated keys: fp32 sin/cos of angles up to ~300 rad
 
 
-@pytest.mark.parametrize("V,k", [(2048, 250), (32, 7), (32000, 25), (50, 25)])
+@pytest.mark.parametrize("V,k", [(2048, 250), (32, 7), (32000, 25), (50, 25), (4000, 250), (151936, 25), (40000, 300), (151936, 1000)])
 def test_sampling_matches_oracle(V, k):
     g = torch.Generator().manual_seed(V)
     B = 3
@@ -144,6 +144,23 @@ def test_sampling_matches_oracle(V, k):
     tok = ops.lm_sample(logits.to(DEV), use_sampling=True, temp=0.8, top_k=k, noise=noise.to(DEV))
     ref = L.sample_token(logits, True, 0.8, k, noise)
     assert torch.equal(tok.cpu(), ref)
+
+
+@pytest.mark.parametrize("V,k", [(2048, 250), (32000, 25), (151936, 25)])
+def test_sampling_plateaus_take_lowest_indices(V, k):
+    """Rows made of a few distinct values (massive ties): top-k order is (value desc, index asc) like torch.topk's stable
+    order on CPU; exercises the tie search and, for the large vocabulary, the candidate-overflow path."""
+    g = torch.Generator().manual_seed(V + k)
+    B = 2
+    logits = torch.randint(0, 3, (B, V), generator=g).float()
+    logits[1] = 1.5
+    noise = torch.empty(B, k).exponential_(1, generator=g)
+    tok = ops.lm_sample(logits.to(DEV), use_sampling=True, temp=0.8, top_k=k, noise=noise.to(DEV))
+    probs = torch.softmax(logits / 0.8, -1)
+    order = torch.argsort(probs, dim=-1, descending=True, stable=True)[:, :k]
+    ref = order.gather(1, (probs.gather(1, order) / noise).argmax(-1, keepdim=True))[:, 0]
+    assert torch.equal(tok.cpu(), ref)
+    assert torch.equal(ops.lm_sample(logits.to(DEV), use_sampling=False, temp=0.8, top_k=k).cpu(), logits.argmax(-1))
 
 
 def _tiny():
