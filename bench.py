@@ -35,15 +35,19 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--workload", choices=["codec", "lm", "e2e"], default="codec",
-                    help="codec = BASELINE configs[1] (the default, headline); lm = configs[2]: Moshi-7B-shaped RQ-Transformer decode, batch 1")
+    ap.add_argument("--workload", choices=["codec", "lm", "e2e", "gpt"], default="codec",
+                    help="codec = BASELINE configs[1] (the default, headline); lm = configs[2]: Moshi-7B-shaped RQ-Transformer decode, "
+                         "batch 1; e2e = configs[3] shape per GPU; gpt = configs[4]: Qwen-0.5B-shaped litgpt backbone + LoRA, batch 32")
     ap.add_argument("--lm-config", choices=["moshi7b", "tiny"], default="moshi7b")
-    ap.add_argument("--lm-batch", type=int, default=1, help="lm / e2e: concurrent streams per GPU (<= 64)")
+    ap.add_argument("--lm-batch", type=int, default=None, help="lm / e2e / gpt: concurrent streams per GPU (<= 64; default 1, gpt 32)")
     ap.add_argument("--greedy", action="store_true", help="lm: greedy decoding instead of temperature / top-k sampling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch GEMM table (shape, ms, TFLOP/s, GB/s) to stderr")
     ap.add_argument("--check", action="store_true", help="also report the code exact-match rate against the CPU oracle on a sample")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.lm_batch is None:
+        args.lm_batch = 32 if args.workload == "gpt" else 1
+    return args
 
 
 def cpu_baseline(sd, seconds_per_clip: float, batch: int = 4):
@@ -175,6 +179,127 @@ def bench_lm(args, rank, world, dev):
     print(json.dumps(result), flush=True)
 
 
+def gpt_cpu_baseline(cfg_d, frames: int = 3):
+    """oracle/gpt_oracle.py on this host at the benchmark's shape, ONE stream, greedy: streamed forward_global step + the
+    dep_q codecformer steps per frame."""
+    from oracle import gpt_oracle as Gp
+    from rstnet_amd import synth
+    keep = set(Gp.GPTConfig.__dataclass_fields__)
+    cfg = Gp.GPTConfig(**{k: v for k, v in cfg_d.items() if k in keep})
+    sd = {k: v.float() for k, v in synth.gpt_state_dict(cfg_d, 0, lora=False).items()}
+    st = Gp.new_global_state(cfg, 1)
+    tok = torch.randint(0, 2048, (1, cfg.num_codebooks, 1))
+    with torch.no_grad():
+        def frame():
+            h, lg = Gp.forward_global(sd, cfg, tok, st, merged=True)
+            cst = Gp.new_codecformer_state(cfg, 1)
+            prev = lg.argmax(-1).view(1, 1, 1)
+            for k in range(cfg.dep_q):
+                prev = Gp.forward_codecformer(sd, cfg, k, prev, h, cst).argmax(-1).view(1, 1, 1)
+        frame()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            frame()
+        dt = time.perf_counter() - t0
+    return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle GPT streamed step + {cfg.dep_q} codecformer steps, {frames} frames, batch 1 (the GPU line is batch "
+                      f"32), greedy, fp32, LoRA pre-merged"}
+
+
+def bench_gpt(args, rank, world, dev):
+    """BASELINE configs[4]: Qwen-0.5B-shaped litgpt backbone (LoRA adapters merged at load) + codecformer, B streams; one step =
+    one frame: text sample + dep_q depth steps with sampling (one graph) + the global T = 1 step of the completed frame (one
+    graph)."""
+    from rstnet_amd import ops, synth
+    from rstnet_amd.lm.generate import GPTGen
+    from rstnet_amd.lm.gpt import GPT, Config
+    cfg_d = dict(synth.GPT_QWEN_0_5B if args.lm_config != "tiny" else synth.GPT_TINY_GQA)
+    B = args.lm_batch
+    sd = synth.gpt_state_dict(cfg_d, seed=0, device=str(dev))
+    model = GPT.from_state_dict(sd, Config.from_dict(cfg_d))
+    del sd
+    n_params = sum(v.numel() for v in model.state_dict().values())
+    n_codes = cfg_d["audio_card"] - 2
+    gen = GPTGen(model, use_sampling=not args.greedy, temp=0.8, temp_text=0.7, top_k=250, top_k_text=25, n_audio_codes=n_codes)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    K = cfg_d["n_q"] + 1
+    prompt = torch.randint(0, n_codes, (B, K, 8), generator=g, device=dev)
+    torch.manual_seed(1234 + rank)
+    gen.begin(B)
+    gen.set_blanking([False] + [True] * (cfg_d["dep_q"] - 1))
+    h, logits = gen.prefill(prompt)
+
+    def frame(h, logits):
+        text, audio = gen.frame(h.contiguous(), logits.contiguous())
+        return gen.advance(text, audio)
+    for _ in range(args.warmup):
+        h, logits = frame(h, logits)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h, logits = frame(h, logits)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gen.end()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    # roofline of the weight-streaming GEMMs: one extra eager frame with HIP events per launch
+    gen2 = GPTGen(model, use_sampling=not args.greedy, n_audio_codes=n_codes, noise=None)
+    os.environ["NO_CUDA_GRAPH"] = "1"
+    gen2.begin(B)
+    h, logits = gen2.prefill(prompt)
+    h, logits = gen2.advance(*gen2.frame(h, logits))
+    recs = []
+    ops.PROFILE = recs
+    h, logits = gen2.advance(*gen2.frame(h.contiguous(), logits.contiguous()))
+    torch.cuda.synchronize()
+    ops.PROFILE = None
+    gen2.end()
+    os.environ["NO_CUDA_GRAPH"] = "0"
+    gemm = [r for r in recs if r[0] in ("gemv_bf16", "gemm_skinny")]
+    ms = sum(r[1].elapsed_time(r[2]) for r in gemm)
+    nbytes = sum(r[4] for r in gemm)
+    if args.layers:
+        agg = {}
+        for _, e0, e1, fl, nb, shp in gemm:
+            d = agg.setdefault(shp, [0, 0.0, 0])
+            d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += nb
+        for shp, (n, t, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print(f"  gemm B,N,K={shp}: {n:4d} launches {t:8.3f} ms  {nb / t / 1e6:8.1f} GB/s", file=sys.stderr)
+    ms_frame = elapsed / args.steps * 1e3
+    result = {
+        "metric": "codec+LM audio frames/sec (24 kHz, 12.5 Hz tokens) at batch=1 and batch=64; RVQ code-index exact-match",
+        "value": round(B * world * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_frame, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16 weights, f32 activations (bf16 hi+lo split on the matrix cores)", "data": "synthetic",
+        "config": {"workload": "GPT (Qwen-1.5-0.5B-shaped litgpt backbone, LoRA r=32 merged) + codecformer: streamed frame = global "
+                               "step + text sample + 8 depth steps with sampling, BASELINE.json configs[4]",
+                   "batch_per_gpu": B, "params": n_params, "sampling": "greedy" if args.greedy else "temp 0.8/0.7 top-k 250/25",
+                   "hip_graphs": True, "gemm_precision": "bf16 (fp8 weight path not built yet, see DESIGN.md)",
+                   "parallelism": f"replica x{world}"},
+        "x_realtime_per_stream": round(args.steps / elapsed / 12.5, 2),
+        "roofline": {"bound": "hbm", "kernel": ("gemv_bf16_kernel" if B <= 4 else "gemm_skinny_kernel") + " (bf16 weight streaming)",
+                     "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": len(gemm),
+                     "avg_launch_ms": round(ms / max(1, len(gemm)), 5), "kernel_ms_per_step": round(ms, 3),
+                     "algorithmic_gb_per_step": round(nbytes / 1e9, 3), "share_of_step_eager": round(ms / ms_frame, 3)},
+    }
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = gpt_cpu_baseline(cfg_d)
+    print(json.dumps(result), flush=True)
+
+
 def bench_e2e(args, rank, world, dev):
     """BASELINE configs[3] shape on one GPU: B concurrent streams, each frame = Mimi encode (1920 samples) -> LMGen.step ->
     Mimi decode; value = B * frames / time."""
@@ -234,8 +359,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    if args.workload in ("lm", "e2e"):
-        (bench_lm if args.workload == "lm" else bench_e2e)(args, rank, world, dev)
+    if args.workload in ("lm", "e2e", "gpt"):
+        {"lm": bench_lm, "e2e": bench_e2e, "gpt": bench_gpt}[args.workload](args, rank, world, dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

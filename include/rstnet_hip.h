@@ -160,15 +160,16 @@ int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, i
 int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, const float* bias, float* y,
                       int B, int N, int K, int ldx, int ldy, int prologue, float eps, rst_stream_t stream);
 
-/* The same contraction for 4 < B <= 64 on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16): weights streamed once,
- * fp32 activations split into bf16 hi + lo (fp32-class accuracy), split-K over K / k_slice workgroups reduced in a fixed
- * order by the last arriver.  prologue 0 or 2 (apply rst_rmsnorm_f32 beforehand where the layer needs it).  K % 16 == 0.
- * rst_gemm_skinny_plan picks k_slice / the split count; ws [splits][B][N] floats and counters [ceil(N/32)] uint32 (zeroed
- * once) are needed when splits > 1. */
-int rst_gemm_skinny_plan(int B, int N, int K, int* k_slice, int* splits);
-int rst_gemm_skinny_bf16_f32(const float* x, const uint16_t* w, const float* res, const float* bias, float* y, float* ws,
-                             uint32_t* counters, int B, int N, int K, int ldx, int ldy, int prologue, int k_slice,
-                             rst_stream_t stream);
+/* The same contraction (identity prologue) for 4 < B <= 64 on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16): weights
+ * streamed once, fp32 activations read from L2 and split into bf16 hi + lo in registers (fp32-class accuracy), one workgroup
+ * per 32 weight rows whose 8 waves split K and meet in LDS in a fixed order (deterministic, no cross-workgroup reduction).
+ * K % 16 == 0, ldx % 4 == 0.  Layers that need RMSNorm / the SiLU gate first run rst_rmsnorm_f32 / rst_silu_gate_f32. */
+int rst_gemm_skinny_bf16_f32(const float* x, const uint16_t* w, const float* res, const float* bias, float* y, int B, int N,
+                             int K, int ldx, int ldy, rst_stream_t stream);
+
+/* y[b][k] = silu(x[b][k]) * x[b][K + k], x [B][ldx] holding [u ; v] (gating_forward_kernel, modules/gating.py:12-22; LLaMAMLP,
+ * models/lit_model.py:399-403) -- the stand-alone form of prologue 2 for batches above 4. */
+int rst_silu_gate_f32(const float* x, float* y, int B, int K, int ldx, rst_stream_t stream);
 
 /* out[b] = (add ? add[b] : 0) + sum_i table_i[tokens[b][tok_index[i]]]: the ScaledEmbedding sums of
  * LMModel.forward_text / forward_depformer (models/model.py:67-91, 372-380, 413-419): id -1 -> zero row, ids clamped

@@ -171,18 +171,15 @@ int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, con
     return rst_launch_gemv_bf16(p, (hipStream_t)stream);
 }
 
-int rst_gemm_skinny_plan(int B, int N, int K, int* k_slice, int* splits) {
-    RST_REQUIRE(k_slice && splits && B >= 1 && N > 0 && K > 0, "gemm_skinny_plan: bad arguments");
-    return rst_skinny_plan_impl(B, N, K, k_slice, splits);
+int rst_gemm_skinny_bf16_f32(const float* x, const uint16_t* w, const float* res, const float* bias, float* y, int B, int N,
+                             int K, int ldx, int ldy, rst_stream_t stream) {
+    SkinnyParams p;
+    p.x = x; p.w = w; p.res = res; p.bias = bias; p.y = y; p.B = B; p.N = N; p.K = K; p.ldx = ldx; p.ldy = ldy;
+    return rst_launch_gemm_skinny(p, (hipStream_t)stream);
 }
 
-int rst_gemm_skinny_bf16_f32(const float* x, const uint16_t* w, const float* res, const float* bias, float* y, float* ws,
-                             uint32_t* counters, int B, int N, int K, int ldx, int ldy, int prologue, int k_slice,
-                             rst_stream_t stream) {
-    SkinnyParams p;
-    p.x = x; p.w = w; p.res = res; p.bias = bias; p.y = y; p.ws = ws; p.counters = counters; p.B = B; p.N = N; p.K = K; p.ldx = ldx;
-    p.ldy = ldy; p.prologue = prologue; p.k_slice = k_slice;
-    return rst_launch_gemm_skinny(p, (hipStream_t)stream);
+int rst_silu_gate_f32(const float* x, float* y, int B, int K, int ldx, rst_stream_t stream) {
+    return rst_launch_silu_gate(x, y, B, K, ldx, (hipStream_t)stream);
 }
 
 int rst_embed_sum_bf16(const int64_t* tokens, const uint16_t* const* tables, const int* tok_index, int n_tables,

@@ -6,6 +6,7 @@
 // RMSNorm and the SiLU gate are prologues of the consuming GEMV and the residual add is its epilogue, so a
 // transformer layer is 7 launches: qkv GEMV | rope + KV append | attention partial | attention combine | out-proj
 // GEMV (+res) | ffn-in GEMV | ffn-out GEMV (+res).  Activations stay fp32 (>= the reference's bf16), weights bf16.
+#include <algorithm>
 #include "rst_common.h"
 #include "rst_kernels.h"
 #include <math.h>
@@ -944,133 +945,103 @@ int rst_launch_lm_sample(const LmSampleParams& p, hipStream_t stream) {
 }
 
 // ======================================================================================================================
-// Skinny GEMM for 4 < batch <= 64: y[b][n] = (res +) sum_k P(x)[b][k] * W[n][k] on the bf16 matrix cores.
-// The weight matrix is still streamed from HBM exactly once (the step stays bandwidth-bound up to batch ~64), but the
-// contraction runs on v_mfma_f32_32x32x16_bf16 with the fp32 activations split into bf16 hi + lo parts (two MFMAs per
-// tile): products carry ~16 mantissa bits of x, i.e. fp32-class accuracy against the fp32 oracle (the reference itself
-// rounds activations to bf16).  Tile = 32 weight rows x 32 batch columns per wave-accumulator; a workgroup = 4 waves on the
-// SAME 32 rows, each taking a quarter of the workgroup's K slice; split-K across gridDim.y workgroups, reduced
-// deterministically by the last arriver (write-through partials + counter, as the attention kernel).
+// Skinny GEMM for 4 < batch <= 64: y[b][n] = (res +) (bias +) sum_k x[b][k] * W[n][k] on the bf16 matrix cores.
+// The weight matrix is streamed from HBM exactly once (the step stays bandwidth-bound up to batch ~64); the contraction runs
+// on v_mfma_f32_32x32x16_bf16 with the fp32 activations split into bf16 hi + lo parts (two MFMAs per step): products carry
+// ~17 mantissa bits of x, i.e. fp32-class accuracy against the fp32 oracle (the reference itself rounds activations to bf16).
 // ======================================================================================================================
 namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned short f32_to_bf16_rn(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);     // round to nearest even (finite inputs)
-    return (unsigned short)(u >> 16);
+// fp32 x 8 -> bf16 hi (truncated: hi is then an exact fp32 prefix, so the residual x - hi is exact) and bf16 lo (residual
+// rounded half-up): x = hi + lo to 2^-17 relative.  v_perm_b32 packs the upper halves of two dwords in one instruction.
+__device__ __forceinline__ void split_hi_lo(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = j < 2 ? x0[2 * j] : x1[2 * j - 4], b = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
+        const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+        h[j] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                 // {hi16(b), hi16(a)}
+        const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);
+        l[j] = __builtin_amdgcn_perm(__float_as_uint(rb) + 0x8000u, __float_as_uint(ra) + 0x8000u, 0x07060302u);
+    }
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
+    hi = __builtin_bit_cast(bf16x8, hv);
+    lo = __builtin_bit_cast(bf16x8, lv);
 }
 
+constexpr int SKINNY_WAVES = 8;
+
+// One workgroup = one tile of 32 weight rows; its 8 waves each take an eighth of K.  Every lane streams its weight row
+// (16 B per step) and reads the activations straight from global memory (they are L2-resident: B*K*4 bytes), splitting them
+// into bf16 hi + lo in registers -- no LDS stage, no barrier in the main loop.  The activations are the MFMA "A" side, so the
+// accumulator is C[b = row(e, lane)][n = lane & 31] and global stores are 128-byte coalesced.  The 8 partial tiles meet in
+// LDS and are summed in wave order (deterministic); there is no cross-workgroup reduction.
 template <int NB>   // batch tiles of 32
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const SkinnyParams p) {
+    __shared__ float red[SKINNY_WAVES][NB * 32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int KS = p.k_slice;                                 // K elements handled by this workgroup
-    const int LDX = KS + 8;                                   // bf16 elements per LDS row (+16 B: conflict-free b128 reads)
-    unsigned short* xhi = reinterpret_cast<unsigned short*>(smem_raw);            // [NB*32][LDX]
-    unsigned short* xlo = xhi + NB * 32 * LDX;
+    const int i = lane & 31, h8 = (lane >> 5) * 8;
     const int n0 = blockIdx.x * 32;
-    const int kbeg = blockIdx.y * KS;
-    const int klen = min(KS, p.K - kbeg);
-
-    // ---- stage hi/lo of P(x) for this K slice (zero rows beyond B, zero columns beyond klen)
-    for (int idx = tid; idx < NB * 32 * (KS / 4); idx += 256) {
-        const int b = idx / (KS / 4), k4 = (idx - b * (KS / 4)) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (b < p.B && k4 < klen) {
-            const float* xp = p.x + (long)b * p.ldx + kbeg + k4;
-            v = *reinterpret_cast<const f32x4*>(xp);
-            if (p.prologue == 2) {   // SiLU gate: x = [u ; v]
-                const f32x4 g = *reinterpret_cast<const f32x4*>(xp + p.K);
-                v[0] = silu(v[0]) * g[0]; v[1] = silu(v[1]) * g[1]; v[2] = silu(v[2]) * g[2]; v[3] = silu(v[3]) * g[3];
-            }
-        }
+    const int steps = p.K / 16;                                      // MFMA steps over the whole K
+    const int per = (steps + SKINNY_WAVES - 1) / SKINNY_WAVES;
+    const int s0 = wave * per, s1 = min(steps, s0 + per);
+    const unsigned short* wrow = p.w + (long)min(n0 + i, p.N - 1) * p.K + h8;
+    const float* xrow[NB];
+    bool xok[NB];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned short h = f32_to_bf16_rn(v[e]);
-            xhi[b * LDX + k4 + e] = h;
-            xlo[b * LDX + k4 + e] = f32_to_bf16_rn(v[e] - __uint_as_float((unsigned)h << 16));
-        }
+    for (int t = 0; t < NB; ++t) {
+        xok[t] = t * 32 + i < p.B;
+        xrow[t] = p.x + (long)min(t * 32 + i, p.B - 1) * p.ldx + h8;
     }
-    __syncthreads();
-
-    // ---- main loop: wave w streams weights of rows n0..n0+31 over its quarter of the slice, 16 k per MFMA step
     f32x16 acc[NB];
 #pragma unroll
     for (int t = 0; t < NB; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    const int i = lane & 31, h8 = (lane >> 5) * 8;
-    const int kq = (klen / 16 + 3) / 4 * 16;                    // k per wave (multiple of 16)
-    const int kw0 = wave * kq, kw1 = min(klen, kw0 + kq);
-    const unsigned short* wrow = p.w + (long)min(n0 + i, p.N - 1) * p.K + kbeg + h8;
-    constexpr int UN = 8;
-    for (int k = kw0; k < kw1; k += 16 * UN) {
+    constexpr int UN = 4;
+    for (int s = s0; s < s1; s += UN) {
         bf16x8 a[UN];
+        f32x4 xa[UN][NB], xb[UN][NB];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int kk = k + 16 * u;
-            a[u] = kk < kw1 ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + kk)) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
+            const int kk = (s + u) * 16;
+            const bool ok = s + u < s1;
+            a[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + kk)) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int kk = k + 16 * u;
-            if (kk < kw1) {
-#pragma unroll
-                for (int t = 0; t < NB; ++t) {
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(xhi + (t * 32 + i) * LDX + kk + h8);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(xlo + (t * 32 + i) * LDX + kk + h8);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], bl, acc[t], 0, 0, 0);
+            for (int t = 0; t < NB; ++t) {
+                xa[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                xb[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok && xok[t]) {
+                    xa[u][t] = *reinterpret_cast<const f32x4*>(xrow[t] + kk);
+                    xb[u][t] = *reinterpret_cast<const f32x4*>(xrow[t] + kk + 4);
                 }
             }
         }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                bf16x8 hi, lo;
+                split_hi_lo(xa[u][t], xb[u][t], hi, lo);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, a[u], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, a[u], acc[t], 0, 0, 0);
+            }
     }
-    __syncthreads();   // everyone is done with the x stage: recycle it for the cross-wave reduction
-
-    // ---- reduce the 4 waves (fixed order), then the split-K partials (fixed order, last arriver)
-    float* red = reinterpret_cast<float*>(smem_raw);             // [4][NB*32][33]: red[w][b][n_local]
 #pragma unroll
     for (int t = 0; t < NB; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-            red[(wave * NB * 32 + t * 32 + (lane & 31)) * 33 + rst_mfma32_row(e, lane)] = acc[t][e];
+        for (int e = 0; e < 16; ++e) red[wave][t * 32 + rst_mfma32_row(e, lane)][i] = acc[t][e];
     __syncthreads();
-    const int SK = gridDim.y;
-    for (int idx = tid; idx < NB * 32 * 32; idx += 256) {
+    for (int idx = tid; idx < NB * 32 * 32; idx += 64 * SKINNY_WAVES) {
         const int b = idx >> 5, nl = idx & 31;
         const int n = n0 + nl;
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) s += red[(w * NB * 32 + b) * 33 + nl];
-        if (b < p.B && n < p.N) {
-            if (SK == 1) {
-                const long o = (long)b * p.ldy + n;
-                if (p.bias) s += p.bias[n];
-                p.y[o] = p.res ? p.res[o] + s : s;
-            } else {
-                __hip_atomic_store(p.ws + ((long)blockIdx.y * p.B + b) * p.N + n, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    if (SK == 1) return;
-    __shared__ int sm_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(p.counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sm_last = prev == (unsigned)SK - 1;
-        if (sm_last) __hip_atomic_store(p.counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!sm_last) return;
-    for (int idx = tid; idx < NB * 32 * 32; idx += 256) {
-        const int b = idx >> 5, n = n0 + (idx & 31);
         if (b < p.B && n < p.N) {
             float s = 0.f;
-            for (int sk = 0; sk < SK; ++sk)
-                s += __hip_atomic_load(p.ws + ((long)sk * p.B + b) * p.N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int w = 0; w < SKINNY_WAVES; ++w) s += red[w][b][nl];
             const long o = (long)b * p.ldy + n;
             if (p.bias) s += p.bias[n];
             p.y[o] = p.res ? p.res[o] + s : s;
@@ -1078,43 +1049,33 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
     }
 }
 
+// y[b][k] = silu(x[b][k]) * x[b][K + k]  (the activation of gating_forward_kernel / LLaMAMLP for batches above 4, where the
+// GEMM no longer fuses it: every one of its N/32 workgroups would redo the transcendental work)
+__global__ __launch_bounds__(256) void silu_gate_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int K, int ldx) {
+    const long total = (long)B * (K / 4);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long b = idx / (K / 4);
+        const int k4 = (int)(idx - b * (K / 4)) * 4;
+        const f32x4 u = *reinterpret_cast<const f32x4*>(x + b * ldx + k4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + b * ldx + K + k4);
+        *reinterpret_cast<f32x4*>(y + b * K + k4) = f32x4{silu(u[0]) * v[0], silu(u[1]) * v[1], silu(u[2]) * v[2], silu(u[3]) * v[3]};
+    }
+}
+
 }  // namespace
 
-int rst_skinny_plan_impl(int B, int N, int K, int* k_slice, int* splits) {
-    // K slice per workgroup: hi+lo bf16 stage of 32 (64) batch rows must fit ~64 KiB; enough workgroups to fill 256 CUs
-    const int nb = B <= 32 ? 1 : 2;
-    int ks = nb == 1 ? 512 : 256;
-    const long row_tiles = (N + 31) / 32;
-    while (ks < 1024 / nb && row_tiles * ((K + ks - 1) / ks) > 2048) ks *= 2;
-    if (ks > K) ks = (K + 15) / 16 * 16;
-    *k_slice = ks;
-    *splits = (K + ks - 1) / ks;
-    return 0;
+int rst_launch_silu_gate(const float* x, float* y, int B, int K, int ldx, hipStream_t stream) {
+    RST_REQUIRE(x && y && B >= 1 && K > 0 && K % 4 == 0 && ldx % 4 == 0, "silu_gate: bad arguments");
+    const long total = (long)B * (K / 4);
+    hipLaunchKernelGGL(silu_gate_kernel, dim3(cap_grid((total + 255) / 256, 2048)), dim3(256), 0, stream, x, y, B, K, ldx);
+    return rst_check_launch("silu_gate");
 }
 
 int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B >= 1 && p.B <= 64 && p.N > 0 && p.K > 0 && p.K % 16 == 0, "gemm_skinny: need 1 <= B <= 64 and K %% 16 == 0 (B=%d K=%d)", p.B, p.K);
-    RST_REQUIRE(p.x && p.w && p.y, "gemm_skinny: null pointer");
-    RST_REQUIRE(p.prologue == 0 || p.prologue == 2, "gemm_skinny: prologue must be 0 (identity) or 2 (SiLU gate); run rst_rmsnorm_f32 first");
-    RST_REQUIRE(p.k_slice > 0 && p.k_slice % 16 == 0, "gemm_skinny: bad k_slice");
-    const int nb = p.B <= 32 ? 1 : 2;
-    const int splits = (p.K + p.k_slice - 1) / p.k_slice;
-    RST_REQUIRE(splits == 1 || (p.ws && p.counters), "gemm_skinny: split-K needs the workspace [splits][B][N] and zeroed counters [N/32]");
-    size_t lds = (size_t)2 * nb * 32 * (p.k_slice + 8) * 2;
-    const size_t red = (size_t)4 * nb * 32 * 33 * 4;
-    if (red > lds) lds = red;
-    RST_REQUIRE(lds <= 150 * 1024, "gemm_skinny: k_slice %d too large", p.k_slice);
-    const dim3 grid((p.N + 31) / 32, splits);
-    auto go = [&](auto kern) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            (void)hipGetLastError();
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
-    };
-    if (nb == 1) go(gemm_skinny_kernel<1>);
-    else go(gemm_skinny_kernel<2>);
+    RST_REQUIRE(p.x && p.w && p.y && p.ldx % 4 == 0, "gemm_skinny: null pointer or row stride not a multiple of 4");
+    const dim3 grid((p.N + 31) / 32);
+    if (p.B <= 32) hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, dim3(64 * SKINNY_WAVES), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, dim3(64 * SKINNY_WAVES), 0, stream, p);
     return rst_check_launch("gemm_skinny");
 }

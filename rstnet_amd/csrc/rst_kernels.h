@@ -182,14 +182,12 @@ struct LmSampleParams {
 int rst_launch_lm_sample(const LmSampleParams& p, hipStream_t stream);
 
 struct SkinnyParams {
-    const float* x;             // [B][ldx] fp32 (prologue 2: [B][2K])
+    const float* x;             // [B][ldx] fp32
     const unsigned short* w;    // [N][K] bf16
     const float* res;           // optional [B][ldy]
     const float* bias;          // optional [N]
     float* y;                   // [B][ldy]
-    float* ws;                  // split-K partials [splits][B][N]
-    unsigned* counters;         // [ceil(N/32)] arrival counters (zero before the first launch, self re-arming)
-    int B, N, K, ldx, ldy, prologue, k_slice;
+    int B, N, K, ldx, ldy;
 };
-int rst_skinny_plan_impl(int B, int N, int K, int* k_slice, int* splits);
 int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream);
+int rst_launch_silu_gate(const float* x, float* y, int B, int K, int ldx, hipStream_t stream);

@@ -366,37 +366,36 @@ def gemv_bf16(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE
     return out
 
 
-_skinny_scratch: dict = {}
+def silu_gate(x: torch.Tensor) -> torch.Tensor:
+    """x fp32 ``[B, 2K]`` = [u ; v] -> ``silu(u) * v`` ``[B, K]`` (rst_silu_gate_f32)."""
+    _chk(x, "x")
+    B, K = x.shape[0], x.shape[1] // 2
+    out = torch.empty(B, K, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_silu_gate_f32(_ptr(x), _ptr(out), B, K, x.shape[1], _stream()))
+    return out
 
 
 def gemm_skinny(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, res: Optional[torch.Tensor] = None,
                 bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``y[B,N] = (res +) P(x) @ w.T`` for 4 < B <= 64 on the bf16 matrix cores (rst_gemm_skinny_bf16_f32); ``P`` is the
-    identity or the SiLU gate.  Split-K scratch (partials + self re-arming counters) is cached per shape: launches on one
-    stream are ordered, so layers of equal shape share it."""
+    """``y[B,N] = (res +) (bias +) P(x) @ w.T`` for 4 < B <= 64 on the bf16 matrix cores (rst_gemm_skinny_bf16_f32); ``P`` is the
+    identity or the SiLU gate (run as its own small kernel first)."""
     _chk(x, "x")
     _chk(w, "w", torch.bfloat16)
     _chk(res, "res")
     _chk(bias, "bias")
+    if prologue == PROLOGUE_SILU_GATE:
+        x = silu_gate(x)
+    elif prologue != PROLOGUE_NONE:
+        raise ValueError("gemm_skinny: run ops.rmsnorm first")
     B = x.shape[0]
     N, K = w.shape
-    assert x.shape[1] == (2 * K if prologue == PROLOGUE_SILU_GATE else K)
-    key = (x.device, B, N, K)
-    sc = _skinny_scratch.get(key)
-    if sc is None:
-        ks, sp = C.c_int(0), C.c_int(0)
-        _lib.check(_lib.lib().rst_gemm_skinny_plan(B, N, K, C.byref(ks), C.byref(sp)))
-        ws = torch.empty(sp.value, B, N, device=x.device, dtype=torch.float32) if sp.value > 1 else None
-        cnt = torch.zeros((N + 31) // 32, device=x.device, dtype=torch.int32) if sp.value > 1 else None
-        sc = _skinny_scratch[key] = (ks.value, ws, cnt)
-    k_slice, ws, cnt = sc
+    assert x.shape[1] == K
     out = torch.empty(B, N, device=x.device, dtype=torch.float32)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.lib().rst_gemm_skinny_bf16_f32(_ptr(x), _ptr(w), _ptr(res), _ptr(bias), _ptr(out), _ptr(ws), _ptr(cnt), B, N, K,
-                                                  x.shape[1], N, prologue, k_slice, _stream()))
+    _lib.check(_lib.lib().rst_gemm_skinny_bf16_f32(_ptr(x), _ptr(w), _ptr(res), _ptr(bias), _ptr(out), B, N, K, x.shape[1], N, _stream()))
     if prof is not None:
         e1.record()
         prof.append(("gemm_skinny", e0, e1, 2.0 * B * N * K, 2 * N * K + 4 * (x.numel() + out.numel()), (B, N, K)))

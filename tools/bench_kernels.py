@@ -27,6 +27,25 @@ def timeit(fn, iters=5, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
+def timeit_graph(fn, iters=50, warm=3):
+    """Device time per call with the host launch cost taken out: `iters` calls captured in one HIP graph, replayed."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
 def res_case(C, B, T, pre=False, post=False):
     g = torch.Generator().manual_seed(0)
     H = C // 2
@@ -58,8 +77,19 @@ def sample_case(V, k, sampling=True):
     logits = (torch.randn(1, V, generator=g) * 3).to(DEV)
     noise = torch.empty(1, k).exponential_(1, generator=g).to(DEV)
     out = torch.empty(1, dtype=torch.long, device=DEV)
-    ms = timeit(lambda: ops.lm_sample(logits, use_sampling=sampling, temp=0.8, top_k=k, noise=noise, out=out), iters=50, warm=5)
+    ms = timeit_graph(lambda: ops.lm_sample(logits, use_sampling=sampling, temp=0.8, top_k=k, noise=noise, out=out))
     return ms, 1.0
+
+
+def skinny_case(B, N, K, gate=False):
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(DEV)
+    x = torch.randn(B, 2 * K if gate else K, generator=g).to(DEV)
+    r = torch.randn(B, N, generator=g).to(DEV)
+    fn = (lambda: ops.gemv_bf16(x, w, res=r, prologue=2 if gate else 0)) if B <= 4 else \
+         (lambda: ops.gemm_skinny(x, w, res=r, prologue=2 if gate else 0))
+    ms = timeit_graph(fn)
+    return ms, 2.0 * N * K
 
 
 def main():
@@ -71,6 +101,12 @@ def main():
             parts = c.split(":")
             ms, fl = sample_case(int(parts[1]), int(parts[2]), sampling="greedy" not in parts)
             print(f"{c:32s} {ms * 1e3:8.1f} us", flush=True)
+            continue
+        if c.startswith("skinny"):
+            parts = c.split(":")
+            Bq, N, K = [int(v) for v in parts[1].split("x")]
+            ms, nbytes = skinny_case(Bq, N, K, gate="gate" in parts[2:])
+            print(f"{c:32s} {ms * 1e3:8.1f} us  {nbytes / ms / 1e6:8.1f} GB/s", flush=True)
             continue
         if c.startswith("res"):
             C = 128 if "128" in c else 64
