@@ -160,16 +160,21 @@ int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, i
 int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, const float* bias, float* y,
                       int B, int N, int K, int ldx, int ldy, int prologue, float eps, rst_stream_t stream);
 
-/* The same contraction (identity prologue) for 4 < B <= 64 on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16): weights
- * streamed once, fp32 activations read from L2 and split into bf16 hi + lo in registers (fp32-class accuracy), one workgroup
- * per 32 weight rows whose 8 waves split K and meet in LDS in a fixed order (deterministic, no cross-workgroup reduction).
- * K % 16 == 0, ldx % 4 == 0.  Layers that need RMSNorm / the SiLU gate first run rst_rmsnorm_f32 / rst_silu_gate_f32. */
-int rst_gemm_skinny_bf16_f32(const float* x, const uint16_t* w, const float* res, const float* bias, float* y, int B, int N,
-                             int K, int ldx, int ldy, rst_stream_t stream);
-
-/* y[b][k] = silu(x[b][k]) * x[b][K + k], x [B][ldx] holding [u ; v] (gating_forward_kernel, modules/gating.py:12-22; LLaMAMLP,
- * models/lit_model.py:399-403) -- the stand-alone form of prologue 2 for batches above 4. */
-int rst_silu_gate_f32(const float* x, float* y, int B, int K, int ldx, rst_stream_t stream);
+/* The same contraction for 4 < B <= 64 on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), in three entry points.
+ * Both operands are kept in the order the MFMA consumes them -- [tile of 32 rows][K/16 steps][64 lanes][8 bf16], lane =
+ * 32 * ((k / 8) % 2) + row % 32 -- so that every wave-level load is one contiguous kilobyte:
+ *   rst_skinny_pack_weight_bf16: w [N][K] row-major -> wp [ceil(N/32)*32][K] in that order (pad rows zero); once per weight.
+ *   rst_skinny_pack_act_f32: P(x) of one decode step, split into bf16 hi + lo planes (x = hi + lo to 2^-17: fp32-class
+ *     accuracy against the fp32 oracle) -> xp [2][ceil(B/32)*32][K]; mode 0 identity, 1 RMSNorm (alpha, eps), 2 SiLU gate
+ *     (x rows = [u ; v] of length 2K) -- the same prologues as rst_gemv_bf16_f32.  K % 16 == 0, ldx % 4 == 0.
+ *   rst_gemm_skinny_bf16_f32: y[b][n] = (res +) (bias +) sum_k P(x)[b][k] w[n][k]: weights streamed from HBM exactly once,
+ *     one workgroup per 32 (64, 128 for large N) weight rows whose 8 waves split K and meet in LDS in a fixed order
+ *     (deterministic, no cross-workgroup reduction). */
+int rst_skinny_pack_weight_bf16(const uint16_t* w, uint16_t* wp, int N, int K, rst_stream_t stream);
+int rst_skinny_pack_act_f32(const float* x, const float* alpha, uint16_t* xp, int B, int K, int ldx, int mode, float eps,
+                            rst_stream_t stream);
+int rst_gemm_skinny_bf16_f32(const uint16_t* xp, const uint16_t* wp, const float* res, const float* bias, float* y, int B, int N,
+                             int K, int ldy, rst_stream_t stream);
 
 /* out[b] = (add ? add[b] : 0) + sum_i table_i[tokens[b][tok_index[i]]]: the ScaledEmbedding sums of
  * LMModel.forward_text / forward_depformer (models/model.py:67-91, 372-380, 413-419): id -1 -> zero row, ids clamped

@@ -171,15 +171,20 @@ int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, con
     return rst_launch_gemv_bf16(p, (hipStream_t)stream);
 }
 
-int rst_gemm_skinny_bf16_f32(const float* x, const uint16_t* w, const float* res, const float* bias, float* y, int B, int N,
-                             int K, int ldx, int ldy, rst_stream_t stream) {
-    SkinnyParams p;
-    p.x = x; p.w = w; p.res = res; p.bias = bias; p.y = y; p.B = B; p.N = N; p.K = K; p.ldx = ldx; p.ldy = ldy;
-    return rst_launch_gemm_skinny(p, (hipStream_t)stream);
+int rst_skinny_pack_weight_bf16(const uint16_t* w, uint16_t* wp, int N, int K, rst_stream_t stream) {
+    return rst_launch_skinny_pack_weight(w, wp, N, K, (hipStream_t)stream);
 }
 
-int rst_silu_gate_f32(const float* x, float* y, int B, int K, int ldx, rst_stream_t stream) {
-    return rst_launch_silu_gate(x, y, B, K, ldx, (hipStream_t)stream);
+int rst_skinny_pack_act_f32(const float* x, const float* alpha, uint16_t* xp, int B, int K, int ldx, int mode, float eps,
+                            rst_stream_t stream) {
+    return rst_launch_skinny_pack_act(x, alpha, xp, B, K, ldx, mode, eps, (hipStream_t)stream);
+}
+
+int rst_gemm_skinny_bf16_f32(const uint16_t* xp, const uint16_t* wp, const float* res, const float* bias, float* y, int B, int N,
+                             int K, int ldy, rst_stream_t stream) {
+    SkinnyParams p;
+    p.xp = xp; p.w = wp; p.res = res; p.bias = bias; p.y = y; p.B = B; p.N = N; p.K = K; p.ldy = ldy;
+    return rst_launch_gemm_skinny(p, (hipStream_t)stream);
 }
 
 int rst_embed_sum_bf16(const int64_t* tokens, const uint16_t* const* tables, const int* tok_index, int n_tables,

@@ -954,128 +954,189 @@ namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-// fp32 x 8 -> bf16 hi (truncated: hi is then an exact fp32 prefix, so the residual x - hi is exact) and bf16 lo (residual
-// rounded half-up): x = hi + lo to 2^-17 relative.  v_perm_b32 packs the upper halves of two dwords in one instruction.
-__device__ __forceinline__ void split_hi_lo(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float a = j < 2 ? x0[2 * j] : x1[2 * j - 4], b = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
-        const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-        h[j] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                 // {hi16(b), hi16(a)}
-        const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);
-        l[j] = __builtin_amdgcn_perm(__float_as_uint(rb) + 0x8000u, __float_as_uint(ra) + 0x8000u, 0x07060302u);
+// ---- operand layouts of the skinny GEMM ------------------------------------------------------------------------------
+// Both operands are stored in the order the 32x32x16 MFMA consumes them, so that every wave-level load is ONE contiguous
+// kilobyte: [tile of 32 rows][step of 16 k][lane = 32 * (k / 8 % 2) + row % 32][8 bf16].
+//   weights  Wp : [ceil(N/32)][K/16][64][8]   (rows beyond N zero)        -- packed once per weight (rst_skinny_pack_weight_bf16)
+//   activations Xp: [2 = hi, lo][ceil(B/32)][K/16][64][8] (rows beyond B zero) -- packed per call by the (fused) prologue kernel
+__device__ __forceinline__ long packed_index(int row, int k, int K) {
+    return ((((long)(row >> 5) * (K >> 4) + (k >> 4)) * 64) + ((k >> 3) & 1) * 32 + (row & 31)) * 8 + (k & 7);
+}
+
+__global__ __launch_bounds__(256) void skinny_pack_weight_kernel(const unsigned short* __restrict__ w, unsigned short* __restrict__ wp,
+                                                                int N, int K) {
+    const long total = (long)((N + 31) / 32) * 32 * (K / 8);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int row = (int)(idx / (K / 8)), k = (int)(idx % (K / 8)) * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < N) v = *reinterpret_cast<const u32x4*>(w + (long)row * K + k);
+        *reinterpret_cast<u32x4*>(wp + packed_index(row, k, K)) = v;
     }
-    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-    const u32x4_ hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
-    hi = __builtin_bit_cast(bf16x8, hv);
-    lo = __builtin_bit_cast(bf16x8, lv);
+}
+
+// Prologue + hi/lo split + packing of one activation row per workgroup (pad rows of the last batch tile are zero-filled).
+// hi = fp32 truncated to bf16 (an exact prefix, so x - hi is exact), lo = the residual rounded half-up: x = hi + lo to 2^-17.
+// mode 0: identity; 1: RMSNorm x * alpha * rsqrt(eps + mean(x^2)); 2: SiLU gate, x row = [u ; v] -> silu(u) * v.
+__global__ __launch_bounds__(256) void skinny_pack_act_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                             unsigned short* __restrict__ xp, int B, int K, int ldx, int mode, float eps) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long half = (long)((B + 31) / 32) * 32 * K;          // elements of the hi (and of the lo) plane
+    float scale = 1.f;
+    if (mode == 1 && b < B) {
+        float s = 0.f;
+        for (int k = tid * 4; k < K; k += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + k);
+            s = fmaf(v[0], v[0], s); s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        scale = 1.0f / sqrtf(eps + (red[0] + red[1] + red[2] + red[3]) / (float)K);
+    }
+    for (int k = tid * 8; k < K; k += 2048) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (b < B) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + k);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + k + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = a0[j]; v[4 + j] = a1[j]; }
+            if (mode == 1) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(alpha + k), g1 = *reinterpret_cast<const f32x4*>(alpha + k + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = v[j] * (g0[j] * scale); v[4 + j] = v[4 + j] * (g1[j] * scale); }
+            } else if (mode == 2) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + K + k);
+                const f32x4 g1 = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + K + k + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = silu(v[j]) * g0[j]; v[4 + j] = silu(v[4 + j]) * g1[j]; }
+            }
+        }
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned ua = __float_as_uint(v[2 * j]), ub = __float_as_uint(v[2 * j + 1]);
+            h[j] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                 // {hi16(b), hi16(a)}
+            const float ra = v[2 * j] - __uint_as_float(ua & 0xffff0000u), rb = v[2 * j + 1] - __uint_as_float(ub & 0xffff0000u);
+            l[j] = __builtin_amdgcn_perm(__float_as_uint(rb) + 0x8000u, __float_as_uint(ra) + 0x8000u, 0x07060302u);
+        }
+        const long at = packed_index(b, k, K);
+        *reinterpret_cast<u32x4*>(xp + at) = u32x4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<u32x4*>(xp + half + at) = u32x4{l[0], l[1], l[2], l[3]};
+    }
 }
 
 constexpr int SKINNY_WAVES = 8;
 
-// One workgroup = one tile of 32 weight rows; its 8 waves each take an eighth of K.  Every lane streams its weight row
-// (16 B per step) and reads the activations straight from global memory (they are L2-resident: B*K*4 bytes), splitting them
-// into bf16 hi + lo in registers -- no LDS stage, no barrier in the main loop.  The activations are the MFMA "A" side, so the
-// accumulator is C[b = row(e, lane)][n = lane & 31] and global stores are 128-byte coalesced.  The 8 partial tiles meet in
-// LDS and are summed in wave order (deterministic); there is no cross-workgroup reduction.
-template <int NB>   // batch tiles of 32
+// One workgroup = CT adjacent tiles of 32 weight rows; its 8 waves each take an eighth of K.  Per MFMA step a wave loads
+// 1 KB of activations (hi), 1 KB (lo) -- L2 hits -- and CT x 1 KB of weights from HBM, all contiguous; no LDS stage and no
+// barrier in the main loop.  The activations are the MFMA "A" side, so an accumulator is C[b = row(e, lane)][n = lane & 31]
+// and the global stores are 128-byte coalesced.  The 8 partial tiles meet in LDS and are summed in wave order
+// (deterministic); there is no cross-workgroup reduction.
+template <int NB, int CT>   // batch tiles of 32, weight-row tiles per workgroup
 __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const SkinnyParams p) {
     __shared__ float red[SKINNY_WAVES][NB * 32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 31, h8 = (lane >> 5) * 8;
-    const int n0 = blockIdx.x * 32;
-    const int steps = p.K / 16;                                      // MFMA steps over the whole K
+    const int tiles = (p.N + 31) / 32;
+    const int tile0 = blockIdx.x * CT;
+    const int steps = p.K / 16;
     const int per = (steps + SKINNY_WAVES - 1) / SKINNY_WAVES;
     const int s0 = wave * per, s1 = min(steps, s0 + per);
-    const unsigned short* wrow = p.w + (long)min(n0 + i, p.N - 1) * p.K + h8;
-    const float* xrow[NB];
-    bool xok[NB];
+    const long xplane = (long)NB * 32 * p.K;                        // elements of the hi plane
+    const unsigned short* xh = p.xp + (long)lane * 8;
+    const unsigned short* xl = xh + xplane;
+    const unsigned short* wt[CT];
 #pragma unroll
-    for (int t = 0; t < NB; ++t) {
-        xok[t] = t * 32 + i < p.B;
-        xrow[t] = p.x + (long)min(t * 32 + i, p.B - 1) * p.ldx + h8;
-    }
-    f32x16 acc[NB];
+    for (int c = 0; c < CT; ++c) wt[c] = p.w + ((long)min(tile0 + c, tiles - 1) * steps * 64 + lane) * 8;
+    f32x16 acc[NB][CT];
 #pragma unroll
     for (int t = 0; t < NB; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    constexpr int UN = 4;
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
+    constexpr int UN = (NB * 2 + CT) <= 4 ? 4 : 2;
     for (int s = s0; s < s1; s += UN) {
-        bf16x8 a[UN];
-        f32x4 xa[UN][NB], xb[UN][NB];
+        bf16x8 a[UN][CT], bh[UN][NB], bl[UN][NB];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int kk = (s + u) * 16;
             const bool ok = s + u < s1;
-            a[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + kk)) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            const long so = (long)(s + u) * 512;
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                a[u][c] = ok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wt[c] + so)) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
-                xa[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                xb[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ok && xok[t]) {
-                    xa[u][t] = *reinterpret_cast<const f32x4*>(xrow[t] + kk);
-                    xb[u][t] = *reinterpret_cast<const f32x4*>(xrow[t] + kk + 4);
-                }
+                bh[u][t] = ok ? *reinterpret_cast<const bf16x8*>(xh + (long)t * steps * 512 + so) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                bl[u][t] = ok ? *reinterpret_cast<const bf16x8*>(xl + (long)t * steps * 512 + so) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u)
 #pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                bf16x8 hi, lo;
-                split_hi_lo(xa[u][t], xb[u][t], hi, lo);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, a[u], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, a[u], acc[t], 0, 0, 0);
+            for (int t = 0; t < NB; ++t)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[u][t], a[u][c], acc[t][c], 0, 0, 0);
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[u][t], a[u][c], acc[t][c], 0, 0, 0);
+                }
+    }
+    const int i = lane & 31;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (c) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wave][t * 32 + rst_mfma32_row(e, lane)][i] = acc[t][c][e];
+        __syncthreads();
+        const int n0 = (tile0 + c) * 32;
+        for (int idx = tid; idx < NB * 32 * 32; idx += 64 * SKINNY_WAVES) {
+            const int b = idx >> 5, nl = idx & 31;
+            const int n = n0 + nl;
+            if (b < p.B && n < p.N) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < SKINNY_WAVES; ++w) s += red[w][b][nl];
+                const long o = (long)b * p.ldy + n;
+                if (p.bias) s += p.bias[n];
+                p.y[o] = p.res ? p.res[o] + s : s;
             }
-    }
-#pragma unroll
-    for (int t = 0; t < NB; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) red[wave][t * 32 + rst_mfma32_row(e, lane)][i] = acc[t][e];
-    __syncthreads();
-    for (int idx = tid; idx < NB * 32 * 32; idx += 64 * SKINNY_WAVES) {
-        const int b = idx >> 5, nl = idx & 31;
-        const int n = n0 + nl;
-        if (b < p.B && n < p.N) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < SKINNY_WAVES; ++w) s += red[w][b][nl];
-            const long o = (long)b * p.ldy + n;
-            if (p.bias) s += p.bias[n];
-            p.y[o] = p.res ? p.res[o] + s : s;
         }
-    }
-}
-
-// y[b][k] = silu(x[b][k]) * x[b][K + k]  (the activation of gating_forward_kernel / LLaMAMLP for batches above 4, where the
-// GEMM no longer fuses it: every one of its N/32 workgroups would redo the transcendental work)
-__global__ __launch_bounds__(256) void silu_gate_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int K, int ldx) {
-    const long total = (long)B * (K / 4);
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long b = idx / (K / 4);
-        const int k4 = (int)(idx - b * (K / 4)) * 4;
-        const f32x4 u = *reinterpret_cast<const f32x4*>(x + b * ldx + k4);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + b * ldx + K + k4);
-        *reinterpret_cast<f32x4*>(y + b * K + k4) = f32x4{silu(u[0]) * v[0], silu(u[1]) * v[1], silu(u[2]) * v[2], silu(u[3]) * v[3]};
     }
 }
 
 }  // namespace
 
-int rst_launch_silu_gate(const float* x, float* y, int B, int K, int ldx, hipStream_t stream) {
-    RST_REQUIRE(x && y && B >= 1 && K > 0 && K % 4 == 0 && ldx % 4 == 0, "silu_gate: bad arguments");
-    const long total = (long)B * (K / 4);
-    hipLaunchKernelGGL(silu_gate_kernel, dim3(cap_grid((total + 255) / 256, 2048)), dim3(256), 0, stream, x, y, B, K, ldx);
-    return rst_check_launch("silu_gate");
+int rst_launch_skinny_pack_weight(const unsigned short* w, unsigned short* wp, int N, int K, hipStream_t stream) {
+    RST_REQUIRE(w && wp && N > 0 && K > 0 && K % 16 == 0, "skinny_pack_weight: bad arguments (K %% 16 == 0 required, K=%d)", K);
+    const long total = (long)((N + 31) / 32) * 32 * (K / 8);
+    hipLaunchKernelGGL(skinny_pack_weight_kernel, dim3(cap_grid((total + 255) / 256, 8192)), dim3(256), 0, stream, w, wp, N, K);
+    return rst_check_launch("skinny_pack_weight");
+}
+
+int rst_launch_skinny_pack_act(const float* x, const float* alpha, unsigned short* xp, int B, int K, int ldx, int mode, float eps,
+                               hipStream_t stream) {
+    RST_REQUIRE(x && xp && B >= 1 && B <= 64 && K > 0 && K % 16 == 0 && ldx % 4 == 0, "skinny_pack_act: bad arguments (B=%d K=%d)", B, K);
+    RST_REQUIRE(mode == 0 || (mode == 1 && alpha) || mode == 2, "skinny_pack_act: mode 0 / 1 (needs alpha) / 2");
+    hipLaunchKernelGGL(skinny_pack_act_kernel, dim3((B + 31) / 32 * 32), dim3(256), 0, stream, x, alpha, xp, B, K, ldx, mode, eps);
+    return rst_check_launch("skinny_pack_act");
 }
 
 int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B >= 1 && p.B <= 64 && p.N > 0 && p.K > 0 && p.K % 16 == 0, "gemm_skinny: need 1 <= B <= 64 and K %% 16 == 0 (B=%d K=%d)", p.B, p.K);
-    RST_REQUIRE(p.x && p.w && p.y && p.ldx % 4 == 0, "gemm_skinny: null pointer or row stride not a multiple of 4");
-    const dim3 grid((p.N + 31) / 32);
-    if (p.B <= 32) hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, dim3(64 * SKINNY_WAVES), 0, stream, p);
-    else hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, dim3(64 * SKINNY_WAVES), 0, stream, p);
+    RST_REQUIRE(p.xp && p.w && p.y, "gemm_skinny: null pointer");
+    const int tiles = (p.N + 31) / 32;
+    const int threads = 64 * SKINNY_WAVES;
+    if (p.B <= 32) {
+        if (tiles >= 2048) hipLaunchKernelGGL((gemm_skinny_kernel<1, 4>), dim3((tiles + 3) / 4), dim3(threads), 0, stream, p);
+        else if (tiles >= 512) hipLaunchKernelGGL((gemm_skinny_kernel<1, 2>), dim3((tiles + 1) / 2), dim3(threads), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<1, 1>), dim3(tiles), dim3(threads), 0, stream, p);
+    } else {
+        if (tiles >= 512) hipLaunchKernelGGL((gemm_skinny_kernel<2, 2>), dim3((tiles + 1) / 2), dim3(threads), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<2, 1>), dim3(tiles), dim3(threads), 0, stream, p);
+    }
     return rst_check_launch("gemm_skinny");
 }

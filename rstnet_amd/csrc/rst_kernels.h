@@ -182,12 +182,14 @@ struct LmSampleParams {
 int rst_launch_lm_sample(const LmSampleParams& p, hipStream_t stream);
 
 struct SkinnyParams {
-    const float* x;             // [B][ldx] fp32
-    const unsigned short* w;    // [N][K] bf16
+    const unsigned short* xp;   // packed activations [2][ceil(B/32)][K/16][64][8] bf16 (hi plane, lo plane)
+    const unsigned short* w;    // packed weights [ceil(N/32)][K/16][64][8] bf16
     const float* res;           // optional [B][ldy]
     const float* bias;          // optional [N]
     float* y;                   // [B][ldy]
-    int B, N, K, ldx, ldy;
+    int B, N, K, ldy;
 };
 int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream);
-int rst_launch_silu_gate(const float* x, float* y, int B, int K, int ldx, hipStream_t stream);
+int rst_launch_skinny_pack_weight(const unsigned short* w, unsigned short* wp, int N, int K, hipStream_t stream);
+int rst_launch_skinny_pack_act(const float* x, const float* alpha, unsigned short* xp, int B, int K, int ldx, int mode, float eps,
+                               hipStream_t stream);

@@ -366,36 +366,53 @@ def gemv_bf16(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE
     return out
 
 
-def silu_gate(x: torch.Tensor) -> torch.Tensor:
-    """x fp32 ``[B, 2K]`` = [u ; v] -> ``silu(u) * v`` ``[B, K]`` (rst_silu_gate_f32)."""
-    _chk(x, "x")
-    B, K = x.shape[0], x.shape[1] // 2
-    out = torch.empty(B, K, device=x.device, dtype=torch.float32)
-    _lib.check(_lib.lib().rst_silu_gate_f32(_ptr(x), _ptr(out), B, K, x.shape[1], _stream()))
-    return out
+_skinny_weights: dict = {}
 
 
-def gemm_skinny(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, res: Optional[torch.Tensor] = None,
-                bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``y[B,N] = (res +) (bias +) P(x) @ w.T`` for 4 < B <= 64 on the bf16 matrix cores (rst_gemm_skinny_bf16_f32); ``P`` is the
-    identity or the SiLU gate (run as its own small kernel first)."""
-    _chk(x, "x")
+def skinny_pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """bf16 ``[N, K]`` -> the MFMA-ordered copy ``[ceil(N/32)*32, K]`` of rst_skinny_pack_weight_bf16, cached per weight
+    storage (the row-major original stays: the batch <= 4 GEMV streams that one)."""
     _chk(w, "w", torch.bfloat16)
+    N, K = w.shape
+    key = (w.device, w.data_ptr(), N, K)
+    hit = _skinny_weights.get(key)
+    if hit is not None and hit[1] == w._version:
+        return hit[0]
+    wp = torch.empty((N + 31) // 32 * 32, K, device=w.device, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().rst_skinny_pack_weight_bf16(_ptr(w), _ptr(wp), N, K, _stream()))
+    _skinny_weights[key] = (wp, w._version, w)      # keeps the source alive so that its address cannot be recycled
+    return wp
+
+
+def skinny_pack_act(x: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
+                    eps: float = 1e-8) -> torch.Tensor:
+    """fp32 ``[B, K]`` (``[B, 2K]`` for the SiLU gate) -> packed bf16 hi / lo planes ``[2, ceil(B/32)*32, K]`` of P(x)."""
+    _chk(x, "x")
+    _chk(alpha, "alpha")
+    B = x.shape[0]
+    K = x.shape[1] // 2 if prologue == PROLOGUE_SILU_GATE else x.shape[1]
+    xp = torch.empty(2, (B + 31) // 32 * 32, K, device=x.device, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().rst_skinny_pack_act_f32(_ptr(x), _ptr(alpha), _ptr(xp), B, K, x.shape[1], prologue, eps, _stream()))
+    return xp
+
+
+def gemm_skinny(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
+                eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``y[B,N] = (res +) (bias +) P(x) @ w.T`` for 4 < B <= 64 on the bf16 matrix cores: prologue + hi/lo split + packing of
+    the activations (one small launch), then rst_gemm_skinny_bf16_f32 against the packed copy of ``w``."""
     _chk(res, "res")
     _chk(bias, "bias")
-    if prologue == PROLOGUE_SILU_GATE:
-        x = silu_gate(x)
-    elif prologue != PROLOGUE_NONE:
-        raise ValueError("gemm_skinny: run ops.rmsnorm first")
     B = x.shape[0]
     N, K = w.shape
-    assert x.shape[1] == K
+    wp = skinny_pack_weight(w)
+    xp = skinny_pack_act(x, prologue=prologue, alpha=alpha, eps=eps)
+    assert xp.shape[2] == K, (tuple(x.shape), N, K, prologue)
     out = torch.empty(B, N, device=x.device, dtype=torch.float32)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.lib().rst_gemm_skinny_bf16_f32(_ptr(x), _ptr(w), _ptr(res), _ptr(bias), _ptr(out), B, N, K, x.shape[1], N, _stream()))
+    _lib.check(_lib.lib().rst_gemm_skinny_bf16_f32(_ptr(xp), _ptr(wp), _ptr(res), _ptr(bias), _ptr(out), B, N, K, N, _stream()))
     if prof is not None:
         e1.record()
         prof.append(("gemm_skinny", e0, e1, 2.0 * B * N * K, 2 * N * K + 4 * (x.numel() + out.numel()), (B, N, K)))
@@ -404,18 +421,15 @@ def gemm_skinny(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NO
 
 def lm_linear(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
               eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Batch-size dispatch of one decode-step linear: weight-streaming GEMV for B <= 4, bf16-MFMA skinny GEMM above
-    (RMSNorm then runs as its own small kernel)."""
+    """Batch-size dispatch of one decode-step linear: weight-streaming GEMV for B <= 4, bf16-MFMA skinny GEMM above (the
+    prologue then runs inside the activation-packing launch)."""
     if x.shape[0] <= 4:
         return gemv_bf16(x, w, prologue=prologue, alpha=alpha, eps=eps, res=res, bias=bias)
-    if prologue == PROLOGUE_RMSNORM:
-        x = rmsnorm(x, alpha, eps)
-        prologue = PROLOGUE_NONE
     if x.shape[0] <= 64:
-        return gemm_skinny(x, w, prologue=prologue, res=res, bias=bias)
+        return gemm_skinny(x, w, prologue=prologue, alpha=alpha, eps=eps, res=res, bias=bias)
     # more rows than one skinny tile set (prompt prefill): chunks of 64 rows, each streaming the weights once
-    return torch.cat([gemm_skinny(x[i:i + 64], w, prologue=prologue, res=None if res is None else res[i:i + 64], bias=bias)
-                      for i in range(0, x.shape[0], 64)])
+    return torch.cat([gemm_skinny(x[i:i + 64], w, prologue=prologue, alpha=alpha, eps=eps,
+                                  res=None if res is None else res[i:i + 64], bias=bias) for i in range(0, x.shape[0], 64)])
 
 
 def embed_sum(tokens: torch.Tensor, tables: Sequence[torch.Tensor], tok_index: Sequence[int],
