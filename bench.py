@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--lm-config", choices=["moshi7b", "tiny"], default="moshi7b")
     ap.add_argument("--lm-batch", type=int, default=None, help="lm / e2e / gpt: concurrent streams per GPU (<= 64; default 1, gpt 32)")
     ap.add_argument("--greedy", action="store_true", help="lm: greedy decoding instead of temperature / top-k sampling")
+    ap.add_argument("--lm-context", type=int, default=0, help="lm: start the timed frames at this ring offset (e.g. 3000 = every "
+                    "temporal attention reads the full 3000-slot KV ring; the ring content is zeros, the bytes are the same)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch GEMM table (shape, ms, TFLOP/s, GB/s) to stderr")
     ap.add_argument("--check", action="store_true", help="also report the code exact-match rate against the CPU oracle on a sample")
@@ -48,6 +50,28 @@ def parse():
     if args.lm_batch is None:
         args.lm_batch = 32 if args.workload == "gpt" else 1
     return args
+
+
+def pmc_traffic(kernel: str, workload: str):
+    """HBM bytes per launch of `kernel` from the committed PMC summary of this workload (tools/pmc_traffic.py over two
+    rocprofv3 --pmc passes of this very command; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), or None.
+    The counters cannot be read from inside the process, so the number is the profiled run's, not this run's."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"*_{workload}_pmc_traffic.json"))):
+        try:
+            with open(path) as f:
+                tab = json.load(f)
+        except (OSError, ValueError):
+            continue
+        rows = [v for name, v in tab.items() if isinstance(v, dict) and name.startswith(kernel)]
+        n = sum(v["launches"] for v in rows)
+        if n:      # all template instances of the kernel, launch-weighted (the latest summary wins)
+            best = {"bytes_per_launch": round(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in rows) / n),
+                    "fetch_bytes_per_launch": round(sum(v["fetch_bytes_per_launch"] * v["launches"] for v in rows) / n),
+                    "write_bytes_per_launch": round(sum(v["write_bytes_per_launch"] * v["launches"] for v in rows) / n),
+                    "launches_profiled": n, "source": f"profiles/{os.path.basename(path)}"}
+    return best
 
 
 def cpu_baseline(sd, seconds_per_clip: float, batch: int = 4):
@@ -114,6 +138,10 @@ def bench_lm(args, rank, world, dev):
     user = torch.randint(0, cfg["card"], (args.warmup + args.steps + 1, B, cfg["n_q"] - cfg["dep_q"], 1), generator=g, device=dev)
     torch.manual_seed(1234 + rank)
     gen.streaming_forever(B)
+    if args.lm_context:
+        st = model.transformer._streaming_state
+        st.pos.fill_(args.lm_context)
+        st.offset_cpu = args.lm_context
     for s in range(args.warmup):
         gen.step(user[s])
     torch.cuda.synchronize()
@@ -163,14 +191,15 @@ def bench_lm(args, rank, world, dev):
         "warmup": args.warmup, "ms_per_step": round(ms_frame, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16 weights, f32 activations", "data": "synthetic",
         "config": {"workload": f"LMGen.step (temporal + 8-step depth transformer + sampling), BASELINE.json configs[2], {args.lm_config}",
-                   "batch_per_gpu": B, "params": n_params, "context_frames": args.warmup + args.steps,
+                   "batch_per_gpu": B, "params": n_params, "context_frames": args.lm_context + args.warmup + args.steps,
                    "sampling": "greedy" if args.greedy else "temp 0.8/0.7 top-k 250/25", "hip_graphs": True,
                    "parallelism": f"replica x{world}"},
         "x_realtime_per_stream": round(args.steps / elapsed / 12.5, 2),
         "roofline": {"bound": "hbm", "kernel": ("gemv_bf16_kernel" if B <= 4 else "gemm_skinny_kernel") + " (bf16 weight streaming)",
                      "achieved": round(nbytes / ms / 1e6, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
-                     "launches_per_step": len(gemv), "avg_launch_ms": round(ms / max(1, len(gemv)), 5),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                     "traffic": pmc_traffic("gemv_bf16_kernel" if B <= 4 else "gemm_skinny_kernel", "lm"),
+                     "algorithmic_bytes_per_launch": round(nbytes / max(1, len(gemv))), "launches_per_step": len(gemv), "avg_launch_ms": round(ms / max(1, len(gemv)), 5),
                      "kernel_ms_per_step": round(ms, 3), "algorithmic_gb_per_step": round(nbytes / 1e9, 3),
                      "share_of_step_eager": round(ms / ms_frame, 3), "all_launches_per_step": None},
     }
@@ -291,7 +320,9 @@ def bench_gpt(args, rank, world, dev):
         "x_realtime_per_stream": round(args.steps / elapsed / 12.5, 2),
         "roofline": {"bound": "hbm", "kernel": ("gemv_bf16_kernel" if B <= 4 else "gemm_skinny_kernel") + " (bf16 weight streaming)",
                      "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": len(gemm),
+                     "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                     "traffic": pmc_traffic("gemv_bf16_kernel" if B <= 4 else "gemm_skinny_kernel", "gpt"),
+                     "algorithmic_bytes_per_launch": round(nbytes / max(1, len(gemm))), "launches_per_step": len(gemm),
                      "avg_launch_ms": round(ms / max(1, len(gemm)), 5), "kernel_ms_per_step": round(ms, 3),
                      "algorithmic_gb_per_step": round(nbytes / 1e9, 3), "share_of_step_eager": round(ms / ms_frame, 3)},
     }
@@ -429,7 +460,8 @@ def main():
         tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": f"{dom}_kernel (fp32 v_mfma_f32_32x32x2_f32)", "achieved": round(tf, 3),
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None, "launches_per_step": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                    "traffic": pmc_traffic(f"{dom}_kernel", "codec"), "launches_per_step": d["launches"],
+                    "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "kernel_ms_per_step": round(d["ms"], 3), "share_of_step": round(d["ms"] / t_step_ms, 3),
                     "algorithmic_gflop_per_step": round(d["flops"] / 1e9, 1),
                     "other_kernels": {k: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"],

@@ -184,3 +184,23 @@ def test_seanet_encoder_streaming_small():
         for t in range(0, 64, 8):
             outs.append(enc(x[..., t:t + 8].contiguous()))
     _close(torch.cat(outs, -1), expected)
+
+
+def test_tokenizer_batch_equals_single():
+    """MimiTokenizer: ragged zero-padded batches give bit-identical int16 codes to one-utterance calls; detokenize inverts
+    the layout (mimi_tokenizer.py:56-82)."""
+    from rstnet_amd.codec.tokenizer import MimiTokenizer
+    model = MimiCodec.from_state_dict(synth.mimi_state_dict(0)).to(DEV)
+    tok = MimiTokenizer(model)
+    lens = [24000, 30001, 1920, 5000, 47999]
+    wavs = [synth.synth_audio(1, n, seed=30 + i)[0, 0] for i, n in enumerate(lens)]
+    single = [tok.tokenize(w[None], 24000) for w in wavs]
+    batched = tok.tokenize_batch(wavs, 24000, max_batch_seconds=3.0)
+    for n, a, b in zip(lens, single, batched):
+        assert a.dtype == torch.int16 and tuple(a.shape) == (8, -(-n // 1920))
+        assert torch.equal(a, b), n
+    d = tok.tokenize_scp({f"utt{i}": w for i, w in enumerate(wavs)})
+    assert list(d) == [f"utt{i}" for i in range(len(wavs))] and torch.equal(d["utt1"], single[1])
+    wav = tok.detokenize(single[0])
+    assert tuple(wav.shape) == (1, single[0].shape[1] * 1920)
+    assert tok.tokenize(single[0][0].long(), 24000).dim() == 1       # 1-D input = offline codes, passed through

@@ -1,0 +1,45 @@
+#!/bin/bash
+# Collect the round's measurements on the GPU box (run through gpurun from the repo root):
+#   bench JSON lines, rocprofv3 kernel traces (--kernel-trace --stats) and the two PMC passes (FETCH_SIZE / WRITE_SIZE) per
+#   workload.  The raw rocprof outputs are reduced on the box (tools/rocpd_summary.py, tools/pmc_traffic.py) to the small
+#   files that are then copied into profiles/ and committed; only those travel back (gpurun_out/ is capped at 64 MiB).
+TAG=${1:-r01d}
+WHAT=${2:-all}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/$TAG
+mkdir -p "$O"
+RAW=/tmp/raw_$TAG
+rm -rf "$RAW"; mkdir -p "$RAW"
+run() { local n=$1; shift; echo "== $n: $*"; "$@" > "$O/$n.out" 2> "$O/$n.err"; local rc=$?; echo "rc=$rc"; [ $rc -ne 0 ] && tail -5 "$O/$n.err"; return 0; }
+prof() { local n=$1; shift
+  run "${n}_trace" rocprofv3 --kernel-trace --stats -d "$RAW/${n}_trace" -o t -- "$@"
+  local db; db=$(find "$RAW/${n}_trace" -name "*.db" | head -1)
+  [ -n "$db" ] && python tools/rocpd_summary.py "$db" "$O/${n}" | tail -1
+  NO_CUDA_GRAPH=1 run "${n}_fetch" rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$RAW/${n}_fetch" -o f -- "$@"
+  NO_CUDA_GRAPH=1 run "${n}_write" rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$RAW/${n}_write" -o w -- "$@"
+  local fc wc; fc=$(find "$RAW/${n}_fetch" -name "*counter_collection.csv" | head -1); wc=$(find "$RAW/${n}_write" -name "*counter_collection.csv" | head -1)
+  [ -n "$fc" ] && [ -n "$wc" ] && python tools/pmc_traffic.py "$fc" "$wc" "$O/${n}_pmc_traffic.json" | head -6
+  rm -f "$O/${n}_trace.out" "$O/${n}_fetch.out" "$O/${n}_write.out"
+}
+if [ "$WHAT" = all ] || [ "$WHAT" = codec ]; then
+  run codec_bench python bench.py --steps 5 --warmup 2 --check
+  prof codec python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = lm ]; then
+  run lm_bench python bench.py --workload lm --steps 60 --warmup 5
+  run lm_ctx3000_bench python bench.py --workload lm --steps 60 --warmup 5 --lm-context 3000 --no-cpu-baseline
+  run lm32_bench python bench.py --workload lm --lm-batch 32 --steps 30 --warmup 5 --no-cpu-baseline
+  prof lm python bench.py --workload lm --steps 6 --warmup 2 --no-cpu-baseline
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = gpt ]; then
+  run gpt_bench python bench.py --workload gpt --steps 40 --warmup 5
+  prof gpt python bench.py --workload gpt --steps 6 --warmup 2 --no-cpu-baseline
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = e2e ]; then
+  run e2e1_bench python bench.py --workload e2e --lm-batch 1 --steps 60 --warmup 6
+  run e2e32_bench python bench.py --workload e2e --lm-batch 32 --steps 30 --warmup 5
+  run e2e1_trace rocprofv3 --kernel-trace --stats -d "$RAW/e2e1_trace" -o t -- python bench.py --workload e2e --lm-batch 1 --steps 30 --warmup 4
+  db=$(find "$RAW/e2e1_trace" -name "*.db" | head -1); [ -n "$db" ] && python tools/rocpd_summary.py "$db" "$O/e2e1" | tail -1
+  rm -f "$O/e2e1_trace.out"
+fi
+du -sh "$O"; ls "$O"
