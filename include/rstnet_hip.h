@@ -94,6 +94,12 @@ int rst_seanet_resblock_f32(const float* x, const float* hist, const float* w0, 
 int rst_linear_f32(const float* x, const float* w, const float* bias, const float* res, const float* scale, float* y,
                    int64_t M, int K, int N, int act_out, rst_stream_t stream);
 
+/* rst_linear_f32 for M = B <= 4 rows (the streaming steps of the Mimi transformers: one or two 25 Hz positions per 80 ms
+ * frame): a weight-streaming GEMV over the fp32 [N][K] matrix -- every CU pulls rows, no split-K hand-off.  Same epilogue
+ * order as rst_linear_f32: y = res + scale[n] * act(bias[n] + x . w[n]), act_out 0 / RST_ACT_GELU.  K % 8 == 0. */
+int rst_gemv_f32(const float* x, const float* w, const float* bias, const float* res, const float* scale, float* y, int B, int N,
+                 int K, int act_out, rst_stream_t stream);
+
 /* nn.LayerNorm(D, eps) over the last dim (modules/transformer.py:113-114). */
 int rst_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int D, float eps,
                       rst_stream_t stream);
@@ -138,9 +144,16 @@ int rst_act_f32(const float* x, float* y, int64_t n, int act, rst_stream_t strea
 /* Layout adapter [B][R][C] -> [B][C][R] (reference [B,C,T] <-> channels-last). */
 int rst_transpose_f32(const float* x, float* y, int B, int R, int C, rst_stream_t stream);
 
+/* Ragged batches: rows t >= lengths[b] of x [B][T][C] (in place) become zero (mode 0) or copies of row lengths[b] - 1 (mode 1).
+ * A zero-padded batch then reproduces what the reference computes for each utterance alone: its convolutions pad the END of
+ * every layer's input themselves -- zeros in pad_for_conv1d (modules/conv.py:82-100), replicate in ConvDownsample1d
+ * (modules/resample.py:14-65) -- so the rows past an utterance's length must hold exactly that when a strided layer reads them. */
+int rst_mask_tail_f32(float* x, const int32_t* lengths, int B, int T, int C, int mode, rst_stream_t stream);
+
 /* Streaming history roll: hist_out [P_out steps] = last P_out steps of concat(hist_in [P_in steps], x [T_in steps])
  * (the `previous` buffer of RawStreamingConv1d, modules/streaming.py:224-236; conv-transpose keeps its input history the
- * same way instead of the reference's `partial` output buffer).  hist_out must not alias hist_in. */
+ * same way instead of the reference's `partial` output buffer).  hist_out == hist_in (in-place roll, what a graph-replayed
+ * streaming step wants) is allowed when P_in == P_out and P_out * C <= 16384; otherwise the buffers must not overlap. */
 int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, int B, int T_in, int P_in, int P_out,
                         int C, rst_stream_t stream);
 

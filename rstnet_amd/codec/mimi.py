@@ -20,6 +20,7 @@ from .resample import ConvDownsample1d, ConvTrUpsample1d
 from .seanet import SEANetDecoder, SEANetEncoder
 from dataclasses import dataclass, field
 
+from .. import ops
 from ..graphs import Graphed
 from .streaming import StreamingModule
 
@@ -77,19 +78,29 @@ class MimiCodec(StreamingModule[_MimiState]):
     def forward(self, audio_data: torch.Tensor, semantic_features: torch.Tensor):
         raise NotImplementedError("the GAN / distillation training forward is out of scope of the inference hot path")
 
-    def encode_latent(self, audio_data: torch.Tensor) -> torch.Tensor:
-        """audio ``[B, 1, T]`` -> un-quantised 12.5 Hz latent, channels-last ``[B, F, latent_dim]``."""
+    def encode_latent(self, audio_data: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """audio ``[B, 1, T]`` -> un-quantised 12.5 Hz latent, channels-last ``[B, F, latent_dim]``.  ``lengths`` (valid samples
+        per batch entry of a zero-padded ragged batch): every entry's frames equal those of that utterance encoded alone."""
         B, C, T = audio_data.shape
         assert C == 1, "MimiCodec is mono"
         x = audio_data.contiguous().view(B, T, 1)
-        z = self.encoder.forward_nlc(x)
+        if lengths is not None:
+            assert not self.is_streaming, "ragged batches are an offline (non-streaming) facility"
+            lengths = torch.as_tensor(lengths, dtype=torch.int32, device=x.device).contiguous()
+        z = self.encoder.forward_nlc(x, lengths)
         z = self.encoder_transformer.forward_nlc(z)[0]
+        if lengths is not None:
+            hop = self.hop_length
+            z = ops.mask_tail(z.contiguous(), torch.div(lengths + (hop - 1), hop, rounding_mode="floor").to(torch.int32), replicate=True)
         return self.downsample.forward_nlc(z)
 
     @torch.no_grad()
-    def encode(self, audio_data: torch.Tensor) -> torch.Tensor:
-        """``[B, 1, T]`` fp32 -> ``[B, K, ceil(T / 1920)]`` int64 (streaming: floor, remainder kept in the conv states)."""
+    def encode(self, audio_data: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``[B, 1, T]`` fp32 -> ``[B, K, ceil(T / 1920)]`` int64 (streaming: floor, remainder kept in the conv states).
+        ``lengths``: see ``encode_latent`` (frames past ``ceil(lengths[b] / 1920)`` of entry b are meaningless)."""
         state = self._streaming_state
+        if lengths is not None:
+            return self.quantizer.encode_nlc(self.encode_latent(audio_data, lengths))
         if state is None or not audio_data.is_cuda:
             return self.quantizer.encode_nlc(self.encode_latent(audio_data))
         # streaming: after two eager frames every step has the same shapes and buffer addresses -> replay a HIP graph

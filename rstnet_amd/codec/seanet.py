@@ -38,10 +38,13 @@ def _activation(name: str, params: dict) -> nn.Module:
     return ELU(**params)
 
 
-def _run_fused(model: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+def _run_fused(model: nn.Sequential, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Walk a SEANet ``Sequential`` channels-last with three fusions:
     * an ELU whose input has no other consumer is applied ONCE, in the producer's epilogue (``act_out``), instead of on
       every window tap of the consumer's operand load; otherwise it is folded into the consumer's load (``act_in``);
+    * ``lengths`` (int32 ``[B]``, valid rows of ``x`` per batch entry; encoder only): the input of every STRIDED convolution is
+      zeroed past the entry's length first -- the zeros the reference's ``pad_for_conv1d`` appends per utterance (ELU(0) = 0,
+      so it does not matter on which side of the ELU the mask sits) -- and the lengths shrink by ``ceil(. / stride)``;
     * the skip-add of a residual block lives in the epilogue of its 1x1 convolution (or the whole block is one launch);
     * the first (1 -> C) / last (C -> 1) convolution is folded into the neighbouring residual block."""
     layers = list(model)
@@ -74,6 +77,10 @@ def _run_fused(model: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
         # this layer's output feeds only "ELU -> conv": apply that ELU here, once per element
         elu_out = isinstance(nxt, ELU) and isinstance(nxt2, convs)
         if isinstance(layer, convs):
+            stride = layer.conv.conv.stride[0] if isinstance(layer, StreamingConv1d) else 1
+            if lengths is not None and stride > 1:
+                ops.mask_tail(x, lengths)
+                lengths = torch.div(lengths + (stride - 1), stride, rounding_mode="floor").to(torch.int32)
             x = layer.forward_nlc(x, act_in=pending, act_out=ops.ACT_ELU_OUT if elu_out else ops.ACT_NONE)
             pending = ops.ACT_NONE
         elif isinstance(layer, SEANetResnetBlock):
@@ -214,8 +221,8 @@ class SEANetEncoder(StreamingContainer):
                                   causal=causal, pad_mode=pad_mode)]
         self.model = nn.Sequential(*model)
 
-    def forward_nlc(self, x: torch.Tensor) -> torch.Tensor:
-        return _run_fused(self.model, x)
+    def forward_nlc(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return _run_fused(self.model, x, lengths)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return _to_ncl(self.forward_nlc(_to_nlc(x)))

@@ -4,8 +4,9 @@ plus the batched path the reference leaves as a TODO (``egs/pretraining/local/of
 Same surface: ``tokenize(wav, sample_rate)`` (path strings are not supported here: there is no audio-file reader in the
 image), ``tokenize2``, ``find_length``, ``detokenize``; codes leave as int16 on the host exactly like the reference
 (``:72``: "reduce the save space").  ``tokenize_batch`` packs utterances of different lengths into one encode call: the codec
-is causal end to end and pads the tail of the last frame with zeros, so frames of a shorter utterance are unaffected by the
-zero samples that follow it -- the per-utterance codes are bit-identical to single-utterance calls
+is causal end to end, so only an utterance's LAST, partial frame can see what follows it; there the reference pads every strided
+layer's input itself (zeros; replicate in the 25 -> 12.5 Hz down-sampling), which ``MimiCodec.encode(batch, lengths)``
+reproduces with ``rst_mask_tail_f32`` -- the per-utterance codes equal those of single-utterance calls
 (``tests/test_mimi_gpu.py::test_tokenizer_batch_equals_single``).
 """
 from __future__ import annotations
@@ -81,7 +82,8 @@ class MimiTokenizer:
             batch = torch.zeros(j - i, 1, longest)
             for r, idx in enumerate(order[i:j]):
                 batch[r, 0, :flat[idx].numel()] = flat[idx]
-            codes = self.model.encode(batch.to(self.device)).cpu()
+            lens = torch.tensor([flat[idx].numel() for idx in order[i:j]], dtype=torch.int32)
+            codes = self.model.encode(batch.to(self.device), lengths=lens).cpu()
             for r, idx in enumerate(order[i:j]):
                 frames = -(-flat[idx].numel() // FRAME_HOP)
                 out[idx] = codes[r, :, :frames].to(torch.int16).contiguous()

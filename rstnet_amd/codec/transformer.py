@@ -81,6 +81,7 @@ class _MHAState:
     v_cache: torch.Tensor
     offset: torch.Tensor    # int64 [1] on device (kept for API parity / graph capture)
     offset_cpu: int
+    shared: Optional[torch.Tensor] = None   # the enclosing transformer's counter: one increment per step instead of one per layer
 
     def reset(self) -> None:
         self.offset.zero_()
@@ -147,12 +148,14 @@ class StreamingMultiheadAttention(StreamingModule[_MHAState]):
             a = ops.attention(q, k, v, pos0=0, ring=False, context=self.context)
         else:
             # position from the device-side counter (graph-replay safe), mirrored on the host in offset_cpu
-            q, k, v = ops.rope_split(qkv, H, k=state.k_cache, v=state.v_cache, pos0=offset, pos_dev=state.offset, ring=True,
+            pos_dev = state.shared if state.shared is not None else state.offset
+            q, k, v = ops.rope_split(qkv, H, k=state.k_cache, v=state.v_cache, pos0=offset, pos_dev=pos_dev, ring=True,
                                      rope=use_rope, max_period=period)
-            a = ops.attention(q, k, v, pos0=offset, pos_dev=state.offset, ring=True, context=self.context)
+            a = ops.attention(q, k, v, pos0=offset, pos_dev=pos_dev, ring=True, context=self.context)
         out = self._project(self.out_proj.weight, a, offset, res=res, scale=scale)
         if state is not None:
-            state.offset.add_(T)
+            if state.shared is None:
+                state.offset.add_(T)
             state.offset_cpu += T
         return out
 
@@ -245,9 +248,13 @@ class StreamingTransformer(StreamingModule[_TransformerState]):
 
     def forward(self, x: torch.Tensor, *args, **kwargs) -> torch.Tensor:
         T = x.shape[1]
-        for layer in self.layers:
-            x = layer(x, *args, **kwargs)
         state = self._streaming_state
+        for layer in self.layers:
+            att = getattr(layer, "self_attn", None)
+            if att is not None and att._streaming_state is not None:
+                # all layers read this transformer's position counter (same value during a step)
+                att._streaming_state.shared = state.offset if state is not None else None
+            x = layer(x, *args, **kwargs)
         if state is not None:
             state.offset.add_(T)
         return x

@@ -157,6 +157,10 @@ int rst_transpose_f32(const float* x, float* y, int B, int R, int C, rst_stream_
     return rst_launch_transpose(x, y, B, R, C, (hipStream_t)stream);
 }
 
+int rst_mask_tail_f32(float* x, const int32_t* lengths, int B, int T, int C, int mode, rst_stream_t stream) {
+    return rst_launch_mask_tail(x, lengths, B, T, C, mode, (hipStream_t)stream);
+}
+
 int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, int B, int T_in, int P_in, int P_out,
                         int C, rst_stream_t stream) {
     return rst_launch_hist_update(x, hist_in, hist_out, B, T_in, P_in, P_out, C, (hipStream_t)stream);
@@ -166,9 +170,17 @@ int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, i
 int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, const float* bias, float* y,
                       int B, int N, int K, int ldx, int ldy, int prologue, float eps, rst_stream_t stream) {
     GemvParams p;
-    p.x = x; p.alpha = alpha; p.w = w; p.res = res; p.bias = bias; p.y = y; p.B = B; p.N = N; p.K = K; p.ldx = ldx; p.ldy = ldy;
-    p.prologue = prologue; p.eps = eps;
-    return rst_launch_gemv_bf16(p, (hipStream_t)stream);
+    p.x = x; p.alpha = alpha; p.w = w; p.res = res; p.bias = bias; p.scale = nullptr; p.y = y; p.B = B; p.N = N; p.K = K;
+    p.ldx = ldx; p.ldy = ldy; p.prologue = prologue; p.act_out = 0; p.w_f32 = 0; p.eps = eps;
+    return rst_launch_gemv(p, (hipStream_t)stream);
+}
+
+int rst_gemv_f32(const float* x, const float* w, const float* bias, const float* res, const float* scale, float* y, int B, int N,
+                 int K, int act_out, rst_stream_t stream) {
+    GemvParams p;
+    p.x = x; p.alpha = nullptr; p.w = w; p.res = res; p.bias = bias; p.scale = scale; p.y = y; p.B = B; p.N = N; p.K = K;
+    p.ldx = K; p.ldy = N; p.prologue = 0; p.act_out = act_out; p.w_f32 = 1; p.eps = 0.f;
+    return rst_launch_gemv(p, (hipStream_t)stream);
 }
 
 int rst_skinny_pack_weight_bf16(const uint16_t* w, uint16_t* wp, int N, int K, rst_stream_t stream) {

@@ -44,9 +44,40 @@ __device__ __forceinline__ bool ring_visible(int slot, long pos, int cap, int co
     return ok;
 }
 
-// y[b][n] = (res ? res[b][n] : 0) + sum_k xs[b][k] * W[n][k],   xs = prologue(x)
-template <int B, int RPW>
-__global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvParams p) {
+// 8 consecutive k of one weight row: 16 bytes of bf16, or 32 bytes of fp32 (the codec's weights)
+template <bool F32W> struct WChunk;
+template <> struct WChunk<false> {
+    u32x4 v;
+    __device__ __forceinline__ void zero() { v = u32x4{0u, 0u, 0u, 0u}; }
+    __device__ __forceinline__ void load(const void* w, long elem) {
+        v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(static_cast<const unsigned short*>(w) + elem));
+    }
+    __device__ __forceinline__ float dot(const f32x4& x0, const f32x4& x1, float a) const {
+        a = fmaf(bf16_lo(v[0]), x0[0], a); a = fmaf(bf16_hi(v[0]), x0[1], a);
+        a = fmaf(bf16_lo(v[1]), x0[2], a); a = fmaf(bf16_hi(v[1]), x0[3], a);
+        a = fmaf(bf16_lo(v[2]), x1[0], a); a = fmaf(bf16_hi(v[2]), x1[1], a);
+        a = fmaf(bf16_lo(v[3]), x1[2], a); a = fmaf(bf16_hi(v[3]), x1[3], a);
+        return a;
+    }
+};
+template <> struct WChunk<true> {
+    f32x4 a0, a1;
+    __device__ __forceinline__ void zero() { a0 = f32x4{0.f, 0.f, 0.f, 0.f}; a1 = a0; }
+    __device__ __forceinline__ void load(const void* w, long elem) {
+        const float* q = static_cast<const float*>(w) + elem;
+        a0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
+        a1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q + 4));
+    }
+    __device__ __forceinline__ float dot(const f32x4& x0, const f32x4& x1, float a) const {
+        a = fmaf(a0[0], x0[0], a); a = fmaf(a0[1], x0[1], a); a = fmaf(a0[2], x0[2], a); a = fmaf(a0[3], x0[3], a);
+        a = fmaf(a1[0], x1[0], a); a = fmaf(a1[1], x1[1], a); a = fmaf(a1[2], x1[2], a); a = fmaf(a1[3], x1[3], a);
+        return a;
+    }
+};
+
+// y[b][n] = (res ? res[b][n] : 0) + (scale ? scale[n] : 1) * act(bias[n] + sum_k xs[b][k] * W[n][k]),   xs = prologue(x)
+template <int B, int RPW, bool F32W>
+__global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_kernel(const GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) float xs[];   // [B][K]
     __shared__ float red[GEMV_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,14 +86,13 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvPa
     // ---- the first weight chunk of this workgroup's first row group is requested BEFORE the activation prologue: the two
     // dependent load chains (x -> norm -> LDS, and W) then overlap instead of adding up (small GEMVs are latency-bound)
     const int groups = (p.N + RPW * GEMV_WAVES - 1) / (RPW * GEMV_WAVES);
-    u32x4 wpre[RPW];
+    WChunk<F32W> wpre[RPW];
     {
         const int n0 = (blockIdx.x * GEMV_WAVES + wave) * RPW;
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            wpre[r] = u32x4{0u, 0u, 0u, 0u};
-            if (blockIdx.x < groups && lane * 8 < K)
-                wpre[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.w + (long)min(n0 + r, p.N - 1) * K + lane * 8));
+            wpre[r].zero();
+            if (blockIdx.x < groups && lane * 8 < K) wpre[r].load(p.w, (long)min(n0 + r, p.N - 1) * K + lane * 8);
         }
     }
 
@@ -112,23 +142,16 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvPa
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
-        const unsigned short* wrow[RPW];
+        long wrow[RPW];
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) wrow[r] = p.w + (long)min(n0 + r, p.N - 1) * K;
-        auto fma8 = [&](const u32x4 (&wv)[RPW], int k) {
+        for (int r = 0; r < RPW; ++r) wrow[r] = (long)min(n0 + r, p.N - 1) * K;
+        auto fma8 = [&](const WChunk<F32W> (&wv)[RPW], int k) {
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + b * K + k);
                 const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + b * K + k + 4);
 #pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    float a = acc[r][b];
-                    a = fmaf(bf16_lo(wv[r][0]), x0[0], a); a = fmaf(bf16_hi(wv[r][0]), x0[1], a);
-                    a = fmaf(bf16_lo(wv[r][1]), x0[2], a); a = fmaf(bf16_hi(wv[r][1]), x0[3], a);
-                    a = fmaf(bf16_lo(wv[r][2]), x1[0], a); a = fmaf(bf16_hi(wv[r][2]), x1[1], a);
-                    a = fmaf(bf16_lo(wv[r][3]), x1[2], a); a = fmaf(bf16_hi(wv[r][3]), x1[3], a);
-                    acc[r][b] = a;
-                }
+                for (int r = 0; r < RPW; ++r) acc[r][b] = wv[r].dot(x0, x1, acc[r][b]);
             }
         };
         int k = lane * 8;
@@ -137,19 +160,19 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvPa
             k += 512;
         }
         for (; k + 512 < K; k += 1024) {
-            u32x4 wa[RPW], wb[RPW];
+            WChunk<F32W> wa[RPW], wb[RPW];
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                wa[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k));
-                wb[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k + 512));
+                wa[r].load(p.w, wrow[r] + k);
+                wb[r].load(p.w, wrow[r] + k + 512);
             }
             fma8(wa, k);
             fma8(wb, k + 512);
         }
         if (k < K) {
-            u32x4 wa[RPW];
+            WChunk<F32W> wa[RPW];
 #pragma unroll
-            for (int r = 0; r < RPW; ++r) wa[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k));
+            for (int r = 0; r < RPW; ++r) wa[r].load(p.w, wrow[r] + k);
             fma8(wa, k);
         }
 #pragma unroll
@@ -160,7 +183,9 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_bf16_kernel(const GemvPa
                 const int n = n0 + r;
                 if (lane == 0 && n < p.N) {
                     const long o = (long)b * p.ldy + n;
-                    const float sb = p.bias ? s + p.bias[n] : s;
+                    float sb = p.bias ? s + p.bias[n] : s;
+                    if (p.act_out == 1) sb = 0.5f * sb * (1.0f + erff(sb * 0.70710678118654752440f));   // exact GELU (F.gelu)
+                    if (p.scale) sb *= p.scale[n];
                     p.y[o] = p.res ? p.res[o] + sb : sb;
                 }
             }
@@ -839,20 +864,21 @@ inline unsigned cap_grid(long g, long cap) { return (unsigned)(g < 1 ? 1 : (g > 
 
 }  // namespace
 
-int rst_launch_gemv_bf16(const GemvParams& p, hipStream_t stream) {
-    RST_REQUIRE(p.B >= 1 && p.B <= 4 && p.N > 0 && p.K > 0 && p.K % 8 == 0, "gemv_bf16: need 1 <= B <= 4 and K %% 8 == 0 (B=%d K=%d)", p.B, p.K);
-    RST_REQUIRE(p.x && p.w && p.y, "gemv_bf16: null pointer");
-    RST_REQUIRE(p.prologue >= 0 && p.prologue <= 2 && (p.prologue != 1 || p.alpha), "gemv_bf16: bad prologue");
-    RST_REQUIRE(((uintptr_t)p.w % 16) == 0 && ((uintptr_t)p.x % 16) == 0, "gemv_bf16: pointers must be 16-byte aligned");
+int rst_launch_gemv(const GemvParams& p, hipStream_t stream) {
+    RST_REQUIRE(p.B >= 1 && p.B <= 4 && p.N > 0 && p.K > 0 && p.K % 8 == 0, "gemv: need 1 <= B <= 4 and K %% 8 == 0 (B=%d K=%d)", p.B, p.K);
+    RST_REQUIRE(p.x && p.w && p.y, "gemv: null pointer");
+    RST_REQUIRE(p.prologue >= 0 && p.prologue <= 2 && (p.prologue != 1 || p.alpha), "gemv: bad prologue");
+    RST_REQUIRE(p.act_out == 0 || p.act_out == 1, "gemv: act_out must be 0 (none) or 1 (GELU)");
+    RST_REQUIRE(((uintptr_t)p.w % 16) == 0 && ((uintptr_t)p.x % 16) == 0, "gemv: pointers must be 16-byte aligned");
     const size_t lds = (size_t)p.B * p.K * sizeof(float);
-    RST_REQUIRE(lds <= 128 * 1024, "gemv_bf16: B*K = %d floats do not fit the activation stage (32768)", p.B * p.K);
+    RST_REQUIRE(lds <= 128 * 1024, "gemv: B*K = %d floats do not fit the activation stage (32768)", p.B * p.K);
     // rows per wave: 4 when that still yields >= 2 workgroups per CU, else 2 (more workgroups -> more loads in flight)
-    const bool rpw4 = ((long)p.N + 15) / 16 >= 512;
+    const bool rpw4 = !p.w_f32 && ((long)p.N + 15) / 16 >= 512;
     const int rows_per_group = (rpw4 ? 4 : 2) * GEMV_WAVES;
     const long groups = ((long)p.N + rows_per_group - 1) / rows_per_group;
     const unsigned grid = cap_grid(groups, lds > 48 * 1024 ? 512 : 768);
     auto go = [&](auto kern) {
-        static bool attr_set = false;
+        static bool attr_set = false;     // one flag per kernel instantiation (generic lambda)
         if (!attr_set) {
             // static LDS (the 16-byte reduction scratch) counts against the 160 KiB budget: ask for what the check above allows
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -861,15 +887,24 @@ int rst_launch_gemv_bf16(const GemvParams& p, hipStream_t stream) {
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GEMV_WAVES), lds, stream, p);
     };
+    if (p.w_f32) {
+        switch (p.B) {
+            case 1: go(gemv_kernel<1, 2, true>); break;
+            case 2: go(gemv_kernel<2, 2, true>); break;
+            case 3: go(gemv_kernel<3, 2, true>); break;
+            default: go(gemv_kernel<4, 2, true>); break;
+        }
+        return rst_check_launch("gemv_f32");
+    }
     switch (p.B * 2 + (rpw4 ? 1 : 0)) {
-        case 2: go(gemv_bf16_kernel<1, 2>); break;
-        case 3: go(gemv_bf16_kernel<1, 4>); break;
-        case 4: go(gemv_bf16_kernel<2, 2>); break;
-        case 5: go(gemv_bf16_kernel<2, 4>); break;
-        case 6: go(gemv_bf16_kernel<3, 2>); break;
-        case 7: go(gemv_bf16_kernel<3, 4>); break;
-        case 8: go(gemv_bf16_kernel<4, 2>); break;
-        default: go(gemv_bf16_kernel<4, 4>); break;
+        case 2: go(gemv_kernel<1, 2, false>); break;
+        case 3: go(gemv_kernel<1, 4, false>); break;
+        case 4: go(gemv_kernel<2, 2, false>); break;
+        case 5: go(gemv_kernel<2, 4, false>); break;
+        case 6: go(gemv_kernel<3, 2, false>); break;
+        case 7: go(gemv_kernel<3, 4, false>); break;
+        case 8: go(gemv_kernel<4, 2, false>); break;
+        default: go(gemv_kernel<4, 4, false>); break;
     }
     return rst_check_launch("gemv_bf16");
 }

@@ -118,6 +118,46 @@ __global__ __launch_bounds__(256) void hist_update_kernel(const float* __restric
     }
 }
 
+// In-place form (hout == hin, P_in == P_out): one workgroup per batch row reads every element of the new history into
+// registers, then -- after a barrier -- writes them; rows are disjoint buffers, so no other hazard exists.
+constexpr int HIST_INPLACE_MAX = 16;   // elements per thread at 1024 threads -> P * C <= 16384
+__global__ __launch_bounds__(1024) void hist_update_inplace_kernel(const float* __restrict__ x, float* h, int T_in, int P, int C) {
+    const long b = blockIdx.x;
+    const int E = P * C;
+    float v[HIST_INPLACE_MAX];
+#pragma unroll
+    for (int j = 0; j < HIST_INPLACE_MAX; ++j) {
+        const int e = threadIdx.x + j * 1024;
+        v[j] = 0.f;
+        if (e < E) {
+            const int c = e % C, pr = e / C;
+            const int src = pr + T_in - P;
+            v[j] = src >= 0 ? x[(b * T_in + src) * C + c] : h[(b * P + (P + src)) * C + c];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < HIST_INPLACE_MAX; ++j) {
+        const int e = threadIdx.x + j * 1024;
+        if (e < E) h[b * (long)E + e] = v[j];
+    }
+}
+
+// Rows t >= len[b] of x [B][T][C] become zero (mode 0) or a copy of row len[b] - 1 (mode 1).
+__global__ __launch_bounds__(256) void mask_tail_kernel(float* __restrict__ x, const int* __restrict__ len, int B, int T, int C, int mode) {
+    const long total = (long)B * T * (C / 4);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c4 = (int)(idx % (C / 4)) * 4;
+        const int t = (int)((idx / (C / 4)) % T);
+        const long b = idx / ((long)(C / 4) * T);
+        const int L = len[b];
+        if (t < L) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (mode == 1 && L > 0) v = *reinterpret_cast<const f32x4*>(x + (b * T + L - 1) * C + c4);
+        *reinterpret_cast<f32x4*>(x + (b * T + t) * C + c4) = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
         y[i] = act == 1 ? rst_elu(x[i]) : (act == 2 ? rst_gelu(x[i]) : x[i]);
@@ -167,10 +207,25 @@ int rst_launch_hist_update(const float* x, const float* hist_in, float* hist_out
                 "hist_update: bad sizes (T_in=%d P_in=%d P_out=%d)", T_in, P_in, P_out);
     const long total = (long)B * P_out * C;
     if (total == 0) return RST_OK;
-    RST_REQUIRE(hist_out && hist_in != hist_out && (x || T_in == 0) && (hist_in || P_in == 0), "hist_update: null / aliased pointer");
+    RST_REQUIRE(hist_out && (x || T_in == 0) && (hist_in || P_in == 0), "hist_update: null pointer");
+    if (hist_out == hist_in) {
+        RST_REQUIRE(P_in == P_out && (long)P_out * C <= 1024L * HIST_INPLACE_MAX,
+                    "hist_update: in-place update needs P_in == P_out and P * C <= %d (P=%d C=%d)", 1024 * HIST_INPLACE_MAX, P_out, C);
+        hipLaunchKernelGGL(hist_update_inplace_kernel, dim3(B), dim3(1024), 0, stream, x, hist_out, T_in, P_out, C);
+        return rst_check_launch("hist_update_inplace");
+    }
     hipLaunchKernelGGL(hist_update_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, hist_in, hist_out, B, T_in, P_in,
                        P_out, C);
     return rst_check_launch("hist_update");
+}
+
+int rst_launch_mask_tail(float* x, const int* lengths, int B, int T, int C, int mode, hipStream_t stream) {
+    RST_REQUIRE(B >= 0 && T >= 0 && C > 0 && C % 4 == 0 && (mode == 0 || mode == 1), "mask_tail: bad arguments (C %% 4 == 0 required, C=%d)", C);
+    const long total = (long)B * T * (C / 4);
+    if (total == 0) return RST_OK;
+    RST_REQUIRE(x && lengths, "mask_tail: null pointer");
+    hipLaunchKernelGGL(mask_tail_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, lengths, B, T, C, mode);
+    return rst_check_launch("mask_tail");
 }
 
 int rst_launch_act(const float* x, float* y, long n, int act, hipStream_t stream) {

@@ -59,6 +59,7 @@ int rst_launch_hist_update(const float* x, const float* hist_in, float* hist_out
                            int C, hipStream_t stream);
 
 int rst_launch_act(const float* x, float* y, long n, int act, hipStream_t stream);  // 1: ELU, 2: GELU
+int rst_launch_mask_tail(float* x, const int* lengths, int B, int T, int C, int mode, hipStream_t stream);
 
 // ---- attention.hip ----------------------------------------------------------------------------
 struct RopeSplitParams {
@@ -120,15 +121,18 @@ int rst_launch_rvq_gather(const RvqGatherParams& p, hipStream_t stream);
 struct GemvParams {
     const float* x;             // [B][ldx] fp32 activations (prologue 2: [B][2K] = [u ; v])
     const float* alpha;         // prologue 1: RMSNorm gain [K]
-    const unsigned short* w;    // [N][K] bf16
+    const void* w;              // [N][K] bf16 (w_f32 == 0) or fp32 (w_f32 == 1)
     const float* res;           // optional [B][ldy]
     const float* bias;          // optional [N]
+    const float* scale;         // optional [N]: LayerScale applied before the residual
     float* y;                   // [B][ldy]
     int B, N, K, ldx, ldy;
     int prologue;               // 0 none, 1 RMSNorm, 2 SiLU gate
+    int act_out;                // 0 none, 1 exact GELU (after the bias)
+    int w_f32;
     float eps;
 };
-int rst_launch_gemv_bf16(const GemvParams& p, hipStream_t stream);
+int rst_launch_gemv(const GemvParams& p, hipStream_t stream);
 
 #define RST_MAX_TABLES 24
 struct EmbedSumParams {

@@ -110,6 +110,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     assert w.shape[1] == K
     M = x.numel() // K if K else 0
     out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    if 1 <= M <= 4 and K % 8 == 0 and K * M <= 32768 and act_out in (ACT_NONE, ACT_GELU):
+        # a streaming step of one or two positions: weight-streaming GEMV (every CU pulls rows of w; no split-K hand-off)
+        _lib.check(_lib.lib().rst_gemv_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, N, K, act_out, _stream()))
+        return out
     split_k, ws, cnt = _gemm_split_scratch(x.device, M, N, K)
     prof = PROFILE
     if prof is not None:
@@ -322,12 +326,26 @@ def transpose12(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def mask_tail(x: torch.Tensor, lengths: torch.Tensor, replicate: bool = False) -> torch.Tensor:
+    """In place: rows ``t >= lengths[b]`` of ``x [B,T,C]`` become zeros (or copies of the last valid row)."""
+    _chk(x, "x")
+    _chk(lengths, "lengths", torch.int32)
+    B, T, Cc = x.shape
+    _lib.check(_lib.lib().rst_mask_tail_f32(_ptr(x), _ptr(lengths), B, T, Cc, int(replicate), _stream()))
+    return x
+
+
 def hist_update(x: torch.Tensor, hist_in: Optional[torch.Tensor], P_out: int) -> torch.Tensor:
-    """Last ``P_out`` steps of concat(hist_in, x) along time; x ``[B,T,C]``, hist ``[B,P,C]``."""
+    """Last ``P_out`` steps of concat(hist_in, x) along time; x ``[B,T,C]``, hist ``[B,P,C]``.  In steady state (same history
+    length, at most 16384 elements per stream) the roll happens IN PLACE and ``hist_in`` itself is returned: the state keeps
+    its address, which is what lets a whole codec step be replayed as a HIP graph."""
     _chk(x, "x")
     _chk(hist_in, "hist_in")
     B, T, Cc = x.shape
     P_in = hist_in.shape[1] if hist_in is not None else 0
+    if hist_in is not None and P_in == P_out and P_out * Cc <= 16384 and P_out > 0:
+        _lib.check(_lib.lib().rst_hist_update_f32(_ptr(x), _ptr(hist_in), _ptr(hist_in), B, T, P_in, P_out, Cc, _stream()))
+        return hist_in
     out = torch.empty(B, P_out, Cc, device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().rst_hist_update_f32(_ptr(x), _ptr(hist_in), _ptr(out), B, T, P_in, P_out, Cc, _stream()))
     return out
