@@ -147,22 +147,28 @@ __global__ __launch_bounds__(256) void rvq_level_kernel(const RvqSearchParams p,
     if (step >= p.group_count[g]) return;
     const int lvl = p.group_begin[g] + step;
     const int m0 = blockIdx.z * FR;
-    // residual of this level: ((x - e_0[c_0]) - e_1[c_1]) - ...   in level order, exactly as the fused kernel does
+    // residual of this level: ((x - e_0[c_0]) - e_1[c_1]) - ...   in level order, exactly as the fused kernel does.  The
+    // winners of ALL previous levels are fetched first (one barrier), then every element gathers its `step` codeword entries
+    // with independent loads and subtracts them in order -- one memory round trip instead of one per level.
+    constexpr int MAX_PREV = 16;
+    for (int idx = tid; idx < step * FR; idx += 256) {
+        const int sidx = idx / FR, f = idx - sidx * FR;
+        const int lv = p.group_begin[g] + sidx;
+        prev[idx] = (m0 + f < p.M) ? (int)(keys[(long)lv * p.M + m0 + f] & 0xffffffffu) : 0;
+    }
+    __syncthreads();
     for (int idx = tid; idx < FR * D; idx += 256) {
         const int f = idx / D, k = idx - f * D;
         const int m = m0 + f;
-        r_pk[f * LD + pk_off(k)] = m < p.M ? p.x[(long)m * p.ldx + g * D + k] : 0.f;
-    }
-    for (int s = 0; s < step; ++s) {
-        const int lv = p.group_begin[g] + s;
-        __syncthreads();
-        if (tid < FR) prev[tid] = (m0 + tid < p.M) ? (int)(keys[(long)lv * p.M + m0 + tid] & 0xffffffffu) : 0;
-        __syncthreads();
-        const float* emb = p.emb + (long)lv * p.n_codes * D;
-        for (int idx = tid; idx < FR * D; idx += 256) {
-            const int f = idx / D, k = idx - f * D;
-            r_pk[f * LD + pk_off(k)] -= emb[(long)prev[f] * D + k];
-        }
+        float r = m < p.M ? p.x[(long)m * p.ldx + g * D + k] : 0.f;
+        float e[MAX_PREV];
+#pragma unroll
+        for (int sidx = 0; sidx < MAX_PREV; ++sidx)
+            e[sidx] = sidx < step ? p.emb[((long)(p.group_begin[g] + sidx) * p.n_codes + prev[sidx * FR + f]) * D + k] : 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < MAX_PREV; ++sidx)
+            if (sidx < step) r -= e[sidx];
+        r_pk[f * LD + pk_off(k)] = r;
     }
     __syncthreads();
     const int c0 = (blockIdx.x * 4 + wave) * 32;
@@ -173,11 +179,22 @@ __global__ __launch_bounds__(256) void rvq_level_kernel(const RvqSearchParams p,
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const float* ap = packed + (long)(c0 + j) * 8 + h * 4;
     const float* rrow = r_pk + j * LD + h * 4;
-    for (int kq = 0; kq < D / 8; ++kq) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + (long)kq * p.n_codes * 8);
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(rrow + kq * 8);
+    // codebook operands: 8 loads in flight per lane (the plain loop waited out one memory latency per 16 bytes); the MFMA
+    // chain still consumes k in ascending order, so the scores stay bit-identical to the fused kernel / rvq_ref.c
+    constexpr int UN = 8;
+    for (int kq0 = 0; kq0 < D / 8; kq0 += UN) {
+        f32x4 a[UN];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bq[e], acc, 0, 0, 0);
+        for (int u = 0; u < UN; ++u)
+            a[u] = kq0 + u < D / 8 ? *reinterpret_cast<const f32x4*>(ap + (long)(kq0 + u) * p.n_codes * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (kq0 + u < D / 8) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(rrow + (kq0 + u) * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], bq[e], acc, 0, 0, 0);
+            }
+        }
     }
     float best = INFINITY;
     int bidx = 0x7fffffff;
@@ -270,10 +287,11 @@ int rst_launch_rvq_search_small(const RvqSearchParams& p, unsigned long long* ke
     RST_REQUIRE(p.F > 0 && p.D > 0 && p.D % 8 == 0 && p.n_codes > 0 && p.n_codes % 32 == 0 && p.M % p.F == 0 &&
                     p.n_groups >= 1 && p.n_groups <= 2,
                 "rvq_search_small: need D %% 8 == 0 and n_codes %% 32 == 0 (D=%d n_codes=%d)", p.D, p.n_codes);
-    const size_t lds = ((size_t)FR * (p.D + 4) + FR) * sizeof(float);
+    const size_t lds = ((size_t)FR * (p.D + 4) + 16 * FR) * sizeof(float);
     int steps = 0;
     for (int g = 0; g < p.n_groups; ++g) steps = p.group_count[g] > steps ? p.group_count[g] : steps;
     const dim3 grid((p.n_codes + 127) / 128, p.n_groups, (p.M + FR - 1) / FR);
+    RST_REQUIRE(steps <= 16, "rvq_search_small: at most 16 levels per group (got %d)", steps);
     for (int s = 0; s < steps; ++s) {
         hipLaunchKernelGGL(rvq_level_kernel, grid, dim3(256), lds, stream, p, keys, s);
         const int rc = rst_check_launch("rvq_level");
