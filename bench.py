@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--lm-config", choices=["moshi7b", "tiny"], default="moshi7b")
     ap.add_argument("--lm-batch", type=int, default=None, help="lm / e2e / gpt: concurrent streams per GPU (<= 64; default 1, gpt 32)")
     ap.add_argument("--greedy", action="store_true", help="lm: greedy decoding instead of temperature / top-k sampling")
+    ap.add_argument("--fp8", action="store_true", help="gpt: fp8 (e4m3, per-row scales) matrix-core path for the global blocks")
     ap.add_argument("--lm-context", type=int, default=0, help="lm: start the timed frames at this ring offset (e.g. 3000 = every "
                     "temporal attention reads the full 3000-slot KV ring; the ring content is zeros, the bytes are the same)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -245,7 +246,7 @@ def bench_gpt(args, rank, world, dev):
     cfg_d = dict(synth.GPT_QWEN_0_5B if args.lm_config != "tiny" else synth.GPT_TINY_GQA)
     B = args.lm_batch
     sd = synth.gpt_state_dict(cfg_d, seed=0, device=str(dev))
-    model = GPT.from_state_dict(sd, Config.from_dict(cfg_d))
+    model = GPT.from_state_dict(sd, Config.from_dict(cfg_d)).use_fp8(args.fp8)
     del sd
     n_params = sum(v.numel() for v in model.state_dict().values())
     n_codes = cfg_d["audio_card"] - 2
@@ -296,7 +297,7 @@ def bench_gpt(args, rank, world, dev):
     ops.PROFILE = None
     gen2.end()
     os.environ["NO_CUDA_GRAPH"] = "0"
-    gemm = [r for r in recs if r[0] in ("gemv_bf16", "gemm_skinny")]
+    gemm = [r for r in recs if r[0] in ("gemv_bf16", "gemm_skinny", "gemm_skinny_fp8")]
     ms = sum(r[1].elapsed_time(r[2]) for r in gemm)
     nbytes = sum(r[4] for r in gemm)
     if args.layers:
@@ -315,7 +316,8 @@ def bench_gpt(args, rank, world, dev):
         "config": {"workload": "GPT (Qwen-1.5-0.5B-shaped litgpt backbone, LoRA r=32 merged) + codecformer: streamed frame = global "
                                "step + text sample + 8 depth steps with sampling, BASELINE.json configs[4]",
                    "batch_per_gpu": B, "params": n_params, "sampling": "greedy" if args.greedy else "temp 0.8/0.7 top-k 250/25",
-                   "hip_graphs": True, "gemm_precision": "bf16 (fp8 weight path not built yet, see DESIGN.md)",
+                   "hip_graphs": True,
+                   "gemm_precision": "fp8 e4m3 (per-row scales) in the global blocks, bf16 hi+lo elsewhere" if args.fp8 else "bf16 hi+lo",
                    "parallelism": f"replica x{world}"},
         "x_realtime_per_stream": round(args.steps / elapsed / 12.5, 2),
         "roofline": {"bound": "hbm", "kernel": ("gemv_bf16_kernel" if B <= 4 else "gemm_skinny_kernel") + " (bf16 weight streaming)",

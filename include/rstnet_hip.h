@@ -189,6 +189,18 @@ int rst_skinny_pack_act_f32(const float* x, const float* alpha, uint16_t* xp, in
 int rst_gemm_skinny_bf16_f32(const uint16_t* xp, const uint16_t* wp, const float* res, const float* bias, float* y, int B, int N,
                              int K, int ldy, rst_stream_t stream);
 
+/* Opt-in fp8 form of the three entry points above (BASELINE.json configs[4]: fp8 MFMA GEMMs on the temporal blocks at batch
+ * 32): OCP e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8, weights with one scale per row (amax / 448, quantised once),
+ * activations with one dynamic scale per batch row (quantised by the prologue launch), y = scale_x[b] * scale_w[n] * acc.
+ * Layout [tile of 32 rows][K/32][64 lanes][16 B = two 8-k steps]; wp N32*K bytes, wscale N32 floats, xp B32*K bytes, xscale
+ * B32 floats (N32 / B32 = rounded up to 32).  K % 32 == 0, K <= 16384.  Half the streamed bytes of the bf16 path at fp8
+ * accuracy (~1e-2 relative on logits): never selected implicitly. */
+int rst_skinny_pack_weight_fp8(const uint16_t* w, uint8_t* wp, float* wscale, int N, int K, rst_stream_t stream);
+int rst_skinny_pack_act_fp8(const float* x, const float* alpha, uint8_t* xp, float* xscale, int B, int K, int ldx, int mode, float eps,
+                            rst_stream_t stream);
+int rst_gemm_skinny_fp8_f32(const uint8_t* xp, const float* xscale, const uint8_t* wp, const float* wscale, const float* res,
+                            const float* bias, float* y, int B, int N, int K, int ldy, rst_stream_t stream);
+
 /* out[b] = (add ? add[b] : 0) + sum_i table_i[tokens[b][tok_index[i]]]: the ScaledEmbedding sums of
  * LMModel.forward_text / forward_depformer (models/model.py:67-91, 372-380, 413-419): id -1 -> zero row, ids clamped
  * at 0, tables bf16 [rows][D], summed in table order in fp32.  `tables` / `tok_index` are HOST arrays (n_tables <= 24). */

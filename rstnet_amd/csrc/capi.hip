@@ -199,6 +199,22 @@ int rst_gemm_skinny_bf16_f32(const uint16_t* xp, const uint16_t* wp, const float
     return rst_launch_gemm_skinny(p, (hipStream_t)stream);
 }
 
+int rst_skinny_pack_weight_fp8(const uint16_t* w, uint8_t* wp, float* wscale, int N, int K, rst_stream_t stream) {
+    return rst_launch_skinny_pack_weight_fp8(w, wp, wscale, N, K, (hipStream_t)stream);
+}
+
+int rst_skinny_pack_act_fp8(const float* x, const float* alpha, uint8_t* xp, float* xscale, int B, int K, int ldx, int mode, float eps,
+                            rst_stream_t stream) {
+    return rst_launch_skinny_pack_act_fp8(x, alpha, xp, xscale, B, K, ldx, mode, eps, (hipStream_t)stream);
+}
+
+int rst_gemm_skinny_fp8_f32(const uint8_t* xp, const float* xscale, const uint8_t* wp, const float* wscale, const float* res,
+                            const float* bias, float* y, int B, int N, int K, int ldy, rst_stream_t stream) {
+    SkinnyFp8Params p;
+    p.xp = xp; p.xscale = xscale; p.wp = wp; p.wscale = wscale; p.res = res; p.bias = bias; p.y = y; p.B = B; p.N = N; p.K = K; p.ldy = ldy;
+    return rst_launch_gemm_skinny_fp8(p, (hipStream_t)stream);
+}
+
 int rst_embed_sum_bf16(const int64_t* tokens, const uint16_t* const* tables, const int* tok_index, int n_tables,
                        const float* add, float* out, int B, int D, int tok_stride, rst_stream_t stream) {
     RST_REQUIRE(n_tables >= 0 && n_tables <= RST_MAX_TABLES && (n_tables == 0 || (tables && tok_index)), "embed_sum: bad tables");

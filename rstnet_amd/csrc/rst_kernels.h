@@ -194,6 +194,20 @@ struct SkinnyParams {
     int B, N, K, ldy;
 };
 int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream);
+struct SkinnyFp8Params {
+    const unsigned char* xp;    // packed fp8 activations [ceil(B/32)][K/32][64][16]
+    const float* xscale;        // [ceil(B/32)*32] per-row scales of the activations
+    const unsigned char* wp;    // packed fp8 weights [ceil(N/32)][K/32][64][16]
+    const float* wscale;        // [ceil(N/32)*32] per-row scales of the weights
+    const float* res;           // optional [B][ldy]
+    const float* bias;          // optional [N]
+    float* y;                   // [B][ldy]
+    int B, N, K, ldy;
+};
+int rst_launch_gemm_skinny_fp8(const SkinnyFp8Params& p, hipStream_t stream);
+int rst_launch_skinny_pack_weight_fp8(const unsigned short* w, unsigned char* wp, float* scale, int N, int K, hipStream_t stream);
+int rst_launch_skinny_pack_act_fp8(const float* x, const float* alpha, unsigned char* xp, float* xscale, int B, int K, int ldx, int mode,
+                                   float eps, hipStream_t stream);
 int rst_launch_skinny_pack_weight(const unsigned short* w, unsigned short* wp, int N, int K, hipStream_t stream);
 int rst_launch_skinny_pack_act(const float* x, const float* alpha, unsigned short* xp, int B, int K, int ldx, int mode, float eps,
                                hipStream_t stream);

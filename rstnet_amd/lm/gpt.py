@@ -349,6 +349,7 @@ class LLAMAStreamingTransformer(StreamingModule[_StepState]):
         self.wte = _Weight(config.padded_vocab_size, config.n_embd, **fk)
         self.h = nn.ModuleList([Block(config, **fk) for _ in range(config.n_layer)])
         self.ln_f = _LitNorm(config.n_embd, config.norm_eps, **fk)
+        self.fp8 = False      # opt-in: run the block linears on the fp8 (e4m3, per-row scales) matrix-core path
 
     def _make_state(self, batch_size: int, capacity: int) -> _StepState:
         c = self.config
@@ -371,9 +372,11 @@ class LLAMAStreamingTransformer(StreamingModule[_StepState]):
         """x fp32 ``[B*T, n_embd]`` (T new positions per stream) -> final-normed hidden ``[B*T, n_embd]``."""
         c = self.config
         H, G, hs, n = c.n_head, c.n_query_groups, c.head_size, c.rope_n_elem
+        f8 = self.fp8
         for l, blk in enumerate(self.h):
             wqkv, bqkv = blk.attn.packed_qkv()
-            qkv = ops.lm_linear(x, wqkv, prologue=ops.PROLOGUE_RMSNORM, alpha=blk.norm_1.gain_f32(), eps=blk.norm_1.eps, bias=bqkv)
+            qkv = ops.lm_linear(x, wqkv, prologue=ops.PROLOGUE_RMSNORM, alpha=blk.norm_1.gain_f32(), eps=blk.norm_1.eps, bias=bqkv,
+                                fp8=f8)
             if T == 1:
                 a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], st.pos, rope=True, context=c.context, max_period=float(c.rope_base),
                                        scratch=st.scratch, heads=H, rope_dims=n)
@@ -381,10 +384,10 @@ class LLAMAStreamingTransformer(StreamingModule[_StepState]):
                 q = ops.lm_rope_append(qkv.view(B, T, -1), st.k[l], st.v[l], st.pos, heads=H, rope=True,
                                        max_period=float(c.rope_base), rope_dims=n)
                 a = ops.attention(q, st.k[l], st.v[l], pos_dev=st.pos, ring=True, context=c.context).view(B * T, H * hs)
-            x = ops.lm_linear(a, blk.attn.proj.weight, res=x, bias=blk.attn.proj.bias_f32())
+            x = ops.lm_linear(a, blk.attn.proj.weight, res=x, bias=blk.attn.proj.bias_f32(), fp8=f8)
             wfc, bfc = blk.mlp.packed_fc()
-            u = ops.lm_linear(x, wfc, prologue=ops.PROLOGUE_RMSNORM, alpha=blk.norm_2.gain_f32(), eps=blk.norm_2.eps, bias=bfc)
-            x = ops.lm_linear(u, blk.mlp.proj.weight, prologue=ops.PROLOGUE_SILU_GATE, res=x, bias=blk.mlp.proj.bias_f32())
+            u = ops.lm_linear(x, wfc, prologue=ops.PROLOGUE_RMSNORM, alpha=blk.norm_2.gain_f32(), eps=blk.norm_2.eps, bias=bfc, fp8=f8)
+            x = ops.lm_linear(u, blk.mlp.proj.weight, prologue=ops.PROLOGUE_SILU_GATE, res=x, bias=blk.mlp.proj.bias_f32(), fp8=f8)
         st.pos.add_(T)
         st.offset_cpu += T
         return ops.rmsnorm(x, self.ln_f.gain_f32(), self.ln_f.eps)
@@ -422,6 +425,12 @@ class GPT(StreamingModule[_GPTState]):
         self.codecformer.set_streaming_propagate(False)
         self.audio_linears = nn.ModuleList([_PlainLinear(config.audio_card, config.codecformer_dim, config.codecformer_bias_proj, **fk)
                                             for _ in range(config.dep_q)])
+
+    def use_fp8(self, enabled: bool = True) -> "GPT":
+        """Opt into the fp8 matrix-core path for the linears of the global transformer blocks (BASELINE.json configs[4]);
+        weights are quantised lazily (e4m3, one scale per row), activations per step (one scale per batch row)."""
+        self.transformer.fp8 = bool(enabled)
+        return self
 
     # ---- token-id conventions (llama_streaming.py:591-649)
     @property

@@ -437,10 +437,59 @@ def gemm_skinny(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NO
     return out
 
 
+_skinny_weights_fp8: dict = {}
+
+
+def skinny_pack_weight_fp8(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """bf16 ``[N, K]`` -> (fp8 e4m3 copy in MFMA order ``[ceil(N/32)*32, K]`` uint8, per-row scales fp32), cached per weight."""
+    _chk(w, "w", torch.bfloat16)
+    N, K = w.shape
+    key = (w.device, w.data_ptr(), N, K)
+    hit = _skinny_weights_fp8.get(key)
+    if hit is not None and hit[2] == w._version:
+        return hit[0], hit[1]
+    n32 = (N + 31) // 32 * 32
+    wp = torch.empty(n32, K, device=w.device, dtype=torch.uint8)
+    sc = torch.empty(n32, device=w.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_skinny_pack_weight_fp8(_ptr(w), _ptr(wp), _ptr(sc), N, K, _stream()))
+    _skinny_weights_fp8[key] = (wp, sc, w._version, w)
+    return wp, sc
+
+
+def gemm_skinny_fp8(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
+                    eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The fp8 (e4m3, per-row scales) form of ``gemm_skinny``: ``y = (res +) (bias +) Q(P(x)) @ Q(w).T`` for 1 <= B <= 64."""
+    _chk(x, "x")
+    _chk(alpha, "alpha")
+    _chk(res, "res")
+    _chk(bias, "bias")
+    B = x.shape[0]
+    N, K = w.shape
+    assert x.shape[1] == (2 * K if prologue == PROLOGUE_SILU_GATE else K)
+    wp, wsc = skinny_pack_weight_fp8(w)
+    b32 = (B + 31) // 32 * 32
+    xp = torch.empty(b32, K, device=x.device, dtype=torch.uint8)
+    xsc = torch.empty(b32, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_skinny_pack_act_fp8(_ptr(x), _ptr(alpha), _ptr(xp), _ptr(xsc), B, K, x.shape[1], prologue, eps, _stream()))
+    out = torch.empty(B, N, device=x.device, dtype=torch.float32)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.lib().rst_gemm_skinny_fp8_f32(_ptr(xp), _ptr(xsc), _ptr(wp), _ptr(wsc), _ptr(res), _ptr(bias), _ptr(out), B, N, K, N,
+                                                 _stream()))
+    if prof is not None:
+        e1.record()
+        prof.append(("gemm_skinny_fp8", e0, e1, 2.0 * B * N * K, N * K + 4 * (x.numel() + out.numel()), (B, N, K)))
+    return out
+
+
 def lm_linear(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
-              eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+              eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, fp8: bool = False) -> torch.Tensor:
     """Batch-size dispatch of one decode-step linear: weight-streaming GEMV for B <= 4, bf16-MFMA skinny GEMM above (the
-    prologue then runs inside the activation-packing launch)."""
+    prologue then runs inside the activation-packing launch).  ``fp8``: the opt-in e4m3 path (any batch <= 64)."""
+    if fp8 and x.shape[0] <= 64 and w.shape[1] % 32 == 0 and w.shape[1] <= 16384:
+        return gemm_skinny_fp8(x, w, prologue=prologue, alpha=alpha, eps=eps, res=res, bias=bias)
     if x.shape[0] <= 4:
         return gemv_bf16(x, w, prologue=prologue, alpha=alpha, eps=eps, res=res, bias=bias)
     if x.shape[0] <= 64:

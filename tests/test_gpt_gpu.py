@@ -242,3 +242,22 @@ def test_sampler_id_blanking():
         lim_dev = torch.tensor([limit], dtype=torch.int32, device=DEV)
         got = ops.lm_sample(logits.to(DEV), use_sampling=True, temp=0.8, top_k=k, noise=noise.to(DEV), limit_dev=lim_dev)
         assert torch.equal(got.cpu(), ref), limit
+
+
+@pytest.mark.parametrize("name", ["gqa", "mha"])
+def test_fp8_blocks_stay_close_to_the_oracle(name):
+    """Opt-in fp8 (e4m3) linears in the global blocks: streamed logits stay within fp8 accuracy of the fp32 oracle and the
+    greedy text token agrees on most steps (tiny random model: logits are far apart)."""
+    model, ocfg, osd, cfg_d = build(name)
+    model.use_fp8(True)
+    B = 6
+    toks = cases.gpt_tokens(cfg_d, steps=5, batch=B)
+    st = Gp.new_global_state(ocfg, B)
+    agree = 0
+    with model.streaming(B), torch.no_grad():
+        for t in range(5):
+            h, lg = model.forward_global(toks[:, :, t:t + 1].to(DEV))
+            h_o, lg_o = Gp.forward_global(osd, ocfg, toks[:, :, t:t + 1], st, merged=True)
+            assert rel_err(lg, lg_o) < 0.15, t
+            agree += int((lg.argmax(-1).cpu() == lg_o.argmax(-1)).sum())
+    assert agree >= 0.8 * 5 * B

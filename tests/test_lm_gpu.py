@@ -163,6 +163,35 @@ def test_sampling_plateaus_take_lowest_indices(V, k):
     assert torch.equal(ops.lm_sample(logits.to(DEV), use_sampling=False, temp=0.8, top_k=k).cpu(), logits.argmax(-1))
 
 
+@pytest.mark.parametrize("B,N,K,prologue", [(32, 4096, 4096, 0), (5, 1000, 1024, 1), (17, 96, 2816, 2), (64, 2048, 1024, 0), (1, 64, 32, 0)])
+def test_gemm_skinny_fp8_matches_emulation(B, N, K, prologue):
+    """fp8 e4m3 path: bit-level agreement of the quantisers with torch.float8_e4m3fn (per-row amax / 448 scales) and of the
+    product with the fp32 product of the SAME quantised operands; and a sanity bound against the unquantised product."""
+    g = torch.Generator().manual_seed(B + N + K)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    x = torch.randn(B, 2 * K if prologue == 2 else K, generator=g)
+    alpha = 1 + 0.1 * torch.randn(K, generator=g)
+    res = torch.randn(B, N, generator=g)
+    if prologue == 0:
+        px = x
+    elif prologue == 1:
+        px = L.rms_norm(x, alpha)
+    else:
+        px = F.silu(x[:, :K]) * x[:, K:]
+
+    def q(t):
+        sc = t.abs().amax(dim=1, keepdim=True).clamp_min(1e-30) / 448.0
+        return (t / sc).to(torch.float8_e4m3fn).float() * sc
+    ref_q = q(px).double() @ q(w.float()).double().t() + res.double()
+    y = ops.gemm_skinny_fp8(x.to(DEV), w.to(DEV), prologue=prologue, alpha=alpha.to(DEV) if prologue == 1 else None, eps=1e-8,
+                            res=res.to(DEV))
+    assert rel_err(y, ref_q) < 2e-3
+    exact = px.double() @ w.double().t() + res.double()
+    assert rel_err(y, exact) < 0.1
+    assert torch.equal(y, ops.gemm_skinny_fp8(x.to(DEV), w.to(DEV), prologue=prologue, alpha=alpha.to(DEV) if prologue == 1 else None,
+                                              eps=1e-8, res=res.to(DEV)))
+
+
 def _tiny():
     cfg = dict(synth.LM_TINY)
     sd = synth.lm_state_dict(cfg, cases.LM_SEED)
