@@ -69,6 +69,9 @@ def lib() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C rstnet_amd/csrc`).  rstnet_amd has no CPU / PyTorch fallback.")
+    # torch first: it ships its own libamdhip64 and owns the device memory / streams this library is handed.  Loading the
+    # system HIP runtime before it would put two runtimes in the process (the second one finds "no ROCm-capable device").
+    import torch  # noqa: F401
     handle = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(handle, name)  # AttributeError if the symbol is missing
