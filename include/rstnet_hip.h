@@ -55,6 +55,21 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
                      int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, int split_k, float* ws,
                      uint32_t* counters, rst_stream_t stream);
 
+/* The few-row form of rst_gemm_win_f32 (M = B*T_out <= 128: one streaming frame for up to 64 streams), three entry points:
+ *   rst_skinny_f32_pack_weight: w [N][K] fp32 -> wp [ceil(N/32)*32][Kp], Kp = K rounded up to 8, in MFMA operand order
+ *     ([tile of 32 rows][Kp/8][64 lanes = 32*(k%2) + row%32][4 floats: k = 8q + 2e + k%2]); once per weight.
+ *   rst_skinny_f32_pack_win: gathers the activation windows A(b,t,k) of rst_gemm_win_f32 (history / zero / replicate padding,
+ *     ELU on load) into xp [32 | 64 | 128 rows: M rounded up to one of these][Kp] in the same order (rows past M zero).
+ *   rst_gemm_skinny_f32: y = epi(A w^T + bias) with the epilogue of rst_gemm_win_f32 (act_out, res, scale); one workgroup per
+ *     32 output columns whose 8 waves split K and meet in LDS in a fixed order (deterministic, no cross-workgroup reduction);
+ *     v_mfma_f32_32x32x2_f32 with k ascending per wave.  Every Conv1d / ConvTranspose1d / Linear of a streaming step
+ *     (modules/streaming.py:216-303, modules/transformer.py:395-562) is weight-bandwidth bound and goes through here. */
+int rst_skinny_f32_pack_weight(const float* w, float* wp, int N, int K, rst_stream_t stream);
+int rst_skinny_f32_pack_win(const float* x, const float* hist, float* xp, int B, int T_in, int T_out, int C, int K, int S, int P,
+                            int pad_mode, int64_t x_bstride, int act_in, rst_stream_t stream);
+int rst_gemm_skinny_f32(const float* xp, const float* wp, const float* bias, const float* res, const float* scale, float* y, int M,
+                        int N, int K, int ldy, int act_out, rst_stream_t stream);
+
 /* Causal Conv1d.  Replaces F.conv1d in RawStreamingConv1d.forward (modules/streaming.py:216-244) together with the
  * padding logic of StreamingConv1d.forward (modules/conv.py:232-254).
  *   x [B][T_in][Cin];  w_packed [Cout][Kw_eff*Cin] with w_packed[co][tap*Cin + ci] = weight[co][ci][tap] (dilated taps

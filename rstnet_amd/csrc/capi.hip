@@ -157,6 +157,26 @@ int rst_transpose_f32(const float* x, float* y, int B, int R, int C, rst_stream_
     return rst_launch_transpose(x, y, B, R, C, (hipStream_t)stream);
 }
 
+int rst_skinny_f32_pack_weight(const float* w, float* wp, int N, int K, rst_stream_t stream) {
+    return rst_launch_skinny_f32_pack_weight(w, wp, N, K, (hipStream_t)stream);
+}
+
+int rst_skinny_f32_pack_win(const float* x, const float* hist, float* xp, int B, int T_in, int T_out, int C, int K, int S, int P,
+                            int pad_mode, int64_t x_bstride, int act_in, rst_stream_t stream) {
+    SkinnyF32PackParams p;
+    p.x = x; p.hist = hist; p.xp = xp; p.B = B; p.T_in = T_in; p.T_out = T_out; p.C = C; p.K = K; p.Kp = (K + 7) / 8 * 8; p.S = S; p.P = P;
+    p.pad_mode = pad_mode; p.act_in = act_in; p.x_bstride = x_bstride;
+    return rst_launch_skinny_f32_pack_win(p, (hipStream_t)stream);
+}
+
+int rst_gemm_skinny_f32(const float* xp, const float* wp, const float* bias, const float* res, const float* scale, float* y, int M,
+                        int N, int K, int ldy, int act_out, rst_stream_t stream) {
+    SkinnyF32Params p;
+    p.xp = xp; p.wp = wp; p.bias = bias; p.res = res; p.scale = scale; p.y = y; p.M = M; p.N = N; p.Kp = (K + 7) / 8 * 8; p.ldy = ldy;
+    p.act_out = act_out;
+    return rst_launch_gemm_skinny_f32(p, (hipStream_t)stream);
+}
+
 int rst_mask_tail_f32(float* x, const int32_t* lengths, int B, int T, int C, int mode, rst_stream_t stream) {
     return rst_launch_mask_tail(x, lengths, B, T, C, mode, (hipStream_t)stream);
 }

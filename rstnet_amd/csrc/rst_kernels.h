@@ -28,6 +28,27 @@ struct GemmWinParams {
 int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream);
 int rst_gemm_split_plan_impl(long M, int N, int K);
 
+// ---- skinny_f32.hip: few-row (M <= 128) fp32 GEMM of the codec streaming steps ---------------------------------------
+struct SkinnyF32PackParams {      // the A operand of GemmWinParams, gathered + packed
+    const float* x;
+    const float* hist;
+    float* xp;                    // [ceil(M/32)][Kp/8][64][4]
+    int B, T_in, T_out, C, K, Kp, S, P, pad_mode, act_in;
+    long x_bstride;
+};
+struct SkinnyF32Params {
+    const float* xp;              // packed activation windows
+    const float* wp;              // packed weights [ceil(N/32)][Kp/8][64][4]
+    const float* bias;            // [N] or nullptr
+    const float* res;             // [M][ldy] or nullptr
+    const float* scale;           // [N] or nullptr
+    float* y;                     // [M][ldy]
+    int M, N, Kp, ldy, act_out;   // act_out as GemmWinParams
+};
+int rst_launch_skinny_f32_pack_weight(const float* w, float* wp, int N, int K, hipStream_t stream);
+int rst_launch_skinny_f32_pack_win(const SkinnyF32PackParams& p, hipStream_t stream);
+int rst_launch_gemm_skinny_f32(const SkinnyF32Params& p, hipStream_t stream);
+
 // ---- resblock.hip ---------------------------------------------------------------------------------
 struct ResblockParams {
     const float* x;     // [B][T][C] block input, or (pre) the mono audio [B][T]

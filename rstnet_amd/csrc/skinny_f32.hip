@@ -1,0 +1,197 @@
+// Few-row fp32 GEMM of the codec's streaming steps (one 80 ms frame for up to 64 streams: M = B * T_out <= 128 rows):
+// every Conv1d / ConvTranspose1d / Linear of a step is weight-bandwidth bound (1 - 33 MB of fp32 weights against a few
+// rows), so it runs like the LM's skinny GEMM instead of the tiled gemm_win kernel:
+//   * both operands in MFMA operand order [tile of 32 rows][K/8][64 lanes][4 floats] -- lane = 32 * (k % 2) + row % 32,
+//     float e of a lane = k = 8 q + 2 e + (k % 2) -- so that one 16-byte lane load feeds four v_mfma_f32_32x32x2_f32 and a
+//     wave-level load is one contiguous KB; weights are packed once, the activation WINDOWS (the overlapping-window A
+//     operand of gemm_win: history / padding / ELU-on-load included) are gathered and packed per call by a small kernel;
+//   * one workgroup = CT tiles of 32 output columns, its 8 waves split K and meet in LDS in a fixed order: deterministic,
+//     no cross-workgroup reduction (the split-K hand-off through device-scope atomics costs more than these GEMMs);
+//   * fp32 MFMA with k ascending per wave: products are exact fp32 fmaf chains like gemm_win's (sums differ only in order).
+#include <hip/hip_runtime.h>
+
+#include "rst_common.h"
+#include "rst_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ long f32_packed_index(int row, int k, int Kp) {
+    return ((((long)(row >> 5) * (Kp >> 3) + (k >> 3)) * 64) + (k & 1) * 32 + (row & 31)) * 4 + ((k & 7) >> 1);
+}
+
+__global__ __launch_bounds__(256) void f32_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int N, int K, int Kp) {
+    const long total = (long)((N + 31) / 32) * 32 * (Kp / 2);            // (row, k pair) items
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int row = (int)(idx / (Kp / 2)), k = (int)(idx % (Kp / 2)) * 2;
+        float v0 = 0.f, v1 = 0.f;
+        if (row < N) {
+            if (k < K) v0 = w[(long)row * K + k];
+            if (k + 1 < K) v1 = w[(long)row * K + k + 1];
+        }
+        wp[f32_packed_index(row, k, Kp)] = v0;
+        wp[f32_packed_index(row, k + 1, Kp)] = v1;
+    }
+}
+
+// rows of the packed activation buffer: the kernel is instantiated for 1, 2 or 4 row tiles
+__host__ __device__ inline int sf_rows(int M) { return M <= 32 ? 32 : (M <= 64 ? 64 : 128); }
+
+// A(b, t, k) = xflat_b[(t * S - P) * C + k] with history / zero / replicate padding (the A operand of gemm_win_kernel), ELU on
+// load if asked, written in packed order; item = (row, q, h): the 4 floats of one lane.
+__global__ __launch_bounds__(256) void f32_pack_win_kernel(const SkinnyF32PackParams p) {
+    const int M = p.B * p.T_out;
+    const int M32 = sf_rows(M);          // rows past M are written as zeros
+    const int TC = p.T_in * p.C, PC = p.P * p.C;
+    const long total = (long)M32 * (p.Kp / 8) * 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int h = (int)(idx & 1);
+        const int q = (int)((idx >> 1) % (p.Kp / 8));
+        const int m = (int)((idx >> 1) / (p.Kp / 8));
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < M) {
+            const int b = m / p.T_out, t = m - b * p.T_out;
+            const long xo = (long)b * p.x_bstride, ho = (long)b * PC;
+            const int f0 = (t * p.S - p.P) * p.C;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 8 * q + 2 * e + h;
+                float a = 0.f;
+                if (k < p.K) {
+                    const int f = f0 + k;
+                    if (f >= 0) {
+                        if (f < TC) a = p.x[xo + f];
+                        else if (p.pad_mode == 1) a = p.x[xo + TC - p.C + f % p.C];
+                    } else if (p.hist) {
+                        a = p.hist[ho + PC + f];
+                    } else if (p.pad_mode == 1) {
+                        int c = f % p.C;
+                        if (c < 0) c += p.C;
+                        a = p.x[xo + c];
+                    }
+                    if (p.act_in == 1) a = rst_elu(a);
+                }
+                v[e] = a;
+            }
+        }
+        *reinterpret_cast<f32x4*>(p.xp + ((((long)(m >> 5) * (p.Kp >> 3) + q) * 64) + h * 32 + (m & 31)) * 4) = v;
+    }
+}
+
+constexpr int SF_WAVES = 8;
+
+template <int NB, int CT>
+__global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const SkinnyF32Params p) {
+    __shared__ float red[SF_WAVES][NB * 32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = (p.N + 31) / 32;
+    const int tile0 = blockIdx.x * CT;
+    const int chunks = p.Kp / 8;
+    const int per = (chunks + SF_WAVES - 1) / SF_WAVES;
+    const int s0 = wave * per, s1 = min(chunks, s0 + per);
+    const float* xq = p.xp + (long)lane * 4;
+    const float* wt[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) wt[c] = p.wp + ((long)min(tile0 + c, tiles - 1) * chunks * 64 + lane) * 4;
+    f32x16 acc[NB][CT];
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
+    constexpr int UN = NB * CT <= 2 ? 4 : 2;
+    for (int s = s0; s < s1; s += UN) {
+        f32x4 a[UN][CT], bx[UN][NB];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const bool ok = s + u < s1;
+            const long so = (long)(s + u) * 256;
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                a[u][c] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wt[c] + so)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+                bx[u][t] = ok ? *reinterpret_cast<const f32x4*>(xq + (long)t * chunks * 256 + so) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < NB; ++t)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(bx[u][t][e], a[u][c][e], acc[t][c], 0, 0, 0);
+    }
+    // activations are the MFMA "A" side: acc[t][c][e] = C[m = 32 t + row(e, lane)][n = 32 (tile0 + c) + (lane & 31)]
+    const int i = lane & 31;
+    const int M = p.M;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (c) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wave][t * 32 + rst_mfma32_row(e, lane)][i] = acc[t][c][e];
+        __syncthreads();
+        const int n0 = (tile0 + c) * 32;
+        for (int idx = tid; idx < NB * 32 * 32; idx += 64 * SF_WAVES) {
+            const int m = idx >> 5, nl = idx & 31;
+            const int n = n0 + nl;
+            if (m < M && n < p.N) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < SF_WAVES; ++w) v += red[w][m][nl];
+                if (p.bias) v += p.bias[n];
+                if (p.act_out == 1) v = rst_gelu(v);
+                const long o = (long)m * p.ldy + n;
+                if (p.res) v = p.res[o] + (p.scale ? p.scale[n] : 1.0f) * v;
+                if (p.act_out == 2) v = rst_elu(v);
+                p.y[o] = v;
+            }
+        }
+    }
+}
+
+inline unsigned sf_grid(long total, long cap) {
+    long g = (total + 255) / 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+int rst_launch_skinny_f32_pack_weight(const float* w, float* wp, int N, int K, hipStream_t stream) {
+    RST_REQUIRE(w && wp && N > 0 && K > 0, "skinny_f32_pack_weight: bad arguments");
+    const int Kp = (K + 7) / 8 * 8;
+    const long total = (long)((N + 31) / 32) * 32 * (Kp / 2);
+    hipLaunchKernelGGL(f32_pack_weight_kernel, dim3(sf_grid(total, 8192)), dim3(256), 0, stream, w, wp, N, K, Kp);
+    return rst_check_launch("skinny_f32_pack_weight");
+}
+
+int rst_launch_skinny_f32_pack_win(const SkinnyF32PackParams& p, hipStream_t stream) {
+    RST_REQUIRE(p.x && p.xp && p.B >= 1 && p.T_out >= 1 && p.T_in >= 0 && p.C > 0 && p.K > 0 && p.S > 0 && p.P >= 0 && p.Kp % 8 == 0 &&
+                    p.Kp >= p.K && (long)p.B * p.T_out <= 128,
+                "skinny_f32_pack_win: bad arguments (M = B * T_out <= 128 required; M=%ld K=%d Kp=%d)", (long)p.B * p.T_out, p.K, p.Kp);
+    const long total = (long)sf_rows(p.B * p.T_out) * (p.Kp / 8) * 2;
+    hipLaunchKernelGGL(f32_pack_win_kernel, dim3(sf_grid(total, 4096)), dim3(256), 0, stream, p);
+    return rst_check_launch("skinny_f32_pack_win");
+}
+
+int rst_launch_gemm_skinny_f32(const SkinnyF32Params& p, hipStream_t stream) {
+    RST_REQUIRE(p.xp && p.wp && p.y && p.M >= 1 && p.M <= 128 && p.N > 0 && p.Kp > 0 && p.Kp % 8 == 0 && p.act_out >= 0 && p.act_out <= 2,
+                "gemm_skinny_f32: bad arguments (1 <= M <= 128, Kp %% 8 == 0; M=%d Kp=%d)", p.M, p.Kp);
+    const int tiles = (p.N + 31) / 32;
+    const dim3 block(64 * SF_WAVES);
+    const int nb = (p.M + 31) / 32;
+    if (nb == 1) {
+        if (tiles >= 512) hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 2>), dim3((tiles + 1) / 2), block, 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 1>), dim3(tiles), block, 0, stream, p);
+    } else if (nb == 2) {
+        hipLaunchKernelGGL((gemm_skinny_f32_kernel<2, 1>), dim3(tiles), block, 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((gemm_skinny_f32_kernel<4, 1>), dim3(tiles), block, 0, stream, p);
+    }
+    return rst_check_launch("gemm_skinny_f32");
+}

@@ -66,6 +66,40 @@ def _gemm_split_scratch(device, M: int, N: int, K: int):
     return sc
 
 
+_skinny_f32_weights: dict = {}
+SKINNY_F32_MAX_ROWS = 128
+
+
+def skinny_f32_pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """fp32 ``[N, K]`` -> MFMA-ordered copy ``[ceil(N/32)*32, ceil(K/8)*8]`` (rst_skinny_f32_pack_weight), cached per storage."""
+    _chk(w, "w")
+    N, K = w.shape
+    key = (w.device, w.data_ptr(), N, K)
+    hit = _skinny_f32_weights.get(key)
+    if hit is not None and hit[1] == w._version:
+        return hit[0]
+    wp = torch.empty((N + 31) // 32 * 32, (K + 7) // 8 * 8, device=w.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_skinny_f32_pack_weight(_ptr(w), _ptr(wp), N, K, _stream()))
+    _skinny_f32_weights[key] = (wp, w._version, w)
+    return wp
+
+
+def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, S, P, pad_mode, act_in, act_out) -> None:
+    """The streaming-step route of gemm_win / linear: gather + pack the activation windows, then the few-row fp32 skinny GEMM."""
+    M = B * T_out
+    wp = skinny_f32_pack_weight(w)
+    xp = torch.empty(32 if M <= 32 else (64 if M <= 64 else 128), wp.shape[1], device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_skinny_f32_pack_win(_ptr(x), _ptr(hist), _ptr(xp), B, T_in, T_out, C_, K, S, P, pad_mode, T_in * C_, act_in,
+                                                 _stream()))
+    _lib.check(_lib.lib().rst_gemm_skinny_f32(_ptr(xp), _ptr(wp), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, N, K, N, act_out,
+                                             _stream()))
+
+
+def _few_rows(M: int, N: int, K: int) -> bool:
+    # weight-bandwidth-bound shapes only: a handful of rows against at least 256 KB of weights
+    return 1 <= M <= SKINNY_F32_MAX_ROWS and N * K >= 65536
+
+
 def gemm_win(x: torch.Tensor, w: torch.Tensor, *, B: int, T_in: int, T_out: int, C_: int, S: int, P: int, N: int,
              hist: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
              res: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, pad_mode: int = PAD_ZERO,
@@ -85,6 +119,9 @@ def gemm_win(x: torch.Tensor, w: torch.Tensor, *, B: int, T_in: int, T_out: int,
         assert res.numel() == out.numel()
     if hist is not None:
         assert hist.numel() == B * P * C_, (tuple(hist.shape), B, P, C_)
+    if _few_rows(B * T_out, N, K) and PROFILE is None:
+        _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, S, P, pad_mode, act_in, act_out)
+        return out
     split_k, ws, cnt = _gemm_split_scratch(x.device, B * T_out, N, K)
     prof = PROFILE
     if prof is not None:
@@ -113,6 +150,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if 1 <= M <= 4 and K % 8 == 0 and K * M <= 32768 and act_out in (ACT_NONE, ACT_GELU):
         # a streaming step of one or two positions: weight-streaming GEMV (every CU pulls rows of w; no split-K hand-off)
         _lib.check(_lib.lib().rst_gemv_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, N, K, act_out, _stream()))
+        return out
+    if _few_rows(M, N, K) and PROFILE is None:
+        _gemm_few_rows(x, None, w, bias, res, scale, out, 1, M, M, K, K, N, 1, 0, 0, ACT_NONE, act_out)
         return out
     split_k, ws, cnt = _gemm_split_scratch(x.device, M, N, K)
     prof = PROFILE
