@@ -1,0 +1,425 @@
+#include <algorithm>
+
+#include "lm_common.h"
+
+// ======================================================================================================================
+// Skinny GEMM for 4 < batch <= 64: y[b][n] = (res +) (bias +) sum_k x[b][k] * W[n][k] on the bf16 matrix cores.
+// The weight matrix is streamed from HBM exactly once (the step stays bandwidth-bound up to batch ~64); the contraction runs
+// on v_mfma_f32_32x32x16_bf16 with the fp32 activations split into bf16 hi + lo parts (two MFMAs per step): products carry
+// ~17 mantissa bits of x, i.e. fp32-class accuracy against the fp32 oracle (the reference itself rounds activations to bf16).
+// ======================================================================================================================
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- operand layouts of the skinny GEMM ------------------------------------------------------------------------------
+// Both operands are stored in the order the 32x32x16 MFMA consumes them, so that every wave-level load is ONE contiguous
+// kilobyte: [tile of 32 rows][step of 16 k][lane = 32 * (k / 8 % 2) + row % 32][8 bf16].
+//   weights  Wp : [ceil(N/32)][K/16][64][8]   (rows beyond N zero)        -- packed once per weight (rst_skinny_pack_weight_bf16)
+//   activations Xp: [2 = hi, lo][ceil(B/32)][K/16][64][8] (rows beyond B zero) -- packed per call by the (fused) prologue kernel
+__device__ __forceinline__ long packed_index(int row, int k, int K) {
+    return ((((long)(row >> 5) * (K >> 4) + (k >> 4)) * 64) + ((k >> 3) & 1) * 32 + (row & 31)) * 8 + (k & 7);
+}
+
+__global__ __launch_bounds__(256) void skinny_pack_weight_kernel(const unsigned short* __restrict__ w, unsigned short* __restrict__ wp,
+                                                                int N, int K) {
+    const long total = (long)((N + 31) / 32) * 32 * (K / 8);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int row = (int)(idx / (K / 8)), k = (int)(idx % (K / 8)) * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < N) v = *reinterpret_cast<const u32x4*>(w + (long)row * K + k);
+        *reinterpret_cast<u32x4*>(wp + packed_index(row, k, K)) = v;
+    }
+}
+
+// Prologue + hi/lo split + packing of one activation row per workgroup (pad rows of the last batch tile are zero-filled).
+// hi = fp32 truncated to bf16 (an exact prefix, so x - hi is exact), lo = the residual rounded half-up: x = hi + lo to 2^-17.
+// mode 0: identity; 1: RMSNorm x * alpha * rsqrt(eps + mean(x^2)); 2: SiLU gate, x row = [u ; v] -> silu(u) * v.
+__global__ __launch_bounds__(256) void skinny_pack_act_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                             unsigned short* __restrict__ xp, int B, int K, int ldx, int mode, float eps) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long half = (long)((B + 31) / 32) * 32 * K;          // elements of the hi (and of the lo) plane
+    float scale = 1.f;
+    if (mode == 1 && b < B) {
+        float s = 0.f;
+        for (int k = tid * 4; k < K; k += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + k);
+            s = fmaf(v[0], v[0], s); s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        scale = 1.0f / sqrtf(eps + (red[0] + red[1] + red[2] + red[3]) / (float)K);
+    }
+    for (int k = tid * 8; k < K; k += 2048) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (b < B) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + k);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + k + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = a0[j]; v[4 + j] = a1[j]; }
+            if (mode == 1) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(alpha + k), g1 = *reinterpret_cast<const f32x4*>(alpha + k + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = v[j] * (g0[j] * scale); v[4 + j] = v[4 + j] * (g1[j] * scale); }
+            } else if (mode == 2) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + K + k);
+                const f32x4 g1 = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + K + k + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = silu(v[j]) * g0[j]; v[4 + j] = silu(v[4 + j]) * g1[j]; }
+            }
+        }
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned ua = __float_as_uint(v[2 * j]), ub = __float_as_uint(v[2 * j + 1]);
+            h[j] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                 // {hi16(b), hi16(a)}
+            const float ra = v[2 * j] - __uint_as_float(ua & 0xffff0000u), rb = v[2 * j + 1] - __uint_as_float(ub & 0xffff0000u);
+            l[j] = __builtin_amdgcn_perm(__float_as_uint(rb) + 0x8000u, __float_as_uint(ra) + 0x8000u, 0x07060302u);
+        }
+        const long at = packed_index(b, k, K);
+        *reinterpret_cast<u32x4*>(xp + at) = u32x4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<u32x4*>(xp + half + at) = u32x4{l[0], l[1], l[2], l[3]};
+    }
+}
+
+constexpr int SKINNY_WAVES = 8;
+
+// One workgroup = CT adjacent tiles of 32 weight rows; its 8 waves each take an eighth of K.  Per MFMA step a wave loads
+// 1 KB of activations (hi), 1 KB (lo) -- L2 hits -- and CT x 1 KB of weights from HBM, all contiguous; no LDS stage and no
+// barrier in the main loop.  The activations are the MFMA "A" side, so an accumulator is C[b = row(e, lane)][n = lane & 31]
+// and the global stores are 128-byte coalesced.  The 8 partial tiles meet in LDS and are summed in wave order
+// (deterministic); there is no cross-workgroup reduction.
+template <int NB, int CT>   // batch tiles of 32, weight-row tiles per workgroup
+__global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const SkinnyParams p) {
+    __shared__ float red[SKINNY_WAVES][NB * 32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = (p.N + 31) / 32;
+    const int tile0 = blockIdx.x * CT;
+    const int steps = p.K / 16;
+    const int per = (steps + SKINNY_WAVES - 1) / SKINNY_WAVES;
+    const int s0 = wave * per, s1 = min(steps, s0 + per);
+    const long xplane = (long)NB * 32 * p.K;                        // elements of the hi plane
+    const unsigned short* xh = p.xp + (long)lane * 8;
+    const unsigned short* xl = xh + xplane;
+    const unsigned short* wt[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) wt[c] = p.w + ((long)min(tile0 + c, tiles - 1) * steps * 64 + lane) * 8;
+    f32x16 acc[NB][CT];
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
+    constexpr int UN = (NB * 2 + CT) <= 4 ? 4 : 2;
+    for (int s = s0; s < s1; s += UN) {
+        bf16x8 a[UN][CT], bh[UN][NB], bl[UN][NB];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const bool ok = s + u < s1;
+            const long so = (long)(s + u) * 512;
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                a[u][c] = ok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wt[c] + so)) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                bh[u][t] = ok ? *reinterpret_cast<const bf16x8*>(xh + (long)t * steps * 512 + so) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                bl[u][t] = ok ? *reinterpret_cast<const bf16x8*>(xl + (long)t * steps * 512 + so) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[u][t], a[u][c], acc[t][c], 0, 0, 0);
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[u][t], a[u][c], acc[t][c], 0, 0, 0);
+                }
+    }
+    const int i = lane & 31;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (c) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wave][t * 32 + rst_mfma32_row(e, lane)][i] = acc[t][c][e];
+        __syncthreads();
+        const int n0 = (tile0 + c) * 32;
+        for (int idx = tid; idx < NB * 32 * 32; idx += 64 * SKINNY_WAVES) {
+            const int b = idx >> 5, nl = idx & 31;
+            const int n = n0 + nl;
+            if (b < p.B && n < p.N) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < SKINNY_WAVES; ++w) s += red[w][b][nl];
+                const long o = (long)b * p.ldy + n;
+                if (p.bias) s += p.bias[n];
+                p.y[o] = p.res ? p.res[o] + s : s;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int rst_launch_skinny_pack_weight(const unsigned short* w, unsigned short* wp, int N, int K, hipStream_t stream) {
+    RST_REQUIRE(w && wp && N > 0 && K > 0 && K % 16 == 0, "skinny_pack_weight: bad arguments (K %% 16 == 0 required, K=%d)", K);
+    const long total = (long)((N + 31) / 32) * 32 * (K / 8);
+    hipLaunchKernelGGL(skinny_pack_weight_kernel, dim3(cap_grid((total + 255) / 256, 8192)), dim3(256), 0, stream, w, wp, N, K);
+    return rst_check_launch("skinny_pack_weight");
+}
+
+int rst_launch_skinny_pack_act(const float* x, const float* alpha, unsigned short* xp, int B, int K, int ldx, int mode, float eps,
+                               hipStream_t stream) {
+    RST_REQUIRE(x && xp && B >= 1 && B <= 64 && K > 0 && K % 16 == 0 && ldx % 4 == 0, "skinny_pack_act: bad arguments (B=%d K=%d)", B, K);
+    RST_REQUIRE(mode == 0 || (mode == 1 && alpha) || mode == 2, "skinny_pack_act: mode 0 / 1 (needs alpha) / 2");
+    hipLaunchKernelGGL(skinny_pack_act_kernel, dim3((B + 31) / 32 * 32), dim3(256), 0, stream, x, alpha, xp, B, K, ldx, mode, eps);
+    return rst_check_launch("skinny_pack_act");
+}
+
+int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream) {
+    RST_REQUIRE(p.B >= 1 && p.B <= 64 && p.N > 0 && p.K > 0 && p.K % 16 == 0, "gemm_skinny: need 1 <= B <= 64 and K %% 16 == 0 (B=%d K=%d)", p.B, p.K);
+    RST_REQUIRE(p.xp && p.w && p.y, "gemm_skinny: null pointer");
+    const int tiles = (p.N + 31) / 32;
+    const int threads = 64 * SKINNY_WAVES;
+    if (p.B <= 32) {
+        if (tiles >= 2048) hipLaunchKernelGGL((gemm_skinny_kernel<1, 4>), dim3((tiles + 3) / 4), dim3(threads), 0, stream, p);
+        else if (tiles >= 512) hipLaunchKernelGGL((gemm_skinny_kernel<1, 2>), dim3((tiles + 1) / 2), dim3(threads), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<1, 1>), dim3(tiles), dim3(threads), 0, stream, p);
+    } else {
+        if (tiles >= 512) hipLaunchKernelGGL((gemm_skinny_kernel<2, 2>), dim3((tiles + 1) / 2), dim3(threads), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<2, 1>), dim3(tiles), dim3(threads), 0, stream, p);
+    }
+    return rst_check_launch("gemm_skinny");
+}
+
+// ======================================================================================================================
+// fp8 (OCP e4m3) variant of the skinny GEMM -- BASELINE.json configs[4]: "fp8 MFMA GEMMs for temporal attention, batch 32".
+// Weights: per-row scale (amax / 448), quantised once; activations: per-row dynamic scale, quantised by the prologue launch.
+// v_mfma_f32_32x32x16_fp8_fp8 consumes 8 bytes per lane per step; two steps are packed per 16-byte lane load:
+//   [tile of 32 rows][K/32][64 lanes = 32 * ((k / 8) % 2) + row % 32][16 B = step 2p (8 k) | step 2p+1 (8 k)].
+// Half the streamed bytes and half the MFMA work of the bf16 hi/lo path, at fp8 accuracy (3 mantissa bits: ~1e-2 on logits);
+// opt-in, never the default.
+// ======================================================================================================================
+namespace {
+
+__device__ __forceinline__ long fp8_packed_index(int row, int k, int K) {     // byte offset
+    return ((((long)(row >> 5) * (K >> 5) + (k >> 5)) * 64) + ((k >> 3) & 1) * 32 + (row & 31)) * 16 + ((k >> 4) & 1) * 8 + (k & 7);
+}
+
+// v / scale with a true division (bit-compatible with `(t / scale).to(float8_e4m3fn)`), round-to-nearest-even conversion
+__device__ __forceinline__ uint2 quant8_fp8(const float (&v)[8], float scale) {
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] / scale, v[1] / scale, 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] / scale, v[3] / scale, lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] / scale, v[5] / scale, 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] / scale, v[7] / scale, hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// one workgroup per (padded) weight row
+__global__ __launch_bounds__(256) void skinny_pack_weight_fp8_kernel(const unsigned short* __restrict__ w, unsigned char* __restrict__ wp,
+                                                                    float* __restrict__ scale, int N, int K) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    float amax = 0.f;
+    if (row < N)
+        for (int k = tid * 8; k < K; k += 2048) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(w + (long)row * K + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bf16_lo(v[j])), fabsf(bf16_hi(v[j]))));
+        }
+    amax = block_max_256(amax, red);
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (tid == 0) scale[row] = sc;
+    const float inv = sc;
+    for (int k = tid * 8; k < K; k += 2048) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (row < N) {
+            const u32x4 q = *reinterpret_cast<const u32x4*>(w + (long)row * K + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = bf16_lo(q[j]); v[2 * j + 1] = bf16_hi(q[j]); }
+        }
+        *reinterpret_cast<uint2*>(wp + fp8_packed_index(row, k, K)) = quant8_fp8(v, inv);
+    }
+}
+
+// one workgroup per (padded) batch row: prologue (0 identity, 1 RMSNorm, 2 SiLU gate) -> per-row amax -> fp8
+constexpr int FP8_ACT_CHUNKS = 8;      // K <= 8 * 2048
+__global__ __launch_bounds__(256) void skinny_pack_act_fp8_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                                 unsigned char* __restrict__ xp, float* __restrict__ xscale, int B, int K,
+                                                                 int ldx, int mode, float eps) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float vals[FP8_ACT_CHUNKS][8];
+    float ssq = 0.f;
+#pragma unroll
+    for (int c = 0; c < FP8_ACT_CHUNKS; ++c) {
+        const int k = tid * 8 + c * 2048;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vals[c][j] = 0.f;
+        if (b < B && k < K) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + k);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + k + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { vals[c][j] = a0[j]; vals[c][4 + j] = a1[j]; }
+            if (mode == 2) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + K + k);
+                const f32x4 g1 = *reinterpret_cast<const f32x4*>(x + (long)b * ldx + K + k + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vals[c][j] = silu(vals[c][j]) * g0[j]; vals[c][4 + j] = silu(vals[c][4 + j]) * g1[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ssq = fmaf(vals[c][j], vals[c][j], ssq);
+        }
+    }
+    if (mode == 1) {
+        float s = wave_sum(ssq);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        const float r = 1.0f / sqrtf(eps + (red[0] + red[1] + red[2] + red[3]) / (float)K);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < FP8_ACT_CHUNKS; ++c) {
+            const int k = tid * 8 + c * 2048;
+            if (b < B && k < K) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(alpha + k), g1 = *reinterpret_cast<const f32x4*>(alpha + k + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vals[c][j] *= g0[j] * r; vals[c][4 + j] *= g1[j] * r; }
+            }
+        }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < FP8_ACT_CHUNKS; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(vals[c][j]));
+    amax = block_max_256(amax, red);
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (tid == 0) xscale[b] = sc;
+    const float inv = sc;
+#pragma unroll
+    for (int c = 0; c < FP8_ACT_CHUNKS; ++c) {
+        const int k = tid * 8 + c * 2048;
+        if (k < K) *reinterpret_cast<uint2*>(xp + fp8_packed_index(b, k, K)) = quant8_fp8(vals[c], inv);
+    }
+}
+
+template <int NB, int CT>
+__global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_fp8_kernel(const SkinnyFp8Params p) {
+    __shared__ float red[SKINNY_WAVES][NB * 32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = (p.N + 31) / 32;
+    const int tile0 = blockIdx.x * CT;
+    const int pairs = p.K / 32;
+    const int per = (pairs + SKINNY_WAVES - 1) / SKINNY_WAVES;
+    const int s0 = wave * per, s1 = min(pairs, s0 + per);
+    const unsigned char* xq = p.xp + (long)lane * 16;
+    const unsigned char* wt[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) wt[c] = p.wp + ((long)min(tile0 + c, tiles - 1) * pairs * 64 + lane) * 16;
+    f32x16 acc[NB][CT];
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
+    typedef long i64x2 __attribute__((ext_vector_type(2)));
+    constexpr int UN = 4;
+    for (int s = s0; s < s1; s += UN) {
+        i64x2 a[UN][CT], bx[UN][NB];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const bool ok = s + u < s1;
+            const long so = (long)(s + u) * 1024;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) a[u][c] = ok ? __builtin_nontemporal_load(reinterpret_cast<const i64x2*>(wt[c] + so)) : i64x2{0, 0};
+#pragma unroll
+            for (int t = 0; t < NB; ++t) bx[u][t] = ok ? *reinterpret_cast<const i64x2*>(xq + (long)t * pairs * 1024 + so) : i64x2{0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(bx[u][t][0], a[u][c][0], acc[t][c], 0, 0, 0);
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(bx[u][t][1], a[u][c][1], acc[t][c], 0, 0, 0);
+                }
+    }
+    const int i = lane & 31;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (c) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wave][t * 32 + rst_mfma32_row(e, lane)][i] = acc[t][c][e];
+        __syncthreads();
+        const int n0 = (tile0 + c) * 32;
+        for (int idx = tid; idx < NB * 32 * 32; idx += 64 * SKINNY_WAVES) {
+            const int b = idx >> 5, nl = idx & 31;
+            const int n = n0 + nl;
+            if (b < p.B && n < p.N) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < SKINNY_WAVES; ++w) s += red[w][b][nl];
+                s *= p.xscale[b] * p.wscale[n];
+                const long o = (long)b * p.ldy + n;
+                if (p.bias) s += p.bias[n];
+                p.y[o] = p.res ? p.res[o] + s : s;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int rst_launch_skinny_pack_weight_fp8(const unsigned short* w, unsigned char* wp, float* scale, int N, int K, hipStream_t stream) {
+    RST_REQUIRE(w && wp && scale && N > 0 && K > 0 && K % 32 == 0, "skinny_pack_weight_fp8: bad arguments (K %% 32 == 0 required, K=%d)", K);
+    hipLaunchKernelGGL(skinny_pack_weight_fp8_kernel, dim3((N + 31) / 32 * 32), dim3(256), 0, stream, w, wp, scale, N, K);
+    return rst_check_launch("skinny_pack_weight_fp8");
+}
+
+int rst_launch_skinny_pack_act_fp8(const float* x, const float* alpha, unsigned char* xp, float* xscale, int B, int K, int ldx, int mode,
+                                   float eps, hipStream_t stream) {
+    RST_REQUIRE(x && xp && xscale && B >= 1 && B <= 64 && K > 0 && K % 32 == 0 && K <= 2048 * FP8_ACT_CHUNKS && ldx % 4 == 0,
+                "skinny_pack_act_fp8: bad arguments (B=%d K=%d; K %% 32 == 0, K <= %d)", B, K, 2048 * FP8_ACT_CHUNKS);
+    RST_REQUIRE(mode == 0 || (mode == 1 && alpha) || mode == 2, "skinny_pack_act_fp8: mode 0 / 1 (needs alpha) / 2");
+    hipLaunchKernelGGL(skinny_pack_act_fp8_kernel, dim3((B + 31) / 32 * 32), dim3(256), 0, stream, x, alpha, xp, xscale, B, K, ldx, mode, eps);
+    return rst_check_launch("skinny_pack_act_fp8");
+}
+
+int rst_launch_gemm_skinny_fp8(const SkinnyFp8Params& p, hipStream_t stream) {
+    RST_REQUIRE(p.B >= 1 && p.B <= 64 && p.N > 0 && p.K > 0 && p.K % 32 == 0, "gemm_skinny_fp8: need 1 <= B <= 64 and K %% 32 == 0 (B=%d K=%d)", p.B, p.K);
+    RST_REQUIRE(p.xp && p.wp && p.xscale && p.wscale && p.y, "gemm_skinny_fp8: null pointer");
+    const int tiles = (p.N + 31) / 32;
+    const int threads = 64 * SKINNY_WAVES;
+    if (p.B <= 32) {
+        if (tiles >= 2048) hipLaunchKernelGGL((gemm_skinny_fp8_kernel<1, 4>), dim3((tiles + 3) / 4), dim3(threads), 0, stream, p);
+        else if (tiles >= 512) hipLaunchKernelGGL((gemm_skinny_fp8_kernel<1, 2>), dim3((tiles + 1) / 2), dim3(threads), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_fp8_kernel<1, 1>), dim3(tiles), dim3(threads), 0, stream, p);
+    } else {
+        if (tiles >= 512) hipLaunchKernelGGL((gemm_skinny_fp8_kernel<2, 2>), dim3((tiles + 1) / 2), dim3(threads), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_fp8_kernel<2, 1>), dim3(tiles), dim3(threads), 0, stream, p);
+    }
+    return rst_check_launch("gemm_skinny_fp8");
+}

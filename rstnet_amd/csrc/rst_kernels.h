@@ -138,7 +138,7 @@ struct RvqGatherParams {
 };
 int rst_launch_rvq_gather(const RvqGatherParams& p, hipStream_t stream);
 
-// ---- lm_step.hip ------------------------------------------------------------------------------
+// ---- lm_step.hip / lm_attn.hip / lm_sample.hip / lm_skinny.hip ------------------------------------------------------------------------------
 struct GemvParams {
     const float* x;             // [B][ldx] fp32 activations (prologue 2: [B][2K] = [u ; v])
     const float* alpha;         // prologue 1: RMSNorm gain [K]

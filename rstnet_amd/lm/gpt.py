@@ -8,7 +8,7 @@ legacy remaps of llama_streaming.py:762-766,1000-1009,1034-1088), method signatu
 ``forward_codecformer``, ``forward_local``, ``forward``, ``_get_initial_token``, token-id properties) and streaming protocol
 (``with gpt.streaming(B)``, ``with gpt.codecformer.streaming(B)``).
 
-Execution (csrc/lm_step.hip): bf16 weights, fp32 activations.
+Execution (csrc/lm_step.hip, lm_attn.hip, lm_skinny.hip): bf16 weights, fp32 activations.
   * LoRA adapters are merged into the dense weights when a state dict is loaded (what the reference's ``merge_lora_weights``
     does before inference, :1120-), including the reference's zero_pad behaviour when q, k and v are all adapted.
   * The fused QKV rows are re-ordered once from the GQA-interleaved ``[group: q.. k v]`` layout to ``[Q | K | V]`` and, inside

@@ -7,7 +7,7 @@ Same constructor keywords, ``state_dict`` keys (``emb.{i}.weight``, ``transforme
 the first ``max_delay`` steps).  Training ``forward`` is out of scope.
 
 Execution: weights bf16 in HBM, activations fp32, one decode step (T = 1) per call through the kernels of
-``csrc/lm_step.hip``; the two per-frame halves (``forward_text`` and ``depformer_step``) are captured into HIP graphs
+``csrc/lm_*.hip``; the two per-frame halves (``forward_text`` and ``depformer_step``) are captured into HIP graphs
 after a warm-up exactly like the reference's ``CUDAGraphed`` wrappers (``MLLM_v2/utils/compile.py:189-277``), and the
 environment flag ``NO_CUDA_GRAPH`` disables that (``compile.py:168-174``).
 """

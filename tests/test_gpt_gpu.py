@@ -1,4 +1,4 @@
-"""GPU parity of the litgpt-style backbone (rstnet_amd/lm/gpt.py over csrc/lm_step.hip) against the CPU oracle
+"""GPU parity of the litgpt-style backbone (rstnet_amd/lm/gpt.py over csrc/lm_*.hip) against the CPU oracle
 (oracle/gpt_oracle.py, pinned to models.llama_streaming.GPT by tests/golden/gpt_tiny.npz).
 
 Both sides compute in fp32 on the SAME bf16 weights: the oracle is fed the product's merged state dict up-cast, so logits

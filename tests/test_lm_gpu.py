@@ -1,4 +1,4 @@
-"""GPU parity of the RQ-Transformer decode step (csrc/lm_step.hip + rstnet_amd/lm) against the CPU oracle
+"""GPU parity of the RQ-Transformer decode step (csrc/lm_*.hip + rstnet_amd/lm) against the CPU oracle
 (oracle/lm_oracle.py) and the reference-generated fixture tests/golden/lm_tiny.npz.
 
 bf16 weights are shared by both sides (the oracle up-casts them), activations are fp32 on both sides, so logits must
