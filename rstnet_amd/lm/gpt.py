@@ -15,8 +15,8 @@ Execution (csrc/lm_step.hip, lm_attn.hip, lm_skinny.hip): bf16 weights, fp32 act
     every q / k head, from rotate-half pairing ``(i, i + n/2)`` to interleaved pairing ``(2i, 2i+1)`` -- a permutation applied to
     q and k alike leaves q.k unchanged -- so the ring-attention kernels of the Moshi path serve this model too.
   * The KV ring stores the n_query_groups key/value heads once (the reference expands them to n_head before caching, :965-971).
-  * One decode step = 5 launches per layer for batch <= 4 (RMSNorm fused into the GEMVs); longer inputs (prompt prefill, batch
-    > 4) use the bf16-MFMA skinny GEMM over all rows + the multi-query ring attention.  T = 1 steps are graph-captured.
+  * One decode step = 5 launches per layer for batch <= 2 (RMSNorm fused into the GEMVs); longer inputs (prompt prefill, batch
+    > 2) use the bf16-MFMA skinny GEMM over all rows + the multi-query ring attention.  T = 1 steps are graph-captured.
 """
 from __future__ import annotations
 

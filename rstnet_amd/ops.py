@@ -526,11 +526,13 @@ def gemm_skinny_fp8(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGU
 
 def lm_linear(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
               eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, fp8: bool = False) -> torch.Tensor:
-    """Batch-size dispatch of one decode-step linear: weight-streaming GEMV for B <= 4, bf16-MFMA skinny GEMM above (the
+    """Batch-size dispatch of one decode-step linear: weight-streaming GEMV for B <= 2, bf16-MFMA skinny GEMM above (the
     prologue then runs inside the activation-packing launch).  ``fp8``: the opt-in e4m3 path (any batch <= 64)."""
     if fp8 and x.shape[0] <= 64 and w.shape[1] % 32 == 0 and w.shape[1] <= 16384:
         return gemm_skinny_fp8(x, w, prologue=prologue, alpha=alpha, eps=eps, res=res, bias=bias)
-    if x.shape[0] <= 4:
+    # the GEMV stages B x K fp32 activations in LDS: beyond two rows that footprint costs occupancy (fewer weight loads in
+    # flight) and the matrix-core path is as fast or faster (measured: 4096 x 4096 at B = 3: 16.4 vs 16.5 us, B = 4: 20.9 vs 16.5)
+    if x.shape[0] <= 2 and x.shape[0] * w.shape[1] <= 32768:
         return gemv_bf16(x, w, prologue=prologue, alpha=alpha, eps=eps, res=res, bias=bias)
     if x.shape[0] <= 64:
         return gemm_skinny(x, w, prologue=prologue, alpha=alpha, eps=eps, res=res, bias=bias)

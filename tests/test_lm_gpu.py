@@ -192,6 +192,19 @@ def test_gemm_skinny_fp8_matches_emulation(B, N, K, prologue):
                                               eps=1e-8, res=res.to(DEV)))
 
 
+@pytest.mark.parametrize("B", [3, 4])
+def test_lm_linear_wide_k_small_batch(B):
+    """Batch 3-4 with K = 11264 (the 7B ffn-out): B*K floats exceed the GEMV's LDS stage, lm_linear must take the skinny path."""
+    g = torch.Generator().manual_seed(B)
+    K, N = 11264, 512
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    u = torch.randn(B, 2 * K, generator=g)
+    res = torch.randn(B, N, generator=g)
+    y = ops.lm_linear(u.to(DEV), w.to(DEV), prologue=ops.PROLOGUE_SILU_GATE, res=res.to(DEV))
+    ref = res.double() + (F.silu(u[:, :K]) * u[:, K:]).double() @ w.double().t()
+    assert rel_err(y, ref) < 5e-5
+
+
 def _tiny():
     cfg = dict(synth.LM_TINY)
     sd = synth.lm_state_dict(cfg, cases.LM_SEED)
