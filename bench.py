@@ -131,7 +131,12 @@ def bench_lm(args, rank, world, dev):
     from rstnet_amd.lm.model import LMGen, LMModel
     cfg = dict(synth.LM_MOSHI_7B if args.lm_config == "moshi7b" else synth.LM_TINY)
     B = args.lm_batch
-    sd = synth.lm_state_dict(cfg, seed=0, device=str(dev))     # generated on the device, bf16
+    # weights: generated on rank 0's device (bf16), then ONE RCCL broadcast over xGMI; the other ranks build their replica on
+    # views of the received blob
+    sd = synth.lm_state_dict(cfg, seed=0, device=str(dev)) if rank == 0 or world == 1 else None
+    if world > 1:
+        from rstnet_amd.parallel import broadcast_state_dict
+        sd = broadcast_state_dict(sd, dev, src=0)
     n_params = sum(v.numel() for v in sd.values())
     model = LMModel.from_state_dict(sd, cfg)
     gen = LMGen(model, use_sampling=not args.greedy, temp=0.8, temp_text=0.7, top_k=250, top_k_text=25)

@@ -22,27 +22,35 @@ def shard_utterances(items: Sequence[T], rank: int, world: int) -> List[T]:
 
 def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]], device: torch.device, src: int = 0,
                          template: Optional[Callable[[], Dict[str, torch.Tensor]]] = None) -> Dict[str, torch.Tensor]:
-    """Rank ``src`` holds ``sd`` (CPU or device tensors); every rank returns the same dict on ``device``.
-    All fp32 tensors travel as ONE flat blob in a single ``dist.broadcast`` (ring collectives over xGMI are
-    per-link bound: one large message beats hundreds of small ones)."""
+    """Rank ``src`` holds ``sd`` (CPU or device tensors, any dtypes); every rank returns the same dict on ``device``.
+    All tensors travel as ONE flat byte blob in a single ``dist.broadcast`` (ring collectives over xGMI are per-link bound:
+    one large message beats hundreds of small ones), each at its own dtype -- a bf16 checkpoint is not widened on the wire.
+    Entries are 16-byte aligned inside the blob, so the returned tensors can be views of it (no second copy of a 15 GB LM)."""
     rank = dist.get_rank()
     meta = [[(k, tuple(v.shape), str(v.dtype)) for k, v in sd.items()]] if rank == src else [None]
     dist.broadcast_object_list(meta, src=src, device=device if device.type == "cuda" else None)
     entries = meta[0]
-    total = sum(int(torch.tensor(shape).prod()) if len(shape) else 1 for _, shape, _ in entries)
-    blob = torch.empty(total, dtype=torch.float32, device=device)
-    if rank == src:
-        off = 0
-        for k, shape, _ in entries:
-            n = sd[k].numel()
-            blob[off:off + n].copy_(sd[k].reshape(-1).to(torch.float32))
-            off += n
-    dist.broadcast(blob, src=src)
-    out, off = {}, 0
-    for k, shape, dtype in entries:
+    offsets, total = [], 0
+    for _, shape, dtype in entries:
+        dt = getattr(torch, dtype.split(".")[1])
         n = 1
-        for s in shape:
-            n *= s
-        out[k] = blob[off:off + n].view(shape).to(getattr(torch, dtype.split(".")[1])).clone()
-        off += n
+        for d in shape:
+            n *= d
+        offsets.append(total)
+        total += (n * torch.empty((), dtype=dt).element_size() + 15) // 16 * 16
+    blob = torch.zeros(total, dtype=torch.uint8, device=device)
+    if rank == src:
+        for (k, shape, _), off in zip(entries, offsets):
+            t = sd[k].detach().contiguous().reshape(-1)
+            nbytes = t.numel() * t.element_size()
+            blob[off:off + nbytes].copy_(t.view(torch.uint8) if t.numel() else t.new_empty(0, dtype=torch.uint8))
+    dist.broadcast(blob, src=src)
+    out = {}
+    for (k, shape, dtype), off in zip(entries, offsets):
+        dt = getattr(torch, dtype.split(".")[1])
+        n = 1
+        for d in shape:
+            n *= d
+        nbytes = n * torch.empty((), dtype=dt).element_size()
+        out[k] = blob[off:off + nbytes].view(dt).view(shape)
     return out

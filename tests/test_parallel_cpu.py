@@ -21,11 +21,16 @@ def _worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g = torch.Generator().manual_seed(3)
-        sd = {"a.weight": torch.randn(5, 7, generator=g), "b.bias": torch.randn(11, generator=g), "c": torch.ones(1)} if rank == 0 else None
+        def make():
+            g = torch.Generator().manual_seed(3)
+            return {"a.weight": torch.randn(5, 7, generator=g), "b.bias": torch.randn(11, generator=g), "c": torch.ones(1),
+                    "w.bf16": torch.randn(3, 5, generator=g).bfloat16(), "ids": torch.arange(7), "flag": torch.tensor([True, False]),
+                    "empty": torch.zeros(0, 4)}
+        sd = make() if rank == 0 else None
         got = parallel.broadcast_state_dict(sd, torch.device("cpu"), src=0)
-        g = torch.Generator().manual_seed(3)
-        exp = {"a.weight": torch.randn(5, 7, generator=g), "b.bias": torch.randn(11, generator=g), "c": torch.ones(1)}
-        ok = list(got) == list(exp) and all(torch.equal(got[k], exp[k]) for k in exp)
+        exp = make()
+        ok = list(got) == list(exp) and all(got[k].dtype == exp[k].dtype and got[k].shape == exp[k].shape and torch.equal(got[k], exp[k])
+                                            for k in exp)
         mine = parallel.shard_utterances(list(range(10)), rank, world)
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
