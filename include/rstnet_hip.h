@@ -111,9 +111,11 @@ int rst_linear_f32(const float* x, const float* w, const float* bias, const floa
 
 /* rst_linear_f32 for M = B <= 4 rows (the streaming steps of the Mimi transformers: one or two 25 Hz positions per 80 ms
  * frame): a weight-streaming GEMV over the fp32 [N][K] matrix -- every CU pulls rows, no split-K hand-off.  Same epilogue
- * order as rst_linear_f32: y = res + scale[n] * act(bias[n] + x . w[n]), act_out 0 / RST_ACT_GELU.  K % 8 == 0. */
-int rst_gemv_f32(const float* x, const float* w, const float* bias, const float* res, const float* scale, float* y, int B, int N,
-                 int K, int act_out, rst_stream_t stream);
+ * order as rst_linear_f32: y = res + scale[n] * act(bias[n] + LN(x) . w[n]), act_out 0 / RST_ACT_GELU.  K % 8 == 0.
+ * ln_gamma / ln_beta [K] (both or neither): the nn.LayerNorm(K, ln_eps) that precedes the linear in a transformer layer
+ * (norm1 -> in_proj, norm2 -> linear1, modules/transformer.py:540-569) runs as the prologue of this launch. */
+int rst_gemv_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* w, const float* bias,
+                 const float* res, const float* scale, float* y, int B, int N, int K, int act_out, rst_stream_t stream);
 
 /* nn.LayerNorm(D, eps) over the last dim (modules/transformer.py:113-114). */
 int rst_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int D, float eps,

@@ -119,9 +119,11 @@ class StreamingMultiheadAttention(StreamingModule[_MHAState]):
         return _MHAState(torch.zeros(shape, device=dev, dtype=torch.float32), torch.zeros(shape, device=dev, dtype=torch.float32),
                          torch.zeros(1, device=dev, dtype=torch.long), 0)
 
-    def _project(self, weight: torch.Tensor, x: torch.Tensor, offset: int, **epilogue) -> torch.Tensor:
+    def _project(self, weight: torch.Tensor, x: torch.Tensor, offset: int, ln=None, **epilogue) -> torch.Tensor:
         if not self.weights_per_step:
-            return ops.linear(x, weight, **epilogue)
+            return ops.linear(x, weight, ln=ln, **epilogue)
+        if ln is not None:
+            x = ops.layernorm(x, *ln)
         # multi_linear (transformer.py:155-179): step t uses weight chunk t + offset
         B, T, _ = x.shape
         w = weight.view(self.weights_per_step, -1, weight.shape[1])
@@ -132,15 +134,16 @@ class StreamingMultiheadAttention(StreamingModule[_MHAState]):
         return torch.stack(outs, 1)
 
     def forward(self, query: torch.Tensor, key: Optional[torch.Tensor] = None, value: Optional[torch.Tensor] = None, *,
-                res: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                res: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, ln=None) -> torch.Tensor:
         """query ``[B, T, C]`` (self-attention: key / value are ignored, as in the reference).  With ``res`` the result
-        is ``res + scale * out_proj(attn)`` computed in the out-projection's epilogue."""
+        is ``res + scale * out_proj(attn)`` computed in the out-projection's epilogue; ``ln = (gamma, beta, eps)``: the layer's
+        ``norm1`` applied to ``query`` inside the in-projection launch."""
         state = self._streaming_state
         x = query.contiguous()
         B, T, _ = x.shape
         H = self.num_heads
         offset = state.offset_cpu if state is not None else 0
-        qkv = self._project(self.in_proj_weight, x, offset)
+        qkv = self._project(self.in_proj_weight, x, offset, ln=ln)
         use_rope = self.rope is not None
         period = self.rope.max_period if use_rope else 10000.0
         if state is None:
@@ -204,11 +207,18 @@ class StreamingTransformerLayer(StreamingModule[_LayerState]):
     def _scale(ls: nn.Module) -> Optional[torch.Tensor]:
         return ls.scale if isinstance(ls, LayerScale) else None
 
+    @staticmethod
+    def _ln(norm: nn.Module):
+        if not isinstance(norm, LayerNorm):
+            raise NotImplementedError(f"norm {type(norm).__name__}")
+        return (norm.weight, norm.bias, norm.eps)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = x.contiguous()
+        # the two LayerNorms run as prologues of the in-projection / linear1 launches where that form exists
         if not self.skip_self_attn:
-            x = self.self_attn(self.norm1(x), res=x, scale=self._scale(self.layer_scale_1))
-        h = self.linear1(self.norm2(x), act_out=ops.ACT_GELU)
+            x = self.self_attn(x, res=x, scale=self._scale(self.layer_scale_1), ln=self._ln(self.norm1))
+        h = self.linear1(x, act_out=ops.ACT_GELU, ln=self._ln(self.norm2))
         x = self.linear2(h, res=x, scale=self._scale(self.layer_scale_2))
         state = self._streaming_state
         if state:

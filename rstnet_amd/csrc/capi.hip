@@ -190,16 +190,17 @@ int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, i
 int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, const float* bias, float* y,
                       int B, int N, int K, int ldx, int ldy, int prologue, float eps, rst_stream_t stream) {
     GemvParams p;
-    p.x = x; p.alpha = alpha; p.w = w; p.res = res; p.bias = bias; p.scale = nullptr; p.y = y; p.B = B; p.N = N; p.K = K;
-    p.ldx = ldx; p.ldy = ldy; p.prologue = prologue; p.act_out = 0; p.w_f32 = 0; p.eps = eps;
+    p.x = x; p.alpha = alpha; p.beta = nullptr; p.w = w; p.res = res; p.bias = bias; p.scale = nullptr; p.y = y; p.B = B; p.N = N;
+    p.K = K; p.ldx = ldx; p.ldy = ldy; p.prologue = prologue; p.act_out = 0; p.w_f32 = 0; p.eps = eps;
     return rst_launch_gemv(p, (hipStream_t)stream);
 }
 
-int rst_gemv_f32(const float* x, const float* w, const float* bias, const float* res, const float* scale, float* y, int B, int N,
-                 int K, int act_out, rst_stream_t stream) {
+int rst_gemv_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* w, const float* bias,
+                 const float* res, const float* scale, float* y, int B, int N, int K, int act_out, rst_stream_t stream) {
+    RST_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "gemv_f32: LayerNorm needs both gamma and beta");
     GemvParams p;
-    p.x = x; p.alpha = nullptr; p.w = w; p.res = res; p.bias = bias; p.scale = scale; p.y = y; p.B = B; p.N = N; p.K = K;
-    p.ldx = K; p.ldy = N; p.prologue = 0; p.act_out = act_out; p.w_f32 = 1; p.eps = 0.f;
+    p.x = x; p.alpha = ln_gamma; p.beta = ln_beta; p.w = w; p.res = res; p.bias = bias; p.scale = scale; p.y = y; p.B = B; p.N = N;
+    p.K = K; p.ldx = K; p.ldy = N; p.prologue = ln_gamma ? 3 : 0; p.act_out = act_out; p.w_f32 = 1; p.eps = ln_eps;
     return rst_launch_gemv(p, (hipStream_t)stream);
 }
 

@@ -93,6 +93,30 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_kernel(const GemvParams 
             }
             for (int k = tid + XR * 64 * GEMV_WAVES; k < K; k += 64 * GEMV_WAVES) xs[b * K + k] = p.x[(long)b * p.ldx + k] * (p.alpha[k] * r);
         }
+    } else if (p.prologue == 3) {    // nn.LayerNorm(K, eps) with affine gamma = alpha, beta (two-pass statistics, biased variance)
+        for (int b = 0; b < B; ++b) {
+            float s = 0.f;
+            for (int k = tid; k < K; k += 64 * GEMV_WAVES) s += p.x[(long)b * p.ldx + k];
+            s = wave_sum(s);
+            __syncthreads();
+            if (lane == 0) red[wave] = s;
+            __syncthreads();
+            float mean = 0.f;
+#pragma unroll
+            for (int w = 0; w < GEMV_WAVES; ++w) mean += red[w];
+            mean /= (float)K;
+            float v = 0.f;
+            for (int k = tid; k < K; k += 64 * GEMV_WAVES) { const float d = p.x[(long)b * p.ldx + k] - mean; v = fmaf(d, d, v); }
+            v = wave_sum(v);
+            __syncthreads();
+            if (lane == 0) red[wave] = v;
+            __syncthreads();
+            float var = 0.f;
+#pragma unroll
+            for (int w = 0; w < GEMV_WAVES; ++w) var += red[w];
+            const float rstd = 1.0f / sqrtf(var / (float)K + p.eps);
+            for (int k = tid; k < K; k += 64 * GEMV_WAVES) xs[b * K + k] = (p.x[(long)b * p.ldx + k] - mean) * rstd * p.alpha[k] + p.beta[k];
+        }
     } else if (p.prologue == 2) {    // SiLU gate: x holds [B][2K] = [u ; v], xs = silu(u) * v   (modules/gating.py:12-22)
         for (int b = 0; b < B; ++b)
             for (int k = tid; k < K; k += 64 * GEMV_WAVES)
@@ -196,7 +220,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 int rst_launch_gemv(const GemvParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B >= 1 && p.B <= 4 && p.N > 0 && p.K > 0 && p.K % 8 == 0, "gemv: need 1 <= B <= 4 and K %% 8 == 0 (B=%d K=%d)", p.B, p.K);
     RST_REQUIRE(p.x && p.w && p.y, "gemv: null pointer");
-    RST_REQUIRE(p.prologue >= 0 && p.prologue <= 2 && (p.prologue != 1 || p.alpha), "gemv: bad prologue");
+    RST_REQUIRE(p.prologue >= 0 && p.prologue <= 3 && (p.prologue != 1 || p.alpha) && (p.prologue != 3 || (p.alpha && p.beta)),
+                "gemv: bad prologue");
     RST_REQUIRE(p.act_out == 0 || p.act_out == 1, "gemv: act_out must be 0 (none) or 1 (GELU)");
     RST_REQUIRE(((uintptr_t)p.w % 16) == 0 && ((uintptr_t)p.x % 16) == 0, "gemv: pointers must be 16-byte aligned");
     const size_t lds = (size_t)p.B * p.K * sizeof(float);

@@ -141,14 +141,15 @@ int rst_launch_rvq_gather(const RvqGatherParams& p, hipStream_t stream);
 // ---- lm_step.hip / lm_attn.hip / lm_sample.hip / lm_skinny.hip ------------------------------------------------------------------------------
 struct GemvParams {
     const float* x;             // [B][ldx] fp32 activations (prologue 2: [B][2K] = [u ; v])
-    const float* alpha;         // prologue 1: RMSNorm gain [K]
+    const float* alpha;         // prologue 1: RMSNorm gain [K]; prologue 3: LayerNorm gamma [K]
+    const float* beta;          // prologue 3: LayerNorm beta [K]
     const void* w;              // [N][K] bf16 (w_f32 == 0) or fp32 (w_f32 == 1)
     const float* res;           // optional [B][ldy]
     const float* bias;          // optional [N]
     const float* scale;         // optional [N]: LayerScale applied before the residual
     float* y;                   // [B][ldy]
     int B, N, K, ldx, ldy;
-    int prologue;               // 0 none, 1 RMSNorm, 2 SiLU gate
+    int prologue;               // 0 none, 1 RMSNorm, 2 SiLU gate, 3 LayerNorm
     int act_out;                // 0 none, 1 exact GELU (after the bias)
     int w_f32;
     float eps;

@@ -138,8 +138,10 @@ def gemm_win(x: torch.Tensor, w: torch.Tensor, *, B: int, T_in: int, T_out: int,
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, res: Optional[torch.Tensor] = None,
-           scale: Optional[torch.Tensor] = None, act_out: int = ACT_NONE) -> torch.Tensor:
-    """``y = epi(x @ w.T + bias)`` over the last dim of ``x`` (rst_linear_f32)."""
+           scale: Optional[torch.Tensor] = None, act_out: int = ACT_NONE,
+           ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> torch.Tensor:
+    """``y = epi(LN(x) @ w.T + bias)`` over the last dim of ``x`` (rst_linear_f32).  ``ln = (gamma, beta, eps)``: the LayerNorm in
+    front of the linear; it is the prologue of the launch on the one/two-position GEMV route and a separate launch otherwise."""
     for t, n in ((x, "x"), (w, "w"), (bias, "bias"), (res, "res"), (scale, "scale")):
         _chk(t, n)
     K = x.shape[-1]
@@ -149,8 +151,13 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
     if 1 <= M <= 4 and K % 8 == 0 and K * M <= 32768 and act_out in (ACT_NONE, ACT_GELU):
         # a streaming step of one or two positions: weight-streaming GEMV (every CU pulls rows of w; no split-K hand-off)
-        _lib.check(_lib.lib().rst_gemv_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, N, K, act_out, _stream()))
+        g, b, eps = ln if ln is not None else (None, None, 0.0)
+        _chk(g, "ln gamma"); _chk(b, "ln beta")
+        _lib.check(_lib.lib().rst_gemv_f32(_ptr(x), _ptr(g), _ptr(b), float(eps), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out),
+                                           M, N, K, act_out, _stream()))
         return out
+    if ln is not None:
+        x = layernorm(x, ln[0], ln[1], ln[2])
     if _few_rows(M, N, K) and PROFILE is None:
         _gemm_few_rows(x, None, w, bias, res, scale, out, 1, M, M, K, K, N, 1, 0, 0, ACT_NONE, act_out)
         return out
