@@ -3,7 +3,7 @@
 #   bench JSON lines, rocprofv3 kernel traces (--kernel-trace --stats) and the two PMC passes (FETCH_SIZE / WRITE_SIZE) per
 #   workload.  The raw rocprof outputs are reduced on the box (tools/rocpd_summary.py, tools/pmc_traffic.py) to the small
 #   files that are then copied into profiles/ and committed; only those travel back (gpurun_out/ is capped at 64 MiB).
-TAG=${1:-r01d}
+TAG=${1:-r01f}
 WHAT=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG
