@@ -27,9 +27,10 @@ def main(root):
             agg[key]["n"] += 1
     for k, c in sorted(agg.items(), key=lambda kv: -kv[1]["ns"])[:16]:
         w = c["SQ_WAVE_CYCLES"] or 1.0
-        print("%-64s n=%3d ms=%7.2f wait_any=%.2f wait_inst=%.2f (lds %.2f) active=%.2f bankconf/lds_active=%.2f" % (
+        print("%-64s n=%3d ms=%7.2f wait_any=%.2f wait_inst=%.2f (lds %.2f) active=%.2f bankconf/lds_active=%.2f waves_resident=%.2f" % (
             k[:64], c["n"], c["ns"] / 1e6, c["SQ_WAIT_ANY"] / w, c["SQ_WAIT_INST_ANY"] / w, c["SQ_WAIT_INST_LDS"] / w,
-            c["SQ_ACTIVE_INST_ANY"] / w, c["SQ_LDS_BANK_CONFLICT"] / max(1.0, c["SQ_LDS_IDX_ACTIVE"])))
+            c["SQ_ACTIVE_INST_ANY"] / w, c["SQ_LDS_BANK_CONFLICT"] / max(1.0, c["SQ_LDS_IDX_ACTIVE"]),
+            c["SQ_WAVE_CYCLES"] / max(1.0, c["SQ_BUSY_CYCLES"])))      # average waves resident per busy SQ (both in quad-cycles)
 
 
 if __name__ == "__main__":
