@@ -28,6 +28,32 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class _PackedWeights:
+    """Cache of device-side re-packed copies of weight tensors, keyed by (device, address, shape).  An entry dies with the
+    STORAGE of its source (weak reference): per-step slices of a parameter are fresh tensor objects on every call but share
+    the parameter's storage, and an address that the allocator hands out again after a free can never hit a stale entry.
+    A changed ``_version`` (in-place update of the weights) re-packs."""
+
+    def __init__(self):
+        self._d: dict = {}
+
+    def get(self, w: torch.Tensor, build):
+        from torch.multiprocessing.reductions import StorageWeakRef
+        key = (w.device, w.data_ptr(), tuple(w.shape), w.dtype)
+        hit = self._d.get(key)
+        if hit is not None and hit[1] == w._version and not hit[2].expired():
+            return hit[0]
+        if len(self._d) > 64:
+            for k in [k for k, v in self._d.items() if v[2].expired()]:
+                del self._d[k]
+        packed = build()
+        self._d[key] = (packed, w._version, StorageWeakRef(w.untyped_storage()))
+        return packed
+
+    def clear(self) -> None:
+        self._d.clear()
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     if t is None:
         return None
@@ -66,7 +92,7 @@ def _gemm_split_scratch(device, M: int, N: int, K: int):
     return sc
 
 
-_skinny_f32_weights: dict = {}
+_skinny_f32_weights = _PackedWeights()
 SKINNY_F32_MAX_ROWS = 128
 
 
@@ -74,14 +100,12 @@ def skinny_f32_pack_weight(w: torch.Tensor) -> torch.Tensor:
     """fp32 ``[N, K]`` -> MFMA-ordered copy ``[ceil(N/32)*32, ceil(K/8)*8]`` (rst_skinny_f32_pack_weight), cached per storage."""
     _chk(w, "w")
     N, K = w.shape
-    key = (w.device, w.data_ptr(), N, K)
-    hit = _skinny_f32_weights.get(key)
-    if hit is not None and hit[1] == w._version:
-        return hit[0]
-    wp = torch.empty((N + 31) // 32 * 32, (K + 7) // 8 * 8, device=w.device, dtype=torch.float32)
-    _lib.check(_lib.lib().rst_skinny_f32_pack_weight(_ptr(w), _ptr(wp), N, K, _stream()))
-    _skinny_f32_weights[key] = (wp, w._version, w)
-    return wp
+
+    def build():
+        wp = torch.empty((N + 31) // 32 * 32, (K + 7) // 8 * 8, device=w.device, dtype=torch.float32)
+        _lib.check(_lib.lib().rst_skinny_f32_pack_weight(_ptr(w), _ptr(wp), N, K, _stream()))
+        return wp
+    return _skinny_f32_weights.get(w, build)
 
 
 def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, S, P, pad_mode, act_in, act_out) -> None:
@@ -431,22 +455,20 @@ def gemv_bf16(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE
     return out
 
 
-_skinny_weights: dict = {}
+_skinny_weights = _PackedWeights()
 
 
 def skinny_pack_weight(w: torch.Tensor) -> torch.Tensor:
     """bf16 ``[N, K]`` -> the MFMA-ordered copy ``[ceil(N/32)*32, K]`` of rst_skinny_pack_weight_bf16, cached per weight
-    storage (the row-major original stays: the batch <= 4 GEMV streams that one)."""
+    storage (the row-major original stays: the batch <= 2 GEMV streams that one)."""
     _chk(w, "w", torch.bfloat16)
     N, K = w.shape
-    key = (w.device, w.data_ptr(), N, K)
-    hit = _skinny_weights.get(key)
-    if hit is not None and hit[1] == w._version:
-        return hit[0]
-    wp = torch.empty((N + 31) // 32 * 32, K, device=w.device, dtype=torch.bfloat16)
-    _lib.check(_lib.lib().rst_skinny_pack_weight_bf16(_ptr(w), _ptr(wp), N, K, _stream()))
-    _skinny_weights[key] = (wp, w._version, w)      # keeps the source alive so that its address cannot be recycled
-    return wp
+
+    def build():
+        wp = torch.empty((N + 31) // 32 * 32, K, device=w.device, dtype=torch.bfloat16)
+        _lib.check(_lib.lib().rst_skinny_pack_weight_bf16(_ptr(w), _ptr(wp), N, K, _stream()))
+        return wp
+    return _skinny_weights.get(w, build)
 
 
 def skinny_pack_act(x: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
@@ -484,23 +506,21 @@ def gemm_skinny(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NO
     return out
 
 
-_skinny_weights_fp8: dict = {}
+_skinny_weights_fp8 = _PackedWeights()
 
 
 def skinny_pack_weight_fp8(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """bf16 ``[N, K]`` -> (fp8 e4m3 copy in MFMA order ``[ceil(N/32)*32, K]`` uint8, per-row scales fp32), cached per weight."""
     _chk(w, "w", torch.bfloat16)
     N, K = w.shape
-    key = (w.device, w.data_ptr(), N, K)
-    hit = _skinny_weights_fp8.get(key)
-    if hit is not None and hit[2] == w._version:
-        return hit[0], hit[1]
-    n32 = (N + 31) // 32 * 32
-    wp = torch.empty(n32, K, device=w.device, dtype=torch.uint8)
-    sc = torch.empty(n32, device=w.device, dtype=torch.float32)
-    _lib.check(_lib.lib().rst_skinny_pack_weight_fp8(_ptr(w), _ptr(wp), _ptr(sc), N, K, _stream()))
-    _skinny_weights_fp8[key] = (wp, sc, w._version, w)
-    return wp, sc
+
+    def build():
+        n32 = (N + 31) // 32 * 32
+        wp = torch.empty(n32, K, device=w.device, dtype=torch.uint8)
+        sc = torch.empty(n32, device=w.device, dtype=torch.float32)
+        _lib.check(_lib.lib().rst_skinny_pack_weight_fp8(_ptr(w), _ptr(wp), _ptr(sc), N, K, _stream()))
+        return wp, sc
+    return _skinny_weights_fp8.get(w, build)
 
 
 def gemm_skinny_fp8(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
