@@ -244,10 +244,13 @@ int rst_lm_rope_append_f32(const float* qkv, float* q, float* k, float* v, const
  * once by the caller (the last-arriving workgroup combines and re-arms its counter; agent-scope release / acquire).
  * Grouped-query attention (CausalSelfAttention, models/llama_streaming.py:935-998): qkv = [q (H*D) | k (G*D) | v (G*D)],
  * ring [B][G][cap][D] with G = kv_heads (0 -> H) -- the reference caches keys expanded to H heads (:965-971), the grouped
- * ring holds the same values once.  rope_dims: leading head dims that rotate (config.rope_n_elem; 0 -> D). */
+ * ring holds the same values once.  rope_dims: leading head dims that rotate (config.rope_n_elem; 0 -> D).
+ * out_packed (optional, then out may be NULL; D = 64 / 128): the result is written as the packed bf16 hi / lo operand
+ * [2][ceil(B/32)*32][H*D] of rst_gemm_skinny_bf16_f32 (the out-projection that follows) instead of fp32 -- one launch less per
+ * layer; rows past B of the buffer are not touched (keep them zero). */
 int rst_lm_attn_decode_f32(const float* qkv, float* k, float* v, float* ws, uint32_t* counters, float* out,
                            const int64_t* pos_dev, int B, int H, int D, int cap, int context, int splits, int ldqkv, int rope,
-                           float rope_coef, int kv_heads, int rope_dims, rst_stream_t stream);
+                           float rope_coef, int kv_heads, int rope_dims, uint16_t* out_packed, rst_stream_t stream);
 
 /* The few-query form of rst_attention_f32(ring = 1) for streaming steps of the codec transformers (T <= a few new steps per
  * call): q [B][H][T][D] already rotated and k / v already appended by rst_rope_split_f32; every (b, t, h) query is split

@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
             O += sm_o[w][tid] * fw;
         }
         if (active == 1) {                          // single split: finished
-            p.out[((b * T + tq) * p.H + h) * (long)D + tid] = L > 0.f ? O / L : 0.f;
+            const float r = L > 0.f ? O / L : 0.f;
+            if (p.out_packed) sm_o[0][tid] = r;     // each thread reads / writes only its own column of sm_o[0]
+            else p.out[((b * T + tq) * p.H + h) * (long)D + tid] = r;
         } else {
             // write-through (sc1) partials: visible at agent scope without an L2 write-back fence (cdna_hip_programming.md G16 R1)
             float* ws = p.ws + ((((long)blockIdx.z * p.H + h) * gridDim.x) + split) * (long)(D + 2);
@@ -187,7 +189,20 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
             }
         }
     }
-    if (active == 1) return;
+    // packed output (the operand layout of the skinny GEMM that consumes the attention result): 8 consecutive dims per thread
+    auto emit_packed = [&]() {
+        __syncthreads();
+        if (tid < D / 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = sm_o[0][tid * 8 + j];
+            store_packed8(p.out_packed, p.out_plane, (int)b, h * D + tid * 8, p.H * D, v);
+        }
+    };
+    if (active == 1) {
+        if (p.out_packed) emit_packed();
+        return;
+    }
     // In-launch reduction of the splits: every storing wave drains its write-through stores, ONE lane bumps the arrival
     // counter; the LAST arriver of (b, h) reads the partials with agent-scope (L1-bypassing) loads, combines, and re-arms the
     // counter for the next launch.  No dispatch-order / placement assumption.
@@ -214,8 +229,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
             L = fmaf(__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fw, L);
             O = fmaf(__hip_atomic_load(w + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fw, O);
         }
-        p.out[((b * T + tq) * p.H + h) * (long)D + tid] = L > 0.f ? O / L : 0.f;
+        const float r = L > 0.f ? O / L : 0.f;
+        if (p.out_packed) sm_o[0][tid] = r;
+        else p.out[((b * T + tq) * p.H + h) * (long)D + tid] = r;
     }
+    if (p.out_packed) emit_packed();
 }
 
 // Short ring (capacity <= 64, e.g. the depth transformer's 8 steps): one wave per (b, h), no split and no workspace.
@@ -317,6 +335,18 @@ __global__ __launch_bounds__(64) void attn_small_kernel(const LmAttnParams p) {
         o[i] = o[i] / l;
     }
     if (g == 0) {
+        if constexpr (DPL % 8 == 0) {
+            if (p.out_packed) {
+#pragma unroll
+                for (int i = 0; i < DPL; i += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = o[i + j];
+                    store_packed8(p.out_packed, p.out_plane, (int)b, h * D + c * DPL + i, p.H * D, v);
+                }
+                return;
+            }
+        }
         float* out = p.out + (b * p.H + h) * (long)D + c * DPL;
 #pragma unroll
         for (int i = 0; i < DPL; i += 4) *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(o + i);
@@ -337,8 +367,9 @@ int rst_launch_lm_rope_append(const LmRopeAppendParams& p, hipStream_t stream) {
 }
 
 int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream) {
-    RST_REQUIRE((p.qkv || p.q_pre) && p.k && p.v && p.out && p.pos_dev && p.B >= 1 && p.H > 0 && p.cap > 0 && p.splits >= 1,
+    RST_REQUIRE((p.qkv || p.q_pre) && p.k && p.v && (p.out || p.out_packed) && p.pos_dev && p.B >= 1 && p.H > 0 && p.cap > 0 && p.splits >= 1,
                 "lm_attn: bad arguments");
+    RST_REQUIRE(!p.out_packed || (!p.q_pre && (p.D == 64 || p.D == 128)), "lm_attn: packed output needs the single-step form and head dim 64 / 128");
     const int T = p.q_pre ? p.T : 1;
     RST_REQUIRE(T >= 1 && (long)p.B * T <= 65535 && p.H <= 65535 && p.D % 2 == 0, "lm_attn: bad sizes");
     RST_REQUIRE(p.G >= 1 && p.H % p.G == 0 && p.rope_dims >= 0 && p.rope_dims <= p.D && p.rope_dims % 2 == 0,

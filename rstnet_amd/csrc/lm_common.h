@@ -37,6 +37,33 @@ __device__ __forceinline__ bool ring_visible(int slot, long pos, int cap, int co
     return ok;
 }
 
+// ---- MFMA-ordered operand layout of the skinny GEMM (lm_skinny.hip) -- shared with the producers that emit it directly
+// [tile of 32 rows][K/16][64 lanes = 32 * ((k / 8) % 2) + row % 32][8 bf16]
+__device__ __forceinline__ long packed_index(int row, int k, int K) {
+    return ((((long)(row >> 5) * (K >> 4) + (k >> 4)) * 64) + ((k >> 3) & 1) * 32 + (row & 31)) * 8 + (k & 7);
+}
+
+// 8 fp32 -> bf16 hi (truncated: an exact fp32 prefix, so x - hi is exact) and bf16 lo (residual rounded half-up): x = hi + lo
+// to 2^-17.  v_perm_b32 packs the upper halves of two dwords in one instruction.
+__device__ __forceinline__ void split_hi_lo8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned ua = __float_as_uint(v[2 * j]), ub = __float_as_uint(v[2 * j + 1]);
+        hi[j] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                 // {hi16(b), hi16(a)}
+        const float ra = v[2 * j] - __uint_as_float(ua & 0xffff0000u), rb = v[2 * j + 1] - __uint_as_float(ub & 0xffff0000u);
+        lo[j] = __builtin_amdgcn_perm(__float_as_uint(rb) + 0x8000u, __float_as_uint(ra) + 0x8000u, 0x07060302u);
+    }
+}
+
+// writes 8 consecutive k (k % 8 == 0) of batch row `row` into the hi and lo planes of a packed activation buffer
+__device__ __forceinline__ void store_packed8(unsigned short* xp, long plane_elems, int row, int k, int K, const float (&v)[8]) {
+    u32x4 hi, lo;
+    split_hi_lo8(v, hi, lo);
+    const long at = packed_index(row, k, K);
+    *reinterpret_cast<u32x4*>(xp + at) = hi;
+    *reinterpret_cast<u32x4*>(xp + plane_elems + at) = lo;
+}
+
 inline unsigned cap_grid(long g, long cap) { return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g)); }
 
 }  // namespace

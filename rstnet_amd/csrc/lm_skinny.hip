@@ -17,10 +17,6 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 // kilobyte: [tile of 32 rows][step of 16 k][lane = 32 * (k / 8 % 2) + row % 32][8 bf16].
 //   weights  Wp : [ceil(N/32)][K/16][64][8]   (rows beyond N zero)        -- packed once per weight (rst_skinny_pack_weight_bf16)
 //   activations Xp: [2 = hi, lo][ceil(B/32)][K/16][64][8] (rows beyond B zero) -- packed per call by the (fused) prologue kernel
-__device__ __forceinline__ long packed_index(int row, int k, int K) {
-    return ((((long)(row >> 5) * (K >> 4) + (k >> 4)) * 64) + ((k >> 3) & 1) * 32 + (row & 31)) * 8 + (k & 7);
-}
-
 __global__ __launch_bounds__(256) void skinny_pack_weight_kernel(const unsigned short* __restrict__ w, unsigned short* __restrict__ wp,
                                                                 int N, int K) {
     const long total = (long)((N + 31) / 32) * 32 * (K / 8);
@@ -72,17 +68,7 @@ __global__ __launch_bounds__(256) void skinny_pack_act_kernel(const float* __res
                 for (int j = 0; j < 4; ++j) { v[j] = silu(v[j]) * g0[j]; v[4 + j] = silu(v[4 + j]) * g1[j]; }
             }
         }
-        unsigned h[4], l[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned ua = __float_as_uint(v[2 * j]), ub = __float_as_uint(v[2 * j + 1]);
-            h[j] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                 // {hi16(b), hi16(a)}
-            const float ra = v[2 * j] - __uint_as_float(ua & 0xffff0000u), rb = v[2 * j + 1] - __uint_as_float(ub & 0xffff0000u);
-            l[j] = __builtin_amdgcn_perm(__float_as_uint(rb) + 0x8000u, __float_as_uint(ra) + 0x8000u, 0x07060302u);
-        }
-        const long at = packed_index(b, k, K);
-        *reinterpret_cast<u32x4*>(xp + at) = u32x4{h[0], h[1], h[2], h[3]};
-        *reinterpret_cast<u32x4*>(xp + half + at) = u32x4{l[0], l[1], l[2], l[3]};
+        store_packed8(xp, half, b, k, K, v);
     }
 }
 

@@ -188,6 +188,8 @@ struct LmAttnParams {
     float* ws;            // [B][H][splits][D+2] workspace: (m, l, o[D]) per split (splits > 1)
     unsigned* counters;   // [B][H] arrival counters, zero before the first launch (re-armed by the kernel)
     float* out;           // [B][H*D]
+    unsigned short* out_packed;   // optional instead of out: bf16 hi / lo planes in skinny-GEMM operand order, K = H*D (T = 1 only)
+    long out_plane;       // elements per plane of out_packed (= ceil(B/32)*32 * H*D); pad rows are never written
     const long* pos_dev;  // position of the new step
     int B, H, D, cap, context, splits, ldqkv, rope;
     float rope_coef;

@@ -379,7 +379,7 @@ class LLAMAStreamingTransformer(StreamingModule[_StepState]):
                                 fp8=f8)
             if T == 1:
                 a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], st.pos, rope=True, context=c.context, max_period=float(c.rope_base),
-                                       scratch=st.scratch, heads=H, rope_dims=n)
+                                       scratch=st.scratch, heads=H, rope_dims=n, packed=B > 2 and not f8)
             else:
                 q = ops.lm_rope_append(qkv.view(B, T, -1), st.k[l], st.v[l], st.pos, heads=H, rope=True,
                                        max_period=float(c.rope_base), rope_dims=n)

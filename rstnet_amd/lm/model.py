@@ -165,7 +165,7 @@ class StreamingTransformer(StreamingModule[_StepState]):
                 w_in, w_out, gate = att.in_proj_weight, att.out_proj.weight, layer.gating
             qkv = ops.lm_linear(x, w_in, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm1.alpha_f32(), eps=layer.norm1.eps)
             a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], st.pos, rope=self.rope, context=self.context,
-                                   max_period=self.max_period, scratch=st.scratch)
+                                   max_period=self.max_period, scratch=st.scratch, packed=x.shape[0] > 2)
             x = ops.lm_linear(a, w_out, res=x)
             h = ops.lm_linear(x, gate.linear_in.weight, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm2.alpha_f32(),
                               eps=layer.norm2.eps)

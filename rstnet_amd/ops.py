@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Optional, Sequence, Tuple
+from typing import NamedTuple, Optional, Sequence, Tuple
 
 import torch
 
@@ -483,16 +483,43 @@ def skinny_pack_act(x: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Op
     return xp
 
 
-def gemm_skinny(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
+class PackedAct(NamedTuple):
+    """Activations already in the skinny GEMM's operand form (bf16 hi / lo planes ``[2, ceil(B/32)*32, K]``, rows past B zero),
+    as emitted directly by a producer kernel (``lm_attn_decode(..., packed=True)``)."""
+    xp: torch.Tensor
+    B: int
+    K: int
+
+
+_packed_out: dict = {}
+
+
+def _packed_buffer(device, B: int, K: int) -> torch.Tensor:
+    """Persistent, zero-initialised operand buffer per shape: producers write rows < B only, so the pad rows stay zero; layers
+    of equal shape share it (launches on one stream are ordered)."""
+    key = (device, B, K)
+    buf = _packed_out.get(key)
+    if buf is None:
+        buf = _packed_out[key] = torch.zeros(2, (B + 31) // 32 * 32, K, device=device, dtype=torch.bfloat16)
+    return buf
+
+
+def gemm_skinny(x, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
                 eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``y[B,N] = (res +) (bias +) P(x) @ w.T`` for 4 < B <= 64 on the bf16 matrix cores: prologue + hi/lo split + packing of
-    the activations (one small launch), then rst_gemm_skinny_bf16_f32 against the packed copy of ``w``."""
+    """``y[B,N] = (res +) (bias +) P(x) @ w.T`` for 2 < B <= 64 on the bf16 matrix cores: prologue + hi/lo split + packing of
+    the activations (one small launch; skipped when ``x`` is a ``PackedAct``), then rst_gemm_skinny_bf16_f32 against the packed
+    copy of ``w``."""
     _chk(res, "res")
     _chk(bias, "bias")
-    B = x.shape[0]
     N, K = w.shape
     wp = skinny_pack_weight(w)
-    xp = skinny_pack_act(x, prologue=prologue, alpha=alpha, eps=eps)
+    if isinstance(x, PackedAct):
+        assert prologue == PROLOGUE_NONE and x.K == K
+        xp, B = x.xp, x.B
+        x = xp
+    else:
+        B = x.shape[0]
+        xp = skinny_pack_act(x, prologue=prologue, alpha=alpha, eps=eps)
     assert xp.shape[2] == K, (tuple(x.shape), N, K, prologue)
     out = torch.empty(B, N, device=x.device, dtype=torch.float32)
     prof = PROFILE
@@ -555,6 +582,8 @@ def lm_linear(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE
               eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, fp8: bool = False) -> torch.Tensor:
     """Batch-size dispatch of one decode-step linear: weight-streaming GEMV for B <= 2, bf16-MFMA skinny GEMM above (the
     prologue then runs inside the activation-packing launch).  ``fp8``: the opt-in e4m3 path (any batch <= 64)."""
+    if isinstance(x, PackedAct):
+        return gemm_skinny(x, w, prologue=prologue, res=res, bias=bias)
     if fp8 and x.shape[0] <= 64 and w.shape[1] % 32 == 0 and w.shape[1] <= 16384:
         return gemm_skinny_fp8(x, w, prologue=prologue, alpha=alpha, eps=eps, res=res, bias=bias)
     # the GEMV stages B x K fp32 activations in LDS: beyond two rows that footprint costs occupancy (fewer weight loads in
@@ -610,7 +639,7 @@ def lm_rope_append(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
 def lm_attn_decode(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos_dev: torch.Tensor, *, rope: bool,
                    context: Optional[int], max_period: float = 10000.0, splits: Optional[int] = None,
                    scratch: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, heads: Optional[int] = None,
-                   rope_dims: int = 0) -> torch.Tensor:
+                   rope_dims: int = 0, packed: bool = False):
     """Single-query attention of the new step given its qkv row ``[B, (H+2G)*D]`` (RoPE, ring append, attention and the
     reduction over slot splits in ONE launch) -> ``[B, H*D]``; the ring is ``[B,G,cap,D]`` (``heads`` = H when G < H).
     ``scratch = (ws [B,H,splits,D+2] fp32, counters [B,H] int32 zeros)`` may be passed to reuse buffers (the counters re-arm
@@ -631,11 +660,14 @@ def lm_attn_decode(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
         ws, counters = scratch
         _chk(ws, "ws"); _chk(counters, "counters", torch.int32)
         assert ws.numel() >= B * H * splits * (D + 2) and counters.numel() >= B * H
-    out = torch.empty(B, H * D, device=qkv.device, dtype=torch.float32)
+    # packed=True (head dim 64 / 128): the result leaves as the bf16 hi / lo operand of the out-projection's skinny GEMM
+    packed = packed and D in (64, 128)
+    out = None if packed else torch.empty(B, H * D, device=qkv.device, dtype=torch.float32)
+    xp = _packed_buffer(qkv.device, B, H * D) if packed else None
     _lib.check(_lib.lib().rst_lm_attn_decode_f32(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(ws), _ptr(counters), _ptr(out),
                                                 _ptr(pos_dev), B, H, D, cap, int(context) if context else 0, splits, qkv.shape[1],
-                                                int(rope), rope_coef(max_period, rope_dims or D), G, rope_dims, _stream()))
-    return out
+                                                int(rope), rope_coef(max_period, rope_dims or D), G, rope_dims, _ptr(xp), _stream()))
+    return PackedAct(xp, B, H * D) if packed else out
 
 
 def lm_sample(logits: torch.Tensor, *, use_sampling: bool, temp: float, top_k: int, noise: Optional[torch.Tensor] = None,
