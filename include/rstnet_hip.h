@@ -194,17 +194,20 @@ int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, con
  * Both operands are kept in the order the MFMA consumes them -- [tile of 32 rows][K/16 steps][64 lanes][8 bf16], lane =
  * 32 * ((k / 8) % 2) + row % 32 -- so that every wave-level load is one contiguous kilobyte:
  *   rst_skinny_pack_weight_bf16: w [N][K] row-major -> wp [ceil(N/32)*32][K] in that order (pad rows zero); once per weight.
+ *     interleave_halves (gated layers, w = [W_u ; W_v], N % 32 == 0): tile t holds rows 16t.. of W_u then the same rows of W_v.
  *   rst_skinny_pack_act_f32: P(x) of one decode step, split into bf16 hi + lo planes (x = hi + lo to 2^-17: fp32-class
  *     accuracy against the fp32 oracle) -> xp [2][ceil(B/32)*32][K]; mode 0 identity, 1 RMSNorm (alpha, eps), 2 SiLU gate
  *     (x rows = [u ; v] of length 2K) -- the same prologues as rst_gemv_bf16_f32.  K % 16 == 0, ldx % 4 == 0.
  *   rst_gemm_skinny_bf16_f32: y[b][n] = (res +) (bias +) sum_k P(x)[b][k] w[n][k]: weights streamed from HBM exactly once,
  *     one workgroup per 32 (64, 128 for large N) weight rows whose 8 waves split K and meet in LDS in a fixed order
- *     (deterministic, no cross-workgroup reduction). */
-int rst_skinny_pack_weight_bf16(const uint16_t* w, uint16_t* wp, int N, int K, rst_stream_t stream);
+ *     (deterministic, no cross-workgroup reduction).  gate_out (optional, then y may be NULL; wp packed with
+ *     interleave_halves, no residual): the epilogue applies silu(u) * v (gating_forward_kernel / LLaMAMLP) and writes the
+ *     result as the packed operand [2][ceil(B/32)*32][N/2] of the next GEMM -- the gated activation never exists in fp32. */
+int rst_skinny_pack_weight_bf16(const uint16_t* w, uint16_t* wp, int N, int K, int interleave_halves, rst_stream_t stream);
 int rst_skinny_pack_act_f32(const float* x, const float* alpha, uint16_t* xp, int B, int K, int ldx, int mode, float eps,
                             rst_stream_t stream);
 int rst_gemm_skinny_bf16_f32(const uint16_t* xp, const uint16_t* wp, const float* res, const float* bias, float* y, int B, int N,
-                             int K, int ldy, rst_stream_t stream);
+                             int K, int ldy, uint16_t* gate_out, rst_stream_t stream);
 
 /* Opt-in fp8 form of the three entry points above (BASELINE.json configs[4]: fp8 MFMA GEMMs on the temporal blocks at batch
  * 32): OCP e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8, weights with one scale per row (amax / 448, quantised once),

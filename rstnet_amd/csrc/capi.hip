@@ -204,8 +204,8 @@ int rst_gemv_f32(const float* x, const float* ln_gamma, const float* ln_beta, fl
     return rst_launch_gemv(p, (hipStream_t)stream);
 }
 
-int rst_skinny_pack_weight_bf16(const uint16_t* w, uint16_t* wp, int N, int K, rst_stream_t stream) {
-    return rst_launch_skinny_pack_weight(w, wp, N, K, (hipStream_t)stream);
+int rst_skinny_pack_weight_bf16(const uint16_t* w, uint16_t* wp, int N, int K, int interleave_halves, rst_stream_t stream) {
+    return rst_launch_skinny_pack_weight(w, wp, N, K, interleave_halves, (hipStream_t)stream);
 }
 
 int rst_skinny_pack_act_f32(const float* x, const float* alpha, uint16_t* xp, int B, int K, int ldx, int mode, float eps,
@@ -214,9 +214,10 @@ int rst_skinny_pack_act_f32(const float* x, const float* alpha, uint16_t* xp, in
 }
 
 int rst_gemm_skinny_bf16_f32(const uint16_t* xp, const uint16_t* wp, const float* res, const float* bias, float* y, int B, int N,
-                             int K, int ldy, rst_stream_t stream) {
+                             int K, int ldy, uint16_t* gate_out, rst_stream_t stream) {
     SkinnyParams p;
     p.xp = xp; p.w = wp; p.res = res; p.bias = bias; p.y = y; p.B = B; p.N = N; p.K = K; p.ldy = ldy;
+    p.gate_out = gate_out; p.gate_plane = (long)((B + 31) / 32 * 32) * (N / 2);
     return rst_launch_gemm_skinny(p, (hipStream_t)stream);
 }
 

@@ -17,13 +17,20 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 // kilobyte: [tile of 32 rows][step of 16 k][lane = 32 * (k / 8 % 2) + row % 32][8 bf16].
 //   weights  Wp : [ceil(N/32)][K/16][64][8]   (rows beyond N zero)        -- packed once per weight (rst_skinny_pack_weight_bf16)
 //   activations Xp: [2 = hi, lo][ceil(B/32)][K/16][64][8] (rows beyond B zero) -- packed per call by the (fused) prologue kernel
+// interleave (gated layers, w = [W_u ; W_v] stacked): packed tile t holds rows 16t..16t+15 of W_u followed by the same rows of W_v,
+// so that one output tile of the GEMM carries matching (u, v) pairs and its epilogue can apply silu(u) * v.
 __global__ __launch_bounds__(256) void skinny_pack_weight_kernel(const unsigned short* __restrict__ w, unsigned short* __restrict__ wp,
-                                                                int N, int K) {
+                                                                int N, int K, int interleave) {
     const long total = (long)((N + 31) / 32) * 32 * (K / 8);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int row = (int)(idx / (K / 8)), k = (int)(idx % (K / 8)) * 8;
+        int src = row;
+        if (interleave) {
+            const int t = row >> 5, r = row & 31;
+            src = (r < 16 ? 0 : N / 2) + t * 16 + (r & 15);
+        }
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < N) v = *reinterpret_cast<const u32x4*>(w + (long)row * K + k);
+        if (row < N) v = *reinterpret_cast<const u32x4*>(w + (long)src * K + k);
         *reinterpret_cast<u32x4*>(wp + packed_index(row, k, K)) = v;
     }
 }
@@ -137,6 +144,28 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
             for (int e = 0; e < 16; ++e) red[wave][t * 32 + rst_mfma32_row(e, lane)][i] = acc[t][c][e];
         __syncthreads();
         const int n0 = (tile0 + c) * 32;
+        if (p.gate_out) {
+            // interleaved gated layer: columns 0..15 of the tile are u, 16..31 the matching v; emit silu(u) * v as the packed
+            // hi / lo operand of the next GEMM (K_out = N / 2), zeros for the pad rows of the batch tile
+            const int half = p.N / 2;
+            for (int idx = tid; idx < NB * 32 * 2; idx += 64 * SKINNY_WAVES) {
+                const int b = idx >> 1, j8 = (idx & 1) * 8;
+                const int kout = (tile0 + c) * 16 + j8;
+                if (kout < half) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float u = 0.f, g = 0.f;
+#pragma unroll
+                        for (int w = 0; w < SKINNY_WAVES; ++w) { u += red[w][b][j8 + j]; g += red[w][b][16 + j8 + j]; }
+                        if (p.bias) { u += p.bias[kout + j]; g += p.bias[half + kout + j]; }
+                        v[j] = b < p.B ? silu(u) * g : 0.f;
+                    }
+                    store_packed8(p.gate_out, p.gate_plane, b, kout, half, v);
+                }
+            }
+            continue;
+        }
         for (int idx = tid; idx < NB * 32 * 32; idx += 64 * SKINNY_WAVES) {
             const int b = idx >> 5, nl = idx & 31;
             const int n = n0 + nl;
@@ -154,10 +183,11 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
 
 }  // namespace
 
-int rst_launch_skinny_pack_weight(const unsigned short* w, unsigned short* wp, int N, int K, hipStream_t stream) {
+int rst_launch_skinny_pack_weight(const unsigned short* w, unsigned short* wp, int N, int K, int interleave, hipStream_t stream) {
     RST_REQUIRE(w && wp && N > 0 && K > 0 && K % 16 == 0, "skinny_pack_weight: bad arguments (K %% 16 == 0 required, K=%d)", K);
+    RST_REQUIRE(!interleave || N % 32 == 0, "skinny_pack_weight: interleaving the two halves needs N %% 32 == 0 (N=%d)", N);
     const long total = (long)((N + 31) / 32) * 32 * (K / 8);
-    hipLaunchKernelGGL(skinny_pack_weight_kernel, dim3(cap_grid((total + 255) / 256, 8192)), dim3(256), 0, stream, w, wp, N, K);
+    hipLaunchKernelGGL(skinny_pack_weight_kernel, dim3(cap_grid((total + 255) / 256, 8192)), dim3(256), 0, stream, w, wp, N, K, interleave);
     return rst_check_launch("skinny_pack_weight");
 }
 
@@ -171,7 +201,8 @@ int rst_launch_skinny_pack_act(const float* x, const float* alpha, unsigned shor
 
 int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B >= 1 && p.B <= 64 && p.N > 0 && p.K > 0 && p.K % 16 == 0, "gemm_skinny: need 1 <= B <= 64 and K %% 16 == 0 (B=%d K=%d)", p.B, p.K);
-    RST_REQUIRE(p.xp && p.w && p.y, "gemm_skinny: null pointer");
+    RST_REQUIRE(p.xp && p.w && (p.y || p.gate_out), "gemm_skinny: null pointer");
+    RST_REQUIRE(!p.gate_out || (p.N % 32 == 0 && !p.res), "gemm_skinny: the gated epilogue needs N %% 32 == 0 and takes no residual");
     const int tiles = (p.N + 31) / 32;
     const int threads = 64 * SKINNY_WAVES;
     if (p.B <= 32) {

@@ -216,6 +216,8 @@ struct SkinnyParams {
     const float* bias;          // optional [N]
     float* y;                   // [B][ldy]
     int B, N, K, ldy;
+    unsigned short* gate_out;   // optional instead of y (weights packed with interleave): silu(u) * v as packed hi / lo planes, K = N/2
+    long gate_plane;            // elements per plane of gate_out
 };
 int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream);
 struct SkinnyFp8Params {
@@ -232,6 +234,6 @@ int rst_launch_gemm_skinny_fp8(const SkinnyFp8Params& p, hipStream_t stream);
 int rst_launch_skinny_pack_weight_fp8(const unsigned short* w, unsigned char* wp, float* scale, int N, int K, hipStream_t stream);
 int rst_launch_skinny_pack_act_fp8(const float* x, const float* alpha, unsigned char* xp, float* xscale, int B, int K, int ldx, int mode,
                                    float eps, hipStream_t stream);
-int rst_launch_skinny_pack_weight(const unsigned short* w, unsigned short* wp, int N, int K, hipStream_t stream);
+int rst_launch_skinny_pack_weight(const unsigned short* w, unsigned short* wp, int N, int K, int interleave, hipStream_t stream);
 int rst_launch_skinny_pack_act(const float* x, const float* alpha, unsigned short* xp, int B, int K, int ldx, int mode, float eps,
                                hipStream_t stream);

@@ -386,8 +386,8 @@ class LLAMAStreamingTransformer(StreamingModule[_StepState]):
                 a = ops.attention(q, st.k[l], st.v[l], pos_dev=st.pos, ring=True, context=c.context).view(B * T, H * hs)
             x = ops.lm_linear(a, blk.attn.proj.weight, res=x, bias=blk.attn.proj.bias_f32(), fp8=f8)
             wfc, bfc = blk.mlp.packed_fc()
-            u = ops.lm_linear(x, wfc, prologue=ops.PROLOGUE_RMSNORM, alpha=blk.norm_2.gain_f32(), eps=blk.norm_2.eps, bias=bfc, fp8=f8)
-            x = ops.lm_linear(u, blk.mlp.proj.weight, prologue=ops.PROLOGUE_SILU_GATE, res=x, bias=blk.mlp.proj.bias_f32(), fp8=f8)
+            x = ops.lm_gated_pair(x, wfc, blk.mlp.proj.weight, alpha=blk.norm_2.gain_f32(), eps=blk.norm_2.eps, res=x, bias_in=bfc,
+                                  bias_out=blk.mlp.proj.bias_f32(), fp8=f8)
         st.pos.add_(T)
         st.offset_cpu += T
         return ops.rmsnorm(x, self.ln_f.gain_f32(), self.ln_f.eps)

@@ -167,9 +167,8 @@ class StreamingTransformer(StreamingModule[_StepState]):
             a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], st.pos, rope=self.rope, context=self.context,
                                    max_period=self.max_period, scratch=st.scratch, packed=x.shape[0] > 2)
             x = ops.lm_linear(a, w_out, res=x)
-            h = ops.lm_linear(x, gate.linear_in.weight, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm2.alpha_f32(),
-                              eps=layer.norm2.eps)
-            x = ops.lm_linear(h, gate.linear_out.weight, prologue=ops.PROLOGUE_SILU_GATE, res=x)
+            x = ops.lm_gated_pair(x, gate.linear_in.weight, gate.linear_out.weight, alpha=layer.norm2.alpha_f32(), eps=layer.norm2.eps,
+                                  res=x)
         st.pos.add_(1)
         st.offset_cpu += 1
         return x

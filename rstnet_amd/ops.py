@@ -456,19 +456,21 @@ def gemv_bf16(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE
 
 
 _skinny_weights = _PackedWeights()
+_skinny_weights_gated = _PackedWeights()
 
 
-def skinny_pack_weight(w: torch.Tensor) -> torch.Tensor:
+def skinny_pack_weight(w: torch.Tensor, interleave_halves: bool = False) -> torch.Tensor:
     """bf16 ``[N, K]`` -> the MFMA-ordered copy ``[ceil(N/32)*32, K]`` of rst_skinny_pack_weight_bf16, cached per weight
-    storage (the row-major original stays: the batch <= 2 GEMV streams that one)."""
+    storage (the row-major original stays: the batch <= 2 GEMV streams that one).  ``interleave_halves``: the layout of gated
+    layers (``w = [W_u ; W_v]``) whose GEMM applies ``silu(u) * v`` in its epilogue."""
     _chk(w, "w", torch.bfloat16)
     N, K = w.shape
 
     def build():
         wp = torch.empty((N + 31) // 32 * 32, K, device=w.device, dtype=torch.bfloat16)
-        _lib.check(_lib.lib().rst_skinny_pack_weight_bf16(_ptr(w), _ptr(wp), N, K, _stream()))
+        _lib.check(_lib.lib().rst_skinny_pack_weight_bf16(_ptr(w), _ptr(wp), N, K, int(interleave_halves), _stream()))
         return wp
-    return _skinny_weights.get(w, build)
+    return (_skinny_weights_gated if interleave_halves else _skinny_weights).get(w, build)
 
 
 def skinny_pack_act(x: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
@@ -494,10 +496,11 @@ class PackedAct(NamedTuple):
 _packed_out: dict = {}
 
 
-def _packed_buffer(device, B: int, K: int) -> torch.Tensor:
+def _packed_buffer(device, B: int, K: int, role: str = "in") -> torch.Tensor:
     """Persistent, zero-initialised operand buffer per shape: producers write rows < B only, so the pad rows stay zero; layers
-    of equal shape share it (launches on one stream are ordered)."""
-    key = (device, B, K)
+    of equal shape share it (launches on one stream are ordered).  ``role`` keeps the output of a GEMM that emits a packed
+    operand apart from the operand it reads."""
+    key = (device, B, K, role)
     buf = _packed_out.get(key)
     if buf is None:
         buf = _packed_out[key] = torch.zeros(2, (B + 31) // 32 * 32, K, device=device, dtype=torch.bfloat16)
@@ -505,14 +508,15 @@ def _packed_buffer(device, B: int, K: int) -> torch.Tensor:
 
 
 def gemm_skinny(x, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
-                eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+                eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, gate_out: bool = False):
     """``y[B,N] = (res +) (bias +) P(x) @ w.T`` for 2 < B <= 64 on the bf16 matrix cores: prologue + hi/lo split + packing of
     the activations (one small launch; skipped when ``x`` is a ``PackedAct``), then rst_gemm_skinny_bf16_f32 against the packed
     copy of ``w``."""
     _chk(res, "res")
     _chk(bias, "bias")
     N, K = w.shape
-    wp = skinny_pack_weight(w)
+    gate_out = gate_out and N % 32 == 0 and res is None
+    wp = skinny_pack_weight(w, interleave_halves=gate_out)
     if isinstance(x, PackedAct):
         assert prologue == PROLOGUE_NONE and x.K == K
         xp, B = x.xp, x.B
@@ -521,16 +525,18 @@ def gemm_skinny(x, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Opt
         B = x.shape[0]
         xp = skinny_pack_act(x, prologue=prologue, alpha=alpha, eps=eps)
     assert xp.shape[2] == K, (tuple(x.shape), N, K, prologue)
-    out = torch.empty(B, N, device=x.device, dtype=torch.float32)
+    # gate_out: w is a stacked [W_u ; W_v]; the epilogue emits silu(u) * v as the packed operand of the next GEMM
+    out = None if gate_out else torch.empty(B, N, device=x.device, dtype=torch.float32)
+    gp = _packed_buffer(x.device, B, N // 2, "gate") if gate_out else None
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.lib().rst_gemm_skinny_bf16_f32(_ptr(xp), _ptr(wp), _ptr(res), _ptr(bias), _ptr(out), B, N, K, N, _stream()))
+    _lib.check(_lib.lib().rst_gemm_skinny_bf16_f32(_ptr(xp), _ptr(wp), _ptr(res), _ptr(bias), _ptr(out), B, N, K, N, _ptr(gp), _stream()))
     if prof is not None:
         e1.record()
-        prof.append(("gemm_skinny", e0, e1, 2.0 * B * N * K, 2 * N * K + 4 * (x.numel() + out.numel()), (B, N, K)))
-    return out
+        prof.append(("gemm_skinny", e0, e1, 2.0 * B * N * K, 2 * N * K + 4 * (x.numel() + B * N), (B, N, K)))
+    return PackedAct(gp, B, N // 2) if gate_out else out
 
 
 _skinny_weights_fp8 = _PackedWeights()
@@ -576,6 +582,19 @@ def gemm_skinny_fp8(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGU
         e1.record()
         prof.append(("gemm_skinny_fp8", e0, e1, 2.0 * B * N * K, N * K + 4 * (x.numel() + out.numel()), (B, N, K)))
     return out
+
+
+def lm_gated_pair(x: torch.Tensor, w_in: torch.Tensor, w_out: torch.Tensor, *, alpha: torch.Tensor, eps: float, res: torch.Tensor,
+                  bias_in: Optional[torch.Tensor] = None, bias_out: Optional[torch.Tensor] = None, fp8: bool = False) -> torch.Tensor:
+    """The gated MLP of a decode step: ``res + W_out (silu(u) * v)``, ``[u ; v] = W_in rmsnorm(x)`` (modules/gating.py:12-51,
+    lit_model.py:399-403).  Batch <= 2: two GEMVs, the gate as the second one's prologue.  Above: the first skinny GEMM applies
+    the gate in its epilogue and hands the packed operand straight to the second -- the gated activation never exists in fp32."""
+    B = x.shape[0]
+    if fp8 or (B <= 2 and B * w_out.shape[1] <= 32768) or B > 64 or w_in.shape[0] % 32:
+        u = lm_linear(x, w_in, prologue=PROLOGUE_RMSNORM, alpha=alpha, eps=eps, bias=bias_in, fp8=fp8)
+        return lm_linear(u, w_out, prologue=PROLOGUE_SILU_GATE, res=res, bias=bias_out, fp8=fp8)
+    g = gemm_skinny(x, w_in, prologue=PROLOGUE_RMSNORM, alpha=alpha, eps=eps, bias=bias_in, gate_out=True)
+    return gemm_skinny(g, w_out, res=res, bias=bias_out)
 
 
 def lm_linear(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,

@@ -64,6 +64,32 @@ def test_gemm_skinny_bf16(B, N, K):
     assert rel_err(y, (F.silu(u[:, :K]) * u[:, K:]).double() @ wf.double().t()) < 5e-5
 
 
+@pytest.mark.parametrize("B,I,K,bias", [(3, 1408, 512, False), (32, 11264, 4096, False), (33, 4864, 896, True), (64, 96, 64, True)])
+def test_gated_pair_epilogue_fusion(B, I, K, bias):
+    """Batch > 2: the first GEMM of the gated MLP applies silu(u) * v in its epilogue and hands the packed hi/lo operand
+    to the second (weights packed with the two halves interleaved).  fp32-class accuracy against the fp64 product."""
+    g = torch.Generator().manual_seed(B + I + K)
+    w_in = (torch.randn(2 * I, K, generator=g) / K ** 0.5).bfloat16()
+    w_out = (torch.randn(K, I, generator=g) / I ** 0.5).bfloat16()
+    b_in = torch.randn(2 * I, generator=g) if bias else None
+    b_out = torch.randn(K, generator=g) if bias else None
+    x = torch.randn(B, K, generator=g)
+    alpha = 1 + 0.1 * torch.randn(K, generator=g)
+    h = L.rms_norm(x, alpha).double() @ w_in.double().t()
+    if bias:
+        h = h + b_in.double()
+    ref = x.double() + (F.silu(h[:, :I]) * h[:, I:]) @ w_out.double().t()
+    if bias:
+        ref = ref + b_out.double()
+    dev = lambda t: None if t is None else t.to(DEV)
+    y = ops.lm_gated_pair(x.to(DEV), w_in.to(DEV), w_out.to(DEV), alpha=alpha.to(DEV), eps=1e-8, res=x.to(DEV), bias_in=dev(b_in),
+                          bias_out=dev(b_out))
+    assert rel_err(y, ref) < 5e-5
+    packed = ops.gemm_skinny(x.to(DEV), w_in.to(DEV), prologue=ops.PROLOGUE_RMSNORM, alpha=alpha.to(DEV), eps=1e-8, bias=dev(b_in),
+                             gate_out=True)
+    assert isinstance(packed, ops.PackedAct) and packed.K == I
+
+
 def test_lm_batch8_matches_oracle():
     """The B > 4 path (rmsnorm + skinny GEMM) through forward_text / forward_depformer on the tiny config."""
     cfg = dict(synth.LM_TINY)
