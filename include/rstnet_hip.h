@@ -186,9 +186,12 @@ int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, i
  * LLaMAMLP fc_1|fc_2 / proj (models/lit_model.py:399-403), lm_head.  w bf16 [N][K] row-major, K % 8 == 0, 1 <= B <= 4;
  * bias optional fp32 [N] (config.bias / lm_head_bias).  prologue P: 0 identity; 1 RMSNorm x*alpha*rsqrt(eps+mean(x^2))
  * (modules/transformer.py:34-46 eps 1e-8; lit_model.py:693-717 with weight as alpha); 2 SiLU gate: x is [B][2K] = [u ; v],
- * P(x) = silu(u)*v. */
+ * P(x) = silu(u)*v.  gate_out != 0 (w = [W_u ; W_v] stacked, N even, no res): the gate moves into the PRODUCER instead --
+ * y[b][q] = silu(row q) * (row N/2 + q) for q < N/2 (each wave owns a (u, v) row pair), so the consumer reads N/2 values with
+ * prologue 0.  Batch-1 RMSNorm layers with N*K >= 2^24, K <= 4096 run a schedule that issues the x loads before the weight
+ * stream (same arithmetic). */
 int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, const float* bias, float* y,
-                      int B, int N, int K, int ldx, int ldy, int prologue, float eps, rst_stream_t stream);
+                      int B, int N, int K, int ldx, int ldy, int prologue, float eps, int gate_out, rst_stream_t stream);
 
 /* The same contraction for 4 < B <= 64 on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), in three entry points.
  * Both operands are kept in the order the MFMA consumes them -- [tile of 32 rows][K/16 steps][64 lanes][8 bf16], lane =

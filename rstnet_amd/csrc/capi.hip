@@ -188,10 +188,10 @@ int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, i
 
 // ---- LM decode step -------------------------------------------------------------------------------------------------
 int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, const float* bias, float* y,
-                      int B, int N, int K, int ldx, int ldy, int prologue, float eps, rst_stream_t stream) {
+                      int B, int N, int K, int ldx, int ldy, int prologue, float eps, int gate_out, rst_stream_t stream) {
     GemvParams p;
     p.x = x; p.alpha = alpha; p.beta = nullptr; p.w = w; p.res = res; p.bias = bias; p.scale = nullptr; p.y = y; p.B = B; p.N = N;
-    p.K = K; p.ldx = ldx; p.ldy = ldy; p.prologue = prologue; p.act_out = 0; p.w_f32 = 0; p.eps = eps;
+    p.K = K; p.ldx = ldx; p.ldy = ldy; p.prologue = prologue; p.act_out = 0; p.w_f32 = 0; p.gate_out = gate_out; p.eps = eps;
     return rst_launch_gemv(p, (hipStream_t)stream);
 }
 
@@ -200,7 +200,7 @@ int rst_gemv_f32(const float* x, const float* ln_gamma, const float* ln_beta, fl
     RST_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "gemv_f32: LayerNorm needs both gamma and beta");
     GemvParams p;
     p.x = x; p.alpha = ln_gamma; p.beta = ln_beta; p.w = w; p.res = res; p.bias = bias; p.scale = scale; p.y = y; p.B = B; p.N = N;
-    p.K = K; p.ldx = K; p.ldy = N; p.prologue = ln_gamma ? 3 : 0; p.act_out = act_out; p.w_f32 = 1; p.eps = ln_eps;
+    p.K = K; p.ldx = K; p.ldy = N; p.prologue = ln_gamma ? 3 : 0; p.act_out = act_out; p.w_f32 = 1; p.gate_out = 0; p.eps = ln_eps;
     return rst_launch_gemv(p, (hipStream_t)stream);
 }
 

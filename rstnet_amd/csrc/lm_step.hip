@@ -54,15 +54,18 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_kernel(const GemvParams 
 
     // ---- the first weight chunk of this workgroup's first row group is requested BEFORE the activation prologue: the two
     // dependent load chains (x -> norm -> LDS, and W) then overlap instead of adding up (small GEMVs are latency-bound)
-    const int groups = (p.N + RPW * GEMV_WAVES - 1) / (RPW * GEMV_WAVES);
+    // gate_out (RPW == 2): the wave's two rows are (q, N/2 + q) = (u_q, v_q) of a stacked gated layer, one output silu(u) * v
+    const int half = p.N / 2;
+    const int groups = p.gate_out ? (half + GEMV_WAVES - 1) / GEMV_WAVES : (p.N + RPW * GEMV_WAVES - 1) / (RPW * GEMV_WAVES);
+    auto row_of = [&](int grp, int r) {
+        const int q = grp * GEMV_WAVES + wave;
+        return p.gate_out ? r * half + min(q, half - 1) : min(q * RPW + r, p.N - 1);
+    };
     WChunk<F32W> wpre[RPW];
-    {
-        const int n0 = (blockIdx.x * GEMV_WAVES + wave) * RPW;
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            wpre[r].zero();
-            if (blockIdx.x < groups && lane * 8 < K) wpre[r].load(p.w, (long)min(n0 + r, p.N - 1) * K + lane * 8);
-        }
+    for (int r = 0; r < RPW; ++r) {
+        wpre[r].zero();
+        if (blockIdx.x < groups && lane * 8 < K) wpre[r].load(p.w, (long)row_of(blockIdx.x, r) * K + lane * 8);
     }
 
     // ---- prologue: stage the activation vector(s) in LDS
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_kernel(const GemvParams 
             for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
         long wrow[RPW];
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) wrow[r] = (long)min(n0 + r, p.N - 1) * K;
+        for (int r = 0; r < RPW; ++r) wrow[r] = (long)row_of(grp, r) * K;
         auto fma8 = [&](const WChunk<F32W> (&wv)[RPW], int k) {
 #pragma unroll
             for (int b = 0; b < B; ++b) {
@@ -171,8 +174,22 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_kernel(const GemvParams 
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
+            for (int b = 0; b < B; ++b) acc[r][b] = wave_sum(acc[r][b]);
+        if (p.gate_out) {
+            const int q = grp * GEMV_WAVES + wave;
+            if (lane == 0 && q < half)
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    const float u = acc[0][b] + (p.bias ? p.bias[q] : 0.f), v = acc[RPW - 1][b] + (p.bias ? p.bias[half + q] : 0.f);
+                    p.y[(long)b * p.ldy + q] = silu(u) * v;
+                }
+            continue;
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
             for (int b = 0; b < B; ++b) {
-                const float s = wave_sum(acc[r][b]);
+                const float s = acc[r][b];
                 const int n = n0 + r;
                 if (lane == 0 && n < p.N) {
                     const long o = (long)b * p.ldy + n;
@@ -182,6 +199,112 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_kernel(const GemvParams 
                     p.y[o] = p.res ? p.res[o] + sb : sb;
                 }
             }
+    }
+}
+
+// Batch-1 RMSNorm -> GEMV for the large layers of the temporal transformer (qkv, ffn-in, text head: 100 .. 260 MB of weights
+// per launch).  Same arithmetic as gemv_kernel<1, 2, false> with prologue 1; the difference is the schedule.  Vector-memory
+// results return in issue order, so the (L2-resident) x and alpha loads go out FIRST, then PRE = 8 weight chunks per row -- all of
+// a K = 4096 row -- and the norm runs on data that arrives ahead of the weights: the memory pipe is full from the first cycle
+// instead of idling behind the x -> reduce -> LDS chain (measured 22.5 -> 19.2 us for 12288 x 4096, 36.8 -> 32.3 us for
+// 22528 x 4096).  GATE: rows (q, N/2 + q) per wave and silu(u) * v as the output (gate_out of gemv_kernel).
+template <bool GATE>
+__global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_norm_kernel(const GemvParams p) {
+    constexpr int RPW = 2, PRE = 8, XR = 16, NT = 64 * GEMV_WAVES;
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [K]
+    __shared__ float red[GEMV_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K, half = p.N / 2;
+    const int groups = GATE ? (half + GEMV_WAVES - 1) / GEMV_WAVES : (p.N + RPW * GEMV_WAVES - 1) / (RPW * GEMV_WAVES);
+    const int nchunks = (K + 511) >> 9;
+    const int kl = lane * 8;
+
+    float xa[XR], al[XR];            // K <= XR * NT = 4096 (launch check)
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int k = tid + i * NT;
+        xa[i] = k < K ? p.x[k] : 0.f;
+        al[i] = k < K ? p.alpha[k] : 0.f;
+    }
+    WChunk<false> buf[PRE][RPW];
+    long wrow[RPW];
+    auto rows_of = [&](int grp) {
+        const int q = grp * GEMV_WAVES + wave;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) wrow[r] = (long)(GATE ? r * half + min(q, half - 1) : min(q * RPW + r, p.N - 1)) * K;
+    };
+    auto issue = [&](int j, int c) {   // chunk c (512 k) of both rows -> slot j
+        const int kk = (c << 9) + kl;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            if (kk < K) buf[j][r].load(p.w, wrow[r] + kk);
+            else buf[j][r].zero();
+        }
+    };
+    rows_of(blockIdx.x);
+#pragma unroll
+    for (int j = 0; j < PRE; ++j) issue(j, j);
+
+    {                                // RMSNorm: x * alpha * rsqrt(eps + mean(x^2))   (modules/transformer.py:34-46)
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) s = fmaf(xa[i], xa[i], s);
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < GEMV_WAVES; ++w) tot += red[w];
+        const float r = 1.0f / sqrtf(p.eps + tot / (float)K);
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const int k = tid + i * NT;
+            if (k < K) xs[k] = xa[i] * (al[i] * r);
+        }
+    }
+    __syncthreads();
+
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        if (grp != (int)blockIdx.x) {
+            rows_of(grp);
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) issue(j, j);
+        }
+        float acc[RPW] = {0.f, 0.f};
+        for (int base = 0; base < nchunks; base += PRE) {
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) {
+                const int c = base + j;
+                const int kk = (c << 9) + kl;
+                if (kk < K) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + kk);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + kk + 4);
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) acc[r] = buf[j][r].dot(x0, x1, acc[r]);
+                }
+                if (c + PRE < nchunks) issue(j, c + PRE);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) acc[r] = wave_sum(acc[r]);
+        const int q = grp * GEMV_WAVES + wave;
+        if (lane != 0) continue;
+        if (GATE) {
+            if (q < half) {
+                const float u = acc[0] + (p.bias ? p.bias[q] : 0.f), v = acc[1] + (p.bias ? p.bias[half + q] : 0.f);
+                p.y[q] = silu(u) * v;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int n = q * RPW + r;
+                if (n < p.N) {
+                    float sb = p.bias ? acc[r] + p.bias[n] : acc[r];
+                    if (p.scale) sb *= p.scale[n];
+                    p.y[n] = p.res ? p.res[n] + sb : sb;
+                }
+            }
+        }
     }
 }
 
@@ -226,11 +349,14 @@ int rst_launch_gemv(const GemvParams& p, hipStream_t stream) {
     RST_REQUIRE(((uintptr_t)p.w % 16) == 0 && ((uintptr_t)p.x % 16) == 0, "gemv: pointers must be 16-byte aligned");
     const size_t lds = (size_t)p.B * p.K * sizeof(float);
     RST_REQUIRE(lds <= 128 * 1024, "gemv: B*K = %d floats do not fit the activation stage (32768)", p.B * p.K);
+    RST_REQUIRE(!p.gate_out || (p.N % 2 == 0 && !p.res && !p.scale && !p.act_out), "gemv: gate_out needs an even N and no residual / scale / activation");
     // rows per wave: 4 when that still yields >= 2 workgroups per CU, else 2 (more workgroups -> more loads in flight)
-    const bool rpw4 = !p.w_f32 && ((long)p.N + 15) / 16 >= 512;
+    const bool rpw4 = !p.w_f32 && !p.gate_out && ((long)p.N + 15) / 16 >= 512;
+    // the large batch-1 RMSNorm layers take the x-first streaming schedule (gemv_norm_kernel)
+    const bool norm_stream = !p.w_f32 && p.B == 1 && p.prologue == 1 && p.K <= 4096 && !p.act_out && (long)p.N * p.K >= (1L << 24);
     const int rows_per_group = (rpw4 ? 4 : 2) * GEMV_WAVES;
-    const long groups = ((long)p.N + rows_per_group - 1) / rows_per_group;
-    const unsigned grid = cap_grid(groups, lds > 48 * 1024 ? 512 : 768);
+    const long groups = p.gate_out ? ((long)p.N / 2 + GEMV_WAVES - 1) / GEMV_WAVES : ((long)p.N + rows_per_group - 1) / rows_per_group;
+    const unsigned grid = cap_grid(groups, norm_stream ? 1024 : (lds > 48 * 1024 ? 512 : 768));
     auto go = [&](auto kern) {
         static bool attr_set = false;     // one flag per kernel instantiation (generic lambda)
         if (!attr_set) {
@@ -249,6 +375,10 @@ int rst_launch_gemv(const GemvParams& p, hipStream_t stream) {
             default: go(gemv_kernel<4, 2, true>); break;
         }
         return rst_check_launch("gemv_f32");
+    }
+    if (norm_stream) {
+        if (p.gate_out) go(gemv_norm_kernel<true>); else go(gemv_norm_kernel<false>);
+        return rst_check_launch("gemv_bf16");
     }
     switch (p.B * 2 + (rpw4 ? 1 : 0)) {
         case 2: go(gemv_kernel<1, 2, false>); break;

@@ -152,6 +152,7 @@ struct GemvParams {
     int prologue;               // 0 none, 1 RMSNorm, 2 SiLU gate, 3 LayerNorm
     int act_out;                // 0 none, 1 exact GELU (after the bias)
     int w_f32;
+    int gate_out;               // bf16, N even, no res / scale / act: y[b][q] = silu(row q) * (row N/2 + q), q < N/2 (stacked gated layer)
     float eps;
 };
 int rst_launch_gemv(const GemvParams& p, hipStream_t stream);

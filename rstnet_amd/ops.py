@@ -430,9 +430,9 @@ PROLOGUE_NONE, PROLOGUE_RMSNORM, PROLOGUE_SILU_GATE = 0, 1, 2
 
 def gemv_bf16(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
               eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, gate_out: bool = False) -> torch.Tensor:
     """``y[B,N] = (res +) (bias +) P(x) @ w.T`` with ``w`` bf16 ``[N,K]`` (rst_gemv_bf16_f32).  ``x`` is fp32 ``[B,K]``
-    (``[B,2K]`` for the SiLU-gate prologue)."""
+    (``[B,2K]`` for the SiLU-gate prologue).  ``gate_out`` (``w = [W_u ; W_v]``): returns ``silu(u) * v`` of shape ``[B, N/2]``."""
     _chk(x, "x")
     _chk(w, "w", torch.bfloat16)
     _chk(alpha, "alpha")
@@ -441,14 +441,15 @@ def gemv_bf16(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE
     B = x.shape[0]
     N, K = w.shape
     assert x.shape[1] == (2 * K if prologue == PROLOGUE_SILU_GATE else K), (tuple(x.shape), N, K, prologue)
+    No = N // 2 if gate_out else N
     if out is None:
-        out = torch.empty(B, N, device=x.device, dtype=torch.float32)
+        out = torch.empty(B, No, device=x.device, dtype=torch.float32)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.lib().rst_gemv_bf16_f32(_ptr(x), _ptr(alpha), _ptr(w), _ptr(res), _ptr(bias), _ptr(out), B, N, K, x.shape[1], N,
-                                           prologue, eps, _stream()))
+    _lib.check(_lib.lib().rst_gemv_bf16_f32(_ptr(x), _ptr(alpha), _ptr(w), _ptr(res), _ptr(bias), _ptr(out), B, N, K, x.shape[1], No,
+                                           prologue, eps, int(gate_out), _stream()))
     if prof is not None:
         e1.record()
         prof.append(("gemv_bf16", e0, e1, 2.0 * B * N * K, 2 * N * K + 4 * (x.numel() + out.numel()), (B, N, K)))
@@ -587,10 +588,14 @@ def gemm_skinny_fp8(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGU
 def lm_gated_pair(x: torch.Tensor, w_in: torch.Tensor, w_out: torch.Tensor, *, alpha: torch.Tensor, eps: float, res: torch.Tensor,
                   bias_in: Optional[torch.Tensor] = None, bias_out: Optional[torch.Tensor] = None, fp8: bool = False) -> torch.Tensor:
     """The gated MLP of a decode step: ``res + W_out (silu(u) * v)``, ``[u ; v] = W_in rmsnorm(x)`` (modules/gating.py:12-51,
-    lit_model.py:399-403).  Batch <= 2: two GEMVs, the gate as the second one's prologue.  Above: the first skinny GEMM applies
+    lit_model.py:399-403).  Batch <= 2: two GEMVs, the gate in the epilogue of the first (row pairs per wave).  Above: the first skinny GEMM applies
     the gate in its epilogue and hands the packed operand straight to the second -- the gated activation never exists in fp32."""
     B = x.shape[0]
-    if fp8 or (B <= 2 and B * w_out.shape[1] <= 32768) or B > 64 or w_in.shape[0] % 32:
+    if not fp8 and B <= 2 and B * max(w_out.shape[1], w_in.shape[1]) <= 32768 and w_in.shape[0] % 2 == 0:
+        # GEMV pair: every wave of the first owns a (u, v) row pair and writes silu(u) * v; the second is a plain GEMV
+        g = gemv_bf16(x, w_in, prologue=PROLOGUE_RMSNORM, alpha=alpha, eps=eps, bias=bias_in, gate_out=True)
+        return gemv_bf16(g, w_out, res=res, bias=bias_out)
+    if fp8 or B <= 2 or B > 64 or w_in.shape[0] % 32:
         u = lm_linear(x, w_in, prologue=PROLOGUE_RMSNORM, alpha=alpha, eps=eps, bias=bias_in, fp8=fp8)
         return lm_linear(u, w_out, prologue=PROLOGUE_SILU_GATE, res=res, bias=bias_out, fp8=fp8)
     g = gemm_skinny(x, w_in, prologue=PROLOGUE_RMSNORM, alpha=alpha, eps=eps, bias=bias_in, gate_out=True)

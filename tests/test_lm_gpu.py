@@ -42,6 +42,12 @@ def test_gemv_bf16_prologues(B, N, K):
     u = torch.randn(B, 2 * K, generator=g)
     y = ops.gemv_bf16(u.to(DEV), w.to(DEV), prologue=ops.PROLOGUE_SILU_GATE)
     assert rel_err(y, (F.silu(u[:, :K]) * u[:, K:]) @ wf.t()) < 1e-5
+    if N % 2 == 0:      # the gate in the producer: rows (q, N/2 + q) per wave
+        bias = torch.randn(N, generator=g)
+        for pro, xin in ((ops.PROLOGUE_NONE, x), (ops.PROLOGUE_RMSNORM, L.rms_norm(x, alpha))):
+            h = xin @ wf.t() + bias
+            y = ops.gemv_bf16(x.to(DEV), w.to(DEV), prologue=pro, alpha=alpha.to(DEV), eps=1e-8, bias=bias.to(DEV), gate_out=True)
+            assert y.shape == (B, N // 2) and rel_err(y, F.silu(h[:, :N // 2]) * h[:, N // 2:]) < 2e-5
 
 
 @pytest.mark.parametrize("B,N,K", [(32, 4096, 4096), (5, 1000, 1024), (17, 37, 2816), (64, 2048, 1024), (33, 12288, 4096), (8, 96, 64)])
@@ -64,7 +70,8 @@ def test_gemm_skinny_bf16(B, N, K):
     assert rel_err(y, (F.silu(u[:, :K]) * u[:, K:]).double() @ wf.double().t()) < 5e-5
 
 
-@pytest.mark.parametrize("B,I,K,bias", [(3, 1408, 512, False), (32, 11264, 4096, False), (33, 4864, 896, True), (64, 96, 64, True)])
+@pytest.mark.parametrize("B,I,K,bias", [(1, 11264, 4096, False), (2, 2816, 1024, True), (1, 24, 16, True), (3, 1408, 512, False),
+                                        (32, 11264, 4096, False), (33, 4864, 896, True), (64, 96, 64, True)])
 def test_gated_pair_epilogue_fusion(B, I, K, bias):
     """Batch > 2: the first GEMM of the gated MLP applies silu(u) * v in its epilogue and hands the packed hi/lo operand
     to the second (weights packed with the two halves interleaved).  fp32-class accuracy against the fp64 product."""
@@ -85,9 +92,10 @@ def test_gated_pair_epilogue_fusion(B, I, K, bias):
     y = ops.lm_gated_pair(x.to(DEV), w_in.to(DEV), w_out.to(DEV), alpha=alpha.to(DEV), eps=1e-8, res=x.to(DEV), bias_in=dev(b_in),
                           bias_out=dev(b_out))
     assert rel_err(y, ref) < 5e-5
-    packed = ops.gemm_skinny(x.to(DEV), w_in.to(DEV), prologue=ops.PROLOGUE_RMSNORM, alpha=alpha.to(DEV), eps=1e-8, bias=dev(b_in),
-                             gate_out=True)
-    assert isinstance(packed, ops.PackedAct) and packed.K == I
+    if B > 2:
+        packed = ops.gemm_skinny(x.to(DEV), w_in.to(DEV), prologue=ops.PROLOGUE_RMSNORM, alpha=alpha.to(DEV), eps=1e-8, bias=dev(b_in),
+                                 gate_out=True)
+        assert isinstance(packed, ops.PackedAct) and packed.K == I
 
 
 def test_lm_batch8_matches_oracle():

@@ -92,7 +92,52 @@ def skinny_case(B, N, K, gate=False):
     return ms, 2.0 * N * K
 
 
+def gemv_case(B, N, K, mode="plain", copies=None):
+    """Batch <= 2 GEMV over ROTATING weight copies (> 1 GB in total, so no launch finds its weights in the 256 MB MALL)."""
+    g = torch.Generator().manual_seed(0)
+    copies = copies or max(2, int(1.5e9 // (2 * N * K)) + 1)
+    ws = [(torch.randn(N, K, device=DEV) * 0.05).bfloat16()]
+    ws += [ws[0].clone() for _ in range(copies - 1)]
+    x = torch.randn(B, 2 * K if mode == "gate" else K, generator=g).to(DEV)
+    r = torch.randn(B, N, generator=g).to(DEV)
+    alpha = torch.ones(K, device=DEV)
+    state = {"i": 0}
+
+    def fn():
+        w = ws[state["i"] % copies]
+        state["i"] += 1
+        if mode == "norm":
+            ops.gemv_bf16(x, w, prologue=ops.PROLOGUE_RMSNORM, alpha=alpha, eps=1e-8)
+        elif mode == "normgate":
+            ops.gemv_bf16(x, w, prologue=ops.PROLOGUE_RMSNORM, alpha=alpha, eps=1e-8, gate_out=True)
+        elif mode == "gate":
+            ops.gemv_bf16(x, w, res=r, prologue=ops.PROLOGUE_SILU_GATE)
+        else:
+            ops.gemv_bf16(x, w, res=r)
+    return fn, max(copies, 48), 2.0 * N * K
+
+
+def gemv_sweep(argv):
+    """python tools/bench_kernels.py gemvsweep 'ENV=V,ENV=V;ENV=V' case ...   -- every case under every knob setting."""
+    settings = [dict(kv.split("=") for kv in st.split(",") if kv) for st in argv[0].split(";")]
+    for c in argv[1:]:
+        parts = c.split(":")
+        Bq, N, K = [int(v) for v in parts[1].split("x")]
+        mode = parts[2] if len(parts) > 2 else "plain"
+        row = []
+        fn, iters, nbytes = gemv_case(Bq, N, K, mode)
+        for st in settings:
+            for k in ("RST_GEMV_PIPE", "RST_GEMV_PRE", "RST_GEMV_RPW", "RST_GEMV_CAP"):
+                os.environ.pop(k, None)
+            os.environ.update(st)
+            ms = timeit_graph(fn, iters=iters)
+            row.append(f"{ms * 1e3:6.1f}us {nbytes / ms / 1e9:5.2f}TB/s")
+        print(f"{c:28s} " + " | ".join(row), flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "gemvsweep":
+        return gemv_sweep(sys.argv[2:])
     cases = sys.argv[1:] or ["res64", "res64pre", "res64post", "res128", "gemm:3840000x128x512:elu", "gemm:16000x1024x8192",
                              "gemm:128000x512x3072", "gemm:16000x512x512"]
     B, T = 16, 240000
