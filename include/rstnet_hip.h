@@ -276,6 +276,17 @@ int rst_lm_sample_f32(const float* logits, const float* noise, int64_t* tokens, 
                       int noise_stride, int tok_stride, int use_sampling, float temp, int v_limit, const int32_t* v_limit_dev,
                       rst_stream_t stream);
 
+/* LMGen.step's token ring and delay pattern (models/model.py:506-562) on the device.  cache int64 [B][K][CT] (CT = max_delay
+ * + 2), delays int32 [K] and the frame counter offset_dev (int64 scalar) stay in HBM, so that a frame is one captured graph.
+ *   begin (:506-521): cache[b][k][(offset + delay_k) % CT] = user_tokens[b][k - first_user_k] for the Ki user codebooks;
+ *     cache[b][k][offset % CT] = initial[k] while offset <= delay_k; input_out[b][k] = cache[b][k][offset % CT].
+ *   commit (:545-562): offset += 1; cache[b][k][offset % CT] = tokens[b][k] for k < n_out (text, then the dep_q audio
+ *     tokens); out[b][k] = cache[b][k][(offset - max_delay + delay_k) % CT] (meaningful once offset > max_delay). */
+int rst_lm_ring_begin_i64(int64_t* cache, const int64_t* user_tokens, const int64_t* initial, const int32_t* delays,
+                          int64_t* offset_dev, int64_t* input_out, int B, int K, int CT, int Ki, int first_user_k, rst_stream_t stream);
+int rst_lm_ring_commit_i64(int64_t* cache, const int64_t* tokens, const int32_t* delays, int64_t* offset_dev, int64_t* out, int B, int K,
+                           int CT, int n_out, int max_delay, rst_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

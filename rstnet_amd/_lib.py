@@ -54,6 +54,8 @@ SIGNATURES = {
     "rst_lm_attn_decode_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p],
     "rst_attn_decode_multi_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rst_lm_sample_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p, _p],
+    "rst_lm_ring_begin_i64": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "rst_lm_ring_commit_i64": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }
 
 _lib: Optional[C.CDLL] = None

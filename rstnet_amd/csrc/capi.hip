@@ -293,4 +293,20 @@ int rst_lm_sample_f32(const float* logits, const float* noise, int64_t* tokens, 
     return rst_launch_lm_sample(p, (hipStream_t)stream);
 }
 
+int rst_lm_ring_begin_i64(int64_t* cache, const int64_t* user_tokens, const int64_t* initial, const int32_t* delays,
+                          int64_t* offset_dev, int64_t* input_out, int B, int K, int CT, int Ki, int first_user_k, rst_stream_t stream) {
+    LmRingParams p{};
+    p.cache = (long*)cache; p.user = (const long*)user_tokens; p.initial = (const long*)initial; p.delays = delays;
+    p.offset_dev = (long*)offset_dev; p.input_out = (long*)input_out; p.B = B; p.K = K; p.CT = CT; p.Ki = Ki; p.first_user = first_user_k;
+    return rst_launch_lm_ring_begin(p, (hipStream_t)stream);
+}
+
+int rst_lm_ring_commit_i64(int64_t* cache, const int64_t* tokens, const int32_t* delays, int64_t* offset_dev, int64_t* out, int B, int K,
+                           int CT, int n_out, int max_delay, rst_stream_t stream) {
+    LmRingParams p{};
+    p.cache = (long*)cache; p.tokens = (const long*)tokens; p.delays = delays; p.offset_dev = (long*)offset_dev; p.out = (long*)out;
+    p.B = B; p.K = K; p.CT = CT; p.n_out = n_out; p.max_delay = max_delay;
+    return rst_launch_lm_ring_commit(p, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -210,6 +210,21 @@ struct LmSampleParams {
 };
 int rst_launch_lm_sample(const LmSampleParams& p, hipStream_t stream);
 
+// ---- lm_ring.hip: LMGen's token ring / delay pattern
+struct LmRingParams {
+    long* cache;                // [B][K][CT] int64
+    const long* user;           // begin: [B][Ki] tokens of the user streams (codebooks first_user .. first_user + Ki - 1)
+    const long* initial;        // begin: [K] initial token per codebook
+    const int* delays;          // [K] device
+    long* offset_dev;           // int64 scalar: frames stepped so far (commit increments it)
+    long* input_out;            // begin: [B][K] the model input of this step
+    const long* tokens;         // commit: [B][n_out] generated (text, audio_0 .. audio_{dep_q-1})
+    long* out;                  // commit: [B][n_out] delay-aligned output
+    int B, K, CT, Ki, first_user, n_out, max_delay;
+};
+int rst_launch_lm_ring_begin(const LmRingParams& p, hipStream_t stream);
+int rst_launch_lm_ring_commit(const LmRingParams& p, hipStream_t stream);
+
 struct SkinnyParams {
     const unsigned short* xp;   // packed activations [2][ceil(B/32)][K/16][64][8] bf16 (hi plane, lo plane)
     const unsigned short* w;    // packed weights [ceil(N/32)][K/16][64][8] bf16

@@ -145,9 +145,10 @@ class StreamingTransformer(StreamingModule[_StepState]):
         return _StepState([torch.zeros(shape, device=dev) for _ in self.layers], [torch.zeros(shape, device=dev) for _ in self.layers],
                           torch.zeros(1, device=dev, dtype=torch.long), scratch)
 
-    def step(self, x: torch.Tensor, step_index: Optional[int] = None) -> torch.Tensor:
+    def step(self, x: torch.Tensor, step_index: Optional[int] = None, pos: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x fp32 ``[B, d_model]`` -> ``[B, d_model]``: one new time step through every layer (4 launches per layer for a short
-        ring, 5 otherwise)."""
+        ring, 5 otherwise).  ``pos`` (int64 device scalar): position of this step supplied by a caller that owns the loop
+        (LMGen's depth steps are always positions 0 .. dep_q - 1); the module's own counter is then left alone."""
         st = self._streaming_state
         if st is None:
             raise RuntimeError("the decode-step transformer only runs in streaming mode")
@@ -164,13 +165,14 @@ class StreamingTransformer(StreamingModule[_StepState]):
             else:
                 w_in, w_out, gate = att.in_proj_weight, att.out_proj.weight, layer.gating
             qkv = ops.lm_linear(x, w_in, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm1.alpha_f32(), eps=layer.norm1.eps)
-            a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], st.pos, rope=self.rope, context=self.context,
+            a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], st.pos if pos is None else pos, rope=self.rope, context=self.context,
                                    max_period=self.max_period, scratch=st.scratch, packed=x.shape[0] > 2)
             x = ops.lm_linear(a, w_out, res=x)
             x = ops.lm_gated_pair(x, gate.linear_in.weight, gate.linear_out.weight, alpha=layer.norm2.alpha_f32(), eps=layer.norm2.eps,
                                   res=x)
-        st.pos.add_(1)
-        st.offset_cpu += 1
+        if pos is None:
+            st.pos.add_(1)
+            st.offset_cpu += 1
         return x
 
 
@@ -290,13 +292,18 @@ class LMModel(StreamingContainer):
         assert K == 1, f"Codebooks for Depformer streaming should be passed 1 by 1, got {K}."
         assert S == 1, f"Steps for Depformer streaming should be passed 1 by 1, got {S}."
         assert transformer_out.shape[1] == 1, "Transformer out should be a for a single step."
-        k = depformer_cb_index
-        h = ops.lm_linear(transformer_out.reshape(B, self.dim).contiguous(), self.depformer_in[k].weight)
-        table = self.depformer_text_emb.weight if k == 0 else self.depformer_emb[k - 1].weight
-        x = ops.embed_sum(sequence.reshape(B, 1).contiguous(), [table], [0], add=h)
-        y = self.depformer.step(x)
-        logits = ops.lm_linear(y, self.linears[k].weight)
+        logits = self._depformer_logits(depformer_cb_index, sequence.reshape(B, 1).contiguous(), 0,
+                                        transformer_out.reshape(B, self.dim).contiguous())
         return logits.view(B, 1, 1, -1)
+
+    def _depformer_logits(self, k: int, tokens: torch.Tensor, col: int, h_t: torch.Tensor, pos: Optional[torch.Tensor] = None,
+                          step_index: Optional[int] = None) -> torch.Tensor:
+        """Depth step ``k``: previous token = ``tokens[:, col]`` (int64 ``[B, n]``), ``h_t`` fp32 ``[B, dim]`` -> logits ``[B, card]``."""
+        h = ops.lm_linear(h_t, self.depformer_in[k].weight)
+        table = self.depformer_text_emb.weight if k == 0 else self.depformer_emb[k - 1].weight
+        x = ops.embed_sum(tokens, [table], [col], add=h)
+        y = self.depformer.step(x, step_index=step_index, pos=pos)
+        return ops.lm_linear(y, self.linears[k].weight)
 
     @classmethod
     def from_state_dict(cls, sd: Dict[str, torch.Tensor], cfg: dict) -> "LMModel":
@@ -322,18 +329,21 @@ class LMModel(StreamingContainer):
 
 @dataclass
 class _LMGenState:
-    cache: torch.Tensor
-    initial: torch.Tensor
-    graphed_main: _Graphed
-    graphed_depth: _Graphed
+    cache: torch.Tensor            # int64 [B, K, max_delay + 2] token ring
+    initial: torch.Tensor          # int64 [1, K, 1]
+    offset_dev: torch.Tensor       # int64 [1]: the frame counter as the ring kernels see it
+    graphed_frame: _Graphed
     offset: int = 0
 
     def reset(self) -> None:
         self.offset = 0
+        self.offset_dev.zero_()
 
 
 class LMGen(StreamingModule[_LMGenState]):
-    """models/model.py:443-597."""
+    """models/model.py:443-597.  The token ring, the delay pattern and the frame counter live on the device
+    (csrc/lm_ring.hip), so one frame -- ring update, temporal step, text sample, ``dep_q`` depth steps with their samples,
+    ring commit + delayed gather -- is ONE captured graph fed by a single copy of the user tokens."""
 
     def __init__(self, lm_model: LMModel, use_sampling: bool = True, temp: float = 0.8, temp_text: float = 0.7,
                  top_k: int = 250, top_k_text: int = 25, check: bool = False):
@@ -344,26 +354,53 @@ class LMGen(StreamingModule[_LMGenState]):
         self.top_k, self.top_k_text, self.check = top_k, top_k_text, check
         self.max_delay = max(lm_model.delays)
         self.delays_cuda = torch.tensor(lm_model.delays, device=lm_model.device, dtype=torch.long)
+        self._delays_i32 = self.delays_cuda.to(torch.int32)
+        self._depth_pos = torch.arange(lm_model.dep_q, device=lm_model.device, dtype=torch.long)
 
     def _init_streaming_state(self, batch_size: int) -> _LMGenState:
         lm = self.lm_model
         cache = torch.full((batch_size, lm.num_codebooks, self.max_delay + 2), lm.ungenerated_token_id, device=lm.device,
                            dtype=torch.long)
         disable = lm.device.type != "cuda"
-        return _LMGenState(cache, lm._get_initial_token(), _Graphed(self._main, disable=disable),
-                           _Graphed(self.depformer_step, disable=disable))
+        return _LMGenState(cache, lm._get_initial_token(), torch.zeros(1, device=lm.device, dtype=torch.long),
+                           _Graphed(self._frame, disable=disable))
 
     def _noise(self, B: int, k: int) -> Optional[torch.Tensor]:
         if not self.use_sampling:
             return None
         return torch.empty(B, k, device=self.lm_model.device, dtype=torch.float32).exponential_(1)   # utils/sampling.py:44
 
-    def _main(self, input_: torch.Tensor):
-        out, text_logits = self.lm_model.forward_text(input_)
-        B = input_.shape[0]
-        text_token = ops.lm_sample(text_logits.view(B, -1), use_sampling=self.use_sampling, temp=self.temp_text,
-                                   top_k=self.top_k_text, noise=self._noise(B, self.top_k_text))
-        return out, text_token
+    def _frame(self, user_tokens: torch.Tensor):
+        """user_tokens int64 ``[B, Ki]`` -> (delay-aligned output ``[B, dep_q + 1]``, model input ``[B, K]``); everything in
+        between stays on the device (this is the function that is captured)."""
+        state, lm = self._streaming_state, self.lm_model
+        B = user_tokens.shape[0]
+        input_ = ops.lm_ring_begin(state.cache, user_tokens, state.initial.reshape(-1), self._delays_i32, state.offset_dev,
+                                   lm.dep_q + 1)
+        # one draw of Exp(1) noise per frame for the text sampler and the dep_q audio samplers (utils/sampling.py:44-46)
+        noise = self._noise(B, self.top_k_text + lm.dep_q * self.top_k)
+        transformer_out, text_logits = lm.forward_text(input_.view(B, -1, 1))
+        tokens = torch.empty(B, lm.dep_q + 1, device=input_.device, dtype=torch.long)
+        ops.lm_sample(text_logits.view(B, -1), use_sampling=self.use_sampling, temp=self.temp_text, top_k=self.top_k_text,
+                      noise=None if noise is None else noise[:, :self.top_k_text], out=tokens[:, 0])
+        self._depth(tokens, transformer_out.view(B, lm.dim), None if noise is None else noise[:, self.top_k_text:])
+        out = ops.lm_ring_commit(state.cache, tokens, self._delays_i32, state.offset_dev, self.max_delay)
+        return out, input_
+
+    def _depth(self, tokens: torch.Tensor, h_t: torch.Tensor, noise: Optional[torch.Tensor]) -> None:
+        """The ``dep_q`` sequential depth-transformer steps (models/model.py:564-597): ``tokens[:, 0]`` is the text token,
+        step ``cb`` embeds ``tokens[:, cb]`` and samples ``tokens[:, cb + 1]`` in place.  The depth KV rings are persistent
+        buffers; the steps are positions 0 .. dep_q - 1 of a ring that restarts every frame (= the reference's fresh
+        ``with depformer.streaming(B)`` context), supplied as constant device scalars instead of a counter to reset and bump."""
+        B = tokens.shape[0]
+        lm = self.lm_model
+        dep = lm.depformer
+        if dep._streaming_state is None or dep._streaming_state.k[0].shape[0] != B:
+            dep._streaming_state = dep._init_streaming_state(B)
+        for cb in range(lm.dep_q):
+            logits = lm._depformer_logits(cb, tokens, cb, h_t, pos=self._depth_pos[cb:cb + 1], step_index=cb)
+            ops.lm_sample(logits, use_sampling=self.use_sampling, temp=self.temp, top_k=self.top_k,
+                          noise=None if noise is None else noise[:, cb * self.top_k:(cb + 1) * self.top_k], out=tokens[:, cb + 1])
 
     @torch.no_grad()
     def step(self, input_tokens: torch.Tensor) -> Optional[torch.Tensor]:
@@ -376,46 +413,22 @@ class LMGen(StreamingModule[_LMGenState]):
         assert S == 1, "Only support being given steps one by one."
         needed = lm.num_codebooks - lm.dep_q - 1
         assert Ki == needed, f"We expect {needed} tokens from the user stream, got {Ki}."
-        CT = state.cache.shape[2]
-        for q_other in range(Ki):
-            k = lm.dep_q + 1 + q_other
-            wp = (state.offset + lm.delays[k]) % CT
-            state.cache[:, k, wp:wp + 1] = input_tokens[:, q_other]
-        position = state.offset % CT
-        for k, delay in enumerate(lm.delays):
-            if state.offset <= delay:
-                state.cache[:, k, position] = state.initial[:, k, 0]
-        input_ = state.cache[:, :, position:position + 1].contiguous()
+        out, input_ = state.graphed_frame(input_tokens.reshape(B, Ki).contiguous())
         if self.check:
             assert not (input_ == lm.ungenerated_token_id).any(), (state.offset, input_)
             assert (input_[:, lm.audio_offset:] <= lm.card).all(), input_
             assert (input_[:, :1] <= lm.text_card).all()
-        transformer_out, text_token = state.graphed_main(input_)
-        audio_tokens = state.graphed_depth(text_token, transformer_out)
         state.offset += 1
-        position = state.offset % CT
-        state.cache[:, 0, position] = text_token
-        state.cache[:, 1:lm.dep_q + 1, position] = audio_tokens
         if state.offset <= self.max_delay:
             return None
-        gen_delays = self.delays_cuda[:lm.dep_q + 1]
-        index = ((state.offset - self.max_delay + gen_delays) % CT).view(1, -1, 1).expand(B, -1, 1)
-        return state.cache.gather(dim=2, index=index)
+        return out.view(B, lm.dep_q + 1, 1).clone()
 
     def depformer_step(self, text_token: torch.Tensor, transformer_out: torch.Tensor) -> torch.Tensor:
-        """8 sequential depth-transformer steps (models/model.py:564-597); the depth KV rings are persistent buffers whose
-        position counter is reset per frame (= the reference's fresh ``with depformer.streaming(B)`` context)."""
+        """text_token int64 ``[B]``, transformer_out fp32 ``[B, 1, dim]`` -> the frame's ``dep_q`` audio tokens ``[B, dep_q]``
+        (models/model.py:564-597)."""
         (B,) = text_token.shape
         lm = self.lm_model
-        dep = lm.depformer
-        if dep._streaming_state is None or dep._streaming_state.k[0].shape[0] != B:
-            dep._streaming_state = dep._init_streaming_state(B)
-        dep._streaming_state.reset()
-        prev = text_token
-        out = torch.empty(B, lm.dep_q, device=text_token.device, dtype=torch.long)
-        for cb in range(lm.dep_q):
-            logits = lm.forward_depformer(cb, prev.view(B, 1, 1), transformer_out)
-            prev = ops.lm_sample(logits.view(B, -1), use_sampling=self.use_sampling, temp=self.temp, top_k=self.top_k,
-                                 noise=self._noise(B, self.top_k))
-            out[:, cb] = prev
-        return out
+        tokens = torch.empty(B, lm.dep_q + 1, device=text_token.device, dtype=torch.long)
+        tokens[:, 0] = text_token
+        self._depth(tokens, transformer_out.reshape(B, lm.dim).contiguous(), self._noise(B, lm.dep_q * self.top_k))
+        return tokens[:, 1:]

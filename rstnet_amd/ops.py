@@ -699,11 +699,46 @@ def lm_sample(logits: torch.Tensor, *, use_sampling: bool, temp: float, top_k: i
     """logits fp32 ``[B, V]`` -> tokens int64 ``[B]`` (greedy, or top-k sampling with Exp(1) ``noise [B, top_k]``).  ``limit``
     (or the int32 device scalar ``limit_dev``): ids >= limit are never drawn when sampling."""
     _chk(logits, "logits")
-    _chk(noise, "noise")
     _chk(limit_dev, "limit_dev", torch.int32)
     B, V = logits.shape
+    if noise is not None:       # a [B, >= top_k] column slice of a wider noise buffer is fine (row stride is passed on)
+        if not noise.is_cuda or noise.dtype != torch.float32 or noise.dim() != 2 or noise.stride(1) != 1 or noise.shape[0] != B:
+            raise ValueError("rstnet_amd.ops: `noise` must be a float32 CUDA/HIP tensor [B, k] with unit column stride")
     if out is None:
         out = torch.empty(B, device=logits.device, dtype=torch.int64)
-    _lib.check(_lib.lib().rst_lm_sample_f32(_ptr(logits), _ptr(noise), _ptr(out), B, V, V, top_k, noise.shape[1] if noise is not None else 0,
-                                           1, int(use_sampling), float(temp), int(limit), _ptr(limit_dev), _stream()))
+    elif not out.is_cuda or out.dtype != torch.int64 or out.dim() != 1 or out.shape[0] != B:   # may be a column of a [B, n] buffer
+        raise ValueError("rstnet_amd.ops: `out` must be an int64 CUDA/HIP vector of length B")
+    _lib.check(_lib.lib().rst_lm_sample_f32(_ptr(logits), _ptr(noise), _ptr(out), B, V, V, top_k, noise.stride(0) if noise is not None else 0,
+                                           out.stride(0) if B > 1 else 1, int(use_sampling), float(temp), int(limit), _ptr(limit_dev),
+                                           _stream()))
+    return out
+
+
+def lm_ring_begin(cache: torch.Tensor, user_tokens: torch.Tensor, initial: torch.Tensor, delays: torch.Tensor,
+                  offset_dev: torch.Tensor, first_user_k: int) -> torch.Tensor:
+    """Start of an ``LMGen.step`` frame on the device (models/model.py:506-521): user streams into the token ring
+    ``cache [B, K, CT]`` at their delayed columns, initial tokens while ``offset <= delay``; returns the model input ``[B, K]``."""
+    for t, n in ((cache, "cache"), (user_tokens, "user_tokens"), (initial, "initial"), (offset_dev, "offset_dev")):
+        _chk(t, n, torch.int64)
+    _chk(delays, "delays", torch.int32)
+    B, K, CT = cache.shape
+    Ki = user_tokens.shape[1]
+    assert user_tokens.shape[0] == B and initial.numel() == K and delays.numel() == K
+    out = torch.empty(B, K, device=cache.device, dtype=torch.int64)
+    _lib.check(_lib.lib().rst_lm_ring_begin_i64(_ptr(cache), _ptr(user_tokens), _ptr(initial), _ptr(delays), _ptr(offset_dev), _ptr(out),
+                                               B, K, CT, Ki, first_user_k, _stream()))
+    return out
+
+
+def lm_ring_commit(cache: torch.Tensor, tokens: torch.Tensor, delays: torch.Tensor, offset_dev: torch.Tensor, max_delay: int) -> torch.Tensor:
+    """End of the frame (models/model.py:545-562): ``offset_dev += 1``, generated ``tokens [B, n]`` into the ring, returns the
+    delay-aligned gather ``[B, n]`` (meaningful once ``offset > max_delay``)."""
+    for t, n in ((cache, "cache"), (tokens, "tokens"), (offset_dev, "offset_dev")):
+        _chk(t, n, torch.int64)
+    _chk(delays, "delays", torch.int32)
+    B, K, CT = cache.shape
+    n_out = tokens.shape[1]
+    out = torch.empty(B, n_out, device=cache.device, dtype=torch.int64)
+    _lib.check(_lib.lib().rst_lm_ring_commit_i64(_ptr(cache), _ptr(tokens), _ptr(delays), _ptr(offset_dev), _ptr(out), B, K, CT, n_out,
+                                                int(max_delay), _stream()))
     return out

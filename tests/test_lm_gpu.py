@@ -246,6 +246,42 @@ def _tiny():
     return cfg, sd, model
 
 
+@pytest.mark.parametrize("B,dep_q,n_user,delays", [(2, 3, 2, [0, 1, 0, 2, 0, 1]), (1, 8, 8, [0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1]),
+                                                   (5, 2, 1, [0, 0, 0, 0])])
+def test_token_ring_kernels_match_host_bookkeeping(B, dep_q, n_user, delays):
+    """rst_lm_ring_begin / commit against the host-side restatement of LMGen.step's cache bookkeeping (models/model.py:506-562)."""
+    K, max_delay = len(delays), max(delays)
+    CT = max_delay + 2
+    g = torch.Generator().manual_seed(B + K)
+    ref = torch.full((B, K, CT), -2, dtype=torch.long)
+    cache = ref.clone().to(DEV)
+    initial = torch.arange(100, 100 + K)
+    off_dev = torch.zeros(1, dtype=torch.long, device=DEV)
+    d32 = torch.tensor(delays, dtype=torch.int32, device=DEV)
+    for offset in range(3 * CT + 1):
+        user = torch.randint(0, 50, (B, n_user), generator=g)
+        gen = torch.randint(50, 99, (B, dep_q + 1), generator=g)
+        for q in range(n_user):                                   # host restatement
+            k = dep_q + 1 + q
+            ref[:, k, (offset + delays[k]) % CT] = user[:, q]
+        position = offset % CT
+        for k, d in enumerate(delays):
+            if offset <= d:
+                ref[:, k, position] = initial[k]
+        want_in = ref[:, :, position].clone()
+        position = (offset + 1) % CT
+        ref[:, :dep_q + 1, position] = gen
+        idx = (offset + 1 - max_delay + torch.tensor(delays[:dep_q + 1])) % CT
+        want_out = ref[:, :dep_q + 1].gather(2, idx.view(1, -1, 1).expand(B, -1, 1))[:, :, 0]
+        got_in = ops.lm_ring_begin(cache, user.to(DEV), initial.to(DEV), d32, off_dev, dep_q + 1)
+        got_out = ops.lm_ring_commit(cache, gen.to(DEV), d32, off_dev, max_delay)
+        assert torch.equal(got_in.cpu(), want_in), offset
+        assert int(off_dev) == offset + 1
+        if offset + 1 > max_delay:
+            assert torch.equal(got_out.cpu(), want_out), offset
+        assert torch.equal(cache.cpu(), ref), offset
+
+
 def test_lm_state_dict_keys():
     cfg, sd, model = _tiny()
     assert set(model.state_dict().keys()) == set(sd.keys())
