@@ -177,14 +177,11 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
 
-    for (int kt = kt0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
+    auto mma_tile = [&](int buf, int ks0 = 0, int ks1 = BK / 8) {
         const float* a = As + buf * BM * LDS_LD + (wm * TM * 32 + frag_row) * LDS_LD + frag_k;
         const float* b = Bs + buf * BN * LDS_LD + (wn * TN * 32 + frag_row) * LDS_LD + frag_k;
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
+        for (int ks = ks0; ks < ks1; ++ks) {
             f32x4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS_LD + ks * 8);
@@ -198,9 +195,53 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
         }
-        __builtin_amdgcn_s_setprio(0);
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
-        __syncthreads();
+    };
+
+    // Interior tiles (every window of the tile lies inside its utterance, full tile, K a multiple of BK -- all but the
+    // first / last tile of an utterance): the K loop is ONE basic block of unconditional 16-byte loads, so the scheduler can
+    // spread the global loads and the LDS writes of the next k-tile between the MFMAs of this one instead of running them
+    // as separate phases with the matrix pipe idle.
+    bool interior = VEC && gridDim.y == 1 && m0 + BM <= M && n0 + BN <= p.N && p.K % BK == 0;
+#pragma unroll
+    for (int j = 0; j < RA; ++j) interior = interior && a_klo[j] == 0 && a_khi[j] == p.K;
+    if (__syncthreads_and(interior)) {
+        const float* ap[RA];
+        const float* bp[RB];
+#pragma unroll
+        for (int j = 0; j < RA; ++j) ap[j] = p.x + a_off[j] + a_f0[j] + lk;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) bp[j] = p.w + (long)(n0 + lrow + 32 * j) * p.K + lk;
+        for (int kt = kt0; kt + 1 < nk; ++kt) {
+#pragma unroll
+            for (int j = 0; j < RA; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ap[j] + (kt + 1) * BK);
+#pragma unroll
+            for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bp[j] + (kt + 1) * BK);
+            // the loads go out first and stay in flight under the MFMAs of this tile (left alone, the scheduler sinks them to
+            // the end of the block to save registers and then waits out the full memory latency) ...
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile(kt & 1, 0, BK / 8 - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // ... and their LDS writes (other buffer) are spread between the last 16 MFMAs
+            mma_tile(kt & 1, BK / 8 - 1, BK / 8);
+            store_tiles((kt & 1) ^ 1);
+#pragma unroll
+            for (int g = 0; g < RA + RB; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, (4 * TM * TN) / (RA + RB) > 0 ? (4 * TM * TN) / (RA + RB) : 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                          // DS write
+            }
+            __syncthreads();
+        }
+        mma_tile((nk - 1) & 1);
+    } else {
+        for (int kt = kt0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_tiles(kt + 1);
+            __builtin_amdgcn_s_setprio(1);
+            mma_tile(buf);
+            __builtin_amdgcn_s_setprio(0);
+            if (kt + 1 < nk) store_tiles(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- split-K reduction: write-through partials + arrival counter; the last workgroup of the tile sums them in a
