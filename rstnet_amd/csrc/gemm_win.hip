@@ -10,8 +10,9 @@
 // with window q steps (S_rows = 1, P = q-1) and N = S*Cout output columns, written as S consecutive output
 // time steps; a Linear layer is the degenerate window (Kw=1).  See DESIGN.md section 3.
 //
-// Tile: 4 waves, each TM x TN tiles of v_mfma_f32_32x32x2_f32, BK = 32, register-prefetched double-buffered
-// LDS ([rows][36] floats: a 16-lane ds_read_b128 group covers 16 distinct 16-byte slots -> conflict free).
+// Tile: 4 waves, each TM x TN tiles of v_mfma_f32_32x32x2_f32, k-chunks of KB = 32 (16 for the large-M 128 x 128 case),
+// register-prefetched double-buffered LDS ([rows][KB + 4] floats: a 16-lane ds_read_b128 group covers 16 distinct 16-byte
+// slots -> conflict free).
 // K order inside a BK chunk is permuted (lane half h owns k = 8s + 4h .. +3) so that fragments are read with
 // one ds_read_b128 per four MFMAs; both operands use the same permutation so the product is unchanged.
 #include "rst_common.h"
@@ -20,14 +21,16 @@
 namespace {
 
 constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;  // floats per LDS row
 
-template <int TM, int TN, int WM, int WN, bool VEC, bool ELU>
-__global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
+template <int TM, int TN, int WM, int WN, bool VEC, bool ELU, int KB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 3 : 1, KB == 16 ? 3 : 2))) void gemm_win_kernel(const GemmWinParams p) {
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
-    constexpr int RA = BM / 32;  // A rows staged per thread
-    constexpr int RB = BN / 32;
+    constexpr int LDS_LD = KB + 4;      // floats per LDS row
+    constexpr int RP = 1024 / KB;       // rows staged per pass of the 256 threads (16 bytes each)
+    constexpr int RA = BM / RP;         // A rows staged per thread
+    constexpr int RB = BN / RP;
+    static_assert(BM % RP == 0 && BN % RP == 0, "tile smaller than one staging pass");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                     // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;   // [2][BN][LDS_LD]
@@ -52,8 +55,8 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
     const int PC = p.P * p.C;
 
     // ---- per-thread staging coordinates
-    const int lrow = tid >> 3;       // 0..31
-    const int lk = (tid & 7) * 4;    // 0,4,..,28
+    const int lrow = tid / (KB / 4);         // 0 .. RP-1
+    const int lk = (tid % (KB / 4)) * 4;     // 0, 4, .., KB-4
     long a_off[RA];                  // float offset of the batch inside x
     long h_off[RA];                  // float offset of the batch inside hist
     int a_f0[RA];                    // flat index of the window start inside the batch (may be < 0)
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
     bool a_ok[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-        const int m = m0 + lrow + 32 * j;
+        const int m = m0 + lrow + RP * j;
         a_ok[j] = m < M;
         const int mm = a_ok[j] ? m : 0;
         const int b = mm / p.T_out;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
     };
 
     auto load_tiles = [&](int kt) {
-        const int k = kt * BK + lk;
+        const int k = kt * KB + lk;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            const int n = n0 + lrow + 32 * j;
+            const int n = n0 + lrow + RP * j;
             if (n < p.N) {
                 const float* wp = p.w + (long)n * p.K + k;
                 if (VEC) {
@@ -148,11 +151,11 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
             if (ELU) {
                 v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]);
             }
-            *reinterpret_cast<f32x4*>(a + (lrow + 32 * j) * LDS_LD + lk) = v;
+            *reinterpret_cast<f32x4*>(a + (lrow + RP * j) * LDS_LD + lk) = v;
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j)
-            *reinterpret_cast<f32x4*>(b + (lrow + 32 * j) * LDS_LD + lk) = rb[j];
+            *reinterpret_cast<f32x4*>(b + (lrow + RP * j) * LDS_LD + lk) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     // split-K (few-row streaming steps): workgroup blockIdx.y owns k-tiles [kt0, kt1)
-    const int nk_all = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + KB - 1) / KB;
     const int per_split = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
     const int kt0 = blockIdx.y * per_split;
     const int nk = min(nk_all, kt0 + per_split);
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
 
-    auto mma_tile = [&](int buf, int ks0 = 0, int ks1 = BK / 8) {
+    auto mma_tile = [&](int buf, int ks0 = 0, int ks1 = KB / 8) {
         const float* a = As + buf * BM * LDS_LD + (wm * TM * 32 + frag_row) * LDS_LD + frag_k;
         const float* b = Bs + buf * BN * LDS_LD + (wn * TN * 32 + frag_row) * LDS_LD + frag_k;
 #pragma unroll
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
     // first / last tile of an utterance): the K loop is ONE basic block of unconditional 16-byte loads, so the scheduler can
     // spread the global loads and the LDS writes of the next k-tile between the MFMAs of this one instead of running them
     // as separate phases with the matrix pipe idle.
-    bool interior = VEC && gridDim.y == 1 && m0 + BM <= M && n0 + BN <= p.N && p.K % BK == 0;
+    bool interior = VEC && gridDim.y == 1 && m0 + BM <= M && n0 + BN <= p.N && p.K % KB == 0;
 #pragma unroll
     for (int j = 0; j < RA; ++j) interior = interior && a_klo[j] == 0 && a_khi[j] == p.K;
     if (__syncthreads_and(interior)) {
@@ -210,19 +213,19 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) ap[j] = p.x + a_off[j] + a_f0[j] + lk;
 #pragma unroll
-        for (int j = 0; j < RB; ++j) bp[j] = p.w + (long)(n0 + lrow + 32 * j) * p.K + lk;
+        for (int j = 0; j < RB; ++j) bp[j] = p.w + (long)(n0 + lrow + RP * j) * p.K + lk;
         for (int kt = kt0; kt + 1 < nk; ++kt) {
 #pragma unroll
-            for (int j = 0; j < RA; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ap[j] + (kt + 1) * BK);
+            for (int j = 0; j < RA; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ap[j] + (kt + 1) * KB);
 #pragma unroll
-            for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bp[j] + (kt + 1) * BK);
+            for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bp[j] + (kt + 1) * KB);
             // the loads go out first and stay in flight under the MFMAs of this tile (left alone, the scheduler sinks them to
             // the end of the block to save registers and then waits out the full memory latency) ...
             __builtin_amdgcn_sched_barrier(0);
-            mma_tile(kt & 1, 0, BK / 8 - 1);
+            mma_tile(kt & 1, 0, KB / 8 - 1);
             __builtin_amdgcn_sched_barrier(0);
             // ... and their LDS writes (other buffer) are spread between the last 16 MFMAs
-            mma_tile(kt & 1, BK / 8 - 1, BK / 8);
+            mma_tile(kt & 1, KB / 8 - 1, KB / 8);
             store_tiles((kt & 1) ^ 1);
 #pragma unroll
             for (int g = 0; g < RA + RB; ++g) {
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(const GemmWinParams p) {
     }
 }
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int KB = BK>
 int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     const long M = (long)p.B * p.T_out;
@@ -327,7 +330,7 @@ int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
         rst_set_error("gemm_win: too many tiles (%ld)", tiles);
         return RST_ERR_UNSUPPORTED;
     }
-    const size_t lds = 2 * (BM + BN) * LDS_LD * sizeof(float);
+    const size_t lds = 2 * (BM + BN) * (KB + 4) * sizeof(float);
     auto go = [&](auto kern) {
         static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel instantiation
         if (!attr_set) {
@@ -339,10 +342,10 @@ int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)(p.split_k > 1 ? p.split_k : 1)), dim3(256), lds, stream, p);
     };
     const bool elu = p.act_in == 1;
-    if (vec && elu) go(gemm_win_kernel<TM, TN, WM, WN, true, true>);
-    else if (vec) go(gemm_win_kernel<TM, TN, WM, WN, true, false>);
-    else if (elu) go(gemm_win_kernel<TM, TN, WM, WN, false, true>);
-    else go(gemm_win_kernel<TM, TN, WM, WN, false, false>);
+    if (vec && elu) go(gemm_win_kernel<TM, TN, WM, WN, true, true, KB>);
+    else if (vec) go(gemm_win_kernel<TM, TN, WM, WN, true, false, KB>);
+    else if (elu) go(gemm_win_kernel<TM, TN, WM, WN, false, true, KB>);
+    else go(gemm_win_kernel<TM, TN, WM, WN, false, false, KB>);
     return rst_check_launch("gemm_win");
 }
 
@@ -371,7 +374,12 @@ int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
                      (!p.hist || (uintptr_t)p.hist % 16 == 0);
     const long M = (long)p.B * p.T_out;
     RST_REQUIRE(p.split_k <= 1 || (p.ws && p.counters && M <= 32 && p.N > 64), "gemm_win: split-K needs M <= 32, N > 64 and the scratch buffers");
-    if (p.N > 64 && M > 64) return launch_cfg<2, 2, 2, 2>(p, vec, stream);   // 128 x 128
+    if (p.N > 64 && M > 64) {                                                // 128 x 128
+        // >= 3 tiles per CU: k-chunks of 16 (40 KB of LDS, accumulators in VGPRs) put three workgroups on a CU instead of two
+        const long tiles = ((M + 127) / 128) * ((p.N + 127) / 128);
+        if (tiles >= 768) return launch_cfg<2, 2, 2, 2, 16>(p, vec, stream);
+        return launch_cfg<2, 2, 2, 2>(p, vec, stream);
+    }
     if (p.N > 64) return launch_cfg<1, 1, 1, 4>(p, vec, stream);             // 32 x 128 (few rows: streaming steps)
     if (p.N > 32) return launch_cfg<1, 2, 4, 1>(p, vec, stream);             // 128 x 64
     return launch_cfg<2, 1, 4, 1>(p, vec, stream);                           // 256 x 32
