@@ -201,10 +201,10 @@ def bench_lm(args, rank, world, dev):
                    "sampling": "greedy" if args.greedy else "temp 0.8/0.7 top-k 250/25", "hip_graphs": True,
                    "parallelism": f"replica x{world}"},
         "x_realtime_per_stream": round(args.steps / elapsed / 12.5, 2),
-        "roofline": {"bound": "hbm", "kernel": ("gemv_kernel" if B <= 2 else "gemm_skinny_kernel") + " (bf16 weight streaming)",
+        "roofline": {"bound": "hbm", "kernel": ("gemv_kernel / gemv_norm_kernel" if B <= 2 else "gemm_skinny_kernel") + " (bf16 weight streaming)",
                      "achieved": round(nbytes / ms / 1e6, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
-                     "traffic": pmc_traffic("gemv_kernel" if B <= 2 else "gemm_skinny_kernel", "lm"),
+                     "traffic": pmc_traffic("gemv_" if B <= 2 else "gemm_skinny_kernel", "lm"),
                      "algorithmic_bytes_per_launch": round(nbytes / max(1, len(gemv))), "launches_per_step": len(gemv), "avg_launch_ms": round(ms / max(1, len(gemv)), 5),
                      "kernel_ms_per_step": round(ms, 3), "algorithmic_gb_per_step": round(nbytes / 1e9, 3),
                      "share_of_step_eager": round(ms / ms_frame, 3), "all_launches_per_step": None},
@@ -325,10 +325,10 @@ def bench_gpt(args, rank, world, dev):
                    "gemm_precision": "fp8 e4m3 (per-row scales) in the global blocks, bf16 hi+lo elsewhere" if args.fp8 else "bf16 hi+lo",
                    "parallelism": f"replica x{world}"},
         "x_realtime_per_stream": round(args.steps / elapsed / 12.5, 2),
-        "roofline": {"bound": "hbm", "kernel": ("gemv_kernel" if B <= 2 else "gemm_skinny_kernel") + " (bf16 weight streaming)",
+        "roofline": {"bound": "hbm", "kernel": ("gemv_kernel / gemv_norm_kernel" if B <= 2 else "gemm_skinny_kernel") + " (bf16 weight streaming)",
                      "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
-                     "traffic": pmc_traffic("gemv_kernel" if B <= 2 else "gemm_skinny_kernel", "gpt"),
+                     "traffic": pmc_traffic("gemv_" if B <= 2 else "gemm_skinny_kernel", "gpt"),
                      "algorithmic_bytes_per_launch": round(nbytes / max(1, len(gemm))), "launches_per_step": len(gemm),
                      "avg_launch_ms": round(ms / max(1, len(gemm)), 5), "kernel_ms_per_step": round(ms, 3),
                      "algorithmic_gb_per_step": round(nbytes / 1e9, 3), "share_of_step_eager": round(ms / ms_frame, 3)},
