@@ -209,7 +209,7 @@ def bench_lm(args, rank, world, dev):
                      "kernel_ms_per_step": round(ms, 3), "algorithmic_gb_per_step": round(nbytes / 1e9, 3),
                      "share_of_step_eager": round(ms / ms_frame, 3), "all_launches_per_step": None},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:    # the CPU leg is timed on rank 0 of the single-GPU run only
         result["cpu_baseline"] = lm_cpu_baseline()
     print(json.dumps(result), flush=True)
 
@@ -333,7 +333,7 @@ def bench_gpt(args, rank, world, dev):
                      "avg_launch_ms": round(ms / max(1, len(gemm)), 5), "kernel_ms_per_step": round(ms, 3),
                      "algorithmic_gb_per_step": round(nbytes / 1e9, 3), "share_of_step_eager": round(ms / ms_frame, 3)},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:    # the CPU leg is timed on rank 0 of the single-GPU run only
         result["cpu_baseline"] = gpt_cpu_baseline(cfg_d)
     print(json.dumps(result), flush=True)
 
@@ -496,7 +496,7 @@ def main():
             with torch.no_grad():
                 ref = O.encode(sd_cpu, O.MimiConfig(), audio[:n].cpu())
             result["code_exact_match_vs_cpu_oracle"] = round(float((codes[:n].cpu() == ref).float().mean()), 6)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:    # the CPU leg is timed on rank 0 of the single-GPU run only
             result["cpu_baseline"] = cpu_baseline(sd_cpu, args.seconds)
         print(json.dumps(result), flush=True)
     if world > 1:
