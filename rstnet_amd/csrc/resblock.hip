@@ -22,20 +22,19 @@ constexpr int WLD = BK + 4;
 
 // LDS carve-up (floats), shared by kernel and launcher.  Region R0 holds the ELU'd input tile during GEMM1 and is
 // recycled afterwards (W2, and the hidden tile when it fits behind W2; POST: the output tile).
-template <int C, int BM, bool W1RES>
+template <int C, int BM>
 struct Carve {
     static constexpr int H = C / 2, XLD = C + 4, HLD = H + 4;
-    int r0, hs_off, w1_off, w1_ld, as_off, w0_off, wf_off, total;
+    int r0, hs_off, w1_off, as_off, w0_off, wf_off, total;
     __host__ __device__ Carve(int Kw, bool pre, bool post) {
         const int xt = (BM + Kw - 1) * XLD, w2 = C * HLD, hs = BM * HLD;
         const bool hs_in_r0 = xt >= w2 + hs;
         r0 = xt > w2 ? xt : w2;
-        w1_ld = W1RES ? Kw * C + 4 : WLD;
-        const int w1 = W1RES ? H * w1_ld : 2 * H * WLD;
+        const int w1 = 2 * H * WLD;        // W1 streams through a double-buffered ring of BK-wide k-tiles
         w1_off = r0;
-        // the hidden tile lives behind W2 inside R0 if there is room, else over the (dead) W1 stream ring, else on its own
-        hs_off = hs_in_r0 ? w2 : ((!W1RES && w1 >= hs) ? w1_off : r0 + w1);
-        const int end = (hs_in_r0 || (!W1RES && w1 >= hs)) ? r0 + w1 : r0 + w1 + hs;
+        // the hidden tile lives behind W2 inside R0 if there is room, else over the (dead) W1 ring, else on its own
+        hs_off = hs_in_r0 ? w2 : (w1 >= hs ? w1_off : r0 + w1);
+        const int end = (hs_in_r0 || w1 >= hs) ? r0 + w1 : r0 + w1 + hs;
         as_off = end;
         w0_off = as_off + (pre ? BM + 24 : 0);
         wf_off = w0_off + (pre ? C * 9 : 0);
@@ -43,7 +42,7 @@ struct Carve {
     }
 };
 
-template <int C, int BM, int WM, int WN, bool PRE, bool POST, bool W1RES>
+template <int C, int BM, int WM, int WN, bool PRE, bool POST>
 __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
     constexpr int H = C / 2;
     constexpr int XLD = C + 4, HLD = H + 4;
@@ -56,14 +55,13 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
     static_assert(!POST || BM == 128, "the fused last conv maps two lanes to each of the BM output rows");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const Carve<C, BM, W1RES> cv(p.Kw, PRE, POST);
+    const Carve<C, BM> cv(p.Kw, PRE, POST);
     float* Xs = smem;                    // [(BM+Kw-1)][XLD] ELU(x); later W2s [C][HLD] (+ Hs); later (POST) Ys [BM][XLD]
     float* Hs = smem + cv.hs_off;        // [BM][HLD]
-    float* W1s = smem + cv.w1_off;       // W1RES: [H][Kw*C+4] whole ; else ring [2][H][WLD]
+    float* W1s = smem + cv.w1_off;       // ring [2][H][WLD]
     float* As = smem + cv.as_off;        // PRE: audio tile [BM + Kw-1 + K0-1]
     float* W0s = smem + cv.w0_off;       // PRE: [C][MAXK0+1]
     float* Wfs = smem + cv.wf_off;       // POST: [Kf][C]
-    const int W1LD = cv.w1_ld;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -155,41 +153,7 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
     const int frow = lane & 31, fk = (lane >> 5) * 4;
-    if (W1RES) {
-        // whole W1 in LDS: one barrier, then an uninterrupted MFMA stream
-        const int KC = Kw * C;
-        constexpr int WCH = H * C / 256;   // chunks per thread at the maximum Kw = 4
-        f32x4 wv[WCH];
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int idx = tid + 256 * i;
-            wv[i] = idx < H * (KC / 4) ? *reinterpret_cast<const f32x4*>(p.w1 + (size_t)idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / (KC / 4), k4 = (idx - row * (KC / 4)) * 4;
-            if (idx < H * (KC / 4)) *reinterpret_cast<f32x4*>(W1s + row * W1LD + k4) = wv[i];
-        }
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int tap = (kt * BK) / C, ci0 = (kt * BK) % C;
-            const float* a = Xs + (wm * 32 + frow + tap) * XLD + ci0 + fk;
-            const float* bw = W1s + (wn * NT1 * 32 + frow) * W1LD + kt * BK + fk;
-#pragma unroll
-            for (int ks = 0; ks < BK / 8; ++ks) {
-                const f32x4 fa = *reinterpret_cast<const f32x4*>(a + ks * 8);
-                f32x4 fb[NT1];
-#pragma unroll
-                for (int j = 0; j < NT1; ++j) fb[j] = *reinterpret_cast<const f32x4*>(bw + j * 32 * W1LD + ks * 8);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int j = 0; j < NT1; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[j][e], acc1[j], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    } else {
+    {
         f32x4 w1r[W1CH];
         auto load_w1 = [&](int kt) {
 #pragma unroll
@@ -351,20 +315,20 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
     }
 }
 
-template <int C, int BM, int WM, int WN, bool PRE, bool POST, bool W1RES>
+template <int C, int BM, int WM, int WN, bool PRE, bool POST>
 int launch(const ResblockParams& p, hipStream_t stream) {
-    const Carve<C, BM, W1RES> cv(p.Kw, PRE, POST);
+    const Carve<C, BM> cv(p.Kw, PRE, POST);
     const size_t lds = (size_t)cv.total * sizeof(float);
     const int halo = POST ? p.Kf - 1 : 0;
     const long tiles = (long)p.B * ((p.T + (BM - halo) - 1) / (BM - halo));
     if (tiles > 0x7fffffffL) { rst_set_error("resblock: grid too large"); return RST_ERR_UNSUPPORTED; }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<C, BM, WM, WN, PRE, POST, W1RES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<C, BM, WM, WN, PRE, POST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((resblock_kernel<C, BM, WM, WN, PRE, POST, W1RES>), dim3((unsigned)tiles), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((resblock_kernel<C, BM, WM, WN, PRE, POST>), dim3((unsigned)tiles), dim3(256), lds, stream, p);
     return rst_check_launch("resblock");
 }
 
@@ -389,10 +353,10 @@ int rst_launch_resblock(const ResblockParams& p, hipStream_t stream) {
     RST_REQUIRE(!p.post || (p.wf && p.bf), "resblock: POST needs wf/bf");
     RST_REQUIRE(!(p.hist && (p.pre || p.post)), "resblock: streaming history is only supported by the plain variant");
     if (p.C == 64) {
-        if (p.pre && p.post) return launch<64, 128, 4, 1, true, true, true>(p, stream);
-        if (p.pre) return launch<64, 128, 4, 1, true, false, true>(p, stream);
-        if (p.post) return launch<64, 128, 4, 1, false, true, true>(p, stream);
-        return launch<64, 128, 4, 1, false, false, true>(p, stream);
+        if (p.pre && p.post) return launch<64, 128, 4, 1, true, true>(p, stream);
+        if (p.pre) return launch<64, 128, 4, 1, true, false>(p, stream);
+        if (p.post) return launch<64, 128, 4, 1, false, true>(p, stream);
+        return launch<64, 128, 4, 1, false, false>(p, stream);
     }
-    return launch<128, 64, 2, 2, false, false, false>(p, stream);
+    return launch<128, 64, 2, 2, false, false>(p, stream);
 }
