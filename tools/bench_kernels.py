@@ -117,27 +117,20 @@ def gemv_case(B, N, K, mode="plain", copies=None):
     return fn, max(copies, 48), 2.0 * N * K
 
 
-def gemv_sweep(argv):
-    """python tools/bench_kernels.py gemvsweep 'ENV=V,ENV=V;ENV=V' case ...   -- every case under every knob setting."""
-    settings = [dict(kv.split("=") for kv in st.split(",") if kv) for st in argv[0].split(";")]
-    for c in argv[1:]:
+def gemv_cases(cases):
+    """python tools/bench_kernels.py gemv:BxNxK[:norm|normgate|gate] ...   -- graph-timed, weights rotating through > 1 GB."""
+    for c in cases:
         parts = c.split(":")
         Bq, N, K = [int(v) for v in parts[1].split("x")]
         mode = parts[2] if len(parts) > 2 else "plain"
-        row = []
         fn, iters, nbytes = gemv_case(Bq, N, K, mode)
-        for st in settings:
-            for k in ("RST_GEMV_PIPE", "RST_GEMV_PRE", "RST_GEMV_RPW", "RST_GEMV_CAP"):
-                os.environ.pop(k, None)
-            os.environ.update(st)
-            ms = timeit_graph(fn, iters=iters)
-            row.append(f"{ms * 1e3:6.1f}us {nbytes / ms / 1e9:5.2f}TB/s")
-        print(f"{c:28s} " + " | ".join(row), flush=True)
+        ms = timeit_graph(fn, iters=iters)
+        print(f"{c:28s} {ms * 1e3:6.1f} us {nbytes / ms / 1e9:5.2f} TB/s", flush=True)
 
 
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "gemvsweep":
-        return gemv_sweep(sys.argv[2:])
+    if len(sys.argv) > 1 and all(a.startswith("gemv:") for a in sys.argv[1:]):
+        return gemv_cases(sys.argv[1:])
     cases = sys.argv[1:] or ["res64", "res64pre", "res64post", "res128", "gemm:3840000x128x512:elu", "gemm:16000x1024x8192",
                              "gemm:128000x512x3072", "gemm:16000x512x512"]
     B, T = 16, 240000
