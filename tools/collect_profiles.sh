@@ -25,6 +25,13 @@ if [ "$WHAT" = all ] || [ "$WHAT" = codec ]; then
   run codec_bench python bench.py --steps 5 --warmup 2 --check
   prof codec python bench.py --steps 2 --warmup 1 --no-cpu-baseline
 fi
+if [ "$WHAT" = all ] || [ "$WHAT" = codec ] || [ "$WHAT" = mfma ]; then
+  # MFMA-pipe busy cycles of the codec step (its own PMC pass; tools/pmc_mfma.py)
+  NO_CUDA_GRAPH=1 run codec_mfma rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$RAW/codec_mfma" -o m -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline
+  mc=$(find "$RAW/codec_mfma" -name "*counter_collection.csv" | head -1)
+  [ -n "$mc" ] && python tools/pmc_mfma.py "$mc" "$O/codec_mfma.json" | head -8
+  rm -f "$O/codec_mfma.out"
+fi
 if [ "$WHAT" = all ] || [ "$WHAT" = lm ]; then
   run lm_bench python bench.py --workload lm --steps 60 --warmup 5
   run lm_ctx3000_bench python bench.py --workload lm --steps 60 --warmup 5 --lm-context 3000 --no-cpu-baseline

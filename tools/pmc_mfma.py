@@ -39,7 +39,10 @@ def main(path, out=None):
     for k, (n, mfma, gui, sqb, ns) in sorted(agg.items(), key=lambda kv: -kv[1][4]):
         if gui <= 0:
             continue
+        # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (the "clock" below is 8 x the shader clock), the MFMA counter
+        # summed over all 1024 SIMDs: busy fraction of a SIMD's matrix pipe = mfma / ((gui / 8) * 1024)
         res[k] = {"launches": n, "total_ms": round(ns / 1e6, 3), "effective_clock_ghz": round(gui / ns, 3),
+                  "shader_clock_ghz": round(gui / ns / 8, 3), "mfma_pipe_busy_frac": round(mfma / (gui / 8 * 1024), 4),
                   "mfma_busy_over_gui_x1024simd": round(mfma / (gui * 1024), 4), "mfma_busy_raw_over_gui": round(mfma / gui, 3)}
     for k, v in list(res.items())[:12]:
         print(f"{k[:60]:60s} {v}")
