@@ -15,6 +15,7 @@
 // slots -> conflict free).
 // K order inside a BK chunk is permuted (lane half h owns k = 8s + 4h .. +3) so that fragments are read with
 // one ds_read_b128 per four MFMAs; both operands use the same permutation so the product is unchanged.
+#include <cstdlib>
 #include "rst_common.h"
 #include "rst_kernels.h"
 
@@ -377,7 +378,9 @@ int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
     if (p.N > 64 && M > 64) {                                                // 128 x 128
         // >= 3 tiles per CU: k-chunks of 16 (40 KB of LDS, accumulators in VGPRs) put three workgroups on a CU instead of two
         const long tiles = ((M + 127) / 128) * ((p.N + 127) / 128);
-        if (tiles >= 768) return launch_cfg<2, 2, 2, 2, 16>(p, vec, stream);
+        // RST_GEMM_KB32 (any value) forces the 32-wide chunks: the calibration knob of the PMC traffic numbers
+        static const bool kb32_only = getenv("RST_GEMM_KB32") != nullptr;
+        if (tiles >= 768 && !kb32_only) return launch_cfg<2, 2, 2, 2, 16>(p, vec, stream);
         return launch_cfg<2, 2, 2, 2>(p, vec, stream);
     }
     if (p.N > 64) return launch_cfg<1, 1, 1, 4>(p, vec, stream);             // 32 x 128 (few rows: streaming steps)
