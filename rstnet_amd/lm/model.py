@@ -7,8 +7,9 @@ Same constructor keywords, ``state_dict`` keys (``emb.{i}.weight``, ``transforme
 the first ``max_delay`` steps).  Training ``forward`` is out of scope.
 
 Execution: weights bf16 in HBM, activations fp32, one decode step (T = 1) per call through the kernels of
-``csrc/lm_*.hip``; the two per-frame halves (``forward_text`` and ``depformer_step``) are captured into HIP graphs
-after a warm-up exactly like the reference's ``CUDAGraphed`` wrappers (``MLLM_v2/utils/compile.py:189-277``), and the
+``csrc/lm_*.hip``; a whole ``LMGen`` frame (token-ring update, ``forward_text``, the depth steps with their samplers, ring
+commit) is captured into ONE HIP graph after a warm-up -- the reference wraps ``forward_text`` and ``depformer_step`` in two
+``CUDAGraphed`` wrappers (``MLLM_v2/utils/compile.py:189-277``) and does the ring arithmetic on the host in between -- and the
 environment flag ``NO_CUDA_GRAPH`` disables that (``compile.py:168-174``).
 """
 from __future__ import annotations
