@@ -7,8 +7,8 @@ with ``sample_token`` and the eight audio tokens with ``sample_token_audio`` / `
 (``utils/sampling.py:85-158``: probabilities of ids >= 2049 / 2048 blanked after the softmax).
 
 Parity status: infer_no_streaming.py itself cannot be imported here (torchaudio / dataloader dependencies are absent), so this
-file is pinned only through its building blocks (forward_global / forward_local against gpt_tiny.npz, sample_token against
-the LM fixture); the loop structure is a restatement ("parity unpinned" at the loop level).
+file is pinned only through its building blocks (forward_global / forward_local against gpt_tiny.npz, the three samplers
+against sampling.npz); the loop structure is a restatement ("parity unpinned" at the loop level).
 Deviations, on purpose: the reference only returns a result for task 'TTS' (the other tasks end in an unbound
 ``prompt_audio``, :301-307); this restatement returns the generated frames for every task.  Special ids are parameters
 (defaults = the reference's literals).

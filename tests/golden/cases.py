@@ -106,3 +106,27 @@ def gpt_tokens(cfg: dict, steps: int = GPT_STEPS, batch: int = GPT_BATCH):
     audio = torch.randint(0, cfg["audio_card"] + 1, (batch, cfg["n_q"], steps), generator=g)
     audio[0, 1, 2] = -1
     return torch.cat([text, audio], 1)
+
+
+# ---- samplers (utils/sampling.py): name -> (function, B, V, top_k, temp, seed)  ----------------------------------------
+# "hot" ids: logits forced up so that the id blanking of sample_token_audio (>= 2049) / _2048 (>= 2048) decides the draw.
+# No case puts the top-k boundary inside a run of EQUAL logits: which of the tied ids torch.topk keeps is unspecified (and
+# differs between the CPU and GPU implementations of the reference's own dependency), so there is no reference answer to pin;
+# the build's rule (lowest index first) is tested on its own in tests/test_lm_gpu.py.
+SAMPLING_CASES = {
+    "text": ("sample_token", 3, 32000, 25, 0.7, 1),
+    "audio": ("sample_token", 4, 2048, 250, 0.8, 2),
+    "audio_blank2049": ("sample_token_audio", 4, 2050, 250, 0.8, 3),
+    "audio_blank2048": ("sample_token_audio_2048", 4, 2050, 200, 1.0, 4),
+    "qwen_vocab": ("sample_token", 2, 151936, 25, 0.7, 6),
+}
+
+
+def sampling_logits(name: str) -> torch.Tensor:
+    """fp32 logits ``[B, 1, 1, V]`` of a sampling case."""
+    fn, B, V, k, temp, seed = SAMPLING_CASES[name]
+    g = torch.Generator().manual_seed(900 + seed)
+    lg = 3.0 * torch.randn(B, 1, 1, V, generator=g)
+    if name.startswith("audio_blank"):
+        lg[..., 2048:] += 12.0       # would win every draw if it were not blanked
+    return lg

@@ -185,7 +185,27 @@ def gen_gpt_tiny():
     np.savez(os.path.join(HERE, "gpt_tiny.npz"), **out)
 
 
+@torch.no_grad()
+def gen_sampling():
+    """F9: the reference samplers (MLLM_v2/utils/sampling.py:85-158) under a known RNG state.  `multinomial` (:44-46) draws
+    its Exp(1) noise with `torch.empty_like(top-k probs).exponential_(1)` right after the seed is set, so the same seed
+    reproduces that noise tensor; it is stored next to the tokens the reference returned (and greedy tokens)."""
+    import utils.sampling as S
+    out = {}
+    for name, (fn, B, V, k, temp, seed) in cases.SAMPLING_CASES.items():
+        lg = cases.sampling_logits(name)
+        torch.manual_seed(seed)
+        tok = getattr(S, fn)(lg.clone(), use_sampling=True, temp=temp, top_k=k)
+        torch.manual_seed(seed)
+        noise = torch.empty(B, k).exponential_(1)
+        greedy = getattr(S, fn)(lg.clone(), use_sampling=False)
+        out[f"{name}.tokens"], out[f"{name}.noise"] = tok.numpy().astype(np.int32), noise.numpy()
+        out[f"{name}.greedy"] = greedy.numpy().astype(np.int32)
+        print("sampling", name, tuple(tok.shape), tok.flatten().tolist())
+    np.savez(os.path.join(HERE, "sampling.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e", "lm_tiny", "gpt_tiny"]
+    which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e", "lm_tiny", "gpt_tiny", "sampling"]
     for w in which:
         globals()[f"gen_{w}"]()

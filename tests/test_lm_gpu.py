@@ -282,6 +282,21 @@ def test_token_ring_kernels_match_host_bookkeeping(B, dep_q, n_user, delays):
         assert torch.equal(cache.cpu(), ref), offset
 
 
+@pytest.mark.parametrize("name", list(cases.SAMPLING_CASES))
+def test_sampler_matches_reference_fixture(name):
+    """rst_lm_sample_f32 against the tokens the REFERENCE samplers returned (tests/golden/sampling.npz, F9): top-k sampling with
+    the stored Exp(1) noise, id blanking (2049 / 2048), the 151 936-entry vocabulary; greedy."""
+    g = np.load(os.path.join(G, "sampling.npz"))
+    fn, B, V, k, temp, seed = cases.SAMPLING_CASES[name]
+    limit = {"sample_token": 0, "sample_token_audio": 2049, "sample_token_audio_2048": 2048}[fn]
+    lg = cases.sampling_logits(name).view(B, V).to(DEV)
+    noise = torch.from_numpy(g[f"{name}.noise"]).to(DEV)
+    tok = ops.lm_sample(lg, use_sampling=True, temp=temp, top_k=k, noise=noise, limit=limit)
+    assert torch.equal(tok.cpu(), torch.from_numpy(g[f"{name}.tokens"]).long().view(B))
+    tok = ops.lm_sample(lg, use_sampling=False, temp=temp, top_k=k)
+    assert torch.equal(tok.cpu(), torch.from_numpy(g[f"{name}.greedy"]).long().view(B))
+
+
 def test_lm_state_dict_keys():
     cfg, sd, model = _tiny()
     assert set(model.state_dict().keys()) == set(sd.keys())

@@ -169,3 +169,25 @@ def test_gpt_oracle_matches_reference(name):
         assert rel_err(torch.stack(dep).view(cases.GPT_STEPS, cfg.dep_q, B, -1), torch.from_numpy(g[f"{name}.stream.dep_logits"])) < 2e-5
         local = Gp.forward_local(sd, cfg, toks[:, 0, :T], toks[:, 1:cfg.dep_q + 1, :T], h_full)
         assert rel_err(local, torch.from_numpy(g[f"{name}.local.logits"])) < 2e-5
+
+
+_BLANK = {"sample_token": 0, "sample_token_audio": 2049, "sample_token_audio_2048": 2048}
+
+
+@pytest.mark.parametrize("name", list(cases.SAMPLING_CASES))
+def test_sampling_oracle_matches_reference(name):
+    """F9: the oracle samplers (oracle/gpt_generate_oracle.py:sample_token = sample_token / sample_token_audio(_2048) with the
+    Exp(1) draws passed in, oracle/lm_oracle.py:sample_token) against the tokens the reference's utils/sampling.py returned
+    for the stored noise (fixture tests/golden/sampling.npz), incl. id blanking and the 151 936-entry vocabulary; greedy too."""
+    from oracle import gpt_generate_oracle as GO
+    from oracle import lm_oracle as L
+    g = np.load(os.path.join(G, "sampling.npz"))
+    fn, B, V, k, temp, seed = cases.SAMPLING_CASES[name]
+    lg = cases.sampling_logits(name)
+    noise = torch.from_numpy(g[f"{name}.noise"]).view(B, 1, 1, k)
+    want = torch.from_numpy(g[f"{name}.tokens"]).long()
+    got = GO.sample_token(lg.clone(), True, temp, k, noise, _BLANK[fn])
+    assert torch.equal(got, want)
+    assert torch.equal(GO.sample_token(lg.clone(), False, temp, k, None, _BLANK[fn]), torch.from_numpy(g[f"{name}.greedy"]).long())
+    if not _BLANK[fn]:
+        assert torch.equal(L.sample_token(lg.clone(), True, temp, k, noise), want)
