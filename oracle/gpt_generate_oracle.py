@@ -6,9 +6,11 @@ the non-streaming ``forward_local`` over the whole prefix (O(T^2), exactly what 
 with ``sample_token`` and the eight audio tokens with ``sample_token_audio`` / ``sample_token_audio_2048``
 (``utils/sampling.py:85-158``: probabilities of ids >= 2049 / 2048 blanked after the softmax).
 
-Parity status: infer_no_streaming.py itself cannot be imported here (torchaudio / dataloader dependencies are absent), so this
-file is pinned only through its building blocks (forward_global / forward_local against gpt_tiny.npz, the three samplers
-against sampling.npz); the loop structure is a restatement ("parity unpinned" at the loop level).
+Parity status: pinned.  infer_no_streaming.py cannot be imported here (torchaudio / dataloader dependencies at its top level),
+but its ``class InferenceImp`` and ``reverse_delay`` need none of them: tests/golden/make_golden.py takes the two definitions
+from the parsed source of the file where it lies and runs them unchanged on the real reference GPT and utils.sampling; the
+codes that run returned and the Exp(1) noise it drew are the fixture tests/golden/gpt_generate.npz, which ``generate`` below
+reproduces exactly (tests/test_oracle_golden.py).  Building blocks: gpt_tiny.npz, sampling.npz, reverse_delay.npz.
 Deviations, on purpose: the reference only returns a result for task 'TTS' (the other tasks end in an unbound
 ``prompt_audio``, :301-307); this restatement returns the generated frames for every task.  Special ids are parameters
 (defaults = the reference's literals).

@@ -250,6 +250,14 @@ GPT_TINY_MHA = dict(block_size=64, n_layer=2, n_embd=256, n_head=4, n_query_grou
                     codecformer_heads=2, codecformer_layers=2, codecformer_dim_feedforward=528, context=10,
                     codecformer_bias_proj=True)
 
+# the smallest config the reference's OFFLINE generation loop runs on unchanged: infer_no_streaming.py hard-codes 8 depth steps,
+# text ids 128002 / 128003 / 151655 and the 2048 / 2049 audio-id rules, so the vocabularies keep their real sizes
+GPT_GEN_TINY = dict(block_size=64, n_layer=2, n_embd=64, n_head=2, n_query_groups=2, padded_vocab_size=151936,
+                    rotary_percentage=1.0, rope_base=10000, norm_class_name="RMSNorm", norm_eps=1e-5, bias=False,
+                    lm_head_bias=False, parallel_residual=False, mlp_class_name="LLaMAMLP", intermediate_size=128,
+                    lora_r=0, audio_card=2050, codecformer_dim=64, n_q=8, dep_q=8, codecformer_heads=2, codecformer_layers=2,
+                    codecformer_dim_feedforward=132, context=32)
+
 
 def gpt_state_dict(cfg: dict, seed: int = 0, device: str = "cpu", dtype: torch.dtype = torch.bfloat16,
                    lora: bool = True) -> Dict[str, torch.Tensor]:

@@ -130,3 +130,28 @@ def sampling_logits(name: str) -> torch.Tensor:
     if name.startswith("audio_blank"):
         lg[..., 2048:] += 12.0       # would win every draw if it were not blanked
     return lg
+
+
+# ---- reverse_delay (infer_no_streaming.py:311-323): name -> shape; [8, L] as generated, [L, 8] exercises the transpose branch
+REVERSE_DELAY_CASES = {"k_major": (8, 13), "t_major": (21, 8), "two_frames": (8, 2)}
+
+
+def reverse_delay_input(name: str) -> torch.Tensor:
+    g = torch.Generator().manual_seed(950 + len(name))
+    return torch.randint(0, 2048, REVERSE_DELAY_CASES[name], generator=g)
+
+
+# ---- the offline generation loop (infer_no_streaming.py:168-308, task TTS -- the only task whose result the reference returns)
+GEN_SEED = 7
+# name -> (L, text positions, RNG seed of the samplers, temp_text, top_k_text, temp, top_k)
+GEN_CASES = {"tts_a": (12, 5, 11, 0.7, 25, 0.8, 250), "tts_b": (15, 4, 12, 1.0, 10, 1.0, 100)}
+
+
+def gen_sequence(name: str) -> torch.Tensor:
+    """[9, L] utterance in the reference's TTS layout: n_text text ids, then text_empty (128002) on row 0; audio rows < 2048."""
+    L, n_text = GEN_CASES[name][:2]
+    g = torch.Generator().manual_seed(970 + L)
+    seq = torch.randint(0, 2048, (9, L), generator=g)
+    seq[0, :n_text] = torch.randint(0, 128000, (n_text,), generator=g)
+    seq[0, n_text:] = 128002
+    return seq

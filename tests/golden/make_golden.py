@@ -205,7 +205,75 @@ def gen_sampling():
     np.savez(os.path.join(HERE, "sampling.npz"), **out)
 
 
+def gen_reverse_delay():
+    """`reverse_delay` of MLLM_v2/infer_no_streaming.py:311-323.  The module itself cannot be imported here (torchaudio,
+    huggingface_hub ... at its top level), so the function definition alone is taken from the parsed source of the file where it
+    lies and executed as is -- no stand-in modules, nothing copied: only its outputs on seeded inputs are stored."""
+    import ast
+    path = "/root/reference/MLLM_v2/infer_no_streaming.py"
+    tree = ast.parse(open(path).read(), path)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "reverse_delay")
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    out = {}
+    for name, shape in cases.REVERSE_DELAY_CASES.items():
+        x = cases.reverse_delay_input(name)
+        out[name] = ns["reverse_delay"](x.clone()).numpy()
+        print("reverse_delay", name, tuple(x.shape), "->", out[name].shape)
+    np.savez(os.path.join(HERE, "reverse_delay.npz"), **out)
+
+
+@torch.no_grad()
+def gen_gpt_generate():
+    """The reference's OFFLINE generation loop itself: class `InferenceImp` and `reverse_delay` of
+    MLLM_v2/infer_no_streaming.py:149-323, taken from the parsed source of the file where it lies (its top-level imports --
+    torchaudio, huggingface_hub, the dataloader -- are absent here, its class body needs none of them) and executed unchanged on
+    the REAL models.llama_streaming.GPT and the REAL utils.sampling functions.  Stored: the codes it returns and the Exp(1)
+    noise its samplers drew (re-drawn from the same seed in call order; the script asserts that the build's restatement of
+    the loop, fed that noise, reproduces the reference's result)."""
+    import ast
+    import utils.sampling as S
+    from models.llama_streaming import GPT, Config
+    from oracle import gpt_generate_oracle as GG
+    from oracle import gpt_oracle as Gp
+    path = "/root/reference/MLLM_v2/infer_no_streaming.py"
+    tree = ast.parse(open(path).read(), path)
+    keep = [n for n in tree.body if (isinstance(n, ast.ClassDef) and n.name == "InferenceImp")
+            or (isinstance(n, ast.FunctionDef) and n.name == "reverse_delay")]
+    assert len(keep) == 2
+    ns = {"torch": torch, "sample_token": S.sample_token, "sample_token_audio": S.sample_token_audio,
+          "sample_token_audio_2048": S.sample_token_audio_2048}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    cfg = dict(synth.GPT_GEN_TINY)
+    sd = {k: v.float() for k, v in synth.gpt_state_dict(cfg, cases.GEN_SEED, lora=False).items()}
+    m = GPT(Config(name="gen", **cfg)).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("lora" in k for k in missing), (missing, unexpected)
+    ocfg = Gp.GPTConfig(**{k: v for k, v in cfg.items() if k in Gp.GPTConfig.__dataclass_fields__})
+    out = {}
+    for name, (L, n_text, seed, temp_text, k_text, temp, k) in cases.GEN_CASES.items():
+        seq = cases.gen_sequence(name)
+        imp = ns["InferenceImp"](None, m, "generate", temp_text, k_text, temp, k, "TTS")
+        torch.manual_seed(seed)
+        codes = imp(seq.clone(), torch.ones_like(seq))
+        n = L - n_text
+        torch.manual_seed(seed)     # the same draws again, in the order the loop made them: text, then 8 audio, per frame
+        nt, na = [], []
+        for _ in range(n):
+            nt.append(torch.empty(1, k_text).exponential_(1))
+            na.append(torch.stack([torch.empty(1, k).exponential_(1) for _ in range(8)]))
+        nt, na = torch.stack(nt), torch.stack(na)      # [n, 1, k_text], [n, 8, 1, k]
+        ref = GG.generate(sd, ocfg, seq, "TTS", temp=temp, top_k=k, temp_text=temp_text, top_k_text=k_text,
+                          noise=lambda kind, g, l: nt[g].view(1, 1, -1) if kind == "text" else na[g, l].view(1, 1, 1, -1))
+        assert torch.equal(ref["codes"], codes), (name, ref["codes"], codes)
+        out[f"{name}.codes"] = codes.numpy().astype(np.int32)
+        out[f"{name}.noise_text"], out[f"{name}.noise_audio"] = nt[:, 0].numpy(), na[:, :, 0].numpy()
+        print("gpt_generate", name, tuple(codes.shape), codes[:, :3].tolist())
+    np.savez_compressed(os.path.join(HERE, "gpt_generate.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e", "lm_tiny", "gpt_tiny", "sampling"]
+    which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e", "lm_tiny", "gpt_tiny", "sampling", "reverse_delay",
+                             "gpt_generate"]
     for w in which:
         globals()[f"gen_{w}"]()

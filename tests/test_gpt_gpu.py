@@ -215,6 +215,25 @@ def test_streaming_generate_matches_offline_loop(name, task, use_sampling):
     assert torch.equal(out["text"].cpu(), ref["text"])
 
 
+@pytest.mark.parametrize("name", list(cases.GEN_CASES))
+def test_streaming_generate_matches_reference_loop_fixture(name):
+    """The streaming O(T) `InferenceImp` of the build against the codes the REFERENCE's offline O(T^2) loop returned on the real
+    reference GPT (tests/golden/gpt_generate.npz: `InferenceImp.__call__` of infer_no_streaming.py executed unchanged), fed the
+    Exp(1) noise that run drew: real vocabularies (151 936 text ids, 2050 audio ids), the literal special ids, both id-blanking
+    samplers, reverse_delay."""
+    from rstnet_amd.lm.generate import InferenceImp
+    g = np.load(os.path.join(GOLD, "gpt_generate.npz"))
+    L, n_text, seed, temp_text, k_text, temp, k = cases.GEN_CASES[name]
+    cfg_d = dict(synth.GPT_GEN_TINY)
+    sd = {kk: v.to(DEV) for kk, v in synth.gpt_state_dict(cfg_d, cases.GEN_SEED, lora=False).items()}
+    model = GPT.from_state_dict(sd, Config.from_dict(cfg_d))
+    nt, na = torch.from_numpy(g[f"{name}.noise_text"]), torch.from_numpy(g[f"{name}.noise_audio"])
+    imp = InferenceImp(None, model, "sample", temp_text, k_text, temp, k, "TTS",
+                       noise=lambda kind, gi, li: nt[gi:gi + 1] if kind == "text" else na[gi, li:li + 1])
+    out = imp.generate(cases.gen_sequence(name))
+    assert torch.equal(out["codes"].cpu(), torch.from_numpy(g[f"{name}.codes"]).long())
+
+
 def test_streaming_generate_graphed_greedy_equals_eager():
     """The production configuration (captured graphs, device-side Exp(1) draws) in greedy mode reproduces the eager loop."""
     from rstnet_amd.lm.generate import GenIds, InferenceImp

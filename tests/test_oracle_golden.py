@@ -191,3 +191,33 @@ def test_sampling_oracle_matches_reference(name):
     assert torch.equal(GO.sample_token(lg.clone(), False, temp, k, None, _BLANK[fn]), torch.from_numpy(g[f"{name}.greedy"]).long())
     if not _BLANK[fn]:
         assert torch.equal(L.sample_token(lg.clone(), True, temp, k, noise), want)
+
+
+@pytest.mark.parametrize("name", list(cases.REVERSE_DELAY_CASES))
+def test_reverse_delay_matches_reference(name):
+    """Oracle and product `reverse_delay` against the reference function's own outputs (tests/golden/reverse_delay.npz)."""
+    from oracle import gpt_generate_oracle as GO
+    from rstnet_amd.lm.generate import reverse_delay
+    want = torch.from_numpy(np.load(os.path.join(G, "reverse_delay.npz"))[name])
+    x = cases.reverse_delay_input(name)
+    assert torch.equal(GO.reverse_delay(x.clone()), want)
+    assert torch.equal(reverse_delay(x.clone()), want)
+
+
+@pytest.mark.parametrize("name", list(cases.GEN_CASES))
+def test_generation_loop_oracle_matches_reference(name):
+    """oracle/gpt_generate_oracle.py:generate against the codes the reference's own `InferenceImp.__call__` returned on the real
+    reference GPT (tests/golden/gpt_generate.npz, generated by executing the class from infer_no_streaming.py unchanged), fed
+    the Exp(1) noise that run drew.  Pins the loop: prompt split, per-frame global + 8 local passes, the 2049 / 2048 sampler
+    choice per step, reverse_delay."""
+    from oracle import gpt_generate_oracle as GG
+    from oracle import gpt_oracle as Gp
+    g = np.load(os.path.join(G, "gpt_generate.npz"))
+    L, n_text, seed, temp_text, k_text, temp, k = cases.GEN_CASES[name]
+    cfg = dict(synth.GPT_GEN_TINY)
+    sd = {kk: v.float() for kk, v in synth.gpt_state_dict(cfg, cases.GEN_SEED, lora=False).items()}
+    ocfg = Gp.GPTConfig(**{kk: v for kk, v in cfg.items() if kk in Gp.GPTConfig.__dataclass_fields__})
+    nt, na = torch.from_numpy(g[f"{name}.noise_text"]), torch.from_numpy(g[f"{name}.noise_audio"])
+    out = GG.generate(sd, ocfg, cases.gen_sequence(name), "TTS", temp=temp, top_k=k, temp_text=temp_text, top_k_text=k_text,
+                      noise=lambda kind, gi, li: nt[gi].view(1, 1, -1) if kind == "text" else na[gi, li].view(1, 1, 1, -1))
+    assert torch.equal(out["codes"], torch.from_numpy(g[f"{name}.codes"]).long())
