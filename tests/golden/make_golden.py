@@ -224,6 +224,35 @@ def gen_reverse_delay():
 
 
 @torch.no_grad()
+def gen_tokenizer():
+    """`MimiTokenizer.tokenize / detokenize / tokenize2 / find_length` (tools/tokenizer/MimiCodec/mimi_tokenizer.py:47-82).  The
+    module imports omegaconf / torchaudio / huggingface_hub at its top level (absent here) and its constructor downloads a
+    checkpoint; the four methods need neither for a 24 kHz tensor input.  The class definition is taken from the parsed source
+    of the file where it lies, instantiated without its constructor and given the real reference MimiCodec with the seeded
+    weights of the other fixtures."""
+    import ast
+    from tools.tokenizer.abs_tokenizer import AbsTokenizer
+    path = "/root/reference/MLLM_v2/tools/tokenizer/MimiCodec/mimi_tokenizer.py"
+    tree = ast.parse(open(path).read(), path)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "MimiTokenizer")
+    ns = {"torch": torch, "AbsTokenizer": AbsTokenizer}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), path, "exec"), ns)
+    tok = ns["MimiTokenizer"].__new__(ns["MimiTokenizer"])
+    torch.nn.Module.__init__(tok)
+    tok.device, tok.sr = torch.device("cpu"), 24000
+    tok.model = ref_mimi(synth.mimi_state_dict(cases.MIMI_SEED))
+    B, T, seed = cases.MIMI_E2E["ragged"]
+    wav = synth.synth_audio(B, T, seed=seed)[1]            # [1, T]: one utterance, T not a multiple of the hop
+    codes = tok.tokenize(wav, 24000)
+    # (the reference's detokenize wants the int64 ids of tokenize2: F.embedding rejects the int16 storage form)
+    out = {"codes": codes.numpy(), "wav": tok.detokenize(tok.tokenize2(codes)).numpy(), "tokenize2": tok.tokenize2(codes).numpy(),
+           "find_length": np.array(tok.find_length(codes)), "passthrough": tok.tokenize(codes[0].clone(), 24000).numpy()}
+    assert codes.dtype == torch.int16
+    print("tokenizer", tuple(codes.shape), codes.dtype, out["wav"].shape, out["tokenize2"].dtype, int(out["find_length"]))
+    np.savez_compressed(os.path.join(HERE, "tokenizer.npz"), **out)
+
+
+@torch.no_grad()
 def gen_gpt_generate():
     """The reference's OFFLINE generation loop itself: class `InferenceImp` and `reverse_delay` of
     MLLM_v2/infer_no_streaming.py:149-323, taken from the parsed source of the file where it lies (its top-level imports --
@@ -274,6 +303,6 @@ def gen_gpt_generate():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e", "lm_tiny", "gpt_tiny", "sampling", "reverse_delay",
-                             "gpt_generate"]
+                             "gpt_generate", "tokenizer"]
     for w in which:
         globals()[f"gen_{w}"]()

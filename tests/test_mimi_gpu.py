@@ -204,3 +204,25 @@ def test_tokenizer_batch_equals_single():
     wav = tok.detokenize(single[0])
     assert tuple(wav.shape) == (1, single[0].shape[1] * 1920)
     assert tok.tokenize(single[0][0].long(), 24000).dim() == 1       # 1-D input = offline codes, passed through
+
+
+def test_tokenizer_matches_reference_fixture():
+    """MimiTokenizer.tokenize / tokenize2 / find_length / detokenize against the outputs of the REFERENCE class
+    (tests/golden/tokenizer.npz: the class of mimi_tokenizer.py executed unchanged around the real reference MimiCodec, one
+    ragged utterance): int16 codes exact, dtypes and shapes, waveform <= 1e-3 relative."""
+    from rstnet_amd.codec.tokenizer import MimiTokenizer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tokenizer.npz"))
+    model = MimiCodec.from_state_dict(synth.mimi_state_dict(cases.MIMI_SEED)).to(DEV)
+    tok = MimiTokenizer(model)
+    B, T, seed = cases.MIMI_E2E["ragged"]
+    wav = synth.synth_audio(B, T, seed=seed)[1]
+    codes = tok.tokenize(wav, 24000)
+    assert codes.dtype == torch.int16 and not codes.is_cuda and torch.equal(codes, torch.from_numpy(g["codes"]))
+    ids = tok.tokenize2(codes)
+    assert ids.dtype == torch.int64 and torch.equal(ids, torch.from_numpy(g["tokenize2"]))
+    assert tok.find_length(codes) == int(g["find_length"])
+    out = tok.detokenize(ids)
+    want = torch.from_numpy(g["wav"])
+    assert out.shape == want.shape and not out.is_cuda
+    assert float((out - want).abs().max() / want.abs().max()) < 1e-3
+    assert torch.equal(tok.tokenize(codes[0].clone(), 24000), torch.from_numpy(g["passthrough"]))
