@@ -86,6 +86,9 @@ LM_STEPS = 14       # > context (10) so the temporal ring wraps, and
 LM_BATCH = 2
 
 
+LM_SAMPLING = dict(seed=21, temp=0.8, temp_text=0.7, top_k=8, top_k_text=6)   # top-k below the tiny cardinalities (32 / 50)
+
+
 def lm_user_tokens(cfg: dict, steps: int = LM_STEPS, batch: int = LM_BATCH):
     """Tokens of the "other" stream fed to LMGen.step: [steps][B, n_q - dep_q, 1]."""
     g = torch.Generator().manual_seed(79)

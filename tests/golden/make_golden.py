@@ -147,6 +147,49 @@ def gen_lm_tiny():
 
 
 @torch.no_grad()
+def gen_lm_tiny_sampling():
+    """F8 with sampling: LMGen.step (models/model.py:490-597) with use_sampling=True under a seeded RNG.  The Exp(1) noise of
+    `multinomial` is re-drawn from the same seed in call order ([B, top_k_text] for the text token, then dep_q x [B, top_k]) and
+    stored with the token streams; the script asserts that the oracle fed that noise reproduces them."""
+    from models.model import LMModel, LMGen
+    from oracle import lm_oracle as L
+    cfg = dict(synth.LM_TINY)
+    sd = {k: v.float() for k, v in synth.lm_state_dict(cfg, cases.LM_SEED).items()}
+    m = LMModel(causal=True, layer_scale=None, gating="silu", norm="rms_norm_f32", positional_embedding="rope",
+                depformer_causal=True, depformer_layer_scale=None, depformer_multi_linear=True, depformer_context=8,
+                depformer_max_period=10000, depformer_gating="silu", depformer_pos_emb="none",
+                depformer_weights_per_step=True, **cfg).eval()
+    m.load_state_dict(sd, strict=True)
+    sp = cases.LM_SAMPLING
+    gen = LMGen(m, use_sampling=True, temp=sp["temp"], temp_text=sp["temp_text"], top_k=sp["top_k"], top_k_text=sp["top_k_text"])
+    user = cases.lm_user_tokens(cfg)
+    B, dep_q = cases.LM_BATCH, cfg["dep_q"]
+    outs = []
+    torch.manual_seed(sp["seed"])
+    with gen.streaming(B):
+        for s in range(cases.LM_STEPS):
+            o = gen.step(user[s])
+            outs.append(torch.full((B, dep_q + 1, 1), -9, dtype=torch.long) if o is None else o)
+    tokens = torch.cat(outs, -1)
+    torch.manual_seed(sp["seed"])
+    nt, na = [], []
+    for s in range(cases.LM_STEPS):
+        nt.append(torch.empty(B, sp["top_k_text"]).exponential_(1))
+        na.append(torch.stack([torch.empty(B, sp["top_k"]).exponential_(1) for _ in range(dep_q)]))
+    nt, na = torch.stack(nt), torch.stack(na)          # [steps, B, k_text], [steps, dep_q, B, k]
+    og = L.LMGenOracle(sd, L.LMConfig(**cfg), B, use_sampling=True, temp=sp["temp"], temp_text=sp["temp_text"], top_k=sp["top_k"],
+                       top_k_text=sp["top_k_text"])
+    o_outs = []
+    for s in range(cases.LM_STEPS):
+        o = og.step(user[s], noise_text=nt[s].view(B, 1, 1, -1), noise_audio=[na[s, c].view(B, 1, 1, -1) for c in range(dep_q)])
+        o_outs.append(torch.full((B, dep_q + 1, 1), -9, dtype=torch.long) if o is None else o)
+    assert torch.equal(torch.cat(o_outs, -1), tokens)
+    np.savez(os.path.join(HERE, "lm_tiny_sampling.npz"), tokens=tokens.numpy().astype(np.int32), noise_text=nt.numpy(),
+             noise_audio=na.numpy())
+    print("lm_tiny_sampling", tuple(tokens.shape), tokens[0, :, -4:].tolist())
+
+
+@torch.no_grad()
 def gen_gpt_tiny():
     """F6 + F7: models.llama_streaming.GPT on the two tiny configs -- non-streaming forward_global (LoRA unmerged and after
     merge_lora_weights), streamed T = 1 forward_global steps across the ring wrap, forward_codecformer steps and the
@@ -303,6 +346,6 @@ def gen_gpt_generate():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e", "lm_tiny", "gpt_tiny", "sampling", "reverse_delay",
-                             "gpt_generate", "tokenizer"]
+                             "gpt_generate", "tokenizer", "lm_tiny_sampling"]
     for w in which:
         globals()[f"gen_{w}"]()

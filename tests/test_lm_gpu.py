@@ -320,6 +320,34 @@ def test_lmgen_greedy_matches_reference_fixture(graphs, monkeypatch):
     assert torch.equal(got, gold)
 
 
+def test_lmgen_sampling_matches_reference_fixture(monkeypatch):
+    """LMGen.step with use_sampling=True against the token streams of the imported reference LMGen under a seeded RNG
+    (tests/golden/lm_tiny_sampling.npz); the Exp(1) noise that run drew replaces the per-frame device draw (text draw, then the
+    dep_q audio draws: the order of the one noise buffer of LMGen._frame).  Eager mode: a captured graph would freeze the noise."""
+    monkeypatch.setenv("NO_CUDA_GRAPH", "1")
+    cfg, sd, model = _tiny()
+    g = np.load(os.path.join(G, "lm_tiny_sampling.npz"))
+    sp = cases.LM_SAMPLING
+    nt, na = torch.from_numpy(g["noise_text"]), torch.from_numpy(g["noise_audio"])      # [steps, B, k_text], [steps, dep_q, B, k]
+    user = cases.lm_user_tokens(cfg)
+    gen = LMGen(model, use_sampling=True, temp=sp["temp"], temp_text=sp["temp_text"], top_k=sp["top_k"], top_k_text=sp["top_k_text"])
+    frame = {"s": 0}
+
+    def noise(B, k):
+        s = frame["s"]
+        buf = torch.cat([nt[s]] + [na[s, c] for c in range(cfg["dep_q"])], dim=1)
+        assert buf.shape == (B, k)
+        return buf.to(DEV)
+    monkeypatch.setattr(gen, "_noise", noise)
+    outs = []
+    with gen.streaming(cases.LM_BATCH):
+        for s in range(cases.LM_STEPS):
+            frame["s"] = s
+            o = gen.step(user[s].to(DEV))
+            outs.append(torch.full((cases.LM_BATCH, cfg["dep_q"] + 1, 1), -9, dtype=torch.long) if o is None else o.cpu())
+    assert torch.equal(torch.cat(outs, -1), torch.from_numpy(g["tokens"]).long())
+
+
 def test_forward_text_and_depformer_logits_match_oracle():
     cfg, sd, model = _tiny()
     g = np.load(os.path.join(G, "lm_tiny.npz"))

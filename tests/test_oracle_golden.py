@@ -221,3 +221,24 @@ def test_generation_loop_oracle_matches_reference(name):
     out = GG.generate(sd, ocfg, cases.gen_sequence(name), "TTS", temp=temp, top_k=k, temp_text=temp_text, top_k_text=k_text,
                       noise=lambda kind, gi, li: nt[gi].view(1, 1, -1) if kind == "text" else na[gi, li].view(1, 1, 1, -1))
     assert torch.equal(out["codes"], torch.from_numpy(g[f"{name}.codes"]).long())
+
+
+def test_lm_oracle_sampling_matches_reference():
+    """LMGenOracle with use_sampling=True against the reference LMGen's token streams under a seeded RNG, fed the noise that run
+    drew (tests/golden/lm_tiny_sampling.npz)."""
+    from oracle import lm_oracle as L
+    cfg_d = dict(synth.LM_TINY)
+    sd = {k: v.float() for k, v in synth.lm_state_dict(cfg_d, cases.LM_SEED).items()}
+    g = np.load(os.path.join(G, "lm_tiny_sampling.npz"))
+    sp = cases.LM_SAMPLING
+    nt, na = torch.from_numpy(g["noise_text"]), torch.from_numpy(g["noise_audio"])
+    B, dep_q = cases.LM_BATCH, cfg_d["dep_q"]
+    gen = L.LMGenOracle(sd, L.LMConfig(**cfg_d), B, use_sampling=True, temp=sp["temp"], temp_text=sp["temp_text"],
+                        top_k=sp["top_k"], top_k_text=sp["top_k_text"])
+    user = cases.lm_user_tokens(cfg_d)
+    outs = []
+    with torch.no_grad():
+        for s in range(cases.LM_STEPS):
+            o = gen.step(user[s], noise_text=nt[s].view(B, 1, 1, -1), noise_audio=[na[s, c].view(B, 1, 1, -1) for c in range(dep_q)])
+            outs.append(torch.full((B, dep_q + 1, 1), -9, dtype=torch.long) if o is None else o)
+    assert torch.equal(torch.cat(outs, -1), torch.from_numpy(g["tokens"]).long())
