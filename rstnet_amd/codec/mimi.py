@@ -155,3 +155,84 @@ class MimiCodec(StreamingModule[_MimiState]):
         if missing or unexpected:
             raise RuntimeError(f"state_dict mismatch: missing={missing[:5]} unexpected={unexpected[:5]}")
         return model.eval()
+
+
+class MimiModel(MimiCodec):
+    """Drop-in for ``MLLM_v2/moshi/models/compression.py:102-423`` -- the composition form of the same codec that the Moshi
+    pipeline uses (``moshi/models/loaders.py:105-139`` builds it): the constructor takes the sub-modules instead of
+    hyper-parameters, the ``state_dict`` keys, ``encode`` / ``decode`` and the streaming protocol are those of ``MimiCodec``
+    (same kernels, same graphs).  Supported: the causal ``resample_method="conv"`` arrangement with both transformers (what the
+    loader builds); ``forward`` (training) is out of scope."""
+
+    def __init__(self, encoder: nn.Module, decoder: nn.Module, quantizer: nn.Module, frame_rate: float, encoder_frame_rate: float,
+                 sample_rate: int, channels: int, causal: bool = False, encoder_transformer: Optional[nn.Module] = None,
+                 decoder_transformer: Optional[nn.Module] = None, resample_method: str = "interpolate",
+                 upsample_channel_wise_bug: bool = True, freeze_encoder: bool = False, freeze_quantizer: bool = False,
+                 freeze_quantizer_level: int = -1, torch_compile_encoder_decoder: bool = False):
+        StreamingModule.__init__(self)
+        assert resample_method in ["interpolate", "conv", "avg_pool"], f"Invalid resample_method {resample_method}"
+        if resample_method != "conv" or encoder_transformer is None or decoder_transformer is None or channels != 1:
+            raise NotImplementedError("MimiModel: the decode path implements mono audio, resample_method='conv' and both transformers "
+                                      "(the arrangement of moshi.models.loaders.get_mimi)")
+        assert encoder_frame_rate > frame_rate, "Cannot upsample with conv."
+        stride = encoder_frame_rate / frame_rate
+        assert stride == int(stride), f"Only integer strides are supported, got {stride}"
+        self.encoder, self.decoder, self.quantizer = encoder, decoder, quantizer
+        self.encoder_transformer, self.decoder_transformer = encoder_transformer, decoder_transformer
+        self._frame_rate, self._sample_rate, self._channels = frame_rate, sample_rate, channels
+        self.encoder_frame_rate, self.target_frame_rate = encoder_frame_rate, frame_rate
+        self.resample_method, self.torch_compile_encoder_decoder = resample_method, torch_compile_encoder_decoder
+        self.freeze_quantizer = freeze_quantizer
+        self.freeze_quantizer_level = freeze_quantizer_level if freeze_quantizer_level > 0 else quantizer.num_codebooks
+        dimension = encoder.dimension
+        assert isinstance(dimension, int), f"Dimension should be int, got {dimension} of type {type(dimension)}."
+        self.dimension = dimension
+        self.hop_length = encoder.hop_length
+        self.learnt = True
+        self.downsample = ConvDownsample1d(int(stride), dimension=dimension, learnt=True, causal=causal)
+        self.upsample = ConvTrUpsample1d(int(stride), dimension=dimension, learnt=True, causal=causal,
+                                         channel_wise=upsample_channel_wise_bug)
+        self.frame_hop = self.hop_length * int(stride)
+
+    @property
+    def channels(self) -> int:
+        return self._channels
+
+    @property
+    def frame_rate(self) -> float:
+        return self._frame_rate
+
+    @property
+    def sample_rate(self) -> int:
+        return self._sample_rate
+
+    @property
+    def total_codebooks(self) -> int:
+        """Total number of quantizer codebooks available."""
+        return self.quantizer.total_codebooks
+
+    @property
+    def num_codebooks(self) -> int:
+        """Active number of codebooks used by the quantizer."""
+        return self.quantizer.num_codebooks
+
+    def set_num_codebooks(self, n: int) -> None:
+        """Set the active number of codebooks used by the quantizer."""
+        self.quantizer.set_num_codebooks(n)
+
+    @property
+    def cardinality(self) -> int:
+        """Cardinality of each codebook."""
+        return self.quantizer.cardinality
+
+    def decode_latent(self, codes: torch.Tensor) -> torch.Tensor:
+        """codes ``[B, K, F]`` -> quantised latent ``[B, dimension, F]`` (compression.py:421-423)."""
+        return self.quantizer.decode(codes)
+
+    def encode_to_latent(self, x: torch.Tensor, quantize: bool = True) -> torch.Tensor:
+        """audio ``[B, 1, T]`` -> 12.5 Hz latent ``[B, dimension, F]``, quantised (the default) or not (compression.py:383-398)."""
+        z = self.encode_latent(x)
+        if quantize:
+            z = self.quantizer.decode_nlc(self.quantizer.encode_nlc(z))
+        return z.transpose(1, 2).contiguous()
+

@@ -267,6 +267,47 @@ def gen_reverse_delay():
 
 
 @torch.no_grad()
+def gen_mimi_model():
+    """The composition form of the codec, `moshi.models.compression.MimiModel` built as `moshi.models.loaders.get_mimi` builds
+    it (loaders.py:105-139; 8 trained codebooks here instead of 32, seeded weights): state_dict keys, properties, batch encode
+    with 8 and with 4 active codebooks, frame-by-frame streaming encode and decode."""
+    from moshi.models import loaders
+    from moshi.models.compression import MimiModel
+    from moshi.modules import SEANetDecoder, SEANetEncoder, transformer
+    from moshi.quantization import SplitResidualVectorQuantizer
+    sd = synth.mimi_state_dict(cases.MIMI_SEED)
+    enc, dec = SEANetEncoder(**loaders._seanet_kwargs), SEANetDecoder(**loaders._seanet_kwargs)
+    m = MimiModel(enc, dec, SplitResidualVectorQuantizer(**{**loaders._quantizer_kwargs, "n_q": 8}), channels=1,
+                  sample_rate=loaders.SAMPLE_RATE, frame_rate=loaders.FRAME_RATE, encoder_frame_rate=loaders.SAMPLE_RATE / enc.hop_length,
+                  causal=True, resample_method="conv",
+                  encoder_transformer=transformer.ProjectedTransformer(device="cpu", **loaders._transformer_kwargs),
+                  decoder_transformer=transformer.ProjectedTransformer(device="cpu", **loaders._transformer_kwargs)).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    out = {"keys": np.array(sorted(m.state_dict().keys())),
+           "props": np.array([m.frame_rate, m.sample_rate, m.channels, m.num_codebooks, m.total_codebooks, m.cardinality])}
+    B, T, seed = cases.MIMI_E2E["ragged"]
+    audio = synth.synth_audio(B, T, seed=seed)
+    out["codes8"] = m.encode(audio).numpy().astype(np.int16)
+    m.set_num_codebooks(4)
+    out["codes4"] = m.encode(audio).numpy().astype(np.int16)
+    out["wav4"] = m.decode(torch.from_numpy(out["codes4"]).long()).numpy()      # decode of 4 of the 8 trained codebooks
+    m.set_num_codebooks(8)
+    a1 = synth.synth_audio(1, 1920 * 12, seed=cases.MIMI_E2E["cfg1"][2])
+    cs, ws = [], []
+    with m.streaming(1):
+        for f in range(12):
+            c = m.encode(a1[:, :, f * 1920:(f + 1) * 1920])
+            cs.append(c)
+            ws.append(m.decode(c))
+    out["stream_codes"], out["stream_wav"] = torch.cat(cs, -1).numpy().astype(np.int16), torch.cat(ws, -1).numpy()
+    assert torch.equal(torch.cat(cs, -1), m.encode(a1))
+    print("mimi_model", out["codes8"].shape, out["codes4"].shape, out["wav4"].shape, out["stream_codes"].shape, out["stream_wav"].shape,
+          out["props"].tolist())
+    np.savez_compressed(os.path.join(HERE, "mimi_model.npz"), **out)
+
+
+@torch.no_grad()
 def gen_tokenizer():
     """`MimiTokenizer.tokenize / detokenize / tokenize2 / find_length` (tools/tokenizer/MimiCodec/mimi_tokenizer.py:47-82).  The
     module imports omegaconf / torchaudio / huggingface_hub at its top level (absent here) and its constructor downloads a
@@ -346,6 +387,6 @@ def gen_gpt_generate():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e", "lm_tiny", "gpt_tiny", "sampling", "reverse_delay",
-                             "gpt_generate", "tokenizer", "lm_tiny_sampling"]
+                             "gpt_generate", "tokenizer", "lm_tiny_sampling", "mimi_model"]
     for w in which:
         globals()[f"gen_{w}"]()

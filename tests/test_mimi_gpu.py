@@ -226,3 +226,31 @@ def test_tokenizer_matches_reference_fixture():
     assert out.shape == want.shape and not out.is_cuda
     assert float((out - want).abs().max() / want.abs().max()) < 1e-3
     assert torch.equal(tok.tokenize(codes[0].clone(), 24000), torch.from_numpy(g["passthrough"]))
+
+
+def test_mimi_model_matches_moshi_fixture():
+    """`MimiModel` (the composition form of moshi/models/compression.py, built by `codec.loaders.get_mimi`) against the REAL
+    moshi MimiModel (tests/golden/mimi_model.npz): batch encode with 8 and 4 active codebooks, decode of 4, frame-by-frame
+    streaming encode / decode."""
+    from rstnet_amd.codec.loaders import get_mimi
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mimi_model.npz"))
+    m = get_mimi(synth.mimi_state_dict(cases.MIMI_SEED), device=DEV)
+    B, T, seed = cases.MIMI_E2E["ragged"]
+    audio = synth.synth_audio(B, T, seed=seed).to(DEV)
+    assert torch.equal(m.encode(audio).cpu(), torch.from_numpy(g["codes8"]).long())
+    m.set_num_codebooks(4)
+    c4 = m.encode(audio)
+    assert m.num_codebooks == 4 and torch.equal(c4.cpu(), torch.from_numpy(g["codes4"]).long())
+    w4, want = m.decode(c4).cpu(), torch.from_numpy(g["wav4"])
+    assert w4.shape == want.shape and float((w4 - want).abs().max() / want.abs().max()) < 1e-3
+    m.set_num_codebooks(8)
+    a1 = synth.synth_audio(1, 1920 * 12, seed=cases.MIMI_E2E["cfg1"][2]).to(DEV)
+    cs, ws = [], []
+    with m.streaming(1):
+        for f in range(12):
+            c = m.encode(a1[:, :, f * 1920:(f + 1) * 1920].contiguous())
+            cs.append(c)
+            ws.append(m.decode(c))
+    assert torch.equal(torch.cat(cs, -1).cpu(), torch.from_numpy(g["stream_codes"]).long())
+    sw, want = torch.cat(ws, -1).cpu(), torch.from_numpy(g["stream_wav"])
+    assert sw.shape == want.shape and float((sw - want).abs().max() / want.abs().max()) < 1e-3
