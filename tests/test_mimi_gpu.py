@@ -254,3 +254,30 @@ def test_mimi_model_matches_moshi_fixture():
     assert torch.equal(torch.cat(cs, -1).cpu(), torch.from_numpy(g["stream_codes"]).long())
     sw, want = torch.cat(ws, -1).cpu(), torch.from_numpy(g["stream_wav"])
     assert sw.shape == want.shape and float((sw - want).abs().max() / want.abs().max()) < 1e-3
+
+
+def test_mimi_model_32_trained_8_active():
+    """The canonical checkpoint layout (32 trained codebooks, 8 active -- loaders.py:44-50,138): extra trained levels must not
+    change the 8-level result, and `set_num_codebooks` widens it."""
+    from rstnet_amd.codec.loaders import get_mimi
+    sd8 = synth.mimi_state_dict(cases.MIMI_SEED)
+    g = torch.Generator().manual_seed(5)
+    sd32 = dict(sd8)
+    for lvl in range(7, 31):
+        for k in ("embedding_sum", "cluster_usage", "_initialized"):
+            src = sd8[f"quantizer.rvq_rest.vq.layers.6._codebook.{k}"]
+            sd32[f"quantizer.rvq_rest.vq.layers.{lvl}._codebook.{k}"] = (torch.randn(src.shape, generator=g) * 0.05).to(src.dtype) \
+                if k == "embedding_sum" else src.clone()
+    m8, m32 = get_mimi(sd8, device=DEV), get_mimi(sd32, device=DEV)
+    assert (m32.total_codebooks, m32.num_codebooks) == (32, 8)
+    audio = synth.synth_audio(2, 1920 * 5 + 700, seed=3).to(DEV)
+    c8, c32 = m8.encode(audio), m32.encode(audio)
+    assert c32.shape == c8.shape and torch.equal(c32, c8)
+    assert torch.equal(m32.decode(c32), m8.decode(c8))
+    with m32.streaming(2):
+        cs = torch.cat([m32.encode(audio[:, :, f * 1920:(f + 1) * 1920].contiguous()) for f in range(5)], -1)
+    assert torch.equal(cs, c8[:, :, :5])
+    m32.set_num_codebooks(12)
+    c12 = m32.encode(audio)
+    assert c12.shape[1] == 12 and torch.equal(c12[:, :8], c8) and int(c12.max()) < 2048
+    assert m32.decode(c12).shape == (2, 1, 6 * 1920)
