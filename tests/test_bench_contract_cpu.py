@@ -1,0 +1,56 @@
+"""The bench.py output contract, checked on the latest committed set of bench lines (profiles/rNNx_*_bench.json, written by
+`python bench.py ...` on an MI355X through tools/collect_profiles.sh): one JSON line with the keys the driver reads, BASELINE.json's metric, a roofline block for
+the dominant kernel and, on the single-GPU run, the CPU baseline leg."""
+import glob
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = max(os.path.basename(p).split("_")[0] for p in glob.glob(os.path.join(ROOT, "profiles", "r*_codec_bench.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{TAG}_*_bench.json")))
+REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": (int, float),
+            "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict}
+
+
+def _last_json(path):
+    with open(path) as f:
+        lines = [ln for ln in f.read().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"{path}: bench.py must print exactly one JSON line"
+    return json.loads(lines[0])
+
+
+def test_bench_lines_exist():
+    names = {os.path.basename(p) for p in LINES}
+    assert {f"{TAG}_{w}_bench.json" for w in ("codec", "lm", "gpt", "e2e1")} <= names
+
+
+@pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
+def test_bench_line_contract(path):
+    d = _last_json(path)
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        base = json.load(f)
+    for k, t in REQUIRED.items():
+        assert k in d and isinstance(d[k], t), (k, d.get(k))
+    assert "vs_baseline" in d and d["vs_baseline"] is None          # BASELINE.md holds no published number for this metric
+    assert d["metric"] == base["metric"] and d["unit"] == "frames/s" and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["data"] == "synthetic" and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"].get("frames_per_step_per_gpu", d["value"] * d["ms_per_step"] / 1e3) / d["ms_per_step"] * 1e3) \
+        <= 0.02 * d["value"] or "frames_per_step_per_gpu" not in d["config"]
+    r = d.get("roofline")
+    if r is not None:
+        assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+        assert "traffic" in r and (r["traffic"] is None or r["traffic"]["bytes_per_launch"] > 0)
+    c = d.get("cpu_baseline")
+    if c is not None:
+        assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
+
+
+def test_default_workload_line_has_roofline_and_cpu_baseline():
+    d = _last_json(os.path.join(ROOT, "profiles", f"{TAG}_codec_bench.json"))
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["peak"] == 157.3 and d["dtype"] == "f32"
+    assert d["cpu_baseline"]["kind"] == "port" and "configs[1]" in d["config"]["workload"]
+    assert d["code_exact_match_vs_cpu_oracle"] == 1.0
