@@ -281,3 +281,43 @@ def test_mimi_model_32_trained_8_active():
     c12 = m32.encode(audio)
     assert c12.shape[1] == 12 and torch.equal(c12[:, :8], c8) and int(c12.max()) < 2048
     assert m32.decode(c12).shape == (2, 1, 6 * 1920)
+
+
+def test_offline_tokenization_cli(tmp_path):
+    """tools/offline_codec_tokenization.py end to end: PCM WAV list in, {utt: int16 codes} .pt out, equal to one-by-one
+    tokenisation of the same (16-bit quantised) waveforms; a wrong-rate file is skipped."""
+    import importlib.util
+    import wave
+    from safetensors.torch import save_file
+    from rstnet_amd.codec import offline
+    from rstnet_amd.codec.loaders import get_mimi
+    from rstnet_amd.codec.tokenizer import MimiTokenizer
+    sd = synth.mimi_state_dict(cases.MIMI_SEED)
+    wpath = os.path.join(tmp_path, "mimi.safetensors")
+    save_file({k: v.contiguous() for k, v in sd.items()}, wpath)
+    lens, lines = [24000, 5003, 41000], []
+    for i, n in enumerate(lens + [8000]):
+        x = synth.synth_audio(1, n, seed=60 + i)[0, 0].numpy()
+        path = os.path.join(tmp_path, f"u{i}.wav")
+        with wave.open(path, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(24000 if i < 3 else 16000)
+            w.writeframes((np.clip(x, -1, 1) * 32767).astype("<i2").tobytes())
+        lines.append(f"utt{i} {path}")
+    scp = os.path.join(tmp_path, "wav.1.scp")
+    with open(scp, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    spec = importlib.util.spec_from_file_location("offline_cli", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools",
+                                                                                "offline_codec_tokenization.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    out = os.path.join(tmp_path, "codec.1.pt")
+    cli.main(["--input-file", scp, "--output-file", out, "--tokenizer", "mimi", "--rank", "1", "--weights", wpath, "--batch-seconds", "2.5"])
+    data = torch.load(out)
+    assert list(data) == ["utt0", "utt1", "utt2"]
+    tok = MimiTokenizer(get_mimi(sd, DEV))
+    for i, n in enumerate(lens):
+        wav, sr = offline.read_audio(os.path.join(tmp_path, f"u{i}.wav"))
+        want = tok.tokenize(wav[None], sr)
+        assert data[f"utt{i}"].dtype == torch.int16 and torch.equal(data[f"utt{i}"], want), i
