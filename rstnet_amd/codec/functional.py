@@ -6,7 +6,7 @@ path runs in librstnet_hip.so.
 from __future__ import annotations
 
 import math
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

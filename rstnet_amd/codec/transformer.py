@@ -9,7 +9,7 @@ linear2 GEMM with fused ``x + scale * .``.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Any, Dict, List, Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 from torch import nn

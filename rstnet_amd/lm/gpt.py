@@ -20,9 +20,8 @@ Execution (csrc/lm_step.hip, lm_attn.hip, lm_skinny.hip): bf16 weights, fp32 act
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass, fields
-from typing import Any, Dict, List, Optional, Tuple
+from typing import Any, Dict, Optional, Tuple
 
 import torch
 from torch import nn

@@ -14,7 +14,6 @@ environment flag ``NO_CUDA_GRAPH`` disables that (``compile.py:168-174``).
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
