@@ -75,6 +75,36 @@ def pmc_traffic(kernel: str, workload: str):
     return best
 
 
+def rocprof_avg_ms(kernel: str, workload: str):
+    """Average launch duration of `kernel` (all template instances whose name starts with it) in the committed
+    `rocprofv3 --kernel-trace --stats` summary of this workload (profiles/*_{workload}_kernel_stats.csv, the latest), or None.
+    The cross-check of the live HIP-event figure: event pairs around a 5 us launch add a few us of their own, the trace does not."""
+    import csv
+    import glob
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"*_{workload}_kernel_stats.csv")))
+    if not paths:
+        return None
+    calls = total = 0.0
+    with open(paths[-1], newline="") as f:
+        for r in csv.DictReader(f):
+            if r["kernel"].startswith(kernel):
+                calls += float(r["calls"])
+                total += float(r["total_us"])
+    if not calls:
+        return None
+    return {"avg_launch_ms": round(total / calls / 1e3, 5), "launches_profiled": int(calls), "source": f"profiles/{os.path.basename(paths[-1])}"}
+
+
+def _with_rocprof(roofline: dict, kernel: str, workload: str, per_launch: float, peak: float) -> dict:
+    """Adds the trace-based figures next to the live ones: `per_launch` algorithmic bytes (GB/s) or flop (TFLOP/s) per launch."""
+    r = rocprof_avg_ms(kernel, workload)
+    if r is not None:
+        ach = per_launch / (r["avg_launch_ms"] * 1e-3) / (1e9 if roofline["unit"] == "GB/s" else 1e12)
+        r.update({"achieved": round(ach, 1 if roofline["unit"] == "GB/s" else 3), "frac": round(ach / peak, 4)})
+    roofline["rocprof"] = r
+    return roofline
+
+
 def cpu_baseline(sd, seconds_per_clip: float, batch: int = 4):
     """The CPU restatement (oracle/mimi_oracle.py, validated bit-exact against the imported reference) on this host."""
     from oracle import mimi_oracle as O
@@ -209,6 +239,7 @@ def bench_lm(args, rank, world, dev):
                      "kernel_ms_per_step": round(ms, 3), "algorithmic_gb_per_step": round(nbytes / 1e9, 3),
                      "share_of_step_eager": round(ms / ms_frame, 3), "all_launches_per_step": None},
     }
+    _with_rocprof(result["roofline"], "gemv_" if B <= 2 else "gemm_skinny_kernel", "lm", nbytes / max(1, len(gemv)), HBM_PEAK_GBS)
     if not args.no_cpu_baseline and world == 1:    # the CPU leg is timed on rank 0 of the single-GPU run only
         result["cpu_baseline"] = lm_cpu_baseline()
     print(json.dumps(result), flush=True)
@@ -333,6 +364,7 @@ def bench_gpt(args, rank, world, dev):
                      "avg_launch_ms": round(ms / max(1, len(gemm)), 5), "kernel_ms_per_step": round(ms, 3),
                      "algorithmic_gb_per_step": round(nbytes / 1e9, 3), "share_of_step_eager": round(ms / ms_frame, 3)},
     }
+    _with_rocprof(result["roofline"], "gemv_" if B <= 2 else "gemm_skinny_kernel", "gpt", nbytes / max(1, len(gemm)), HBM_PEAK_GBS)
     if not args.no_cpu_baseline and world == 1:    # the CPU leg is timed on rank 0 of the single-GPU run only
         result["cpu_baseline"] = gpt_cpu_baseline(cfg_d)
     print(json.dumps(result), flush=True)
@@ -474,6 +506,7 @@ def main():
                     "other_kernels": {k: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"],
                                           "achieved_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                                       for k, v in per_kernel.items() if k != dom}}
+        _with_rocprof(roofline, f"{dom}_kernel", "codec", d["flops"] / d["launches"], FP32_MFMA_PEAK_TFLOPS)
 
     result = None
     if rank == 0:
