@@ -190,6 +190,103 @@ def projected_transformer(sd: SD, prefix: str, cfg: MimiConfig, x: torch.Tensor)
 
 
 # --------------------------------------------------------------------------
+# streaming transformer: ring KV cache (modules/transformer.py:211-278, 376-423)
+# --------------------------------------------------------------------------
+
+class RingKVCache:
+    """RingKVCache for appends of T >= 1 steps (modules/transformer.py:211-278), positions incl. the `delta <= 0` branch that
+    gives the slot at end_index the position end_offset once the ring has wrapped."""
+
+    def __init__(self, B: int, H: int, D: int, capacity: int):
+        self.capacity = capacity
+        self.k = torch.zeros(B, H, capacity, D)
+        self.v = torch.zeros(B, H, capacity, D)
+        self.end_offset = 0
+
+    def complete(self, k: torch.Tensor, v: torch.Tensor):
+        """k, v [B,H,T,D] -> (keys [B,H,cap,D], values, positions [cap] int64)."""
+        T = k.shape[2]
+        idx = (torch.arange(T) + self.end_offset) % self.capacity
+        self.k.index_copy_(2, idx, k)
+        self.v.index_copy_(2, idx, v)
+        self.end_offset += T
+        slots = torch.arange(self.capacity)
+        delta = slots - self.end_offset % self.capacity
+        pos = torch.where(delta <= 0, self.end_offset + delta, self.end_offset + delta - self.capacity)
+        pos = torch.where(slots >= self.end_offset, torch.full_like(pos, -1), pos)
+        return self.k, self.v, pos
+
+
+def ring_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, ring: RingKVCache, offset: int,
+                   context: Optional[int], max_period: Optional[float]) -> torch.Tensor:
+    """The streaming branch of StreamingMultiheadAttention.forward (modules/transformer.py:392-416): RoPE at `offset`, ring
+    append, position mask, SDPA.  q, k, v [B,H,T,D] -> [B,T,H*D]."""
+    B, H, T, D = q.shape
+    if max_period is not None:
+        q, k = rope_interleaved(q.contiguous(), k.contiguous(), offset, max_period)
+    keys, vals, pos_k = ring.complete(k, v)
+    delta = (offset + torch.arange(T)).view(-1, 1) - pos_k.view(1, -1)
+    mask = (pos_k.view(1, -1) >= 0) & (delta >= 0)
+    if context is not None:
+        mask = mask & (delta < context)
+    a = F.scaled_dot_product_attention(q, keys, vals, mask, dropout_p=0.0)
+    return a.permute(0, 2, 1, 3).reshape(B, T, H * D)
+
+
+class TransformerStream:
+    """ProjectedTransformer in streaming mode (modules/transformer.py:595-750): one ring per layer, shared offset."""
+
+    def __init__(self, sd: SD, prefix: str, cfg: MimiConfig, B: int):
+        self.sd, self.prefix, self.cfg, self.offset = sd, prefix, cfg, 0
+        self.rings = [RingKVCache(B, cfg.num_heads, cfg.latent_dim // cfg.num_heads, cfg.context) for _ in range(cfg.num_layers)]
+
+    def step(self, x: torch.Tensor) -> torch.Tensor:
+        """x [B,C,T] (conv layout) -> [B,C,T]."""
+        sd, cfg = self.sd, self.cfg
+        x = x.transpose(1, 2)
+        B, T, C = x.shape
+        H = cfg.num_heads
+        for l, ring in enumerate(self.rings):
+            p = f"{self.prefix}.transformer.layers.{l}"
+            h = F.layer_norm(x, (C,), sd[f"{p}.norm1.weight"], sd[f"{p}.norm1.bias"], eps=1e-5)
+            q, k, v = F.linear(h, sd[f"{p}.self_attn.in_proj_weight"]).view(B, T, 3, H, C // H).permute(2, 0, 3, 1, 4)
+            a = ring_attention(q, k, v, ring, self.offset, cfg.context, cfg.max_period)
+            x = x + sd[f"{p}.layer_scale_1.scale"] * F.linear(a, sd[f"{p}.self_attn.out_proj.weight"])
+            h = F.layer_norm(x, (C,), sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"], eps=1e-5)
+            u = F.linear(F.gelu(F.linear(h, sd[f"{p}.linear1.weight"])), sd[f"{p}.linear2.weight"])
+            x = x + sd[f"{p}.layer_scale_2.scale"] * u
+        self.offset += T
+        return x.transpose(1, 2)
+
+
+def encode_latent_streamed(sd: SD, cfg: MimiConfig, audio: torch.Tensor, frames_per_chunk: int = 1) -> torch.Tensor:
+    """The latent of `MimiModel.encode` called chunk by chunk inside `streaming()` (moshi/models/compression.py:368-380).  The
+    causal convolutions give the same values streamed or not (modules/streaming.py:205-303), so only the transformer -- whose
+    ring cache hides one key once it has wrapped -- is actually stepped; audio length must be a multiple of the hop."""
+    B, _, T = audio.shape
+    assert T % cfg.hop_length == 0
+    z = seanet_encoder(sd, cfg, audio)
+    tr = TransformerStream(sd, "encoder_transformer", cfg, B)
+    n = cfg.resample_stride * frames_per_chunk
+    z = torch.cat([tr.step(z[:, :, i:i + n]) for i in range(0, z.shape[-1], n)], -1)
+    return downsample(sd, cfg, z)
+
+
+def encode_streamed(sd: SD, cfg: MimiConfig, audio: torch.Tensor, frames_per_chunk: int = 1) -> torch.Tensor:
+    return rvq_encode(sd, cfg, encode_latent_streamed(sd, cfg, audio, frames_per_chunk))
+
+
+def decode_streamed(sd: SD, cfg: MimiConfig, codes: torch.Tensor, frames_per_chunk: int = 1) -> torch.Tensor:
+    """`MimiModel.decode` chunk by chunk inside `streaming()` (compression.py:398-419); see `encode_streamed`."""
+    B = codes.shape[0]
+    z = upsample(sd, cfg, rvq_decode(sd, cfg, codes))
+    tr = TransformerStream(sd, "decoder_transformer", cfg, B)
+    n = cfg.resample_stride * frames_per_chunk
+    z = torch.cat([tr.step(z[:, :, i:i + n]) for i in range(0, z.shape[-1], n)], -1)
+    return seanet_decoder(sd, cfg, z)
+
+
+# --------------------------------------------------------------------------
 # residual vector quantiser (quantization/vq.py, quantization/core_vq.py)
 # --------------------------------------------------------------------------
 

@@ -19,6 +19,11 @@ MIMI_E2E = {
     "ragged": (2, 30001, 1),
 }
 
+# (batch, frames, audio seed) of the long streamed clip: 150 frames = 300 transformer positions, i.e. the 250-slot KV rings of
+# the codec's transformers wrap at frame 125 (SURVEY Q1 / fixture F4); the last MIMI_STREAM_LONG_TAIL frames of waveform are stored
+MIMI_STREAM_LONG = (2, 150, 7)
+MIMI_STREAM_LONG_TAIL = 20
+
 # name -> (B, Cin, Cout, T, K, stride); first four = MLLM_v2/moshi/modules/conv_test.py:11-28, the strided
 # ones are the SEANet encoder shapes at reduced width.
 CONV_CASES = {

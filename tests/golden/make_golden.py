@@ -308,6 +308,55 @@ def gen_mimi_model():
 
 
 @torch.no_grad()
+def gen_mimi_stream_long():
+    """F4 at model level: the moshi `MimiModel` streamed frame by frame for MIMI_STREAM_LONG frames, batch 2 -- past the point
+    (frame 125 = position 250) where the 250-slot KV rings of the encoder / decoder transformers wrap
+    (modules/transformer.py:211-278).  Stored: all codes, the waveform of the last frames (past the wrap) and of a
+    few early ones, and the top-2 relative gap of every RVQ decision of the streamed latent."""
+    from moshi.models import loaders
+    from moshi.models.compression import MimiModel
+    from moshi.modules import SEANetDecoder, SEANetEncoder, transformer
+    from moshi.quantization import SplitResidualVectorQuantizer
+    sd = synth.mimi_state_dict(cases.MIMI_SEED, layer_scale=cases.TRANSFORMER_LAYER_SCALE)   # attention must matter
+    enc, dec = SEANetEncoder(**loaders._seanet_kwargs), SEANetDecoder(**loaders._seanet_kwargs)
+    m = MimiModel(enc, dec, SplitResidualVectorQuantizer(**{**loaders._quantizer_kwargs, "n_q": 8}), channels=1,
+                  sample_rate=loaders.SAMPLE_RATE, frame_rate=loaders.FRAME_RATE, encoder_frame_rate=loaders.SAMPLE_RATE / enc.hop_length,
+                  causal=True, resample_method="conv",
+                  encoder_transformer=transformer.ProjectedTransformer(device="cpu", **loaders._transformer_kwargs),
+                  decoder_transformer=transformer.ProjectedTransformer(device="cpu", **loaders._transformer_kwargs)).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    B, frames, seed = cases.MIMI_STREAM_LONG
+    audio = synth.synth_audio(B, 1920 * frames, seed=seed)
+    cs, ws, gaps, zs = [], [], [], []
+    with m.streaming(B):
+        for f in range(frames):
+            x = audio[:, :, f * 1920:(f + 1) * 1920]
+            z = m._to_framerate(m.encoder_transformer(m.encoder(x))[0])
+            c = m.quantizer.encode(z)
+            zs.append(z)
+            g = []
+            for rvq in (m.quantizer.rvq_first, m.quantizer.rvq_rest):
+                r = rvq.input_proj(z).transpose(1, 2).reshape(-1, 256)
+                for layer in list(rvq.vq.layers)[:(1 if rvq is m.quantizer.rvq_first else 7)]:
+                    d = torch.cdist(r[None], layer.embedding[None])[0]
+                    t2 = d.topk(2, largest=False)
+                    g.append(((t2.values[:, 1] - t2.values[:, 0]) / t2.values[:, 0]).view(B, -1))
+                    r = r - layer.embedding[t2.indices[:, 0]]
+            gaps.append(torch.stack(g, 1))
+            cs.append(c)
+            ws.append(m.decode(c))
+    codes, wav, gaps = torch.cat(cs, -1), torch.cat(ws, -1), torch.cat(gaps, -1)
+    tail = cases.MIMI_STREAM_LONG_TAIL
+    out = {"codes": codes.numpy().astype(np.int16), "wav_head": wav[:, :, :1920 * 4].numpy(),
+           "wav_tail": wav[:, :, -1920 * tail:].numpy(), "rel_gap": gaps.numpy(),
+           "latent_tail": torch.cat(zs, -1)[:, :, -tail:].numpy()}
+    print("mimi_stream_long", tuple(codes.shape), tuple(wav.shape), "min rel gap %.2e" % gaps.min(),
+          "decisions below 1e-5:", int((gaps < 1e-5).sum()))
+    np.savez_compressed(os.path.join(HERE, "mimi_stream_long.npz"), **out)
+
+
+@torch.no_grad()
 def gen_tokenizer():
     """`MimiTokenizer.tokenize / detokenize / tokenize2 / find_length` (tools/tokenizer/MimiCodec/mimi_tokenizer.py:47-82).  The
     module imports omegaconf / torchaudio / huggingface_hub at its top level (absent here) and its constructor downloads a
@@ -387,6 +436,6 @@ def gen_gpt_generate():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e", "lm_tiny", "gpt_tiny", "sampling", "reverse_delay",
-                             "gpt_generate", "tokenizer", "lm_tiny_sampling", "mimi_model"]
+                             "gpt_generate", "tokenizer", "lm_tiny_sampling", "mimi_model", "mimi_stream_long"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -290,3 +290,65 @@ def test_empty_inputs():
     y = RF.conv1d(torch.zeros(2, 0, 4, device=DEV), w, None, k_eff=3)
     assert y.shape == (2, 0, 8)
     assert ops.linear(torch.zeros(0, 12, device=DEV), w).shape == (0, 8)
+
+
+# ---- the gemm_win instance that carries the headline step (VERDICT r1 "what's weak" #2): launches with >= 768 tiles of
+# 128 x 128 take 16-wide k-chunks (gemm_win.hip: launch_cfg<2, 2, 2, 2, 16>), which none of the small cases above reaches
+
+def _tiles(M, N):
+    return -(-M // 128) * -(-N // 128)
+
+
+def test_gemm_win_kb16_strided_conv():
+    """SEANet encoder shape 64 -> 128, k8 s4 at B * T_out = 98 307 rows (769 tiles): interior tiles, utterance-boundary tiles
+    (3 utterances whose row counts are not multiples of 128) and the ceil-mode right padding."""
+    g = torch.Generator().manual_seed(31)
+    B, cin, cout, K, S, T = 3, 64, 128, 8, 4, 131073
+    x = torch.rand(B, cin, T, generator=g) * 2 - 1
+    w = synth._xavier(g, cout, cin, K)
+    b = 0.1 * torch.randn(cout, generator=g)
+    y = RF.conv1d(nlc(x), RF.pack_conv_weight(w).to(DEV), b.to(DEV), k_eff=K, stride=S)
+    assert _tiles(y.shape[0] * y.shape[1], cout) >= 768
+    ref = O.causal_conv1d(x, w, b, stride=S)
+    assert ncl(y).shape == ref.shape and rel_err(ncl(y), ref) < TOL
+
+
+def test_gemm_win_kb16_elu_on_load_with_residual():
+    """k3 s1 32 -> 256 with the ELU applied on operand load and a fused residual + ELU-out epilogue (the res-block form),
+    49 200 rows x 256 columns = 770 tiles."""
+    g = torch.Generator().manual_seed(32)
+    B, cin, cout, T = 2, 32, 256, 24600
+    x = torch.rand(B, cin, T, generator=g) * 4 - 2
+    w = synth._xavier(g, cout, cin, 3)
+    b = 0.1 * torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, T, generator=g)
+    y = RF.conv1d(nlc(x), RF.pack_conv_weight(w).to(DEV), b.to(DEV), k_eff=3, act_in=ops.ACT_ELU, res=nlc(res), act_out=ops.ACT_ELU_OUT)
+    assert _tiles(B * T, cout) >= 768
+    ref = F.elu(res + O.causal_conv1d(F.elu(x), w, b))
+    assert rel_err(ncl(y), ref) < TOL
+
+
+def test_gemm_win_kb16_convtr():
+    """SEANet decoder shape 128 -> 64, k8 s4 (GEMM N = S * Cout = 256, window of q = 2 input steps), 49 160 input steps = 770 tiles."""
+    g = torch.Generator().manual_seed(33)
+    B, cin, cout, K, S, T = 2, 128, 64, 8, 4, 24580
+    x = torch.rand(B, cin, T, generator=g) * 2 - 1
+    w = synth._xavier(g, cin, cout, K)
+    b = 0.1 * torch.randn(cout, generator=g)
+    y = RF.convtr1d(nlc(x), RF.pack_convtr_weight(w, S).to(DEV), b.repeat(S).to(DEV), kernel=K, stride=S)
+    assert _tiles(B * T, S * cout) >= 768
+    ref = O.causal_convtr1d(x, w, b, stride=S)
+    assert ncl(y).shape == ref.shape and rel_err(ncl(y), ref) < TOL
+
+
+def test_gemm_win_kb16_linear_epilogues():
+    """Linear 12 295 x 512 -> 1024 (776 tiles) with GELU, LayerScale and residual in the epilogue (the transformer FFN form)."""
+    g = torch.Generator().manual_seed(34)
+    M, K, N = 12295, 512, 1024
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    res, scale = torch.randn(M, N, generator=g), torch.rand(N, generator=g)
+    assert _tiles(M, N) >= 768
+    ref = F.linear(x, w)
+    assert rel_err(ops.linear(x.to(DEV), w.to(DEV)), ref) < TOL
+    y = ops.linear(x.to(DEV), w.to(DEV), res=res.to(DEV), scale=scale.to(DEV), act_out=ops.ACT_GELU)
+    assert rel_err(y, res + scale * F.gelu(ref)) < TOL

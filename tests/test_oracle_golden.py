@@ -9,6 +9,7 @@ import torch
 from oracle import mimi_oracle as O
 from rstnet_amd import synth
 from tests.golden import cases
+from tests.parity import codes_match_up_to_near_ties
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -92,6 +93,29 @@ def test_mimi_encode_decode_matches_reference(mimi_sd, name):
     assert rel_err(z, torch.from_numpy(g[f"{name}.latent"])) < 1e-5
     assert torch.equal(codes, ref_codes)
     assert rel_err(wav, torch.from_numpy(g[f"{name}.wav"])) < 1e-5
+
+
+def test_mimi_long_stream_ring_wrap_matches_reference():
+    """The oracle's ring cache (RingKVCache.complete incl. the `delta <= 0` slot) against the real moshi MimiModel
+    streamed 150 frames -- 300 transformer positions through 250-slot rings: codes exact, waveform past the wrap 1e-5."""
+    cfg = O.MimiConfig()
+    mimi_sd = synth.mimi_state_dict(cases.MIMI_SEED, layer_scale=cases.TRANSFORMER_LAYER_SCALE)   # LayerScale 0.25: attention matters
+    g = np.load(os.path.join(G, "mimi_stream_long.npz"))
+    B, frames, seed = cases.MIMI_STREAM_LONG
+    audio = synth.synth_audio(B, 1920 * frames, seed=seed)
+    ref_codes = torch.from_numpy(g["codes"]).long()
+    with torch.no_grad():
+        z = O.encode_latent_streamed(mimi_sd, cfg, audio)
+        codes = O.rvq_encode(mimi_sd, cfg, z)
+        wav = O.decode_streamed(mimi_sd, cfg, ref_codes)
+        batch_codes = O.encode(mimi_sd, cfg, audio)
+    assert codes_match_up_to_near_ties(codes, ref_codes, torch.from_numpy(g["rel_gap"])) <= 2
+    tail = cases.MIMI_STREAM_LONG_TAIL
+    assert rel_err(z[:, :, -tail:], torch.from_numpy(g["latent_tail"])) < 1e-5
+    assert rel_err(wav[:, :, :1920 * 4], torch.from_numpy(g["wav_head"])) < 1e-5
+    assert rel_err(wav[:, :, -1920 * tail:], torch.from_numpy(g["wav_tail"])) < 1e-5
+    # the wrap matters: the non-streaming pass (250-key window, no hidden slot) gives other codes past frame 125
+    assert torch.equal(batch_codes[:, :, :120], ref_codes[:, :, :120]) and not torch.equal(batch_codes[:, :, 126:], ref_codes[:, :, 126:])
 
 
 def test_lm_oracle_matches_reference():
