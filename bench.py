@@ -7,13 +7,23 @@
 
 One "step" = one pass of the hot path (encode + decode) over one batch that is already resident in HBM.
 Multi-GPU: utterances are independent, so each rank owns its own batch (weak scaling); the only collective is the
-one-off RCCL broadcast of the weights from rank 0.  Rank 0 prints ONE JSON line with the contract fields plus
-`roofline` (dominant kernel: the fp32-MFMA windowed GEMM, timed per launch with HIP events on the launch stream in an
-extra instrumented step) and `cpu_baseline` (the CPU oracle timed on this host on a bounded sample).
+one-off RCCL broadcast of the weights from rank 0 (`python bench.py --gpus N` spawns the N ranks itself when it was not
+started by torchrun).  Rank 0 prints ONE JSON line with the contract fields plus
+  * `roofline` (dominant kernel: the fp32-MFMA windowed GEMM, timed per launch with HIP events on the launch stream in an
+    extra instrumented step) and `cpu_baseline` (the CPU oracle timed on this host on a bounded sample),
+  * `timing`: median / p95 of >= 50 individually synchronised steps, next to the contract's K-step mean,
+  * `code_exact_match_vs_cpu_oracle` / `wav_rel_err_vs_cpu_oracle`: two clips of the batch through the CPU oracle (the
+    "RVQ code-index exact-match" half of the metric), and
+  * on the single-GPU run the sub-objects `lm_b1` (BASELINE configs[2]: Moshi-7B-shaped LMGen.step, batch 1) and `e2e_b1`
+    (the north-star target: Mimi encode -> LMGen.step -> Mimi decode per 80 ms frame, batch 1), each with its own
+    `ms_per_step`, `timing`, `roofline` and `cpu_baseline` (skip with --no-sub).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -24,6 +34,7 @@ os.environ.setdefault("NO_TORCH_COMPILE", "1")
 
 import torch  # noqa: E402
 
+METRIC = "codec+LM audio frames/sec (24 kHz, 12.5 Hz tokens) at batch=1 and batch=64; RVQ code-index exact-match"   # BASELINE.json
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 FRAME_HOP = 1920
 
@@ -46,7 +57,12 @@ def parse():
                     "temporal attention reads the full 3000-slot KV ring; the ring content is zeros, the bytes are the same)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch GEMM table (shape, ms, TFLOP/s, GB/s) to stderr")
-    ap.add_argument("--check", action="store_true", help="also report the code exact-match rate against the CPU oracle on a sample")
+    ap.add_argument("--no-check", action="store_true", help="codec: skip the parity sample (2 clips through the CPU oracle: code "
+                    "exact-match of encode, waveform error of decode)")
+    ap.add_argument("--check", action="store_true", help=argparse.SUPPRESS)      # the parity sample is on by default since round 2
+    ap.add_argument("--no-sub", action="store_true", help="codec: skip the lm_b1 / e2e_b1 sub-benchmarks of the single-GPU line")
+    ap.add_argument("--sub-steps", type=int, default=60, help="timed frames of the lm_b1 / e2e_b1 sub-benchmarks (>= 50: median + p95)")
+    ap.add_argument("--timing-samples", type=int, default=50, help="individually synchronised steps behind `timing` (median, p95)")
     args = ap.parse_args()
     if args.lm_batch is None:
         args.lm_batch = 32 if args.workload == "gpt" else 1
@@ -135,6 +151,50 @@ def cpu_baseline(sd, seconds_per_clip: float, batch: int = 4):
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def _timing(samples_ms):
+    """median / p95 of individually synchronised steps (median + p95 over >= 50 iterations)."""
+    xs = sorted(samples_ms)
+    p95 = xs[min(len(xs) - 1, int(round(0.95 * (len(xs) - 1))))]
+    return {"median_ms": round(statistics.median(xs), 4), "p95_ms": round(p95, 4), "min_ms": round(xs[0], 4), "samples": len(xs),
+            "method": "wall clock around each step, torch.cuda.synchronize() on both sides"}
+
+
+def _sample_steps(step, n):
+    out = []
+    for i in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step(i)
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) * 1e3)
+    return out
+
+
+def _timed_loop(step, warmup, steps, world, dev):
+    """The contract's timing: `warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides,
+    MAX over ranks.  `step(i)` runs step number i (0-based over warm-up + timed)."""
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
 def lm_cpu_baseline(frames: int = 6):
     """The LM oracle on this host at the depth-transformer's real shape with a Qwen-0.5B-sized temporal stack (BASELINE.md
     section 3: the 7B temporal step is GPU-only -- a CPU step would take seconds and tells nothing)."""
@@ -152,15 +212,31 @@ def lm_cpu_baseline(frames: int = 6):
         dt = time.perf_counter() - t0
     return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle LMGen greedy, {frames} frames, batch 1, fp32, temporal 24 x 1024 (Qwen-0.5B-sized) + the real "
-                      f"8-step depth transformer (6 x 1024); the 7B temporal stack is not run on CPU"}
+                      f"8-step depth transformer (6 x 1024); the 7B temporal stack is not run on CPU", "_seconds_per_frame": dt / frames}
 
 
-def bench_lm(args, rank, world, dev):
-    """BASELINE configs[2]: one step = one 80 ms frame of LMGen.step (temporal step + 8 depth steps + sampling), batch 1."""
-    from rstnet_amd import ops, synth
-    from rstnet_amd.lm.model import LMGen, LMModel
+def e2e_cpu_baseline(lm_cpu: dict, frames: int = 6):
+    """End-to-end CPU leg = the LM oracle's frame time (above) + the codec oracle's encode and decode of the same number of
+    80 ms frames of ONE stream (fp32, torch CPU)."""
+    from oracle import mimi_oracle as O
+    from rstnet_amd import synth
+    sd, cfg = synth.mimi_state_dict(0), O.MimiConfig()
+    audio = synth.synth_audio(1, frames * FRAME_HOP, seed=12)
+    with torch.no_grad():
+        O.decode(sd, cfg, O.encode(sd, cfg, audio))
+        t0 = time.perf_counter()
+        O.decode(sd, cfg, O.encode(sd, cfg, audio))
+        codec_s = (time.perf_counter() - t0) / frames
+    per_frame = codec_s + lm_cpu["_seconds_per_frame"]
+    return {"value": round(1.0 / per_frame, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"per frame: codec oracle encode + decode of {frames} frames of one stream ({codec_s * 1e3:.0f} ms / frame) + the LM "
+                      f"oracle leg of lm_b1 ({lm_cpu['_seconds_per_frame'] * 1e3:.0f} ms / frame, Qwen-0.5B-sized temporal stack)"}
+
+
+def build_lm(args, rank, world, dev):
+    from rstnet_amd import synth
+    from rstnet_amd.lm.model import LMModel
     cfg = dict(synth.LM_MOSHI_7B if args.lm_config == "moshi7b" else synth.LM_TINY)
-    B = args.lm_batch
     # weights: generated on rank 0's device (bf16), then ONE RCCL broadcast over xGMI; the other ranks build their replica on
     # views of the received blob
     sd = synth.lm_state_dict(cfg, seed=0, device=str(dev)) if rank == 0 or world == 1 else None
@@ -168,37 +244,32 @@ def bench_lm(args, rank, world, dev):
         from rstnet_amd.parallel import broadcast_state_dict
         sd = broadcast_state_dict(sd, dev, src=0)
     n_params = sum(v.numel() for v in sd.values())
-    model = LMModel.from_state_dict(sd, cfg)
+    return cfg, LMModel.from_state_dict(sd, cfg), n_params
+
+
+def run_lm(args, rank, world, dev, lm=None, steps=None, warmup=None, cpu=True):
+    """BASELINE configs[2]: one step = one 80 ms frame of LMGen.step (temporal step + 8 depth steps + sampling).  Returns the
+    result dict on rank 0 (None elsewhere)."""
+    from rstnet_amd import ops
+    from rstnet_amd.lm.model import LMGen
+    cfg, model, n_params = lm if lm is not None else build_lm(args, rank, world, dev)
+    B = args.lm_batch
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    n_samples = max(args.timing_samples, 1)
     gen = LMGen(model, use_sampling=not args.greedy, temp=0.8, temp_text=0.7, top_k=250, top_k_text=25)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    user = torch.randint(0, cfg["card"], (args.warmup + args.steps + 1, B, cfg["n_q"] - cfg["dep_q"], 1), generator=g, device=dev)
+    user = torch.randint(0, cfg["card"], (warmup + steps + n_samples + 1, B, cfg["n_q"] - cfg["dep_q"], 1), generator=g, device=dev)
     torch.manual_seed(1234 + rank)
-    gen.streaming_forever(B)
-    if args.lm_context:
-        st = model.transformer._streaming_state
-        st.pos.fill_(args.lm_context)
-        st.offset_cpu = args.lm_context
-    for s in range(args.warmup):
-        gen.step(user[s])
-    torch.cuda.synchronize()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        gen.step(user[args.warmup + s])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    with gen.streaming(B):
+        if args.lm_context:
+            st = model.transformer._streaming_state
+            st.pos.fill_(args.lm_context)
+            st.offset_cpu = args.lm_context
+        elapsed = _timed_loop(lambda i: gen.step(user[i]), warmup, steps, world, dev)
+        samples = _sample_steps(lambda i: gen.step(user[warmup + steps + i]), n_samples)
     if rank != 0:
-        return
+        return None
     # roofline of the dominant kernel (weight-streaming GEMV): one extra frame, eager (no graph), HIP events per launch
     os.environ["NO_CUDA_GRAPH"] = "1"
     gen2 = LMGen(model, use_sampling=not args.greedy)
@@ -220,29 +291,36 @@ def bench_lm(args, rank, world, dev):
             d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += nb
         for shp, (n, t, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             print(f"  gemv B,N,K={shp}: {n:4d} launches {t:8.3f} ms  {nb / t / 1e6:8.1f} GB/s", file=sys.stderr)
-    ms_frame = elapsed / args.steps * 1e3
+    ms_frame = elapsed / steps * 1e3
+    timing = _timing(samples)
+    kern = "gemv_" if B <= 2 else "gemm_skinny_kernel"
     result = {
-        "metric": "codec+LM audio frames/sec (24 kHz, 12.5 Hz tokens) at batch=1 and batch=64; RVQ code-index exact-match",
-        "value": round(B * world * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_frame, 3), "higher_is_better": True, "scaling": "weak",
+        "metric": METRIC,
+        "value": round(B * world * steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(ms_frame, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16 weights, f32 activations", "data": "synthetic",
         "config": {"workload": f"LMGen.step (temporal + 8-step depth transformer + sampling), BASELINE.json configs[2], {args.lm_config}",
-                   "batch_per_gpu": B, "params": n_params, "context_frames": args.lm_context + args.warmup + args.steps,
+                   "batch_per_gpu": B, "params": n_params, "context_frames": args.lm_context + warmup + steps,
+                   "kv_dtype": str(model.kv_dtype).replace("torch.", "") if hasattr(model, "kv_dtype") else "float32",
                    "sampling": "greedy" if args.greedy else "temp 0.8/0.7 top-k 250/25", "hip_graphs": True,
                    "parallelism": f"replica x{world}"},
-        "x_realtime_per_stream": round(args.steps / elapsed / 12.5, 2),
+        "x_realtime_per_stream": round(steps / elapsed / 12.5, 2),
+        "timing": timing,
         "roofline": {"bound": "hbm", "kernel": ("gemv_kernel / gemv_norm_kernel" if B <= 2 else "gemm_skinny_kernel") + " (bf16 weight streaming)",
                      "achieved": round(nbytes / ms / 1e6, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
-                     "traffic": pmc_traffic("gemv_" if B <= 2 else "gemm_skinny_kernel", "lm"),
+                     "traffic": pmc_traffic(kern, "lm"),
                      "algorithmic_bytes_per_launch": round(nbytes / max(1, len(gemv))), "launches_per_step": len(gemv), "avg_launch_ms": round(ms / max(1, len(gemv)), 5),
                      "kernel_ms_per_step": round(ms, 3), "algorithmic_gb_per_step": round(nbytes / 1e9, 3),
-                     "share_of_step_eager": round(ms / ms_frame, 3), "all_launches_per_step": None},
+                     "share_of_step_eager": round(ms / ms_frame, 3),
+                     # the whole frame against the HBM roofline: every algorithmic byte of the frame / the median frame time
+                     "frame": {"algorithmic_gb": round(nbytes / 1e9, 3), "achieved": round(nbytes / timing["median_ms"] / 1e6, 1),
+                               "frac": round(nbytes / timing["median_ms"] / 1e6 / HBM_PEAK_GBS, 4)}},
     }
-    _with_rocprof(result["roofline"], "gemv_" if B <= 2 else "gemm_skinny_kernel", "lm", nbytes / max(1, len(gemv)), HBM_PEAK_GBS)
-    if not args.no_cpu_baseline and world == 1:    # the CPU leg is timed on rank 0 of the single-GPU run only
+    _with_rocprof(result["roofline"], kern, "lm", nbytes / max(1, len(gemv)), HBM_PEAK_GBS)
+    if cpu and not args.no_cpu_baseline and world == 1:    # the CPU leg is timed on rank 0 of the single-GPU run only
         result["cpu_baseline"] = lm_cpu_baseline()
-    print(json.dumps(result), flush=True)
+    return result
 
 
 def gpt_cpu_baseline(cfg_d, frames: int = 3):
@@ -345,7 +423,7 @@ def bench_gpt(args, rank, world, dev):
             print(f"  gemm B,N,K={shp}: {n:4d} launches {t:8.3f} ms  {nb / t / 1e6:8.1f} GB/s", file=sys.stderr)
     ms_frame = elapsed / args.steps * 1e3
     result = {
-        "metric": "codec+LM audio frames/sec (24 kHz, 12.5 Hz tokens) at batch=1 and batch=64; RVQ code-index exact-match",
+        "metric": METRIC,
         "value": round(B * world * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_frame, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16 weights, f32 activations (bf16 hi+lo split on the matrix cores)", "data": "synthetic",
@@ -370,53 +448,85 @@ def bench_gpt(args, rank, world, dev):
     print(json.dumps(result), flush=True)
 
 
-def bench_e2e(args, rank, world, dev):
+def run_e2e(args, rank, world, dev, lm=None, steps=None, warmup=None, lm_result=None):
     """BASELINE configs[3] shape on one GPU: B concurrent streams, each frame = Mimi encode (1920 samples) -> LMGen.step ->
-    Mimi decode; value = B * frames / time."""
+    Mimi decode; value = B * frames / time.  Returns the result dict on rank 0."""
     from rstnet_amd import synth
     from rstnet_amd.codec.mimi import MimiCodec
-    from rstnet_amd.lm.model import LMGen, LMModel
+    from rstnet_amd.lm.model import LMGen
     from rstnet_amd.pipeline import StreamingPipeline
-    cfg = dict(synth.LM_MOSHI_7B if args.lm_config == "moshi7b" else synth.LM_TINY)
+    cfg, model, n_params = lm if lm is not None else build_lm(args, rank, world, dev)
     B = args.lm_batch
-    mimi = MimiCodec.from_state_dict(synth.mimi_state_dict(0)).to(dev)
-    model = LMModel.from_state_dict(synth.lm_state_dict(cfg, seed=0, device=str(dev)), cfg)
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    n_samples = max(args.timing_samples, 1)
+    mimi_sd = synth.mimi_state_dict(0)
+    mimi = MimiCodec.from_state_dict(mimi_sd).to(dev)
     gen = LMGen(model, use_sampling=not args.greedy)
-    pcm = synth.synth_audio(B, 1920 * (args.warmup + args.steps), seed=200 + rank).to(dev)
+    pcm = synth.synth_audio(B, 1920 * (warmup + steps + n_samples), seed=200 + rank).to(dev)
     torch.manual_seed(1234 + rank)
     with StreamingPipeline(mimi, gen, B) as pipe:
-        for s in range(args.warmup):
-            pipe.step(pcm[:, :, s * 1920:(s + 1) * 1920].contiguous())
-        torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for s in range(args.warmup, args.warmup + args.steps):
-            out = pipe.step(pcm[:, :, s * 1920:(s + 1) * 1920].contiguous())
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "codec+LM audio frames/sec (24 kHz, 12.5 Hz tokens) at batch=1 and batch=64; RVQ code-index exact-match",
-            "value": round(B * world * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "codec f32; LM bf16 weights, f32 activations", "data": "synthetic",
-            "config": {"workload": f"end-to-end streaming: Mimi encode -> LMGen.step -> Mimi decode, BASELINE.json configs[3] shape, {args.lm_config}",
-                       "streams_per_gpu": B, "parallelism": f"replica x{world}, streams sharded"},
-            "x_realtime_per_stream": round(args.steps / elapsed / 12.5, 2)}), flush=True)
+        step = lambda s: pipe.step(pcm[:, :, s * 1920:(s + 1) * 1920].contiguous())     # noqa: E731
+        elapsed = _timed_loop(step, warmup, steps, world, dev)
+        samples = _sample_steps(lambda i: step(warmup + steps + i), n_samples)
+    if rank != 0:
+        return None
+    timing = _timing(samples)
+    codec_bytes = 4 * sum(v.numel() for k, v in mimi_sd.items() if v.is_floating_point())
+    lm_bytes = lm_result["roofline"]["algorithmic_gb_per_step"] * 1e9 if lm_result else None
+    result = {
+        "metric": METRIC,
+        "value": round(B * world * steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "codec f32; LM bf16 weights, f32 activations", "data": "synthetic",
+        "config": {"workload": f"end-to-end streaming: Mimi encode -> LMGen.step -> Mimi decode, BASELINE.json configs[3] shape, {args.lm_config}",
+                   "streams_per_gpu": B, "parallelism": f"replica x{world}, streams sharded"},
+        "x_realtime_per_stream": round(steps / elapsed / 12.5, 2),
+        "timing": timing}
+    if lm_bytes is not None and B <= 2:
+        # batch 1: the frame is weight streaming end to end -- every LM weight byte once (bf16) and every codec weight once (fp32)
+        total = lm_bytes + codec_bytes
+        result["roofline"] = {"bound": "hbm", "kernel": "whole frame: LM weight-streaming GEMVs + codec few-row GEMMs", "unit": "GB/s",
+                              "achieved": round(total / timing["median_ms"] / 1e6, 1), "peak": HBM_PEAK_GBS,
+                              "frac": round(total / timing["median_ms"] / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                              "algorithmic_gb_per_step": round(total / 1e9, 3), "lm_gb": round(lm_bytes / 1e9, 3),
+                              "codec_weight_gb": round(codec_bytes / 1e9, 3), "per_kernel": "see lm_b1.roofline (gemv)"}
+    return result
+
+
+def _free_port() -> int:
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_command(n_gpus: int, argv, port: int):
+    """The launch line of the contract: one rank per GPU of one node, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def parity_sample(model, sd_cpu, audio, codes, n=2):
+    """The "RVQ code-index exact-match" half of the metric on the first `n` clips of the timed batch: encode against the CPU
+    oracle's codes, decode (of the oracle's codes) against the oracle's waveform."""
+    from oracle import mimi_oracle as O
+    n = min(n, audio.shape[0])
+    cfg = O.MimiConfig()
+    with torch.no_grad():
+        ref_codes = O.encode(sd_cpu, cfg, audio[:n].cpu())
+        ref_wav = O.decode(sd_cpu, cfg, ref_codes)
+        wav = model.decode(ref_codes.to(audio.device)).cpu()
+    match = float((codes[:n].cpu() == ref_codes).float().mean())
+    err = float((wav - ref_wav).abs().max() / ref_wav.abs().max())
+    return round(match, 6), float(f"{err:.3e}"), n
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not started by torchrun: spawn the ranks ourselves (same command line) and relay their output
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(spawn_command(args.gpus, sys.argv[1:], _free_port()), env=env))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -430,7 +540,14 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     if args.workload in ("lm", "e2e", "gpt"):
-        {"lm": bench_lm, "e2e": bench_e2e, "gpt": bench_gpt}[args.workload](args, rank, world, dev)
+        if args.workload == "gpt":
+            bench_gpt(args, rank, world, dev)
+        else:
+            lm = build_lm(args, rank, world, dev)
+            res = run_lm(args, rank, world, dev, lm=lm) if args.workload == "lm" else run_e2e(args, rank, world, dev, lm=lm)
+            if rank == 0:
+                res.get("cpu_baseline", {}).pop("_seconds_per_frame", None)
+                print(json.dumps(res), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -451,29 +568,14 @@ def main():
     T = int(args.seconds * 24000)
     audio = synth.synth_audio(args.batch, T, seed=100 + rank).to(dev)   # rank-private utterances, resident in HBM
     frames_per_step = args.batch * (-(-T // FRAME_HOP))
+    last = {}
 
-    def step():
+    def step(_i=0):
         codes = model.encode(audio)
-        return codes, model.decode(codes)
+        last["codes"], last["wav"] = codes, model.decode(codes)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        codes, wav = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = _timed_loop(step, args.warmup, args.steps, world, dev)
+    codes = last["codes"]
 
     # ---- roofline of the dominant kernel: one extra instrumented step, HIP events around every GEMM launch
     roofline = None
@@ -497,6 +599,7 @@ def main():
         dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])     # the dominant kernel of the step
         d = per_kernel[dom]
         tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        all_flops = sum(v["flops"] for v in per_kernel.values())
         roofline = {"bound": "mfma", "kernel": f"{dom}_kernel (fp32 v_mfma_f32_32x32x2_f32)", "achieved": round(tf, 3),
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": pmc_traffic(f"{dom}_kernel", "codec"), "launches_per_step": d["launches"],
@@ -504,15 +607,19 @@ def main():
                     "kernel_ms_per_step": round(d["ms"], 3), "share_of_step": round(d["ms"] / t_step_ms, 3),
                     "algorithmic_gflop_per_step": round(d["flops"] / 1e9, 1),
                     "other_kernels": {k: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"],
-                                          "achieved_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
-                                      for k, v in per_kernel.items() if k != dom}}
+                                          "achieved_tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                          "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                                      for k, v in per_kernel.items() if k != dom},
+                    # the whole step against the MFMA roofline: every algorithmic flop of the GEMM-shaped launches / the step time
+                    "step": {"algorithmic_gflop": round(all_flops / 1e9, 1), "achieved": round(all_flops / t_step_ms / 1e9, 3),
+                             "frac": round(all_flops / t_step_ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}}
         _with_rocprof(roofline, f"{dom}_kernel", "codec", d["flops"] / d["launches"], FP32_MFMA_PEAK_TFLOPS)
 
     result = None
     if rank == 0:
         total_frames = frames_per_step * world * args.steps
         result = {
-            "metric": "codec+LM audio frames/sec (24 kHz, 12.5 Hz tokens) at batch=1 and batch=64; RVQ code-index exact-match",
+            "metric": METRIC,
             "value": round(total_frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -523,14 +630,32 @@ def main():
             "x_realtime_per_stream": round(total_frames / elapsed / 12.5 / (args.batch * world), 1),
             "roofline": roofline,
         }
-        if args.check:
-            from oracle import mimi_oracle as O
-            n = min(2, args.batch)
-            with torch.no_grad():
-                ref = O.encode(sd_cpu, O.MimiConfig(), audio[:n].cpu())
-            result["code_exact_match_vs_cpu_oracle"] = round(float((codes[:n].cpu() == ref).float().mean()), 6)
+        if world == 1:
+            result["timing"] = _timing(_sample_steps(step, max(args.timing_samples, 1)))
+        if not args.no_check:
+            match, err, n = parity_sample(model, sd_cpu, audio, codes)
+            result["code_exact_match_vs_cpu_oracle"] = match
+            result["wav_rel_err_vs_cpu_oracle"] = err
+            result["parity_sample"] = f"{n} clips x {args.seconds:g} s of the timed batch: encode codes vs oracle/mimi_oracle.py, decode of the oracle's codes vs its waveform"
         if not args.no_cpu_baseline and world == 1:    # the CPU leg is timed on rank 0 of the single-GPU run only
             result["cpu_baseline"] = cpu_baseline(sd_cpu, args.seconds)
+    if world == 1 and not args.no_sub:
+        # the north-star targets ride on the same line: batch-1 LM decode and the batch-1 end-to-end streaming frame
+        del audio, last, codes
+        model = None
+        torch.cuda.empty_cache()
+        args.lm_batch = 1
+        lm = build_lm(args, rank, world, dev)
+        lm_res = run_lm(args, rank, world, dev, lm=lm, steps=args.sub_steps, warmup=10)
+        e2e_res = run_e2e(args, rank, world, dev, lm=lm, steps=args.sub_steps, warmup=10, lm_result=lm_res)
+        if not args.no_cpu_baseline and "cpu_baseline" in lm_res:
+            e2e_res["cpu_baseline"] = e2e_cpu_baseline(lm_res["cpu_baseline"])
+            lm_res["cpu_baseline"].pop("_seconds_per_frame", None)
+        for sub in (lm_res, e2e_res):      # sub-objects: drop what the enclosing line already states
+            for k in ("metric", "n_gpus", "higher_is_better", "scaling", "vs_baseline", "data"):
+                sub.pop(k, None)
+        result["lm_b1"], result["e2e_b1"] = lm_res, e2e_res
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

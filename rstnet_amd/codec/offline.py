@@ -4,7 +4,8 @@ GPU picked by ``--rank``), with the batching the reference leaves as a TODO (``:
 length and encoded as zero-padded ragged batches (``MimiTokenizer.tokenize_batch``).
 
 Audio files are read without torchaudio / soundfile: RIFF PCM ``.wav`` through the standard library, ``.npy`` / ``.pt`` arrays
-as they are.  24 kHz mono is required (no resampler in this build)."""
+as they are.  Files at other sample rates are resampled to 24 kHz on the host (``codec/audio_resample.py``), as the reference's
+``MimiTokenizer`` does with torchaudio."""
 from __future__ import annotations
 
 import logging
@@ -14,6 +15,8 @@ from typing import Dict, Iterable, Iterator, List, Sequence, Tuple
 
 import numpy as np
 import torch
+
+from .audio_resample import resample
 
 SAMPLE_RATE = 24000
 
@@ -70,24 +73,42 @@ def chunks(items: Sequence, size: int) -> Iterator[Sequence]:
 
 
 def tokenize_list(tokenizer, items: Iterable[Tuple[str, str]], chunk_size: int = 256, max_batch_seconds: float = 1920.0,
-                  reader=read_audio) -> Dict[str, torch.Tensor]:
-    """``items``: (utt-id, path) pairs -> ``{utt-id: int16 codes [8, ceil(T/1920)]}`` in input order.  Unreadable / empty /
-    wrong-rate files are logged and skipped, as the reference does (``:100-101``)."""
+                  reader=read_audio, skipped: List[str] = None) -> Dict[str, torch.Tensor]:
+    """``items``: (utt-id, path) pairs -> ``{utt-id: int16 codes [8, ceil(T/1920)]}`` in input order.  Unreadable / empty files
+    are logged and skipped, as the reference does (``:100-101``); a batch whose encode fails (e.g. out of memory on one very long
+    utterance) is retried one utterance at a time so that only the offending utterance is lost.  ``skipped`` (optional list)
+    receives the ids that produced no codes -- the CLI turns a non-empty list into a non-zero exit status under ``--strict``."""
     out: Dict[str, torch.Tensor] = {}
+    skipped = skipped if skipped is not None else []
     for part in chunks(list(items), chunk_size):
         keys, wavs = [], []
         for key, path in part:
             try:
                 wav, sr = reader(path)
-                if sr != SAMPLE_RATE:
-                    raise ValueError(f"sample rate {sr}, expected {SAMPLE_RATE}")
                 if wav.numel() == 0:
                     raise ValueError("empty waveform")
+                if sr != SAMPLE_RATE:
+                    wav = resample(wav, sr, SAMPLE_RATE)
                 keys.append(key)
                 wavs.append(wav)
             except Exception as e:      # noqa: BLE001  (one bad file must not stop a shard)
                 logging.error(f"an error instance: {key} {path}, {e}")
-        if wavs:
-            for key, codes in zip(keys, tokenizer.tokenize_batch(wavs, SAMPLE_RATE, max_batch_seconds=max_batch_seconds)):
-                out[key] = codes
+                skipped.append(key)
+        if not wavs:
+            continue
+        try:
+            codes = tokenizer.tokenize_batch(wavs, SAMPLE_RATE, max_batch_seconds=max_batch_seconds)
+        except Exception as e:          # noqa: BLE001
+            logging.error(f"a batch of {len(wavs)} utterances failed ({e}); retrying them one by one")
+            codes = []
+            for key, wav in zip(keys, wavs):
+                try:
+                    codes.append(tokenizer.tokenize(wav.reshape(1, -1), SAMPLE_RATE))
+                except Exception as e1:  # noqa: BLE001
+                    logging.error(f"an error instance: {key}, {e1}")
+                    codes.append(None)
+                    skipped.append(key)
+        for key, c in zip(keys, codes):
+            if c is not None:
+                out[key] = c
     return out

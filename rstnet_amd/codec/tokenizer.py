@@ -1,8 +1,8 @@
 """``MimiTokenizer`` -- the tokenizer wrapper of ``MLLM_v2/tools/tokenizer/MimiCodec/mimi_tokenizer.py:14-82`` over the HIP codec,
 plus the batched path the reference leaves as a TODO (``egs/pretraining/local/offline_codec_tokenization.py:79``).
 
-Same surface: ``tokenize(wav, sample_rate)`` (path strings are not supported here: there is no audio-file reader in the
-image), ``tokenize2``, ``find_length``, ``detokenize``; codes leave as int16 on the host exactly like the reference
+Same surface: ``tokenize(wav, sample_rate)`` (other rates are resampled to 24 kHz on the host first, as the reference does with torchaudio;
+path strings are not supported here: the image has no general audio-file reader), ``tokenize2``, ``find_length``, ``detokenize``; codes leave as int16 on the host exactly like the reference
 (``:72``: "reduce the save space").  ``tokenize_batch`` packs utterances of different lengths into one encode call: the codec
 is causal end to end, so only an utterance's LAST, partial frame can see what follows it; there the reference pads every strided
 layer's input itself (zeros; replicate in the 25 -> 12.5 Hz down-sampling), which ``MimiCodec.encode(batch, lengths)``
@@ -15,6 +15,7 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
+from .audio_resample import resample
 from .mimi import MimiCodec
 
 FRAME_HOP = 1920
@@ -35,9 +36,9 @@ class MimiTokenizer:
             return token.to(torch.int64)
         raise NotImplementedError
 
-    def _check_rate(self, sample_rate: int) -> None:
-        if sample_rate != self.sr:
-            raise NotImplementedError(f"resample to {self.sr} Hz before tokenizing (torchaudio is not part of this build)")
+    def _to_codec_rate(self, wav: torch.Tensor, sample_rate: int) -> torch.Tensor:
+        """``torchaudio.transforms.Resample(sample_rate, self.sr)(wav)`` of mimi_tokenizer.py:66-67 (host side, before the codec)."""
+        return wav if sample_rate == self.sr else resample(wav.detach().cpu().float(), sample_rate, self.sr)
 
     @torch.no_grad()
     def tokenize(self, wav, sample_rate: int = 24000):
@@ -52,8 +53,7 @@ class MimiTokenizer:
         if wav.dim() == 2:
             if wav.numel() == 0:
                 return None
-            self._check_rate(sample_rate)
-            wav = wav.unsqueeze(1)
+            wav = self._to_codec_rate(wav, sample_rate).unsqueeze(1)
         codes = self.model.encode(wav.to(self.device, torch.float32))
         return codes.squeeze(0).detach().cpu().to(torch.int16)
 
@@ -68,8 +68,7 @@ class MimiTokenizer:
     def tokenize_batch(self, wavs: Sequence[torch.Tensor], sample_rate: int = 24000, max_batch_seconds: float = 1920.0) -> List[torch.Tensor]:
         """Mono waveforms (1-D ``[T_i]`` or ``[1, T_i]``) -> list of int16 codes ``[8, ceil(T_i/1920)]`` in input order.  Utterances are
         sorted by length and packed into zero-padded batches of at most ``max_batch_seconds`` of padded audio."""
-        self._check_rate(sample_rate)
-        flat = [w.reshape(-1).float() for w in wavs]
+        flat = [self._to_codec_rate(w.reshape(-1).float(), sample_rate) for w in wavs]
         order = sorted(range(len(flat)), key=lambda i: flat[i].numel())
         out: List[Optional[torch.Tensor]] = [None] * len(flat)
         budget = int(max_batch_seconds * self.sr)

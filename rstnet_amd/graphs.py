@@ -25,6 +25,13 @@ class Graphed:
     def __call__(self, *args: torch.Tensor):
         if self.disable:
             return self.fn(*args)
+        dev = next((a.device for a in args if isinstance(a, torch.Tensor) and a.is_cuda), None)
+        if dev is not None and dev.index != torch.cuda.current_device():
+            with torch.cuda.device(dev):        # capture / replay on the device the arguments live on
+                return self._call(*args)
+        return self._call(*args)
+
+    def _call(self, *args: torch.Tensor):
         if self.graph is None:
             self.calls += 1
             if self.calls <= self.warmup:

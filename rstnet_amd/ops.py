@@ -1,12 +1,19 @@
 """Tensor-level front of the C ABI: PyTorch is used for device memory and streams only.
 
 Every function takes / returns CUDA (HIP) fp32 tensors in the CHANNELS-LAST layout ``[B, T, C]`` unless
-stated otherwise, launches on ``torch.cuda.current_stream()`` and raises if handed CPU tensors -- there is no
-host fallback.
+stated otherwise, launches on the current stream OF THE DEVICE THE TENSORS LIVE ON (every public function runs under a
+device guard for its first tensor argument, so a process may drive ``cuda:N`` without making it the current device) and raises
+if handed CPU tensors -- there is no host fallback.
+
+Scratch (split-K partials + arrival counters, attention split workspaces, packed operand buffers, RVQ atomic keys) is cached
+per (device, STREAM, shape): launches on one stream are ordered, so layers of equal shape share a buffer; work issued on another
+stream gets its own.  A captured graph owns the buffers of its capture stream -- replays of graphs captured on the same stream
+must not overlap each other (the server and the pipelines run one session at a time, as the reference's lock does).
 """
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import math
 from typing import NamedTuple, Optional, Sequence, Tuple
 
@@ -26,6 +33,28 @@ PROFILE = None
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def _first_tensor(args):
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            return a
+        if isinstance(a, (tuple, list)) and a and isinstance(a[0], torch.Tensor):
+            return a[0]
+    return None
+
+
+def _on_tensor_device(fn):
+    """Device guard: run ``fn`` with the device of its first tensor argument current, so that ``_stream()``, the scratch
+    allocations and the launch itself all address that device (a tool driving ``cuda:3`` need not call ``set_device``)."""
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        t = _first_tensor(args)
+        if t is not None and t.is_cuda and t.device.index != torch.cuda.current_device():
+            with torch.cuda.device(t.device):
+                return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return guarded
 
 
 class _PackedWeights:
@@ -75,11 +104,11 @@ _gemm_scratch: dict = {}
 
 
 def _gemm_split_scratch(device, M: int, N: int, K: int):
-    """Split-K plan + scratch of the few-row (streaming step) GEMMs, cached per shape; launches on one stream are ordered
-    and the counters re-arm themselves, so layers of equal shape share the buffers."""
+    """Split-K plan + scratch of the few-row (streaming step) GEMMs, cached per (stream, shape); launches on one stream are
+    ordered and the counters re-arm themselves, so layers of equal shape share the buffers."""
     if M > 32 or M == 0:
         return 1, None, None
-    key = (device, M, N, K)
+    key = (device, _stream(), M, N, K)
     sc = _gemm_scratch.get(key)
     if sc is None:
         sk = int(_lib.lib().rst_gemm_win_split_plan(M, N, K))
@@ -301,7 +330,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, pos0: int = 
         # streaming step with a handful of new queries: split every query over the occupied ring slots instead of walking
         # the ring tile by tile with one wave per head
         splits = max(1, min(4, cap // 64))
-        key = (q.device, B * T, H, splits, D)
+        key = (q.device, _stream(), B * T, H, splits, D)
         sc = _attn_scratch.get(key)
         if sc is None:
             sc = _attn_scratch[key] = (torch.empty(B * T, H, splits, D + 2, device=q.device, dtype=torch.float32),
@@ -344,7 +373,7 @@ def rvq_search(x: torch.Tensor, emb: torch.Tensor, packed: torch.Tensor, e2: tor
     dist = torch.zeros(L, M, device=x.device, dtype=torch.float32) if return_dist else None
     keys = None
     if 0 < M <= 64:     # streaming step: the few-frame form (codes spread over workgroups)
-        kk = (x.device, L, M)
+        kk = (x.device, _stream(), L, M)
         keys = _rvq_keys.get(kk)
         if keys is None:
             keys = _rvq_keys[kk] = torch.full((L, M), -1, device=x.device, dtype=torch.int64)
@@ -498,10 +527,10 @@ _packed_out: dict = {}
 
 
 def _packed_buffer(device, B: int, K: int, role: str = "in") -> torch.Tensor:
-    """Persistent, zero-initialised operand buffer per shape: producers write rows < B only, so the pad rows stay zero; layers
-    of equal shape share it (launches on one stream are ordered).  ``role`` keeps the output of a GEMM that emits a packed
+    """Persistent, zero-initialised operand buffer per (stream, shape): producers write rows < B only, so the pad rows stay zero;
+    layers of equal shape share it (launches on one stream are ordered).  ``role`` keeps the output of a GEMM that emits a packed
     operand apart from the operand it reads."""
-    key = (device, B, K, role)
+    key = (device, _stream(), B, K, role)
     buf = _packed_out.get(key)
     if buf is None:
         buf = _packed_out[key] = torch.zeros(2, (B + 31) // 32 * 32, K, device=device, dtype=torch.bfloat16)
@@ -742,3 +771,12 @@ def lm_ring_commit(cache: torch.Tensor, tokens: torch.Tensor, delays: torch.Tens
     _lib.check(_lib.lib().rst_lm_ring_commit_i64(_ptr(cache), _ptr(tokens), _ptr(delays), _ptr(offset_dev), _ptr(out), B, K, CT, n_out,
                                                 int(max_delay), _stream()))
     return out
+
+
+# every public entry point runs under the device guard of its first tensor argument
+for _name in ("skinny_f32_pack_weight", "gemm_win", "linear", "seanet_resblock", "layernorm", "rope_split", "attention", "rvq_pack",
+              "rvq_search", "rvq_gather", "convtr_depthwise", "activation", "transpose12", "mask_tail", "hist_update", "gemv_bf16",
+              "skinny_pack_weight", "skinny_pack_act", "gemm_skinny", "skinny_pack_weight_fp8", "gemm_skinny_fp8", "lm_gated_pair",
+              "lm_linear", "embed_sum", "rmsnorm", "lm_rope_append", "lm_attn_decode", "lm_sample", "lm_ring_begin", "lm_ring_commit"):
+    globals()[_name] = _on_tensor_device(globals()[_name])
+del _name

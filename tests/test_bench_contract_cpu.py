@@ -2,6 +2,7 @@
 `python bench.py ...` on an MI355X through tools/collect_profiles.sh): one JSON line with the keys the driver reads, BASELINE.json's metric, a roofline block for
 the dominant kernel and, on the single-GPU run, the CPU baseline leg."""
 import glob
+import sys
 import json
 import os
 
@@ -54,3 +55,41 @@ def test_default_workload_line_has_roofline_and_cpu_baseline():
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["peak"] == 157.3 and d["dtype"] == "f32"
     assert d["cpu_baseline"]["kind"] == "port" and "configs[1]" in d["config"]["workload"]
     assert d["code_exact_match_vs_cpu_oracle"] == 1.0
+
+
+# ---- host logic of bench.py itself (no GPU needed)
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_self_spawn_command_is_the_contract_launch_line():
+    b = _bench_module()
+    cmd = b.spawn_command(4, ["--gpus", "4", "--steps", "7"], 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5].endswith("bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+
+
+def test_gpus_flag_without_torchrun_spawns_the_ranks(monkeypatch):
+    """`python bench.py --gpus 8` from a plain shell must not die on WORLD_SIZE (VERDICT r1 #10): it re-launches itself."""
+    b = _bench_module()
+    calls = []
+    monkeypatch.setattr(b.subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        b.main()
+    assert e.value.code == 0 and len(calls) == 1
+    cmd, env = calls[0]
+    assert "--nproc-per-node=2" in cmd and cmd[-4:] == ["--gpus", "2", "--steps", "3"] and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_timing_summary_is_median_and_p95():
+    b = _bench_module()
+    t = b._timing([float(i) for i in range(1, 101)])
+    assert t["samples"] == 100 and t["median_ms"] == 50.5 and t["p95_ms"] == 95.0 and t["min_ms"] == 1.0

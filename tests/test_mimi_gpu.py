@@ -285,7 +285,7 @@ def test_mimi_model_32_trained_8_active():
 
 def test_offline_tokenization_cli(tmp_path):
     """tools/offline_codec_tokenization.py end to end: PCM WAV list in, {utt: int16 codes} .pt out, equal to one-by-one
-    tokenisation of the same (16-bit quantised) waveforms; a wrong-rate file is skipped."""
+    tokenisation of the same (16-bit quantised) waveforms; a 16 kHz file is resampled to 24 kHz on the host first."""
     import importlib.util
     import wave
     from safetensors.torch import save_file
@@ -315,7 +315,8 @@ def test_offline_tokenization_cli(tmp_path):
     out = os.path.join(tmp_path, "codec.1.pt")
     cli.main(["--input-file", scp, "--output-file", out, "--tokenizer", "mimi", "--rank", "1", "--weights", wpath, "--batch-seconds", "2.5"])
     data = torch.load(out)
-    assert list(data) == ["utt0", "utt1", "utt2"]
+    assert list(data) == ["utt0", "utt1", "utt2", "utt3"]
+    assert data["utt3"].dtype == torch.int16 and tuple(data["utt3"].shape) == (8, -(-8000 * 3 // 2 // 1920))   # 16 kHz -> 24 kHz
     tok = MimiTokenizer(get_mimi(sd, DEV))
     for i, n in enumerate(lens):
         wav, sr = offline.read_audio(os.path.join(tmp_path, f"u{i}.wav"))

@@ -27,6 +27,8 @@ def get_parser():
     p.add_argument("--weights", type=str, required=True, help="Mimi checkpoint (.safetensors / torch.save'd {'model': ...})")
     p.add_argument("--batch-seconds", type=float, default=600.0, help="padded audio per encode batch")
     p.add_argument("--chunk-size", type=int, default=256, help="utterances read before sorting into batches")
+    p.add_argument("--strict", action="store_true", help="exit with status 1 when any listed utterance produced no codes "
+                   "(default: log and skip it, as the reference does)")
     return p
 
 
@@ -37,15 +39,22 @@ def main(argv=None):
     from rstnet_amd.codec.loaders import get_mimi
     from rstnet_amd.codec.tokenizer import MimiTokenizer
     device = torch.device("cuda", offline.device_index(args.rank, torch.cuda.device_count()))
+    torch.cuda.set_device(device)     # kernels, graphs and scratch of this process all live on the rank's GPU
     logging.info(f"Using device: {device}")
     tokenizer = MimiTokenizer(get_mimi(args.weights, device))
     items = offline.read_list(args.input_file or args.wav_scp)
     t0 = time.time()
-    data = offline.tokenize_list(tokenizer, items, chunk_size=args.chunk_size, max_batch_seconds=args.batch_seconds)
+    skipped = []
+    data = offline.tokenize_list(tokenizer, items, chunk_size=args.chunk_size, max_batch_seconds=args.batch_seconds, skipped=skipped)
     torch.save(data, args.output_file)
     frames = sum(v.shape[1] for v in data.values())
     logging.info(f"processed {len(data)} / {len(items)} examples, {frames} frames in {time.time() - t0:.1f} s")
+    if skipped:
+        logging.warning(f"{len(skipped)} utterances produced no codes: {skipped[:10]}{' ...' if len(skipped) > 10 else ''}")
+        if args.strict:
+            return 1
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
