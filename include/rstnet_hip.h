@@ -193,6 +193,28 @@ int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, i
 int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, const float* bias, float* y,
                       int B, int N, int K, int ldx, int ldy, int prologue, float eps, int gate_out, rst_stream_t stream);
 
+/* Two fused forms of the batch <= 2 GEMV for the depth transformer ("depformer", models/model.py:392-428,564-597;
+ * "codecformer", models/llama_streaming.py:727-749), whose 8 steps x 6 layers are a chain of ~5 us launches:
+ *
+ * rst_gemv_attn_bf16_f32 -- out_proj of a layer with the attention itself as the prologue (modules/transformer.py:376-423 for
+ *   a ring of cap <= 8 slots and no rotary embedding, the depth transformer's setup): qkv [B][ldqkv] = [q | k | v] (H heads of
+ *   D dims each, D a power of two), k_cache / v_cache [B][H][cap][D] fp32 rings, *pos_dev = position of the new step.  Every
+ *   workgroup recomputes softmax(q K^T / sqrt(D)) V over the slots RingKVCache.complete makes visible (slot -> position map
+ *   :254-278 incl. the `delta <= 0` slot) plus the new step, taken straight from the qkv row; workgroup 0 appends the new
+ *   k / v at slot pos % cap.  y[b][n] = (res +) (bias +) sum_k attn[b][k] w[n][k], w bf16 [N][H*D].
+ *
+ * rst_gemv_embed_bf16_f32 -- in_proj of the FIRST layer of a depth step with the step's input as the prologue:
+ *   x_in[b] = add[b] (fp32 row, ld_add apart: depformer_in[k](transformer_out), e.g. a column block of one up-front
+ *   [B][dep_q * K] product) + table[tokens[b * tok_stride + tok_col]] (ScaledEmbedding, models/model.py:67-91: id -1 gives the
+ *   zero row; other ids are clamped into [0, table_rows) -- the reference raises on an out-of-range id);
+ *   y = (bias +) RMSNorm(x_in; alpha, eps) w^T, and x_in is stored to x_out [B][K] (the residual of the layer). */
+int rst_gemv_attn_bf16_f32(const float* qkv, float* k_cache, float* v_cache, const int64_t* pos_dev, const uint16_t* w,
+                           const float* res, const float* bias, float* y, int B, int N, int H, int D, int cap, int context, int ldqkv,
+                           int ldy, rst_stream_t stream);
+int rst_gemv_embed_bf16_f32(const float* add, const uint16_t* table, const int64_t* tokens, float* x_out, const float* alpha,
+                            const uint16_t* w, const float* bias, float* y, int B, int N, int K, int ld_add, int ldy, int tok_stride,
+                            int tok_col, int table_rows, float eps, rst_stream_t stream);
+
 /* The same contraction for 4 < B <= 64 on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), in three entry points.
  * Both operands are kept in the order the MFMA consumes them -- [tile of 32 rows][K/16 steps][64 lanes][8 bf16], lane =
  * 32 * ((k / 8) % 2) + row % 32 -- so that every wave-level load is one contiguous kilobyte:

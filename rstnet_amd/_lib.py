@@ -42,6 +42,8 @@ SIGNATURES = {
     "rst_mask_tail_f32": [_p, _p, _i, _i, _i, _i, _p],
     "rst_gemv_f32": [_p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "rst_gemv_bf16_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "rst_gemv_attn_bf16_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rst_gemv_embed_bf16_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "rst_skinny_pack_weight_bf16": [_p, _p, _i, _i, _i, _p],
     "rst_skinny_pack_act_f32": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     "rst_skinny_pack_weight_fp8": [_p, _p, _p, _i, _i, _p],

@@ -187,11 +187,43 @@ int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, i
 }
 
 // ---- LM decode step -------------------------------------------------------------------------------------------------
+static void gemv_defaults(GemvParams& p) {
+    p.beta = nullptr; p.scale = nullptr; p.act_out = 0; p.w_f32 = 0; p.gate_out = 0;
+    p.at_k = p.at_v = nullptr; p.at_pos = nullptr; p.at_H = p.at_D = p.at_cap = p.at_context = 0;
+    p.em_table = nullptr; p.em_tokens = nullptr; p.em_x_out = nullptr; p.em_tok_stride = p.em_col = p.em_rows = 0;
+}
+
 int rst_gemv_bf16_f32(const float* x, const float* alpha, const uint16_t* w, const float* res, const float* bias, float* y,
                       int B, int N, int K, int ldx, int ldy, int prologue, float eps, int gate_out, rst_stream_t stream) {
+    RST_REQUIRE(prologue >= 0 && prologue <= 2, "gemv_bf16: prologue must be 0 (none), 1 (RMSNorm) or 2 (SiLU gate)");
     GemvParams p;
-    p.x = x; p.alpha = alpha; p.beta = nullptr; p.w = w; p.res = res; p.bias = bias; p.scale = nullptr; p.y = y; p.B = B; p.N = N;
-    p.K = K; p.ldx = ldx; p.ldy = ldy; p.prologue = prologue; p.act_out = 0; p.w_f32 = 0; p.gate_out = gate_out; p.eps = eps;
+    gemv_defaults(p);
+    p.x = x; p.alpha = alpha; p.w = w; p.res = res; p.bias = bias; p.y = y; p.B = B; p.N = N;
+    p.K = K; p.ldx = ldx; p.ldy = ldy; p.prologue = prologue; p.gate_out = gate_out; p.eps = eps;
+    return rst_launch_gemv(p, (hipStream_t)stream);
+}
+
+int rst_gemv_attn_bf16_f32(const float* qkv, float* k_cache, float* v_cache, const int64_t* pos_dev, const uint16_t* w,
+                           const float* res, const float* bias, float* y, int B, int N, int H, int D, int cap, int context, int ldqkv,
+                           int ldy, rst_stream_t stream) {
+    GemvParams p;
+    gemv_defaults(p);
+    p.x = qkv; p.alpha = nullptr; p.w = w; p.res = res; p.bias = bias; p.y = y; p.B = B; p.N = N; p.K = H * D; p.ldx = ldqkv; p.ldy = ldy;
+    p.prologue = 4; p.eps = 0.f;
+    p.at_k = k_cache; p.at_v = v_cache; p.at_pos = reinterpret_cast<const long*>(pos_dev); p.at_H = H; p.at_D = D; p.at_cap = cap;
+    p.at_context = context;
+    return rst_launch_gemv(p, (hipStream_t)stream);
+}
+
+int rst_gemv_embed_bf16_f32(const float* add, const uint16_t* table, const int64_t* tokens, float* x_out, const float* alpha,
+                            const uint16_t* w, const float* bias, float* y, int B, int N, int K, int ld_add, int ldy, int tok_stride,
+                            int tok_col, int table_rows, float eps, rst_stream_t stream) {
+    GemvParams p;
+    gemv_defaults(p);
+    p.x = add; p.alpha = alpha; p.w = w; p.res = nullptr; p.bias = bias; p.y = y; p.B = B; p.N = N; p.K = K; p.ldx = ld_add; p.ldy = ldy;
+    p.prologue = 5; p.eps = eps;
+    p.em_table = table; p.em_tokens = reinterpret_cast<const long*>(tokens); p.em_x_out = x_out; p.em_tok_stride = tok_stride;
+    p.em_col = tok_col; p.em_rows = table_rows;
     return rst_launch_gemv(p, (hipStream_t)stream);
 }
 
@@ -199,6 +231,7 @@ int rst_gemv_f32(const float* x, const float* ln_gamma, const float* ln_beta, fl
                  const float* res, const float* scale, float* y, int B, int N, int K, int act_out, rst_stream_t stream) {
     RST_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "gemv_f32: LayerNorm needs both gamma and beta");
     GemvParams p;
+    gemv_defaults(p);
     p.x = x; p.alpha = ln_gamma; p.beta = ln_beta; p.w = w; p.res = res; p.bias = bias; p.scale = scale; p.y = y; p.B = B; p.N = N;
     p.K = K; p.ldx = K; p.ldy = N; p.prologue = ln_gamma ? 3 : 0; p.act_out = act_out; p.w_f32 = 1; p.gate_out = 0; p.eps = ln_eps;
     return rst_launch_gemv(p, (hipStream_t)stream);

@@ -45,7 +45,9 @@ template <> struct WChunk<true> {
 };
 
 // y[b][n] = (res ? res[b][n] : 0) + (scale ? scale[n] : 1) * act(bias[n] + sum_k xs[b][k] * W[n][k]),   xs = prologue(x)
-template <int B, int RPW, bool F32W>
+// FUSED instances (B <= 2, bf16) also carry prologue 4 (short-ring attention) and 5 (embedding + RMSNorm); they are kept apart
+// so that their register footprint (the K / V rows of 8 ring slots) does not cost the plain instances their occupancy.
+template <int B, int RPW, bool F32W, bool FUSED = false>
 __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_kernel(const GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) float xs[];   // [B][K]
     __shared__ float red[GEMV_WAVES];
@@ -119,6 +121,94 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_kernel(const GemvParams 
             for (int w = 0; w < GEMV_WAVES; ++w) var += red[w];
             const float rstd = 1.0f / sqrtf(var / (float)K + p.eps);
             for (int k = tid; k < K; k += 64 * GEMV_WAVES) xs[b * K + k] = (p.x[(long)b * p.ldx + k] - mean) * rstd * p.alpha[k] + p.beta[k];
+        }
+    } else if (FUSED && p.prologue == 4) {    // attention over the short ring (modules/transformer.py:376-416 with cap <= 8, no rope)
+        // Thread = 4 consecutive dims of one head; the D/4 lanes of a head are neighbours inside a wave, so a score is a
+        // butterfly over lane bits < D/4.  K / V of all cap slots are requested before the position scalar is known
+        // (they are L2 hits: the ring was written by earlier launches); the new step's k / v come from the qkv row.
+        const int D = p.at_D, lph = D >> 2, cap = p.at_cap;
+        const float sc_scale = 1.0f / sqrtf((float)D);
+        for (int b = 0; b < B; ++b) {
+            const float* row = p.x + (long)b * p.ldx;
+            for (int e = tid * 4; e < K; e += 4 * 64 * GEMV_WAVES) {
+                const int h = e / D, d = e - h * D;
+                const f32x4 q = *reinterpret_cast<const f32x4*>(row + e);
+                const f32x4 kn = *reinterpret_cast<const f32x4*>(row + K + e);
+                const f32x4 vn = *reinterpret_cast<const f32x4*>(row + 2 * K + e);
+                const long base = (((long)b * p.at_H + h) * cap) * D + d;
+                f32x4 kk[8], vv[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    kk[s] = f32x4{0.f, 0.f, 0.f, 0.f}; vv[s] = kk[s];
+                    if (s < cap) {
+                        kk[s] = *reinterpret_cast<const f32x4*>(p.at_k + base + (long)s * D);
+                        vv[s] = *reinterpret_cast<const f32x4*>(p.at_v + base + (long)s * D);
+                    }
+                }
+                const long pos = *p.at_pos;
+                const int slot_cur = (int)(pos % cap);
+                float sc[8], m = -INFINITY;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const bool cur = s == slot_cur;
+                    if (cur) { kk[s] = kn; vv[s] = vn; }
+                    float dd = fmaf(kk[s][3], q[3], fmaf(kk[s][2], q[2], fmaf(kk[s][1], q[1], kk[s][0] * q[0])));
+                    for (int o = 1; o < lph; o <<= 1) dd += __shfl_xor(dd, o);
+                    const bool ok = s < cap && ring_visible(s, pos, cap, p.at_context, pos + 1);
+                    sc[s] = ok ? dd * sc_scale : -INFINITY;
+                    m = fmaxf(m, sc[s]);
+                }
+                float l = 0.f;
+                f32x4 o4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float pw = sc[s] == -INFINITY ? 0.f : expf(sc[s] - m);
+                    l += pw;
+                    o4[0] = fmaf(pw, vv[s][0], o4[0]); o4[1] = fmaf(pw, vv[s][1], o4[1]);
+                    o4[2] = fmaf(pw, vv[s][2], o4[2]); o4[3] = fmaf(pw, vv[s][3], o4[3]);
+                }
+                const float inv = 1.0f / l;     // the new step itself is always visible: l > 0
+                *reinterpret_cast<f32x4*>(xs + b * K + e) = f32x4{o4[0] * inv, o4[1] * inv, o4[2] * inv, o4[3] * inv};
+                if (blockIdx.x == 0) {          // ring append (RingKVCache.complete: index_copy_ at end_offset % capacity)
+                    *reinterpret_cast<f32x4*>(p.at_k + base + (long)slot_cur * D) = kn;
+                    *reinterpret_cast<f32x4*>(p.at_v + base + (long)slot_cur * D) = vn;
+                }
+            }
+        }
+    } else if (FUSED && p.prologue == 5) {    // ScaledEmbedding lookup + add + RMSNorm (models/model.py:411-417 then transformer.py:34-46)
+        for (int b = 0; b < B; ++b) {
+            constexpr int XR = 16;   // K <= XR * 256 = 4096 (launch check)
+            long tok = p.em_tokens[(long)b * p.em_tok_stride + p.em_col];
+            const bool zero = tok == -1;
+            tok = tok < 0 ? 0 : (tok >= p.em_rows ? p.em_rows - 1 : tok);
+            const unsigned short* er = p.em_table + tok * (long)K;
+            float xr[XR];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const int k = tid + i * 64 * GEMV_WAVES;
+                float v = 0.f;
+                if (k < K) {
+                    v = p.x[(long)b * p.ldx + k];
+                    if (!zero) v += __uint_as_float((unsigned)er[k] << 16);
+                    if (blockIdx.x == 0) p.em_x_out[(long)b * K + k] = v;
+                }
+                xr[i] = v;
+                s = fmaf(v, v, s);
+            }
+            s = wave_sum(s);
+            __syncthreads();
+            if (lane == 0) red[wave] = s;
+            __syncthreads();
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < GEMV_WAVES; ++w) tot += red[w];
+            const float r = 1.0f / sqrtf(p.eps + tot / (float)K);
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const int k = tid + i * 64 * GEMV_WAVES;
+                if (k < K) xs[b * K + k] = xr[i] * (p.alpha[k] * r);
+            }
         }
     } else if (p.prologue == 2) {    // SiLU gate: x holds [B][2K] = [u ; v], xs = silu(u) * v   (modules/gating.py:12-22)
         for (int b = 0; b < B; ++b)
@@ -343,15 +433,26 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 int rst_launch_gemv(const GemvParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B >= 1 && p.B <= 4 && p.N > 0 && p.K > 0 && p.K % 8 == 0, "gemv: need 1 <= B <= 4 and K %% 8 == 0 (B=%d K=%d)", p.B, p.K);
     RST_REQUIRE(p.x && p.w && p.y, "gemv: null pointer");
-    RST_REQUIRE(p.prologue >= 0 && p.prologue <= 3 && (p.prologue != 1 || p.alpha) && (p.prologue != 3 || (p.alpha && p.beta)),
+    RST_REQUIRE(p.prologue >= 0 && p.prologue <= 5 && (p.prologue != 1 || p.alpha) && (p.prologue != 3 || (p.alpha && p.beta)),
                 "gemv: bad prologue");
+    if (p.prologue == 4) {
+        RST_REQUIRE(!p.w_f32 && p.at_k && p.at_v && p.at_pos && p.at_cap >= 1 && p.at_cap <= 8 && p.at_H >= 1 && p.at_D >= 4 &&
+                    p.at_D <= 256 && (p.at_D & (p.at_D - 1)) == 0 && p.at_H * p.at_D == p.K && p.ldx >= 3 * p.K && p.ldx % 4 == 0,
+                    "gemv_attn: needs a ring of <= 8 slots, a power-of-two head dim in 4..256, K = H * D and a [q | k | v] row (H=%d D=%d cap=%d K=%d ldx=%d)",
+                    p.at_H, p.at_D, p.at_cap, p.K, p.ldx);
+        RST_REQUIRE(((uintptr_t)p.at_k % 16) == 0 && ((uintptr_t)p.at_v % 16) == 0, "gemv_attn: ring pointers must be 16-byte aligned");
+    }
+    if (p.prologue == 5)
+        RST_REQUIRE(!p.w_f32 && p.alpha && p.em_table && p.em_tokens && p.em_x_out && p.em_rows >= 1 && p.K <= 4096 && p.em_tok_stride >= 1 &&
+                    p.em_col >= 0 && p.em_col < p.em_tok_stride, "gemv_embed: bad arguments (K=%d rows=%d col=%d stride=%d)", p.K, p.em_rows,
+                    p.em_col, p.em_tok_stride);
     RST_REQUIRE(p.act_out == 0 || p.act_out == 1, "gemv: act_out must be 0 (none) or 1 (GELU)");
     RST_REQUIRE(((uintptr_t)p.w % 16) == 0 && ((uintptr_t)p.x % 16) == 0, "gemv: pointers must be 16-byte aligned");
     const size_t lds = (size_t)p.B * p.K * sizeof(float);
     RST_REQUIRE(lds <= 128 * 1024, "gemv: B*K = %d floats do not fit the activation stage (32768)", p.B * p.K);
     RST_REQUIRE(!p.gate_out || (p.N % 2 == 0 && !p.res && !p.scale && !p.act_out), "gemv: gate_out needs an even N and no residual / scale / activation");
     // rows per wave: 4 when that still yields >= 2 workgroups per CU, else 2 (more workgroups -> more loads in flight)
-    const bool rpw4 = !p.w_f32 && !p.gate_out && ((long)p.N + 15) / 16 >= 512;
+    const bool rpw4 = !p.w_f32 && !p.gate_out && p.prologue < 4 && ((long)p.N + 15) / 16 >= 512;
     // the large batch-1 RMSNorm layers take the x-first streaming schedule (gemv_norm_kernel)
     const bool norm_stream = !p.w_f32 && p.B == 1 && p.prologue == 1 && p.K <= 4096 && !p.act_out && (long)p.N * p.K >= (1L << 24);
     const int rows_per_group = (rpw4 ? 4 : 2) * GEMV_WAVES;
@@ -375,6 +476,11 @@ int rst_launch_gemv(const GemvParams& p, hipStream_t stream) {
             default: go(gemv_kernel<4, 2, true>); break;
         }
         return rst_check_launch("gemv_f32");
+    }
+    if (p.prologue >= 4) {
+        RST_REQUIRE(p.B <= 2, "gemv: the fused attention / embedding prologues serve B <= 2 (got %d)", p.B);
+        if (p.B == 1) go(gemv_kernel<1, 2, false, true>); else go(gemv_kernel<2, 2, false, true>);
+        return rst_check_launch("gemv_fused");
     }
     if (norm_stream) {
         if (p.gate_out) go(gemv_norm_kernel<true>); else go(gemv_norm_kernel<false>);

@@ -154,6 +154,20 @@ struct GemvParams {
     int w_f32;
     int gate_out;               // bf16, N even, no res / scale / act: y[b][q] = silu(row q) * (row N/2 + q), q < N/2 (stacked gated layer)
     float eps;
+    // prologue 4 -- attention over a short un-rotated ring (the depth transformer): x = the qkv row [B][ldx] = [q | k | v] of
+    // at_H heads of at_D dims (K = at_H * at_D); P(x) = softmax(q.K^T / sqrt(D)) V over the ring slots visible at *at_pos plus
+    // the new step itself; workgroup 0 appends the new k / v to slot *at_pos % at_cap of at_k / at_v [B][H][cap][D].
+    float* at_k;
+    float* at_v;
+    const long* at_pos;
+    int at_H, at_D, at_cap, at_context;
+    // prologue 5 -- embedding + RMSNorm (first layer of a depth step): x_in = x[b] (fp32, e.g. depformer_in[k](h)) +
+    // em_table[em_tokens[b * em_tok_stride + em_col]] (bf16 [em_rows][K]; id -1 = zero row, other ids clamped into the
+    // table); P(x) = RMSNorm(x_in) with alpha / eps; workgroup 0 stores x_in to em_x_out [B][K] (the layer's residual).
+    const unsigned short* em_table;
+    const long* em_tokens;
+    float* em_x_out;
+    int em_tok_stride, em_col, em_rows;
 };
 int rst_launch_gemv(const GemvParams& p, hipStream_t stream);
 

@@ -97,8 +97,9 @@ class GPTGen:
         out = torch.empty(B, cfg.dep_q, device=text_token.device, dtype=torch.long)
         prev = text_token
         k_eff = min(self.top_k, cfg.audio_card)
+        h_all = ops.lm_linear(h, m.codecformer_in_all())      # codecformer_in[k](h) of all dep_q steps in one launch
         for l_idx in range(cfg.dep_q):
-            y = dep.step(m._codec_in(l_idx, prev, h))
+            y = m._codec_step(l_idx, prev, None, h_all)
             head = m.audio_linears[l_idx]
             logits = ops.lm_linear(y, head.weight, bias=head.bias_f32())
             prev = ops.lm_sample(logits, use_sampling=self.use_sampling, temp=self.temp, top_k=k_eff,

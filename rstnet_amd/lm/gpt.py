@@ -508,6 +508,23 @@ class GPT(StreamingModule[_GPTState]):
         return h.view(B, T, c.n_embd), logits.view(B, T, -1)
 
     # ---- local (depth) transformer
+    def codecformer_in_all(self) -> torch.Tensor:
+        """``[dep_q * codecformer_dim, n_embd]``: the dep_q ``codecformer_in[k]`` matrices stacked (built once per weight version),
+        so that a frame's dep_q products with ``transformer_out`` are one weight-streaming launch."""
+        if not hasattr(self, "_in_cat"):
+            from ..codec.conv import _PackedCache
+            self._in_cat = _PackedCache()
+        ws = [m.weight for m in self.codecformer_in]
+        return self._in_cat.get(tuple(ws), lambda: torch.cat([w.detach() for w in ws], 0).contiguous())
+
+    def _codec_step(self, k: int, prev: torch.Tensor, h: Optional[torch.Tensor], h_all: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One depth step: (codecformer_in[k](h) + embedding of the previous token ``prev`` int64 [N]) through the codecformer ->
+        ``[N, codecformer_dim]``; the sum is formed inside the first launch of the step.  ``h_all``: ``h @ codecformer_in_all().T``."""
+        E = self.config.codecformer_dim
+        add = h_all[:, k * E:(k + 1) * E] if h_all is not None else ops.lm_linear(h, self.codecformer_in[k].weight)
+        table = self.codecformer_text_emb.weight if k == 0 else self.codecformer_emb[k - 1].weight
+        return self.codecformer.step(None, embed=(add, table, prev.reshape(-1, 1).contiguous(), 0))
+
     def _codec_in(self, k: int, prev: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
         """codecformer_in[k](h) + embedding of the previous token (text embedding for k = 0): prev int64 [N], h fp32 [N, n_embd]."""
         x = ops.lm_linear(h, self.codecformer_in[k].weight)
@@ -523,8 +540,7 @@ class GPT(StreamingModule[_GPTState]):
         assert S == 1, f"Steps for Depformer streaming should be passed 1 by 1, got {S}."
         assert transformer_out.shape[1] == 1, "Transformer out should be a for a single step."
         k = codecformer_cb_index
-        x = self._codec_in(k, sequence.reshape(B), transformer_out.reshape(B, -1).float().contiguous())
-        y = self.codecformer.step(x)
+        y = self._codec_step(k, sequence.reshape(B), transformer_out.reshape(B, -1).float().contiguous())
         head = self.audio_linears[k]
         return ops.lm_linear(y, head.weight, bias=head.bias_f32()).view(B, 1, 1, -1)
 

@@ -145,17 +145,26 @@ class StreamingTransformer(StreamingModule[_StepState]):
         return _StepState([torch.zeros(shape, device=dev) for _ in self.layers], [torch.zeros(shape, device=dev) for _ in self.layers],
                           torch.zeros(1, device=dev, dtype=torch.long), scratch)
 
-    def step(self, x: torch.Tensor, step_index: Optional[int] = None, pos: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x fp32 ``[B, d_model]`` -> ``[B, d_model]``: one new time step through every layer (4 launches per layer for a short
-        ring, 5 otherwise).  ``pos`` (int64 device scalar): position of this step supplied by a caller that owns the loop
-        (LMGen's depth steps are always positions 0 .. dep_q - 1); the module's own counter is then left alone."""
+    def step(self, x: Optional[torch.Tensor], step_index: Optional[int] = None, pos: Optional[torch.Tensor] = None,
+             embed: Optional[tuple] = None) -> torch.Tensor:
+        """x fp32 ``[B, d_model]`` -> ``[B, d_model]``: one new time step through every layer.  ``pos`` (int64 device scalar):
+        position of this step supplied by a caller that owns the loop (LMGen's depth steps are always positions 0 .. dep_q - 1);
+        the module's own counter is then left alone.  ``embed = (add, table, tokens, col)`` instead of ``x``: the input is
+        ``add + table[tokens[:, col]]`` (``add`` fp32 ``[B, d_model]``, any row stride) and is formed inside the first launch.
+
+        Launches per layer -- batch <= 2: 4 for a short un-rotated ring (qkv GEMV | out-proj GEMV with the attention as its
+        prologue | ffn-in GEMV with the gate | ffn-out GEMV), 5 otherwise (attention on its own); batch > 2: 5."""
         st = self._streaming_state
         if st is None:
             raise RuntimeError("the decode-step transformer only runs in streaming mode")
-        E = self.d_model
+        E, H = self.d_model, self.num_heads
+        B = x.shape[0] if x is not None else embed[0].shape[0]
+        cap = st.k[0].shape[2]
+        fused_attn = ops.gemv_attn_supported(B, H, E // H, cap, self.rope)
         k_idx = 0
         if self.weights_per_step:
             k_idx = st.offset_cpu if step_index is None else step_index
+        pos_t = st.pos if pos is None else pos
         for l, layer in enumerate(self.layers):
             att = layer.self_attn
             if self.weights_per_step:
@@ -164,10 +173,20 @@ class StreamingTransformer(StreamingModule[_StepState]):
                 gate = layer.gating[k_idx]
             else:
                 w_in, w_out, gate = att.in_proj_weight, att.out_proj.weight, layer.gating
-            qkv = ops.lm_linear(x, w_in, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm1.alpha_f32(), eps=layer.norm1.eps)
-            a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], st.pos if pos is None else pos, rope=self.rope, context=self.context,
-                                   max_period=self.max_period, scratch=st.scratch, packed=x.shape[0] > 2)
-            x = ops.lm_linear(a, w_out, res=x)
+            if l == 0 and embed is not None:
+                add, table, tokens, col = embed
+                if B <= 2 and E <= 4096 and E % 8 == 0:
+                    qkv, x = ops.gemv_embed(add, table, tokens, col, w_in, alpha=layer.norm1.alpha_f32(), eps=layer.norm1.eps)
+                else:
+                    x = ops.embed_sum(tokens, [table], [col], add=add.contiguous())
+            if l > 0 or embed is None or not (B <= 2 and E <= 4096 and E % 8 == 0):
+                qkv = ops.lm_linear(x, w_in, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm1.alpha_f32(), eps=layer.norm1.eps)
+            if fused_attn:
+                x = ops.gemv_attn(qkv, st.k[l], st.v[l], pos_t, w_out, context=self.context, res=x)
+            else:
+                a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], pos_t, rope=self.rope, context=self.context,
+                                       max_period=self.max_period, scratch=st.scratch, packed=B > 2)
+                x = ops.lm_linear(a, w_out, res=x)
             x = ops.lm_gated_pair(x, gate.linear_in.weight, gate.linear_out.weight, alpha=layer.norm2.alpha_f32(), eps=layer.norm2.eps,
                                   res=x)
         if pos is None:
@@ -222,6 +241,13 @@ class LMModel(StreamingContainer):
         self.depformer.set_streaming_propagate(False)
         self.linears = nn.ModuleList([_Weight(card, depformer_dim, **fk) for _ in range(dep_q)])
         self.config = ModelConfig(model_type="lora")
+        self._in_cat = _PackedCache()
+
+    def depformer_in_all(self) -> torch.Tensor:
+        """``[dep_q * depformer_dim, dim]``: the dep_q ``depformer_in[k]`` matrices stacked (a second copy, built once per weight
+        version): all of a frame's ``depformer_in[k](transformer_out)`` products are ONE weight-streaming launch."""
+        ws = [m.weight for m in self.depformer_in]
+        return self._in_cat.get(tuple(ws), lambda: torch.cat([w.detach() for w in ws], 0).contiguous())
 
     # ---- token-id conventions (models/model.py:226-277)
     @property
@@ -296,13 +322,14 @@ class LMModel(StreamingContainer):
                                         transformer_out.reshape(B, self.dim).contiguous())
         return logits.view(B, 1, 1, -1)
 
-    def _depformer_logits(self, k: int, tokens: torch.Tensor, col: int, h_t: torch.Tensor, pos: Optional[torch.Tensor] = None,
-                          step_index: Optional[int] = None) -> torch.Tensor:
-        """Depth step ``k``: previous token = ``tokens[:, col]`` (int64 ``[B, n]``), ``h_t`` fp32 ``[B, dim]`` -> logits ``[B, card]``."""
-        h = ops.lm_linear(h_t, self.depformer_in[k].weight)
+    def _depformer_logits(self, k: int, tokens: torch.Tensor, col: int, h_t: Optional[torch.Tensor], pos: Optional[torch.Tensor] = None,
+                          step_index: Optional[int] = None, h_all: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Depth step ``k``: previous token = ``tokens[:, col]`` (int64 ``[B, n]``), ``h_t`` fp32 ``[B, dim]`` -> logits ``[B, card]``.
+        ``h_all`` (``[B, dep_q * depformer_dim]``, the stacked ``depformer_in`` products of the frame) replaces ``h_t``."""
+        E = self.depformer.d_model
+        h = h_all[:, k * E:(k + 1) * E] if h_all is not None else ops.lm_linear(h_t, self.depformer_in[k].weight)
         table = self.depformer_text_emb.weight if k == 0 else self.depformer_emb[k - 1].weight
-        x = ops.embed_sum(tokens, [table], [col], add=h)
-        y = self.depformer.step(x, step_index=step_index, pos=pos)
+        y = self.depformer.step(None, step_index=step_index, pos=pos, embed=(h, table, tokens, col))
         return ops.lm_linear(y, self.linears[k].weight)
 
     @classmethod
@@ -333,6 +360,7 @@ class _LMGenState:
     initial: torch.Tensor          # int64 [1, K, 1]
     offset_dev: torch.Tensor       # int64 [1]: the frame counter as the ring kernels see it
     graphed_frame: _Graphed
+    depth: Optional[_StepState] = None     # the depth transformer's KV rings of THIS session (a captured frame points at them)
     offset: int = 0
 
     def reset(self) -> None:
@@ -363,7 +391,7 @@ class LMGen(StreamingModule[_LMGenState]):
                            dtype=torch.long)
         disable = lm.device.type != "cuda"
         return _LMGenState(cache, lm._get_initial_token(), torch.zeros(1, device=lm.device, dtype=torch.long),
-                           _Graphed(self._frame, disable=disable))
+                           _Graphed(self._frame, disable=disable), depth=lm.depformer._init_streaming_state(batch_size))
 
     def _noise(self, B: int, k: int) -> Optional[torch.Tensor]:
         if not self.use_sampling:
@@ -383,7 +411,7 @@ class LMGen(StreamingModule[_LMGenState]):
         tokens = torch.empty(B, lm.dep_q + 1, device=input_.device, dtype=torch.long)
         ops.lm_sample(text_logits.view(B, -1), use_sampling=self.use_sampling, temp=self.temp_text, top_k=self.top_k_text,
                       noise=None if noise is None else noise[:, :self.top_k_text], out=tokens[:, 0])
-        self._depth(tokens, transformer_out.view(B, lm.dim), None if noise is None else noise[:, self.top_k_text:])
+        self._depth(tokens, transformer_out.view(B, lm.dim).contiguous(), None if noise is None else noise[:, self.top_k_text:])
         out = ops.lm_ring_commit(state.cache, tokens, self._delays_i32, state.offset_dev, self.max_delay)
         return out, input_
 
@@ -395,12 +423,21 @@ class LMGen(StreamingModule[_LMGenState]):
         B = tokens.shape[0]
         lm = self.lm_model
         dep = lm.depformer
-        if dep._streaming_state is None or dep._streaming_state.k[0].shape[0] != B:
-            dep._streaming_state = dep._init_streaming_state(B)
-        for cb in range(lm.dep_q):
-            logits = lm._depformer_logits(cb, tokens, cb, h_t, pos=self._depth_pos[cb:cb + 1], step_index=cb)
-            ops.lm_sample(logits, use_sampling=self.use_sampling, temp=self.temp, top_k=self.top_k,
-                          noise=None if noise is None else noise[:, cb * self.top_k:(cb + 1) * self.top_k], out=tokens[:, cb + 1])
+        # the rings belong to the session (so that a frame graph captured by another live session keeps valid pointers and
+        # exiting `streaming()` releases them); a bare `depformer_step` call outside any session gets throw-away rings
+        state = self._streaming_state
+        rings = state.depth if state is not None and state.depth is not None and state.depth.k[0].shape[0] == B \
+            else dep._init_streaming_state(B)
+        saved, dep._streaming_state = dep._streaming_state, rings
+        try:
+            # depformer_in[k](transformer_out) for all dep_q steps at once: one 8 x larger launch instead of eight
+            h_all = ops.lm_linear(h_t, lm.depformer_in_all())
+            for cb in range(lm.dep_q):
+                logits = lm._depformer_logits(cb, tokens, cb, None, pos=self._depth_pos[cb:cb + 1], step_index=cb, h_all=h_all)
+                ops.lm_sample(logits, use_sampling=self.use_sampling, temp=self.temp, top_k=self.top_k,
+                              noise=None if noise is None else noise[:, cb * self.top_k:(cb + 1) * self.top_k], out=tokens[:, cb + 1])
+        finally:
+            dep._streaming_state = saved
 
     @torch.no_grad()
     def step(self, input_tokens: torch.Tensor) -> Optional[torch.Tensor]:

@@ -485,6 +485,63 @@ def gemv_bf16(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE
     return out
 
 
+def gemv_attn_supported(B: int, H: int, D: int, cap: int, rope: bool, G: Optional[int] = None) -> bool:
+    """Whether ``gemv_attn`` serves this attention: batch <= 2, a ring of <= 8 slots, no rotary embedding, one kv head per query
+    head and a power-of-two head dim -- the depth transformer of both LM families."""
+    return B <= 2 and 1 <= cap <= 8 and not rope and (G is None or G == H) and 4 <= D <= 256 and D & (D - 1) == 0 and B * H * D <= 32768
+
+
+def gemv_attn(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos_dev: torch.Tensor, w: torch.Tensor, *,
+              context: Optional[int] = None, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``res + W_out attention(qkv)`` in ONE launch (rst_gemv_attn_bf16_f32): ``qkv [B, 3*H*D]`` un-rotated, the ring
+    ``[B, H, cap <= 8, D]`` (the new step is appended by the launch), ``w`` bf16 ``[N, H*D]``."""
+    _chk(qkv, "qkv"); _chk(k_cache, "k_cache"); _chk(v_cache, "v_cache"); _chk(res, "res"); _chk(bias, "bias")
+    _chk(pos_dev, "pos_dev", torch.int64)
+    _chk(w, "w", torch.bfloat16)
+    B, H, cap, D = k_cache.shape
+    N = w.shape[0]
+    assert qkv.shape == (B, 3 * H * D) and w.shape[1] == H * D, (tuple(qkv.shape), tuple(w.shape), H, D)
+    out = torch.empty(B, N, device=qkv.device, dtype=torch.float32)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.lib().rst_gemv_attn_bf16_f32(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(pos_dev), _ptr(w), _ptr(res), _ptr(bias),
+                                                _ptr(out), B, N, H, D, cap, int(context) if context else 0, qkv.shape[1], N, _stream()))
+    if prof is not None:
+        e1.record()
+        prof.append(("gemv_bf16", e0, e1, 2.0 * B * N * H * D, 2 * N * H * D + 4 * (qkv.numel() + out.numel()), (B, N, H * D)))
+    return out
+
+
+def gemv_embed(add: torch.Tensor, table: torch.Tensor, tokens: torch.Tensor, col: int, w: torch.Tensor, *, alpha: torch.Tensor,
+               eps: float = 1e-8, bias: Optional[torch.Tensor] = None):
+    """First GEMV of a depth step (rst_gemv_embed_bf16_f32): ``x = add + table[tokens[:, col]]`` (``add`` fp32 ``[B, K]``, possibly a
+    column block of a wider row-major buffer: unit column stride, any row stride), ``y = RMSNorm(x) @ w.T``.  Returns ``(y, x)``."""
+    _chk(tokens, "tokens", torch.int64)
+    _chk(table, "table", torch.bfloat16)
+    _chk(w, "w", torch.bfloat16)
+    _chk(alpha, "alpha"); _chk(bias, "bias")
+    if not add.is_cuda or add.dtype != torch.float32 or add.dim() != 2 or add.stride(1) != 1:
+        raise ValueError("rstnet_amd.ops: `add` must be a float32 CUDA/HIP matrix with unit column stride")
+    B, K = add.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and table.shape[1] == K and tokens.shape[0] == B and 0 <= col < tokens.shape[1]
+    y = torch.empty(B, N, device=add.device, dtype=torch.float32)
+    x = torch.empty(B, K, device=add.device, dtype=torch.float32)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.lib().rst_gemv_embed_bf16_f32(_ptr(add), _ptr(table), _ptr(tokens), _ptr(x), _ptr(alpha), _ptr(w), _ptr(bias), _ptr(y),
+                                                 B, N, K, add.stride(0) if B > 1 else K, N, tokens.shape[1], col, table.shape[0], float(eps),
+                                                 _stream()))
+    if prof is not None:
+        e1.record()
+        prof.append(("gemv_bf16", e0, e1, 2.0 * B * N * K, 2 * N * K + 4 * (2 * B * K + y.numel()), (B, N, K)))
+    return y, x
+
+
 _skinny_weights = _PackedWeights()
 _skinny_weights_gated = _PackedWeights()
 
@@ -776,7 +833,7 @@ def lm_ring_commit(cache: torch.Tensor, tokens: torch.Tensor, delays: torch.Tens
 # every public entry point runs under the device guard of its first tensor argument
 for _name in ("skinny_f32_pack_weight", "gemm_win", "linear", "seanet_resblock", "layernorm", "rope_split", "attention", "rvq_pack",
               "rvq_search", "rvq_gather", "convtr_depthwise", "activation", "transpose12", "mask_tail", "hist_update", "gemv_bf16",
-              "skinny_pack_weight", "skinny_pack_act", "gemm_skinny", "skinny_pack_weight_fp8", "gemm_skinny_fp8", "lm_gated_pair",
+              "gemv_attn", "gemv_embed", "skinny_pack_weight", "skinny_pack_act", "gemm_skinny", "skinny_pack_weight_fp8", "gemm_skinny_fp8", "lm_gated_pair",
               "lm_linear", "embed_sum", "rmsnorm", "lm_rope_append", "lm_attn_decode", "lm_sample", "lm_ring_begin", "lm_ring_commit"):
     globals()[_name] = _on_tensor_device(globals()[_name])
 del _name

@@ -379,3 +379,56 @@ def test_lmgen_requires_streaming():
     gen = LMGen(model, use_sampling=False)
     with pytest.raises(RuntimeError):
         gen.step(torch.zeros(1, cfg["n_q"] - cfg["dep_q"], 1, dtype=torch.long, device=DEV))
+
+
+# ---- fused GEMV prologues of the depth transformer (rst_gemv_attn_bf16_f32, rst_gemv_embed_bf16_f32)
+
+@pytest.mark.parametrize("B,H,D,cap,context,steps", [(1, 16, 64, 8, None, 8), (2, 16, 64, 8, None, 8), (2, 2, 64, 2, None, 7), (1, 2, 32, 3, None, 10),
+                                                     (2, 4, 128, 8, 5, 20), (1, 1, 16, 8, None, 8), (2, 8, 4, 5, None, 12), (1, 32, 32, 8, 8, 17)])
+def test_gemv_attn_out_proj_matches_oracle(B, H, D, cap, context, steps):
+    """Out-projection with the short-ring attention as its prologue, step by step against the oracle's RingKV (no rope): covers the
+    depth transformer's own shape (16 x 64, ring 8), rings that wrap (the `delta <= 0` slot), a context shorter than
+    the ring, odd head counts / dims, both batch sizes; the ring contents written by the launch are checked at the end."""
+    g = torch.Generator().manual_seed(H * D + cap)
+    E, N = H * D, 3 * H * D // 2 + 5
+    w = (torch.randn(N, E, generator=g) / E ** 0.5).bfloat16()
+    ring = L.RingKV(B, H, D, cap)
+    kc = torch.zeros(B, H, cap, D, device=DEV)
+    vc = torch.zeros(B, H, cap, D, device=DEV)
+    pos = torch.zeros(1, dtype=torch.long, device=DEV)
+    for s in range(steps):
+        qkv = torch.randn(B, 3 * E, generator=g)
+        res = torch.randn(B, N, generator=g)
+        q, k, v = qkv.view(B, 1, 3, H, D).permute(2, 0, 3, 1, 4)
+        keys, vals, pos_k = ring.complete(k, v)
+        delta = s - pos_k
+        mask = (pos_k >= 0) & (delta >= 0)
+        if context is not None:
+            mask = mask & (delta < context)
+        a = F.scaled_dot_product_attention(q, keys, vals, mask.view(1, -1)).permute(0, 2, 1, 3).reshape(B, E)
+        ref = res + a @ w.float().t()
+        out = ops.gemv_attn(qkv.to(DEV), kc, vc, pos, w.to(DEV), context=context, res=res.to(DEV))
+        pos.add_(1)
+        assert rel_err(out, ref) < 1e-4, f"step {s}"
+    assert torch.equal(kc.cpu(), ring.k) and torch.equal(vc.cpu(), ring.v)
+
+
+@pytest.mark.parametrize("B,K,N", [(1, 1024, 3072), (2, 1024, 3072), (2, 128, 384), (1, 64, 200), (2, 4096, 64)])
+def test_gemv_embed_in_proj_matches_oracle(B, K, N):
+    """First GEMV of a depth step: x = add + table[token] (id -1 -> zero row; `add` a column block of a wider buffer), RMSNorm,
+    in-projection; the launch also returns x (the layer's residual)."""
+    g = torch.Generator().manual_seed(K + N)
+    rows = 37
+    table = (0.5 * torch.randn(rows, K, generator=g)).bfloat16()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    alpha = 1 + 0.1 * torch.randn(K, generator=g)
+    wide = torch.randn(B, 3 * K, generator=g)
+    for toks in ([[5, 36, 0], [7, -1, 2]], [[0, 0, 0], [36, 1, 1]], [[3, -1, 9], [2, 2, 2]]):
+        tokens = torch.tensor(toks[:B])
+        for col in (0, 1):
+            add = wide[:, K:2 * K]
+            x_ref = add + L.scaled_embedding(table, tokens[:, col])
+            y_ref = L.rms_norm(x_ref, alpha) @ w.float().t()
+            y, x = ops.gemv_embed(wide.to(DEV)[:, K:2 * K], table.to(DEV), tokens.to(DEV), col, w.to(DEV), alpha=alpha.to(DEV), eps=1e-8)
+            assert torch.equal(x.cpu(), x_ref), (toks, col)
+            assert rel_err(y, y_ref) < 1e-5
