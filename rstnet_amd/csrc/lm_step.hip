@@ -69,6 +69,17 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_kernel(const GemvParams 
         wpre[r].zero();
         if (blockIdx.x < groups && lane * 8 < K) wpre[r].load(p.w, (long)row_of(blockIdx.x, r) * K + lane * 8);
     }
+    // the residual of the first row group is requested up front as well: loaded in the epilogue it is one more dependent
+    // memory round trip at the very end of a kernel whose whole life is a few microseconds
+    float rpre[RPW][B];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            rpre[r][b] = 0.f;
+            const int n = (blockIdx.x * GEMV_WAVES + wave) * RPW + r;
+            if (p.res && !p.gate_out && lane == 0 && n < p.N) rpre[r][b] = p.res[(long)b * p.ldy + n];
+        }
 
     // ---- prologue: stage the activation vector(s) in LDS
     if (p.prologue == 1) {           // RMSNorm: x * alpha * rsqrt(eps + mean(x^2))   (modules/transformer.py:34-46)
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_kernel(const GemvParams 
                     float sb = p.bias ? s + p.bias[n] : s;
                     if (p.act_out == 1) sb = 0.5f * sb * (1.0f + erff(sb * 0.70710678118654752440f));   // exact GELU (F.gelu)
                     if (p.scale) sb *= p.scale[n];
-                    p.y[o] = p.res ? p.res[o] + sb : sb;
+                    p.y[o] = p.res ? (grp == (int)blockIdx.x ? rpre[r][b] : p.res[o]) + sb : sb;
                 }
             }
     }

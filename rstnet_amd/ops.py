@@ -485,10 +485,17 @@ def gemv_bf16(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE
     return out
 
 
+# Measured on MI355X (tools/bench_depth.py, graph-replayed chains at the depth transformer's shape): the out-projection with the
+# attention as its prologue costs 8.8 us per launch against 4.0 us (plain out-projection) + 3.2 us (attn_small) for the two
+# launches it replaces -- the prologue's dependent chain (qkv row -> 16 K/V rows -> scores -> softmax -> LDS) is longer than a
+# kernel boundary.  The fused form stays available (and tested) but is not the default.
+FUSE_SHORT_RING_ATTENTION = False
+
+
 def gemv_attn_supported(B: int, H: int, D: int, cap: int, rope: bool, G: Optional[int] = None) -> bool:
-    """Whether ``gemv_attn`` serves this attention: batch <= 2, a ring of <= 8 slots, no rotary embedding, one kv head per query
-    head and a power-of-two head dim -- the depth transformer of both LM families."""
-    return B <= 2 and 1 <= cap <= 8 and not rope and (G is None or G == H) and 4 <= D <= 256 and D & (D - 1) == 0 and B * H * D <= 32768
+    """Whether ``gemv_attn`` serves this attention AND is wanted: batch <= 2, a ring of <= 8 slots, no rotary embedding, one kv
+    head per query head and a power-of-two head dim -- the depth transformer of both LM families."""
+    return FUSE_SHORT_RING_ATTENTION and B <= 2 and 1 <= cap <= 8 and not rope and (G is None or G == H) and 4 <= D <= 256 and D & (D - 1) == 0 and B * H * D <= 32768
 
 
 def gemv_attn(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos_dev: torch.Tensor, w: torch.Tensor, *,

@@ -166,6 +166,10 @@ LM_TINY = dict(dim=256, text_card=50, existing_text_padding_id=3, n_q=4, dep_q=2
                hidden_scale=4.125, context=10, max_period=10000.0, depformer_dim=128, depformer_dim_feedforward=528,
                depformer_num_heads=2, depformer_num_layers=2, delays=[0, 0, 1, 0, 1])
 
+# the tiny LM with Moshi's stream layout (16 audio streams of 2048 codes, 8 of them generated, the delay pattern of
+# loaders.py:97): small enough for tests, shaped so that it plugs into the real Mimi (8 codebooks x 2048) end to end
+LM_TINY_16Q = dict(LM_TINY, card=2048, n_q=16, dep_q=8, delays=[0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1])
+
 
 def _gating_hidden(dim: int, dim_feedforward: int) -> int:
     return (21 * dim) // 8 if dim_feedforward == 4 * dim else (2 * dim_feedforward) // 3
