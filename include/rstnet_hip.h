@@ -215,6 +215,32 @@ int rst_gemv_embed_bf16_f32(const float* add, const uint16_t* table, const int64
                             const uint16_t* w, const float* bias, float* y, int B, int N, int K, int ld_add, int ldy, int tok_stride,
                             int tok_col, int table_rows, float eps, rst_stream_t stream);
 
+/* rst_depth_decode_frame -- the WHOLE depth phase of a frame as ONE persistent launch, batch 1 or 2:
+ * LMGen.depformer_step (models/model.py:564-597: per codebook k forward_depformer :392-428 = depformer_in[k](h) + embedding of
+ * the previous token -> the L-layer depth transformer in streaming mode with per-step weights (modules/transformer.py:155-179,
+ * 376-423, 551-592; modules/gating.py:12-51) -> linears[k] -> sample_token (utils/sampling.py:85-105)), which the reference
+ * wraps in one CUDA graph (:486); equally the codecformer loop of models/llama_streaming.py:727-749.  Tables are HOST arrays of
+ * device pointers: in_proj[l] bf16 [dep_q * 3E][E] and out_proj[l] bf16 [dep_q * E][E] (step-major slices), norm1[l] / norm2[l]
+ * fp32 [E], gate_in[l * dep_q + k] bf16 [2 * Hd][E], gate_out[l * dep_q + k] bf16 [E][Hd], heads[k] bf16 [card][E] (+ optional
+ * head_bias[k] fp32 [card]), emb[k] bf16 [emb_rows[k]][E] = the table of step k's input token (text table for k = 0).
+ * h_all fp32 [B][ld_h]: columns [k * E, (k + 1) * E) hold depformer_in[k](transformer_out) (one up-front GEMV).  tokens int64
+ * [B][tok_stride]: column 0 is the text token (input), column k + 1 receives the token of step k.  noise fp32 [B][noise_stride]:
+ * Exp(1) draws, step k reads columns [k * top_k, (k + 1) * top_k).  v_limit_dev: optional device int [dep_q], ids >= v_limit[k]
+ * are never drawn at step k (the id blanking of sample_token_audio / _2048).  context <= 0: none (the depth transformer's).
+ * The KV ring of the depth transformer (ring_cap >= dep_q slots: dep_q for LMGen -- RingKVCache.complete's positions then hide
+ * step 0 at the last step, the `delta <= 0` slot -- or dep_q + 1 for a caller that sized its ring so) lives in the LDS of the launch; ops hand their output vectors over in `workspace` (rst_depth_frame_workspace_bytes bytes, 8-byte
+ * {epoch, value} granules, zeroed by the call itself on `stream`).  *status is OR-ed with a non-zero code if a hand-off timed
+ * out (bounded spins: the launch always terminates; the frame's tokens are then undefined).  One launch = grid of one workgroup
+ * per CU, all of which must be resident: nothing else may run on the device concurrently with it. */
+int rst_depth_frame_workspace_bytes(int B, int E, int Hd, int card);
+int rst_depth_decode_frame(const uint16_t* const* in_proj, const uint16_t* const* out_proj, const float* const* norm1,
+                           const float* const* norm2, const uint16_t* const* gate_in, const uint16_t* const* gate_out,
+                           const uint16_t* const* heads, const float* const* head_bias, const uint16_t* const* emb, const int* emb_rows,
+                           const float* h_all, int64_t* tokens, const float* noise, const int* v_limit_dev, void* workspace,
+                           uint32_t* status, int B, int E, int H, int Hd, int card, int dep_q, int L, int ld_h, int tok_stride,
+                           int noise_stride, int top_k, int use_sampling, float temp, float eps, int context, int ring_cap,
+                           rst_stream_t stream);
+
 /* The same contraction for 4 < B <= 64 on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), in three entry points.
  * Both operands are kept in the order the MFMA consumes them -- [tile of 32 rows][K/16 steps][64 lanes][8 bf16], lane =
  * 32 * ((k / 8) % 2) + row % 32 -- so that every wave-level load is one contiguous kilobyte:

@@ -227,6 +227,37 @@ int rst_gemv_embed_bf16_f32(const float* add, const uint16_t* table, const int64
     return rst_launch_gemv(p, (hipStream_t)stream);
 }
 
+int rst_depth_frame_workspace_bytes(int B, int E, int Hd, int card) {
+    return (int)(rst_depth_frame_workspace_granules(B, E, Hd, card) * 8);
+}
+
+int rst_depth_decode_frame(const uint16_t* const* in_proj, const uint16_t* const* out_proj, const float* const* norm1,
+                           const float* const* norm2, const uint16_t* const* gate_in, const uint16_t* const* gate_out,
+                           const uint16_t* const* heads, const float* const* head_bias, const uint16_t* const* emb, const int* emb_rows,
+                           const float* h_all, int64_t* tokens, const float* noise, const int* v_limit_dev, void* workspace,
+                           uint32_t* status, int B, int E, int H, int Hd, int card, int dep_q, int L, int ld_h, int tok_stride,
+                           int noise_stride, int top_k, int use_sampling, float temp, float eps, int context, int ring_cap,
+                           rst_stream_t stream) {
+    RST_REQUIRE(ring_cap >= dep_q, "depth_decode_frame: a ring of %d slots cannot hold the %d steps of a frame", ring_cap, dep_q);
+    RST_REQUIRE(in_proj && out_proj && norm1 && norm2 && gate_in && gate_out && heads && emb && emb_rows, "depth_decode_frame: null table");
+    RST_REQUIRE(L >= 1 && L <= RST_DEPTH_MAX_L && dep_q >= 1 && dep_q <= RST_DEPTH_MAX_Q, "depth_decode_frame: L=%d (<= %d), dep_q=%d (<= %d)", L,
+                RST_DEPTH_MAX_L, dep_q, RST_DEPTH_MAX_Q);
+    RST_REQUIRE(H > 0 && E % H == 0, "depth_decode_frame: %d heads do not divide E=%d", H, E);
+    DepthFrameParams p = {};
+    for (int l = 0; l < L; ++l) {
+        p.in_proj[l] = in_proj[l]; p.out_proj[l] = out_proj[l]; p.norm1[l] = norm1[l]; p.norm2[l] = norm2[l];
+        for (int k = 0; k < dep_q; ++k) { p.gate_in[l][k] = gate_in[l * dep_q + k]; p.gate_out[l][k] = gate_out[l * dep_q + k]; }
+    }
+    for (int k = 0; k < dep_q; ++k) {
+        p.heads[k] = heads[k]; p.head_bias[k] = head_bias ? head_bias[k] : nullptr; p.emb[k] = emb[k]; p.emb_rows[k] = emb_rows[k];
+    }
+    p.h_all = h_all; p.tokens = reinterpret_cast<long*>(tokens); p.noise = noise; p.v_limit = v_limit_dev;
+    p.gran = static_cast<unsigned long long*>(workspace); p.status = status;
+    p.B = B; p.E = E; p.H = H; p.D = E / H; p.Hd = Hd; p.card = card; p.dep_q = dep_q; p.L = L; p.ld_h = ld_h; p.tok_stride = tok_stride;
+    p.noise_stride = noise_stride; p.top_k = top_k; p.use_sampling = use_sampling; p.context = context; p.ring_cap = ring_cap; p.eps = eps; p.temp = temp;
+    return rst_launch_depth_frame(p, (hipStream_t)stream);
+}
+
 int rst_gemv_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* w, const float* bias,
                  const float* res, const float* scale, float* y, int B, int N, int K, int act_out, rst_stream_t stream) {
     RST_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "gemv_f32: LayerNorm needs both gamma and beta");

@@ -224,6 +224,33 @@ struct LmSampleParams {
 };
 int rst_launch_lm_sample(const LmSampleParams& p, hipStream_t stream);
 
+// ---- lm_depth.hip: the depth phase of a frame as one persistent launch
+#define RST_DEPTH_MAX_L 8
+#define RST_DEPTH_MAX_Q 8
+struct DepthFrameParams {
+    const unsigned short* in_proj[RST_DEPTH_MAX_L];     // per layer bf16 [dep_q * 3E][E] (step-major slices, multi_linear)
+    const unsigned short* out_proj[RST_DEPTH_MAX_L];    // per layer bf16 [dep_q * E][E]
+    const float* norm1[RST_DEPTH_MAX_L];                // fp32 RMSNorm gains [E]
+    const float* norm2[RST_DEPTH_MAX_L];
+    const unsigned short* gate_in[RST_DEPTH_MAX_L][RST_DEPTH_MAX_Q];    // bf16 [2 * Hd][E]  (rows u then v)
+    const unsigned short* gate_out[RST_DEPTH_MAX_L][RST_DEPTH_MAX_Q];   // bf16 [E][Hd]
+    const unsigned short* heads[RST_DEPTH_MAX_Q];       // bf16 [card][E]
+    const float* head_bias[RST_DEPTH_MAX_Q];            // optional fp32 [card]
+    const unsigned short* emb[RST_DEPTH_MAX_Q];         // embedding table of step k's input token, bf16 [emb_rows[k]][E]
+    int emb_rows[RST_DEPTH_MAX_Q];
+    const float* h_all;         // fp32 [B][ld_h]: columns [k * E, (k + 1) * E) = depformer_in[k](transformer_out)
+    long* tokens;               // int64 [B][tok_stride]: column 0 = the text token (input), column k + 1 = token sampled at step k
+    const float* noise;         // fp32 [B][noise_stride] Exp(1): step k uses columns [k * top_k, (k + 1) * top_k)   (sampling only)
+    const int* v_limit;         // optional device int [dep_q]: ids >= v_limit[k] are never drawn at step k
+    unsigned long long* gran;   // granule workspace, rst_depth_frame_workspace_granules(B, E, Hd, card) 8-byte words
+    unsigned* status;           // device word: 0 = ok, else a bit per timed-out hand-off (the frame's tokens are then undefined)
+    int B, E, H, D, Hd, card, dep_q, L, ld_h, tok_stride, noise_stride, top_k, use_sampling, context;
+    int ring_cap;               // capacity of the (virtual) KV ring: dep_q for LMGen, dep_q + 1 where the caller sized it so (no hidden slot)
+    float eps, temp;
+};
+long rst_depth_frame_workspace_granules(int B, int E, int Hd, int card);
+int rst_launch_depth_frame(const DepthFrameParams& p, hipStream_t stream);
+
 // ---- lm_ring.hip: LMGen's token ring / delay pattern
 struct LmRingParams {
     long* cache;                // [B][K][CT] int64

@@ -98,6 +98,19 @@ class GPTGen:
         prev = text_token
         k_eff = min(self.top_k, cfg.audio_card)
         h_all = ops.lm_linear(h, m.codecformer_in_all())      # codecformer_in[k](h) of all dep_q steps in one launch
+        E, H = dep.d_model, dep.num_heads
+        Hd = dep.layers[0].gating[0].linear_out.weight.shape[1]
+        if ops.depth_frame_enabled() and ops.depth_frame_supported(B, E, H, Hd, cfg.audio_card, cfg.dep_q, len(dep.layers), k_eff):
+            # batch 1 / 2: the dep_q steps with their samplers are one persistent launch (csrc/lm_depth.hip)
+            tokens = torch.empty(B, cfg.dep_q + 1, device=text_token.device, dtype=torch.long)
+            tokens[:, 0] = text_token
+            noise = None
+            if self.use_sampling:
+                noise = torch.cat([self._exp_noise("audio", g_idx, l_idx, B, k_eff) for l_idx in range(cfg.dep_q)], 1)
+            ops.depth_decode_frame(m.depth_frame_tables(), h_all, tokens, noise, use_sampling=self.use_sampling, temp=self.temp, top_k=k_eff,
+                                   eps=dep.layers[0].norm1.eps, context=dep.context, limits=self._limits,
+                                   ring_cap=dep._streaming_state.k[0].shape[2])
+            return tokens[:, 1:].contiguous()
         for l_idx in range(cfg.dep_q):
             y = m._codec_step(l_idx, prev, None, h_all)
             head = m.audio_linears[l_idx]

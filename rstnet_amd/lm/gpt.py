@@ -517,6 +517,21 @@ class GPT(StreamingModule[_GPTState]):
         ws = [m.weight for m in self.codecformer_in]
         return self._in_cat.get(tuple(ws), lambda: torch.cat([w.detach() for w in ws], 0).contiguous())
 
+    def depth_frame_tables(self):
+        """Pointer tables of the persistent depth-frame launch (``lm.depth_frame.DepthFrameTables``), rebuilt when a weight changes."""
+        from ..codec.conv import _PackedCache
+        from .depth_frame import DepthFrameTables
+        if not hasattr(self, "_depth_tables"):
+            self._depth_tables = _PackedCache()
+        dep = self.codecformer
+        params = [p for l in dep.layers for p in (l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.norm1.alpha, l.norm2.alpha)]
+        params += [g.linear_in.weight for l in dep.layers for g in l.gating] + [g.linear_out.weight for l in dep.layers for g in l.gating]
+        params += [m.weight for m in self.audio_linears] + [m.bias for m in self.audio_linears]
+        params += [self.codecformer_text_emb.weight] + [m.weight for m in self.codecformer_emb]
+        return self._depth_tables.get(tuple(params), lambda: DepthFrameTables(
+            dep, [m.weight for m in self.audio_linears], [m.bias_f32() for m in self.audio_linears],
+            [self.codecformer_text_emb.weight] + [m.weight for m in self.codecformer_emb][:self.config.dep_q - 1]))
+
     def _codec_step(self, k: int, prev: torch.Tensor, h: Optional[torch.Tensor], h_all: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One depth step: (codecformer_in[k](h) + embedding of the previous token ``prev`` int64 [N]) through the codecformer ->
         ``[N, codecformer_dim]``; the sum is formed inside the first launch of the step.  ``h_all``: ``h @ codecformer_in_all().T``."""

@@ -242,6 +242,18 @@ class LMModel(StreamingContainer):
         self.linears = nn.ModuleList([_Weight(card, depformer_dim, **fk) for _ in range(dep_q)])
         self.config = ModelConfig(model_type="lora")
         self._in_cat = _PackedCache()
+        self._depth_tables = _PackedCache()
+
+    def depth_frame_tables(self):
+        """Pointer tables of the persistent depth-frame launch (``lm.depth_frame.DepthFrameTables``), rebuilt when a weight changes."""
+        from .depth_frame import DepthFrameTables
+        dep = self.depformer
+        params = [p for l in dep.layers for p in (l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.norm1.alpha, l.norm2.alpha)]
+        params += [g.linear_in.weight for l in dep.layers for g in l.gating] + [g.linear_out.weight for l in dep.layers for g in l.gating]
+        params += [m.weight for m in self.linears] + [self.depformer_text_emb.weight] + [m.weight for m in self.depformer_emb]
+        return self._depth_tables.get(tuple(params), lambda: DepthFrameTables(
+            dep, [m.weight for m in self.linears], [None] * self.dep_q,
+            [self.depformer_text_emb.weight] + [m.weight for m in self.depformer_emb]))
 
     def depformer_in_all(self) -> torch.Tensor:
         """``[dep_q * depformer_dim, dim]``: the dep_q ``depformer_in[k]`` matrices stacked (a second copy, built once per weight
@@ -425,13 +437,21 @@ class LMGen(StreamingModule[_LMGenState]):
         dep = lm.depformer
         # the rings belong to the session (so that a frame graph captured by another live session keeps valid pointers and
         # exiting `streaming()` releases them); a bare `depformer_step` call outside any session gets throw-away rings
+        # depformer_in[k](transformer_out) for all dep_q steps at once: one 8 x larger launch instead of eight
+        h_all = ops.lm_linear(h_t, lm.depformer_in_all())
+        E, H = dep.d_model, dep.num_heads
+        Hd = dep.layers[0].gating[0].linear_out.weight.shape[1]
+        if ops.depth_frame_enabled() and h_t.is_cuda and ops.depth_frame_supported(B, E, H, Hd, lm.card, lm.dep_q, len(dep.layers), self.top_k):
+            # batch 1 / 2: the whole phase (dep_q x (L layers + head + sampler)) is ONE persistent launch whose ops hand their
+            # vectors over in-kernel; the depth KV ring lives in its LDS
+            ops.depth_decode_frame(lm.depth_frame_tables(), h_all, tokens, noise, use_sampling=self.use_sampling, temp=self.temp,
+                                   top_k=self.top_k, eps=dep.layers[0].norm1.eps, context=dep.context)
+            return
         state = self._streaming_state
         rings = state.depth if state is not None and state.depth is not None and state.depth.k[0].shape[0] == B \
             else dep._init_streaming_state(B)
         saved, dep._streaming_state = dep._streaming_state, rings
         try:
-            # depformer_in[k](transformer_out) for all dep_q steps at once: one 8 x larger launch instead of eight
-            h_all = ops.lm_linear(h_t, lm.depformer_in_all())
             for cb in range(lm.dep_q):
                 logits = lm._depformer_logits(cb, tokens, cb, None, pos=self._depth_pos[cb:cb + 1], step_index=cb, h_all=h_all)
                 ops.lm_sample(logits, use_sampling=self.use_sampling, temp=self.temp, top_k=self.top_k,
@@ -452,6 +472,8 @@ class LMGen(StreamingModule[_LMGenState]):
         assert Ki == needed, f"We expect {needed} tokens from the user stream, got {Ki}."
         out, input_ = state.graphed_frame(input_tokens.reshape(B, Ki).contiguous())
         if self.check:
+            if lm._depth_tables._val is not None:
+                lm._depth_tables._val.check()       # a timed-out hand-off of the persistent depth launch
             assert not (input_ == lm.ungenerated_token_id).any(), (state.offset, input_)
             assert (input_[:, lm.audio_offset:] <= lm.card).all(), input_
             assert (input_[:, :1] <= lm.text_card).all()

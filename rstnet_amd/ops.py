@@ -837,10 +837,72 @@ def lm_ring_commit(cache: torch.Tensor, tokens: torch.Tensor, delays: torch.Tens
     return out
 
 
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The depth phase of a frame as ONE persistent launch (rst_depth_decode_frame)
+# ----------------------------------------------------------------------------------------------------------------------
+DEPTH_FRAME_MAX_L, DEPTH_FRAME_MAX_Q = 8, 8
+_depth_ws: dict = {}
+
+
+def depth_frame_enabled() -> bool:
+    """RST_DEPTH_FRAME=0 keeps the launch-per-op depth phase (A/B measurements, or a device shared with other work: the persistent
+    launch needs every CU)."""
+    import os
+    return os.environ.get("RST_DEPTH_FRAME", "1") not in ("0", "")
+
+
+def depth_frame_supported(B: int, E: int, H: int, Hd: int, card: int, dep_q: int, L: int, top_k: int) -> bool:
+    """Shapes ``rst_depth_decode_frame`` serves (the checks of rst_launch_depth_frame, so that callers can pick the per-op path
+    instead of catching an error): batch 1 / 2, E and Hd multiples of 8, card <= 4096, at most 8 layers and 8 steps."""
+    if not (1 <= B <= 2 and E % 8 == 0 and Hd % 8 == 0 and H >= 1 and E % H == 0 and 0 < card <= 4096):
+        return False
+    if not (1 <= dep_q <= DEPTH_FRAME_MAX_Q and 1 <= L <= DEPTH_FRAME_MAX_L and H <= 64):
+        return False
+    D = E // H
+    k = top_k if 0 < top_k < card else card
+    lds = 4 * (512 + B * max(E, Hd) + B * E + B * card + B * 3 * D + L * dep_q * B * 2 * D + 1) + 8 * ((k + 7) // 8 * 8)
+    return lds <= 150 * 1024
+
+
+def depth_decode_frame(tables, h_all: torch.Tensor, tokens: torch.Tensor, noise: Optional[torch.Tensor], *, use_sampling: bool,
+                       temp: float, top_k: int, eps: float, context: Optional[int] = None, limits: Optional[torch.Tensor] = None,
+                       ring_cap: Optional[int] = None) -> None:
+    """``tables``: a ``lm.depth_frame.DepthFrameTables``; ``h_all`` fp32 ``[B, dep_q * E]``; ``tokens`` int64 ``[B, >= dep_q + 1]`` with the
+    text token in column 0 -- columns 1 .. dep_q are written; ``noise`` fp32 ``[B, >= dep_q * top_k]`` (unit column stride);
+    ``limits`` int32 ``[dep_q]`` on the device (optional id blanking per step); ``ring_cap``: capacity of the depth transformer's KV
+    ring (default dep_q, the LMGen setup; the slot -> position map of RingKVCache.complete depends on it)."""
+    _chk(h_all, "h_all")
+    _chk(limits, "limits", torch.int32)
+    if not tokens.is_cuda or tokens.dtype != torch.int64 or tokens.dim() != 2 or tokens.stride(1) != 1:
+        raise ValueError("rstnet_amd.ops: `tokens` must be an int64 CUDA/HIP matrix with unit column stride")
+    B = h_all.shape[0]
+    t = tables
+    assert h_all.shape[1] == t.dep_q * t.E and tokens.shape[0] == B and tokens.shape[1] >= t.dep_q + 1
+    sampling = bool(use_sampling and temp > 0)
+    if sampling:
+        if noise is None or not noise.is_cuda or noise.dtype != torch.float32 or noise.dim() != 2 or noise.stride(1) != 1 or \
+                noise.shape[0] != B or noise.shape[1] < t.dep_q * top_k:
+            raise ValueError("rstnet_amd.ops: `noise` must be float32 CUDA/HIP [B, >= dep_q * top_k] with unit column stride")
+    key = (h_all.device, _stream(), B, t.E, t.Hd, t.card)
+    ws = _depth_ws.get(key)
+    if ws is None:
+        nbytes = int(_lib.lib().rst_depth_frame_workspace_bytes(B, t.E, t.Hd, t.card))
+        ws = _depth_ws[key] = torch.zeros(nbytes // 8, device=h_all.device, dtype=torch.int64)
+    _lib.check(_lib.lib().rst_depth_decode_frame(
+        t.in_proj, t.out_proj, t.norm1, t.norm2, t.gate_in, t.gate_out, t.heads, t.head_bias, t.emb, t.emb_rows,
+        _ptr(h_all), _ptr(tokens), _ptr(noise) if sampling else None, _ptr(limits), _ptr(ws), _ptr(t.status),
+        B, t.E, t.H, t.Hd, t.card, t.dep_q, t.L, h_all.stride(0) if B > 1 else h_all.shape[1], tokens.stride(0) if B > 1 else tokens.shape[1],
+        noise.stride(0) if (sampling and B > 1) else (noise.shape[1] if sampling else 0), int(top_k), int(sampling), float(temp), float(eps),
+        int(context) if context else 0, int(ring_cap) if ring_cap else t.dep_q, _stream()))
+
+
 # every public entry point runs under the device guard of its first tensor argument
 for _name in ("skinny_f32_pack_weight", "gemm_win", "linear", "seanet_resblock", "layernorm", "rope_split", "attention", "rvq_pack",
               "rvq_search", "rvq_gather", "convtr_depthwise", "activation", "transpose12", "mask_tail", "hist_update", "gemv_bf16",
               "gemv_attn", "gemv_embed", "skinny_pack_weight", "skinny_pack_act", "gemm_skinny", "skinny_pack_weight_fp8", "gemm_skinny_fp8", "lm_gated_pair",
-              "lm_linear", "embed_sum", "rmsnorm", "lm_rope_append", "lm_attn_decode", "lm_sample", "lm_ring_begin", "lm_ring_commit"):
+              "lm_linear", "embed_sum", "rmsnorm", "lm_rope_append", "lm_attn_decode", "lm_sample", "lm_ring_begin", "lm_ring_commit",
+              "depth_decode_frame"):
     globals()[_name] = _on_tensor_device(globals()[_name])
 del _name

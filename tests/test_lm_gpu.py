@@ -302,10 +302,12 @@ def test_lm_state_dict_keys():
     assert set(model.state_dict().keys()) == set(sd.keys())
 
 
-@pytest.mark.parametrize("graphs", [False, True])
-def test_lmgen_greedy_matches_reference_fixture(graphs, monkeypatch):
-    """LMGen.step token streams == the imported reference's (fixture), logits == oracle; with and without HIP graphs."""
+@pytest.mark.parametrize("graphs,depth_frame", [(False, True), (True, True), (False, False), (True, False)])
+def test_lmgen_greedy_matches_reference_fixture(graphs, depth_frame, monkeypatch):
+    """LMGen.step token streams == the imported reference's (fixture); with and without HIP graphs, and with the depth phase as
+    the persistent launch (rst_depth_decode_frame, the default at batch <= 2) or as the launch-per-op chain."""
     monkeypatch.setenv("NO_CUDA_GRAPH", "0" if graphs else "1")
+    monkeypatch.setenv("RST_DEPTH_FRAME", "1" if depth_frame else "0")
     cfg, sd, model = _tiny()
     gold = torch.from_numpy(np.load(os.path.join(G, "lm_tiny.npz"))["tokens"]).long()
     user = cases.lm_user_tokens(cfg)
@@ -318,13 +320,17 @@ def test_lmgen_greedy_matches_reference_fixture(graphs, monkeypatch):
     got = torch.cat(outs, -1)
     assert (got[..., 0] == -9).all() and (got[..., 1:] != -9).all()       # None exactly for the first max_delay steps (Q14)
     assert torch.equal(got, gold)
+    if depth_frame:
+        model.depth_frame_tables().check()
 
 
-def test_lmgen_sampling_matches_reference_fixture(monkeypatch):
+@pytest.mark.parametrize("depth_frame", [True, False])
+def test_lmgen_sampling_matches_reference_fixture(depth_frame, monkeypatch):
     """LMGen.step with use_sampling=True against the token streams of the imported reference LMGen under a seeded RNG
     (tests/golden/lm_tiny_sampling.npz); the Exp(1) noise that run drew replaces the per-frame device draw (text draw, then the
     dep_q audio draws: the order of the one noise buffer of LMGen._frame).  Eager mode: a captured graph would freeze the noise."""
     monkeypatch.setenv("NO_CUDA_GRAPH", "1")
+    monkeypatch.setenv("RST_DEPTH_FRAME", "1" if depth_frame else "0")
     cfg, sd, model = _tiny()
     g = np.load(os.path.join(G, "lm_tiny_sampling.npz"))
     sp = cases.LM_SAMPLING
@@ -432,3 +438,37 @@ def test_gemv_embed_in_proj_matches_oracle(B, K, N):
             y, x = ops.gemv_embed(wide.to(DEV)[:, K:2 * K], table.to(DEV), tokens.to(DEV), col, w.to(DEV), alpha=alpha.to(DEV), eps=1e-8)
             assert torch.equal(x.cpu(), x_ref), (toks, col)
             assert rel_err(y, y_ref) < 1e-5
+
+
+# ---- the depth phase as one persistent launch (rst_depth_decode_frame, csrc/lm_depth.hip)
+
+@pytest.mark.parametrize("B,sampling", [(1, False), (1, True), (2, True), (2, False)])
+def test_depth_frame_equals_launch_per_op_path_at_the_real_shape(B, sampling, monkeypatch):
+    """Moshi-7B's depth transformer (6 x 1024, 16 heads, 8 steps, 2048-way heads; the temporal stack cut to one layer): the
+    persistent launch must give the tokens of the launch-per-op chain -- same noise, several frames, and the hand-offs must not
+    have timed out.  (The launch-per-op chain is the path the oracle / fixture tests above pin.)"""
+    cfg = dict(synth.LM_MOSHI_7B, num_layers=1)
+    model = LMModel.from_state_dict(synth.lm_state_dict(cfg, seed=4, device=DEV), cfg)
+    gen = LMGen(model, use_sampling=sampling)
+    g = torch.Generator(device=DEV).manual_seed(8)
+    for frame in range(4):
+        h_t = torch.randn(B, cfg["dim"], device=DEV, generator=g)
+        text = torch.randint(0, cfg["text_card"], (B,), device=DEV, generator=g)
+        noise = torch.empty(B, cfg["dep_q"] * gen.top_k, device=DEV).exponential_(1, generator=g) if sampling else None
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("RST_DEPTH_FRAME", mode)
+            tokens = torch.full((B, cfg["dep_q"] + 1), -7, dtype=torch.long, device=DEV)
+            tokens[:, 0] = text
+            gen._depth(tokens, h_t, noise)
+            got[mode] = tokens.cpu()
+        assert (got["1"][:, 1:] >= 0).all() and (got["1"][:, 1:] < cfg["card"]).all()
+        assert torch.equal(got["1"], got["0"]), f"frame {frame}: {got['1'].tolist()} vs {got['0'].tolist()}"
+    model.depth_frame_tables().check()
+
+
+def test_depth_frame_supported_shapes():
+    assert ops.depth_frame_supported(1, 1024, 16, 2816, 2048, 8, 6, 250) and ops.depth_frame_supported(2, 128, 2, 352, 32, 2, 2, 8)
+    assert not ops.depth_frame_supported(3, 1024, 16, 2816, 2048, 8, 6, 250)       # batch > 2: the skinny-GEMM chain
+    assert not ops.depth_frame_supported(1, 1024, 16, 2816, 2048, 9, 6, 250)       # more steps than the tables hold
+    assert not ops.depth_frame_supported(1, 1020, 15, 2816, 2048, 8, 6, 250)

@@ -47,9 +47,15 @@ def main():
     tokens = torch.zeros(B, cfg["dep_q"] + 1, dtype=torch.long, device=DEV)
     h_t = torch.randn(B, cfg["dim"], device=DEV)
     noise = None if args.greedy else torch.empty(B, cfg["dep_q"] * gen.top_k, device=DEV).exponential_(1)
-    with gen.streaming(B):
-        ms = graph_time(lambda: gen._depth(tokens, h_t, noise))
-    print(f"depth phase (8 steps x 6 layers, batch {B}, {'greedy' if args.greedy else 'sampling'}): {ms * 1e3:8.1f} us per frame", flush=True)
+    for mode, name in (("1", "ONE persistent launch (rst_depth_decode_frame)"), ("0", "launch per op")):
+        os.environ["RST_DEPTH_FRAME"] = mode
+        with gen.streaming(B):
+            ms = graph_time(lambda: gen._depth(tokens, h_t, noise))
+        print(f"depth phase (8 steps x 6 layers, batch {B}, {'greedy' if args.greedy else 'sampling'}), {name}: {ms * 1e3:8.1f} us per frame",
+              flush=True)
+    model.depth_frame_tables().check()
+    if os.environ.get("BENCH_DEPTH_CHAINS", "1") == "0":
+        return
 
     # single-op chains at the depth shapes: N launches of the same op in one graph (dependent through the stream), rotating weights
     E, Hd = 1024, 2816
