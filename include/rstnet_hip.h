@@ -45,11 +45,12 @@ const char* rst_last_error(void);
  *   epi(v) = res ? res + (scale ? scale[n] : 1) * act_out(v) : act_out(v)
  * Elements before the start of a batch item come from hist ([B][P][C]) if given, else are zero / replicated;
  * elements past the end are zero.  All three named wrappers below are thin fronts for it.
- * split_k > 1 (only for B*T_out <= 32 rows, N > 64: the per-frame streaming steps, which are weight-bandwidth bound):
- * K is split over split_k workgroups per N tile; ws [split_k][B*T_out][N] floats and counters [ceil(N/128)] uint32
- * (zeroed once by the caller, self re-arming) carry the deterministic in-launch reduction.
- * rst_gemm_win_split_plan(M, N, K) returns the recommended split_k (1 = no split). */
+ * split_k > 1 (B*T_out <= 4096 rows -- the per-frame streaming steps, whose few tiles leave the chip idle and walk K as a chain
+ * of exposed load latencies): K is split over split_k workgroups per tile; ws [split_k][B*T_out][N] floats and counters
+ * [rst_gemm_win_split_tiles(M, N)] uint32 (zeroed once by the caller, self re-arming) carry the deterministic in-launch
+ * reduction.  rst_gemm_win_split_plan(M, N, K) returns the recommended split_k (1 = no split). */
 int rst_gemm_win_split_plan(int64_t M, int N, int K);
+int rst_gemm_win_split_tiles(int64_t M, int N);
 int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const float* bias, const float* res,
                      const float* scale, float* y, int B, int T_in, int T_out, int C, int K, int N, int S, int P,
                      int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, int split_k, float* ws,
@@ -63,12 +64,16 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
  *   rst_gemm_skinny_f32: y = epi(A w^T + bias) with the epilogue of rst_gemm_win_f32 (act_out, res, scale); one workgroup per
  *     32 output columns whose 8 waves split K and meet in LDS in a fixed order (deterministic, no cross-workgroup reduction);
  *     v_mfma_f32_32x32x2_f32 with k ascending per wave.  Every Conv1d / ConvTranspose1d / Linear of a streaming step
- *     (modules/streaming.py:216-303, modules/transformer.py:395-562) is weight-bandwidth bound and goes through here. */
+ *     (modules/streaming.py:216-303, modules/transformer.py:395-562) is weight-bandwidth bound and goes through here.
+ *     split_k > 1 (rst_skinny_f32_split_plan(M, N, K); 1 = none): K is also split over split_k workgroups per column tile --
+ *     N / 32 workgroups alone stream a 6-33 MB layer at well under 1 TB/s; ws [split_k][M][N] floats and counters [ceil(N/32)]
+ *     uint32 (zeroed once by the caller, self re-arming) carry the deterministic in-launch reduction. */
 int rst_skinny_f32_pack_weight(const float* w, float* wp, int N, int K, rst_stream_t stream);
 int rst_skinny_f32_pack_win(const float* x, const float* hist, float* xp, int B, int T_in, int T_out, int C, int K, int S, int P,
                             int pad_mode, int64_t x_bstride, int act_in, rst_stream_t stream);
+int rst_skinny_f32_split_plan(int M, int N, int K);
 int rst_gemm_skinny_f32(const float* xp, const float* wp, const float* bias, const float* res, const float* scale, float* y, int M,
-                        int N, int K, int ldy, int act_out, rst_stream_t stream);
+                        int N, int K, int ldy, int act_out, int split_k, float* ws, uint32_t* counters, rst_stream_t stream);
 
 /* Causal Conv1d.  Replaces F.conv1d in RawStreamingConv1d.forward (modules/streaming.py:216-244) together with the
  * padding logic of StreamingConv1d.forward (modules/conv.py:232-254).
@@ -173,6 +178,13 @@ int rst_mask_tail_f32(float* x, const int32_t* lengths, int B, int T, int C, int
  * streaming step wants) is allowed when P_in == P_out and P_out * C <= 16384; otherwise the buffers must not overlap. */
 int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, int B, int T_in, int P_in, int P_out,
                         int C, rst_stream_t stream);
+
+/* The in-place rolls of up to 32 histories in ONE launch: entry i rolls hist[i] [B][P[i]][C[i]] over x[i] [B][T_in[i]][C[i]]
+ * (P[i] * C[i] <= 16384).  A streaming codec step ends with one of these per codec half instead of a roll launch behind every
+ * convolution (`previous` of every RawStreamingConv1d / the input history of every RawStreamingConvTranspose1d,
+ * modules/streaming.py:224-236,279-303).  x, hist, T_in, P, C are HOST arrays of length n. */
+int rst_hist_update_batch_f32(const float* const* x, float* const* hist, const int* T_in, const int* P, const int* C, int n, int B,
+                              rst_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * RQ-Transformer decode step (T = 1 per call, small batch).  bf16 weights, fp32 activations / accumulation.

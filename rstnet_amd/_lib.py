@@ -20,6 +20,7 @@ _f = C.c_float
 # name -> argtypes (all functions return int); mirrors include/rstnet_hip.h one to one
 SIGNATURES = {
     "rst_gemm_win_split_plan": [_l, _i, _i],
+    "rst_gemm_win_split_tiles": [_l, _i],
     "rst_gemm_win_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _i, _i, _i, _p, _p, _p],
     "rst_conv1d_causal_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rst_convtr1d_causal_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -36,9 +37,11 @@ SIGNATURES = {
     "rst_act_f32": [_p, _p, _l, _i, _p],
     "rst_transpose_f32": [_p, _p, _i, _i, _i, _p],
     "rst_hist_update_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "rst_hist_update_batch_f32": [C.POINTER(_p), C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, _i, _p],
     "rst_skinny_f32_pack_weight": [_p, _p, _i, _i, _p],
     "rst_skinny_f32_pack_win": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _p],
-    "rst_gemm_skinny_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "rst_skinny_f32_split_plan": [_i, _i, _i],
+    "rst_gemm_skinny_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "rst_mask_tail_f32": [_p, _p, _i, _i, _i, _i, _p],
     "rst_gemv_f32": [_p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "rst_gemv_bf16_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],

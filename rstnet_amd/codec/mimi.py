@@ -37,12 +37,20 @@ class _MimiState:
 
 
 class MimiCodec(StreamingModule[_MimiState]):
+    code_layout = "bkt"      # class default (also for subclasses with their own constructor, e.g. MimiModel)
+
     def __init__(self, sample_rate: int = 24000, n_filters: int = 64, encoder_rates: List[int] = [4, 5, 6, 8],
                  compress: int = 2, causal: bool = True, latent_dim: int = 512, codebook_size: int = 4096,
                  codebook_dim: int = 32, rvq_layers: int = 8, num_heads: int = 8, num_layers: int = 8,
                  layer_scale: float = 0.01, context: int = 250, dim_feedforward: int = 2048,
-                 semantic_feature_dim: int = 1024, target_frame_rate: float = 12.5):
+                 semantic_feature_dim: int = 1024, target_frame_rate: float = 12.5, code_layout: str = "bkt"):
         super().__init__()
+        if code_layout not in ("bkt", "btk"):
+            raise ValueError(f"code_layout must be 'bkt' or 'btk', got {code_layout!r}")
+        # "bkt": codes [B, K, F] -- the tokenizer copy (MLLM_v2/tools/tokenizer/MimiCodec/model/models/MimiCodec.py:93-110) and moshi.
+        # "btk": codes [B, F, K] -- the AudioCodec twin (AudioCodec/MimiCodec/models/MimiCodec.py:94-111 over
+        #        quantization/vq_dc.py:148-162, whose third-party ResidualVQ concatenates the per-level indices on the LAST axis).
+        self.code_layout = code_layout
         self.sample_rate = sample_rate
         seanet_kwargs = dict(channels=1, dimension=latent_dim, causal=causal, n_filters=n_filters, n_residual_layers=1,
                              activation="ELU", compress=compress, dilation_base=2, disable_norm_outer_blocks=0, kernel_size=7,
@@ -87,6 +95,12 @@ class MimiCodec(StreamingModule[_MimiState]):
         if lengths is not None:
             assert not self.is_streaming, "ragged batches are an offline (non-streaming) facility"
             lengths = torch.as_tensor(lengths, dtype=torch.int32, device=x.device).contiguous()
+        if self.is_streaming:
+            # a frame step: the history rolls of all convolutions run as one launch at the end of the step
+            with ops.hist_batch():
+                z = self.encoder.forward_nlc(x, lengths)
+                z = self.encoder_transformer.forward_nlc(z)[0]
+                return self.downsample.forward_nlc(z)
         z = self.encoder.forward_nlc(x, lengths)
         z = self.encoder_transformer.forward_nlc(z)[0]
         if lengths is not None:
@@ -98,6 +112,10 @@ class MimiCodec(StreamingModule[_MimiState]):
     def encode(self, audio_data: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``[B, 1, T]`` fp32 -> ``[B, K, ceil(T / 1920)]`` int64 (streaming: floor, remainder kept in the conv states).
         ``lengths``: see ``encode_latent`` (frames past ``ceil(lengths[b] / 1920)`` of entry b are meaningless)."""
+        codes = self._encode_bkt(audio_data, lengths)
+        return codes.transpose(1, 2).contiguous() if self.code_layout == "btk" else codes
+
+    def _encode_bkt(self, audio_data: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
         state = self._streaming_state
         if lengths is not None:
             return self.quantizer.encode_nlc(self.encode_latent(audio_data, lengths))
@@ -111,7 +129,9 @@ class MimiCodec(StreamingModule[_MimiState]):
 
     @torch.no_grad()
     def decode(self, codes: torch.Tensor) -> torch.Tensor:
-        """``[B, K, F]`` int64 -> ``[B, 1, F * 1920]`` fp32 (not trimmed, as in the reference)."""
+        """``[B, K, F]`` int64 (``[B, F, K]`` with ``code_layout="btk"``) -> ``[B, 1, F * 1920]`` fp32 (not trimmed, as in the reference)."""
+        if self.code_layout == "btk":
+            codes = codes.transpose(1, 2)
         state = self._streaming_state
         if state is None or not codes.is_cuda:
             return self._decode(codes)
@@ -122,6 +142,12 @@ class MimiCodec(StreamingModule[_MimiState]):
 
     def _decode(self, codes: torch.Tensor) -> torch.Tensor:
         z = self.quantizer.decode_nlc(codes.contiguous())
+        if self.is_streaming:
+            with ops.hist_batch():       # see encode_latent
+                z = self.upsample.forward_nlc(z)
+                z = self.decoder_transformer.forward_nlc(z)[0]
+                y = self.decoder.forward_nlc(z)
+            return y.view(y.shape[0], 1, y.shape[1])
         z = self.upsample.forward_nlc(z)
         z = self.decoder_transformer.forward_nlc(z)[0]
         y = self.decoder.forward_nlc(z)
@@ -147,7 +173,7 @@ class MimiCodec(StreamingModule[_MimiState]):
         kw = dict(n_filters=n_filters, encoder_rates=list(reversed(rates)), latent_dim=sd["downsample.conv.conv.conv.weight"].shape[0],
                   codebook_size=emb.shape[0], codebook_dim=emb.shape[1], rvq_layers=1 + rest, num_layers=n_layers,
                   dim_feedforward=sd["encoder_transformer.transformer.layers.0.linear1.weight"].shape[0])
-        kw.update(overrides)
+        kw.update(overrides)      # e.g. code_layout="btk" for the AudioCodec twin
         model = cls(**kw)
         missing, unexpected = model.load_state_dict(sd, strict=False)
         missing = [k for k in missing if not k.startswith("semantic_mapping_layer")]

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .conv import StreamingConv1d, StreamingConvTranspose1d, _to_ncl, _to_nlc
+from .conv import StreamingConv1d, StreamingConvTranspose1d, _keep_address, _to_ncl, _to_nlc
 from .streaming import StreamingAdd, StreamingContainer
 
 
@@ -161,12 +161,50 @@ class SEANetResnetBlock(StreamingContainer):
         return ops.seanet_resblock(x, c1.packed_weight(), c1.bias, c2.packed_weight(), c2.bias, Kw=c1.kernel_size[0],
                                    pre=pre_w, post=post_w, elu_out=elu_out)
 
+    def _can_fuse_streaming(self) -> bool:
+        """Streaming form of ``can_fuse`` (no neighbouring convolution folded in): the fused kernel takes the k-tap convolution's
+        input history ``[B, k - 1, C]`` directly."""
+        convs = [m for m in self.block if isinstance(m, StreamingConv1d)]
+        if not self.is_streaming or not isinstance(self.shortcut, nn.Identity) or len(convs) != 2:
+            return False
+        c1, c2 = convs
+        for c in (c1, c2):
+            raw = c.conv.conv
+            if not (c.causal and c.pad_mode == "constant" and raw.stride[0] == 1 and raw.dilation[0] == 1 and raw.bias is not None
+                    and c.is_streaming and raw.is_streaming):
+                return False
+        C, H, Kw = c2.conv.conv.out_channels, c1.conv.conv.out_channels, c1.conv.conv.kernel_size[0]
+        if c2.conv.conv.kernel_size[0] != 1 or c1.conv.conv.in_channels != C or c2.conv.conv.in_channels != H or Kw < 2:
+            return False
+        return c1.conv.conv.weight.dtype == torch.float32 and ops.resblock_supported(C, H, Kw)
+
+    def _fused_streaming(self, x: torch.Tensor, elu_out: bool) -> torch.Tensor:
+        """One launch per block and frame: the first convolution's history (its last ``k - 1`` input steps, zeros before the first
+        chunk: modules/conv.py:249-253, streaming.py:224-236) goes straight into the kernel and is rolled afterwards."""
+        c1, c2 = [m for m in self.block if isinstance(m, StreamingConv1d)]
+        raw1, raw2 = c1.conv.conv, c2.conv.conv
+        st, rs = c1._streaming_state, raw1._streaming_state
+        B, T, C = x.shape
+        Kw = raw1.kernel_size[0]
+        if st.padding_to_add > 0 and T > 0:
+            rs.previous = x.new_zeros(B, st.padding_to_add, C)
+            st.padding_to_add = 0
+        hist = rs.previous
+        assert hist is not None and hist.shape[1] == Kw - 1, "fused streaming residual block: unexpected history length"
+        y = ops.seanet_resblock(x, raw1.packed_weight(), raw1.bias, raw2.packed_weight(), raw2.bias, Kw=Kw, hist=hist, elu_out=elu_out)
+        rs.previous = _keep_address(hist, ops.hist_update(x, hist, Kw - 1))
+        if c2._streaming_state is not None:
+            c2._streaming_state.padding_to_add = 0
+        return y
+
     def forward_nlc(self, x: torch.Tensor, pre: Optional[StreamingConv1d] = None,
                     post: Optional[StreamingConv1d] = None, elu_out: bool = False) -> torch.Tensor:
         """``elu_out``: return ELU(block(x)) (the caller's next layer is ``ELU -> conv``)."""
         if self.can_fuse(pre, post):
             return self._fused(x, pre, post, elu_out)
         assert pre is None and post is None
+        if x.shape[1] > 0 and self._can_fuse_streaming():
+            return self._fused_streaming(x, elu_out)
         u = x if isinstance(self.shortcut, nn.Identity) else self.shortcut.forward_nlc(x)
         convs = [m for m in self.block if isinstance(m, StreamingConv1d)]
         h = x

@@ -45,6 +45,7 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
 }
 
 int rst_gemm_win_split_plan(int64_t M, int N, int K) { return rst_gemm_split_plan_impl((long)M, N, K); }
+int rst_gemm_win_split_tiles(int64_t M, int N) { return rst_gemm_split_tiles_impl((long)M, N); }
 
 int rst_conv1d_causal_f32(const float* x, const float* hist, const float* w_packed, const float* bias,
                           const float* res, float* y, int B, int T_in, int T_out, int Cin, int Cout, int Kw_eff,
@@ -169,12 +170,23 @@ int rst_skinny_f32_pack_win(const float* x, const float* hist, float* xp, int B,
     return rst_launch_skinny_f32_pack_win(p, (hipStream_t)stream);
 }
 
+int rst_skinny_f32_split_plan(int M, int N, int K) { return rst_skinny_f32_split_plan_impl(M, N, K); }
+
 int rst_gemm_skinny_f32(const float* xp, const float* wp, const float* bias, const float* res, const float* scale, float* y, int M,
-                        int N, int K, int ldy, int act_out, rst_stream_t stream) {
+                        int N, int K, int ldy, int act_out, int split_k, float* ws, uint32_t* counters, rst_stream_t stream) {
     SkinnyF32Params p;
     p.xp = xp; p.wp = wp; p.bias = bias; p.res = res; p.scale = scale; p.y = y; p.M = M; p.N = N; p.Kp = (K + 7) / 8 * 8; p.ldy = ldy;
-    p.act_out = act_out;
+    p.act_out = act_out; p.split_k = split_k; p.ws = ws; p.counters = counters;
     return rst_launch_gemm_skinny_f32(p, (hipStream_t)stream);
+}
+
+int rst_hist_update_batch_f32(const float* const* x, float* const* hist, const int* T_in, const int* P, const int* C, int n, int B,
+                              rst_stream_t stream) {
+    RST_REQUIRE(n >= 0 && n <= RST_HIST_BATCH_MAX && (n == 0 || (x && hist && T_in && P && C)), "hist_update_batch: bad table (n=%d)", n);
+    HistBatchParams p = {};
+    for (int i = 0; i < n; ++i) { p.x[i] = x[i]; p.hist[i] = hist[i]; p.T_in[i] = T_in[i]; p.P[i] = P[i]; p.C[i] = C[i]; }
+    p.n = n; p.B = B;
+    return rst_launch_hist_update_batch(p, (hipStream_t)stream);
 }
 
 int rst_mask_tail_f32(float* x, const int32_t* lengths, int B, int T, int C, int mode, rst_stream_t stream) {

@@ -352,13 +352,29 @@ int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
 
 }  // namespace
 
+// Tile shape the launcher picks for (M, N): 0 = 128 x 128, 1 = 32 x 128, 2 = 128 x 64, 3 = 256 x 32.
+// Medium M (one 80 ms frame of a single stream at the 24 kHz .. 1.2 kHz layers: 96 .. 1920 rows) takes the 32-row tiles for wide
+// outputs: four times the workgroups of the 128-row tile, and with split-K enough of them to hide each other's load latency.
+static int gw_tile_cfg(long M, int N) {
+    if (N > 64) return M > 4096 ? 0 : 1;
+    if (N > 32) return 2;
+    return 3;
+}
+static void gw_tile_dims(int cfg, int& BM, int& BN) {
+    BM = cfg == 0 ? 128 : cfg == 1 ? 32 : cfg == 2 ? 128 : 256;
+    BN = cfg == 0 ? 128 : cfg == 1 ? 128 : cfg == 2 ? 64 : 32;
+}
+
 int rst_gemm_split_plan_impl(long M, int N, int K) {
-    // few-row calls (streaming steps) are weight-bandwidth bound: spread K over enough workgroups to fill the chip
-    if (M > 32 || N <= 64) return 1;
-    const int tiles = (N + 127) / 128;
+    // Few- and medium-row calls (the streaming steps) leave most of the chip idle and walk K as a chain of exposed load latencies
+    // (one k-tile per memory round trip): spread K over workgroups until ~256 of them run, keeping >= 2 k-tiles per split.
+    if (M <= 0 || M > 4096 || (M <= 32 && N <= 64)) return 1;
+    int BM, BN;
+    gw_tile_dims(gw_tile_cfg(M, N), BM, BN);
+    const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int nk = (K + BK - 1) / BK;
     int s = 1;
-    while (tiles * s < 256 && nk / (2 * s) >= 2 && s < 64) s *= 2;
+    while (tiles * s * 2 <= 256 && nk / (2 * s) >= 2 && s < 64) s *= 2;
     return s;
 }
 
@@ -374,16 +390,25 @@ int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
                      ((uintptr_t)p.x % 16 == 0) && ((uintptr_t)p.w % 16 == 0) &&
                      (!p.hist || (uintptr_t)p.hist % 16 == 0);
     const long M = (long)p.B * p.T_out;
-    RST_REQUIRE(p.split_k <= 1 || (p.ws && p.counters && M <= 32 && p.N > 64), "gemm_win: split-K needs M <= 32, N > 64 and the scratch buffers");
-    if (p.N > 64 && M > 64) {                                                // 128 x 128
-        // >= 3 tiles per CU: k-chunks of 16 (40 KB of LDS, accumulators in VGPRs) put three workgroups on a CU instead of two
-        const long tiles = ((M + 127) / 128) * ((p.N + 127) / 128);
-        // RST_GEMM_KB32 (any value) forces the 32-wide chunks: the calibration knob of the PMC traffic numbers
-        static const bool kb32_only = getenv("RST_GEMM_KB32") != nullptr;
-        if (tiles >= 768 && !kb32_only) return launch_cfg<2, 2, 2, 2, 16>(p, vec, stream);
-        return launch_cfg<2, 2, 2, 2>(p, vec, stream);
+    RST_REQUIRE(p.split_k <= 1 || (p.ws && p.counters && M <= 4096), "gemm_win: split-K needs M <= 4096 and the scratch buffers");
+    switch (gw_tile_cfg(M, p.N)) {
+        case 0: {                                                            // 128 x 128
+            // >= 3 tiles per CU: k-chunks of 16 (40 KB of LDS, accumulators in VGPRs) put three workgroups on a CU instead of two
+            const long tiles = ((M + 127) / 128) * ((p.N + 127) / 128);
+            // RST_GEMM_KB32 (any value) forces the 32-wide chunks: the calibration knob of the PMC traffic numbers
+            static const bool kb32_only = getenv("RST_GEMM_KB32") != nullptr;
+            if (tiles >= 768 && !kb32_only) return launch_cfg<2, 2, 2, 2, 16>(p, vec, stream);
+            return launch_cfg<2, 2, 2, 2>(p, vec, stream);
+        }
+        case 1: return launch_cfg<1, 1, 1, 4>(p, vec, stream);               // 32 x 128 (few / medium rows: streaming steps)
+        case 2: return launch_cfg<1, 2, 4, 1>(p, vec, stream);               // 128 x 64
+        default: return launch_cfg<2, 1, 4, 1>(p, vec, stream);              // 256 x 32
     }
-    if (p.N > 64) return launch_cfg<1, 1, 1, 4>(p, vec, stream);             // 32 x 128 (few rows: streaming steps)
-    if (p.N > 32) return launch_cfg<1, 2, 4, 1>(p, vec, stream);             // 128 x 64
-    return launch_cfg<2, 1, 4, 1>(p, vec, stream);                           // 256 x 32
+}
+
+// scratch sizes of a split launch: counters (one per tile of the shape the launcher picks)
+int rst_gemm_split_tiles_impl(long M, int N) {
+    int BM, BN;
+    gw_tile_dims(gw_tile_cfg(M, N), BM, BN);
+    return (int)(((M + BM - 1) / BM) * ((N + BN - 1) / BN));
 }

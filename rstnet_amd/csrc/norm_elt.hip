@@ -143,6 +143,34 @@ __global__ __launch_bounds__(1024) void hist_update_inplace_kernel(const float* 
     }
 }
 
+// The in-place roll of up to RST_HIST_BATCH_MAX histories in ONE launch (blockIdx.y = entry): a streaming codec step rolls the
+// input history of every convolution; as separate launches those are ~20 dependent 4-5 us kernels per frame.
+__global__ __launch_bounds__(1024) void hist_update_batch_kernel(const HistBatchParams p) {
+    const int en = blockIdx.y;
+    const float* __restrict__ x = p.x[en];
+    float* h = p.hist[en];
+    const int T_in = p.T_in[en], P = p.P[en], C = p.C[en];
+    const long b = blockIdx.x;
+    const int E = P * C;
+    float v[HIST_INPLACE_MAX];
+#pragma unroll
+    for (int j = 0; j < HIST_INPLACE_MAX; ++j) {
+        const int e = threadIdx.x + j * 1024;
+        v[j] = 0.f;
+        if (e < E) {
+            const int c = e % C, pr = e / C;
+            const int src = pr + T_in - P;
+            v[j] = src >= 0 ? x[(b * T_in + src) * C + c] : h[(b * P + (P + src)) * C + c];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < HIST_INPLACE_MAX; ++j) {
+        const int e = threadIdx.x + j * 1024;
+        if (e < E) h[b * (long)E + e] = v[j];
+    }
+}
+
 // Rows t >= len[b] of x [B][T][C] become zero (mode 0) or a copy of row len[b] - 1 (mode 1).
 __global__ __launch_bounds__(256) void mask_tail_kernel(float* __restrict__ x, const int* __restrict__ len, int B, int T, int C, int mode) {
     const long total = (long)B * T * (C / 4);
@@ -217,6 +245,16 @@ int rst_launch_hist_update(const float* x, const float* hist_in, float* hist_out
     hipLaunchKernelGGL(hist_update_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, hist_in, hist_out, B, T_in, P_in,
                        P_out, C);
     return rst_check_launch("hist_update");
+}
+
+int rst_launch_hist_update_batch(const HistBatchParams& p, hipStream_t stream) {
+    RST_REQUIRE(p.n >= 0 && p.n <= RST_HIST_BATCH_MAX && p.B >= 0, "hist_update_batch: %d entries (max %d)", p.n, RST_HIST_BATCH_MAX);
+    if (p.n == 0 || p.B == 0) return RST_OK;
+    for (int i = 0; i < p.n; ++i)
+        RST_REQUIRE(p.x[i] && p.hist[i] && p.T_in[i] >= 0 && p.P[i] > 0 && p.C[i] > 0 && (long)p.P[i] * p.C[i] <= 1024L * HIST_INPLACE_MAX,
+                    "hist_update_batch: entry %d (T_in=%d P=%d C=%d; P * C <= %d)", i, p.T_in[i], p.P[i], p.C[i], 1024 * HIST_INPLACE_MAX);
+    hipLaunchKernelGGL(hist_update_batch_kernel, dim3(p.B, p.n), dim3(1024), 0, stream, p);
+    return rst_check_launch("hist_update_batch");
 }
 
 int rst_launch_mask_tail(float* x, const int* lengths, int B, int T, int C, int mode, hipStream_t stream) {

@@ -21,12 +21,13 @@ struct GemmWinParams {
     int ldy;             // floats between consecutive output rows (>= N)
     int act_in;          // 0: none, 1: ELU applied to A on load
     int act_out;         // 0: none, 1: exact GELU (before the residual), 2: ELU (applied last, after the residual)
-    int split_k;         // > 1: K split over gridDim.y workgroups (M <= 32 only), partials in ws, counters per N tile
+    int split_k;         // > 1: K split over gridDim.y workgroups (M <= 4096), partials in ws, one counter per tile
     float* ws;           // [split_k][M][N]
-    unsigned* counters;  // [ceil(N/128)], zero before the first launch (self re-arming)
+    unsigned* counters;  // [rst_gemm_split_tiles_impl(M, N)], zero before the first launch (self re-arming)
 };
 int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream);
 int rst_gemm_split_plan_impl(long M, int N, int K);
+int rst_gemm_split_tiles_impl(long M, int N);
 
 // ---- skinny_f32.hip: few-row (M <= 128) fp32 GEMM of the codec streaming steps ---------------------------------------
 struct SkinnyF32PackParams {      // the A operand of GemmWinParams, gathered + packed
@@ -44,7 +45,11 @@ struct SkinnyF32Params {
     const float* scale;           // [N] or nullptr
     float* y;                     // [M][ldy]
     int M, N, Kp, ldy, act_out;   // act_out as GemmWinParams
+    int split_k;                  // > 1: K split over gridDim.y workgroups (rst_skinny_f32_split_plan_impl), partials in ws
+    float* ws;                    // [split_k][M][N]
+    unsigned* counters;           // [ceil(N/32)], zero before the first launch (self re-arming)
 };
+int rst_skinny_f32_split_plan_impl(int M, int N, int K);
 int rst_launch_skinny_f32_pack_weight(const float* w, float* wp, int N, int K, hipStream_t stream);
 int rst_launch_skinny_f32_pack_win(const SkinnyF32PackParams& p, hipStream_t stream);
 int rst_launch_gemm_skinny_f32(const SkinnyF32Params& p, hipStream_t stream);
@@ -78,6 +83,15 @@ int rst_launch_convtr_depthwise(const float* x, const float* hist, const float* 
 // hist_out [P_out rows] = last P_out rows of concat(hist_in [P_in rows], x [T_in rows]); no aliasing
 int rst_launch_hist_update(const float* x, const float* hist_in, float* hist_out, int B, int T_in, int P_in, int P_out,
                            int C, hipStream_t stream);
+
+#define RST_HIST_BATCH_MAX 32
+struct HistBatchParams {          // in-place rolls: hist[i] [B][P][C] <- last P rows of concat(hist[i], x[i] [B][T_in][C])
+    const float* x[RST_HIST_BATCH_MAX];
+    float* hist[RST_HIST_BATCH_MAX];
+    int T_in[RST_HIST_BATCH_MAX], P[RST_HIST_BATCH_MAX], C[RST_HIST_BATCH_MAX];
+    int n, B;
+};
+int rst_launch_hist_update_batch(const HistBatchParams& p, hipStream_t stream);
 
 int rst_launch_act(const float* x, float* y, long n, int act, hipStream_t stream);  // 1: ELU, 2: GELU
 int rst_launch_mask_tail(float* x, const int* lengths, int B, int T, int C, int mode, hipStream_t stream);

@@ -151,16 +151,23 @@ __global__ __launch_bounds__(256) void rvq_level_kernel(const RvqSearchParams p,
     // winners of ALL previous levels are fetched first (one barrier), then every element gathers its `step` codeword entries
     // with independent loads and subtracts them in order -- one memory round trip instead of one per level.
     constexpr int MAX_PREV = 16;
-    for (int idx = tid; idx < step * FR; idx += 256) {
-        const int sidx = idx / FR, f = idx - sidx * FR;
+    // only the frames that exist are derived (one or two per stream and step in streaming use); the other rows of the MFMA
+    // operand are zeros
+    const int frv = min(FR, p.M - m0);
+    for (int idx = tid; idx < step * frv; idx += 256) {
+        const int sidx = idx / frv, f = idx - sidx * frv;
         const int lv = p.group_begin[g] + sidx;
-        prev[idx] = (m0 + f < p.M) ? (int)(keys[(long)lv * p.M + m0 + f] & 0xffffffffu) : 0;
+        prev[sidx * FR + f] = (int)(keys[(long)lv * p.M + m0 + f] & 0xffffffffu);
+    }
+    for (int idx = tid + frv * D; idx < FR * D; idx += 256) {
+        const int f = idx / D, k = idx - f * D;
+        r_pk[f * LD + pk_off(k)] = 0.f;
     }
     __syncthreads();
-    for (int idx = tid; idx < FR * D; idx += 256) {
+    for (int idx = tid; idx < frv * D; idx += 256) {
         const int f = idx / D, k = idx - f * D;
         const int m = m0 + f;
-        float r = m < p.M ? p.x[(long)m * p.ldx + g * D + k] : 0.f;
+        float r = p.x[(long)m * p.ldx + g * D + k];
         float e[MAX_PREV];
 #pragma unroll
         for (int sidx = 0; sidx < MAX_PREV; ++sidx)
@@ -179,9 +186,9 @@ __global__ __launch_bounds__(256) void rvq_level_kernel(const RvqSearchParams p,
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const float* ap = packed + (long)(c0 + j) * 8 + h * 4;
     const float* rrow = r_pk + j * LD + h * 4;
-    // codebook operands: 8 loads in flight per lane (the plain loop waited out one memory latency per 16 bytes); the MFMA
+    // codebook operands: 16 loads in flight per lane (the plain loop waited out one memory latency per 16 bytes); the MFMA
     // chain still consumes k in ascending order, so the scores stay bit-identical to the fused kernel / rvq_ref.c
-    constexpr int UN = 8;
+    constexpr int UN = 16;
     for (int kq0 = 0; kq0 < D / 8; kq0 += UN) {
         f32x4 a[UN];
 #pragma unroll

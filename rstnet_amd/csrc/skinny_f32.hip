@@ -79,15 +79,23 @@ __global__ __launch_bounds__(256) void f32_pack_win_kernel(const SkinnyF32PackPa
 
 constexpr int SF_WAVES = 8;
 
+// gridDim.y > 1: K is also split across workgroups (blockIdx.y owns a contiguous range of the 8-k chunks) -- a layer of 6-33 MB
+// behind N / 32 = 16 or 32 workgroups streams at well under 1 TB/s (measured 62 us for the 33 MB 512 -> 1024 k16 convolution);
+// the partial tiles go to `ws` with write-through stores, one arrival counter per column tile, and the LAST workgroup to arrive
+// sums them in split order (deterministic) and runs the epilogue (the protocol of gemm_win's split-K: cdna_hip_programming.md G16).
 template <int NB, int CT>
 __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const SkinnyF32Params p) {
     __shared__ float red[SF_WAVES][NB * 32][33];
+    __shared__ int sm_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = (p.N + 31) / 32;
     const int tile0 = blockIdx.x * CT;
     const int chunks = p.Kp / 8;
-    const int per = (chunks + SF_WAVES - 1) / SF_WAVES;
-    const int s0 = wave * per, s1 = min(chunks, s0 + per);
+    const int nsplit = gridDim.y;
+    const int per_split = (chunks + nsplit - 1) / nsplit;
+    const int c_lo = blockIdx.y * per_split, c_hi = min(chunks, c_lo + per_split);
+    const int per = (max(c_hi - c_lo, 0) + SF_WAVES - 1) / SF_WAVES;
+    const int s0 = c_lo + wave * per, s1 = min(c_hi, s0 + per);
     const float* xq = p.xp + (long)lane * 4;
     const float* wt[CT];
 #pragma unroll
@@ -126,6 +134,14 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
     // activations are the MFMA "A" side: acc[t][c][e] = C[m = 32 t + row(e, lane)][n = 32 (tile0 + c) + (lane & 31)]
     const int i = lane & 31;
     const int M = p.M;
+    auto epilogue = [&](float v, int m, int n) {
+        if (p.bias) v += p.bias[n];
+        if (p.act_out == 1) v = rst_gelu(v);
+        const long o = (long)m * p.ldy + n;
+        if (p.res) v = p.res[o] + (p.scale ? p.scale[n] : 1.0f) * v;
+        if (p.act_out == 2) v = rst_elu(v);
+        p.y[o] = v;
+    };
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         if (c) __syncthreads();
@@ -142,12 +158,32 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < SF_WAVES; ++w) v += red[w][m][nl];
-                if (p.bias) v += p.bias[n];
-                if (p.act_out == 1) v = rst_gelu(v);
-                const long o = (long)m * p.ldy + n;
-                if (p.res) v = p.res[o] + (p.scale ? p.scale[n] : 1.0f) * v;
-                if (p.act_out == 2) v = rst_elu(v);
-                p.y[o] = v;
+                if (nsplit == 1) epilogue(v, m, n);
+                else __hip_atomic_store(p.ws + ((long)blockIdx.y * M + m) * p.N + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (nsplit == 1) return;
+    // every storing wave drains its write-through stores, ONE lane bumps the tile's counter; the last arriver combines
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(p.counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sm_last = prev == (unsigned)nsplit - 1;
+        if (sm_last) __hip_atomic_store(p.counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!sm_last) return;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int n0 = (tile0 + c) * 32;
+        for (int idx = tid; idx < NB * 32 * 32; idx += 64 * SF_WAVES) {
+            const int m = idx >> 5, n = n0 + (idx & 31);
+            if (m < M && n < p.N) {
+                float v = 0.f;
+                for (int ks = 0; ks < nsplit; ++ks)
+                    v += __hip_atomic_load(p.ws + ((long)ks * M + m) * p.N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                epilogue(v, m, n);
             }
         }
     }
@@ -179,19 +215,31 @@ int rst_launch_skinny_f32_pack_win(const SkinnyF32PackParams& p, hipStream_t str
     return rst_check_launch("skinny_f32_pack_win");
 }
 
+int rst_skinny_f32_split_plan_impl(int M, int N, int K) {
+    // few workgroups (N / 32 column tiles) against MBs of weights: split K until ~128-256 workgroups run, >= 2 chunks per wave
+    if (M < 1 || M > 128) return 1;
+    const int tiles = (N + 31) / 32, chunks = (K + 7) / 8;
+    if (tiles >= 512) return 1;
+    int s = 1;
+    while (tiles * s * 2 <= 256 && chunks / (2 * s * SF_WAVES) >= 2 && s < 32) s *= 2;
+    return s;
+}
+
 int rst_launch_gemm_skinny_f32(const SkinnyF32Params& p, hipStream_t stream) {
     RST_REQUIRE(p.xp && p.wp && p.y && p.M >= 1 && p.M <= 128 && p.N > 0 && p.Kp > 0 && p.Kp % 8 == 0 && p.act_out >= 0 && p.act_out <= 2,
                 "gemm_skinny_f32: bad arguments (1 <= M <= 128, Kp %% 8 == 0; M=%d Kp=%d)", p.M, p.Kp);
     const int tiles = (p.N + 31) / 32;
+    const int split = p.split_k > 1 ? p.split_k : 1;
+    RST_REQUIRE(split == 1 || (p.ws && p.counters && tiles < 512), "gemm_skinny_f32: split-K needs the scratch buffers (and < 512 column tiles)");
     const dim3 block(64 * SF_WAVES);
     const int nb = (p.M + 31) / 32;
     if (nb == 1) {
         if (tiles >= 512) hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 2>), dim3((tiles + 1) / 2), block, 0, stream, p);
-        else hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 1>), dim3(tiles), block, 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 1>), dim3(tiles, split), block, 0, stream, p);
     } else if (nb == 2) {
-        hipLaunchKernelGGL((gemm_skinny_f32_kernel<2, 1>), dim3(tiles), block, 0, stream, p);
+        hipLaunchKernelGGL((gemm_skinny_f32_kernel<2, 1>), dim3(tiles, split), block, 0, stream, p);
     } else {
-        hipLaunchKernelGGL((gemm_skinny_f32_kernel<4, 1>), dim3(tiles), block, 0, stream, p);
+        hipLaunchKernelGGL((gemm_skinny_f32_kernel<4, 1>), dim3(tiles, split), block, 0, stream, p);
     }
     return rst_check_launch("gemm_skinny_f32");
 }

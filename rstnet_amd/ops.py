@@ -104,9 +104,9 @@ _gemm_scratch: dict = {}
 
 
 def _gemm_split_scratch(device, M: int, N: int, K: int):
-    """Split-K plan + scratch of the few-row (streaming step) GEMMs, cached per (stream, shape); launches on one stream are
-    ordered and the counters re-arm themselves, so layers of equal shape share the buffers."""
-    if M > 32 or M == 0:
+    """Split-K plan + scratch of the few- / medium-row (streaming step) GEMMs, cached per (stream, shape); launches on one stream
+    are ordered and the counters re-arm themselves, so layers of equal shape share the buffers."""
+    if M > 4096 or M == 0:
         return 1, None, None
     key = (device, _stream(), M, N, K)
     sc = _gemm_scratch.get(key)
@@ -114,7 +114,7 @@ def _gemm_split_scratch(device, M: int, N: int, K: int):
         sk = int(_lib.lib().rst_gemm_win_split_plan(M, N, K))
         if sk > 1:
             sc = (sk, torch.empty(sk, M, N, device=device, dtype=torch.float32),
-                  torch.zeros((N + 127) // 128, device=device, dtype=torch.int32))
+                  torch.zeros(int(_lib.lib().rst_gemm_win_split_tiles(M, N)), device=device, dtype=torch.int32))
         else:
             sc = (1, None, None)
         _gemm_scratch[key] = sc
@@ -144,8 +144,14 @@ def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, 
     xp = torch.empty(32 if M <= 32 else (64 if M <= 64 else 128), wp.shape[1], device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().rst_skinny_f32_pack_win(_ptr(x), _ptr(hist), _ptr(xp), B, T_in, T_out, C_, K, S, P, pad_mode, T_in * C_, act_in,
                                                  _stream()))
+    key = (x.device, _stream(), "skinny", M, N, K)
+    sc = _gemm_scratch.get(key)
+    if sc is None:
+        sk = int(_lib.lib().rst_skinny_f32_split_plan(M, N, K))
+        sc = _gemm_scratch[key] = (sk, torch.empty(sk, M, N, device=x.device, dtype=torch.float32),
+                                   torch.zeros((N + 31) // 32, device=x.device, dtype=torch.int32)) if sk > 1 else (1, None, None)
     _lib.check(_lib.lib().rst_gemm_skinny_f32(_ptr(xp), _ptr(wp), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, N, K, N, act_out,
-                                             _stream()))
+                                             sc[0], _ptr(sc[1]), _ptr(sc[2]), _stream()))
 
 
 def _few_rows(M: int, N: int, K: int) -> bool:
@@ -435,6 +441,40 @@ def mask_tail(x: torch.Tensor, lengths: torch.Tensor, replicate: bool = False) -
     return x
 
 
+_hist_pending: Optional[list] = None      # deferred in-place rolls of the enclosing `hist_batch()` block
+HIST_BATCH_MAX = 32
+
+
+class hist_batch:
+    """``with ops.hist_batch():`` -- the steady-state (in-place) history rolls requested inside the block are deferred and run as
+    ONE launch at its end (rst_hist_update_batch_f32).  Valid because a layer's history is read only by that layer's own
+    convolution, which has run by then; the block keeps the layer inputs alive until the roll."""
+
+    def __enter__(self):
+        global _hist_pending
+        self._outer = _hist_pending
+        _hist_pending = []
+        return self
+
+    def __exit__(self, *exc):
+        global _hist_pending
+        pending, _hist_pending = _hist_pending, self._outer
+        if exc[0] is None:
+            flush_hist_updates(pending)
+        return False
+
+
+def flush_hist_updates(pending: list) -> None:
+    for i in range(0, len(pending), HIST_BATCH_MAX):
+        part = pending[i:i + HIST_BATCH_MAX]
+        n, B = len(part), part[0][0].shape[0]
+        xs = (C.c_void_p * n)(*[x.data_ptr() for x, _ in part])
+        hs = (C.c_void_p * n)(*[h.data_ptr() for _, h in part])
+        ti, pp, cc = _int_array([x.shape[1] for x, _ in part]), _int_array([h.shape[1] for _, h in part]), _int_array([h.shape[2] for _, h in part])
+        with torch.cuda.device(part[0][0].device):
+            _lib.check(_lib.lib().rst_hist_update_batch_f32(xs, hs, ti, pp, cc, n, B, _stream()))
+
+
 def hist_update(x: torch.Tensor, hist_in: Optional[torch.Tensor], P_out: int) -> torch.Tensor:
     """Last ``P_out`` steps of concat(hist_in, x) along time; x ``[B,T,C]``, hist ``[B,P,C]``.  In steady state (same history
     length, at most 16384 elements per stream) the roll happens IN PLACE and ``hist_in`` itself is returned: the state keeps
@@ -444,6 +484,9 @@ def hist_update(x: torch.Tensor, hist_in: Optional[torch.Tensor], P_out: int) ->
     B, T, Cc = x.shape
     P_in = hist_in.shape[1] if hist_in is not None else 0
     if hist_in is not None and P_in == P_out and P_out * Cc <= 16384 and P_out > 0:
+        if _hist_pending is not None and (not _hist_pending or _hist_pending[0][0].shape[0] == B):
+            _hist_pending.append((x, hist_in))       # rolled by the enclosing hist_batch() block, in one launch with its peers
+            return hist_in
         _lib.check(_lib.lib().rst_hist_update_f32(_ptr(x), _ptr(hist_in), _ptr(hist_in), B, T, P_in, P_out, Cc, _stream()))
         return hist_in
     out = torch.empty(B, P_out, Cc, device=x.device, dtype=torch.float32)

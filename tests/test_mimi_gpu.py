@@ -358,3 +358,41 @@ def test_encode_decode_8x10s_full_size_kernels_vs_oracle(mimi):
         ref_wav = O.decode(sd, cfg, ref_codes)
     assert wav.shape == ref_wav.shape == (B, 1, 240000)
     assert rel_err(wav, ref_wav) < 1e-3
+
+
+def test_audiocodec_twin_code_layout(mimi):
+    """The AudioCodec/MimiCodec twin (AudioCodec/MimiCodec/models/MimiCodec.py:94-111) moves codes as [B, T, K] (vq_dc.py:148-162
+    concatenates the per-level indices on the last axis): `code_layout="btk"` gives exactly the transposed tensors, both ways,
+    also frame by frame."""
+    sd, model = mimi
+    twin = MimiCodec.from_state_dict(sd, code_layout="btk").to(DEV)
+    audio = synth.synth_audio(2, 1920 * 4 + 500, seed=17).to(DEV)
+    codes = model.encode(audio)
+    codes_t = twin.encode(audio)
+    assert codes_t.shape == (2, 5, 8) and codes_t.is_contiguous() and torch.equal(codes_t, codes.transpose(1, 2))
+    assert torch.equal(twin.decode(codes_t), model.decode(codes))
+    with twin.streaming(2):
+        c0 = twin.encode(audio[:, :, :1920].contiguous())
+        assert c0.shape == (2, 1, 8) and torch.equal(c0[:, 0], codes[:, :, 0])
+        assert twin.decode(c0).shape == (2, 1, 1920)
+    with pytest.raises(ValueError):
+        MimiCodec(code_layout="tkb")
+
+
+@pytest.mark.parametrize("dim,B,chunk", [(64, 2, 1920), (128, 1, 480), (128, 3, 7), (256, 2, 96)])
+def test_resnet_block_streaming_equals_batch(dim, B, chunk):
+    """SEANetResnetBlock in streaming mode (one fused launch per chunk for C = 64 / 128: the k3 convolution's two-step history goes
+    straight into rst_seanet_resblock_f32) == the non-streaming block."""
+    blk = SEANetResnetBlock(dim, kernel_sizes=[3, 1], dilations=[1, 1], causal=True, pad_mode="constant", compress=2)
+    _init_weights(blk, torch.Generator().manual_seed(41))
+    for name, p in blk.named_parameters():
+        if "bias" in name:
+            torch.nn.init.normal_(p, std=0.05, generator=torch.Generator().manual_seed(7))
+    blk = blk.to(DEV)
+    x = (torch.rand(B, dim, 4 * chunk + 3) * 2 - 1).to(DEV)
+    expected = blk(x)
+    outs = []
+    with blk.streaming(B):
+        for s in range(0, x.shape[-1], chunk):
+            outs.append(blk(x[..., s:s + chunk].contiguous()))
+    _close(torch.cat(outs, -1), expected)

@@ -352,3 +352,46 @@ def test_gemm_win_kb16_linear_epilogues():
     assert rel_err(ops.linear(x.to(DEV), w.to(DEV)), ref) < TOL
     y = ops.linear(x.to(DEV), w.to(DEV), res=res.to(DEV), scale=scale.to(DEV), act_out=ops.ACT_GELU)
     assert rel_err(y, res + scale * F.gelu(ref)) < TOL
+
+
+# ---- streaming-step shapes: split-K across workgroups (medium-M gemm_win, few-row skinny GEMM)
+
+@pytest.mark.parametrize("B,cin,cout,K,S,T,elu", [(1, 64, 128, 8, 4, 1920, True), (1, 128, 64, 3, 1, 480, True), (2, 64, 32, 3, 1, 1920, True),
+                                                  (1, 256, 512, 12, 6, 96, False), (3, 128, 256, 10, 5, 480, True)])
+def test_conv_streaming_step_shapes_with_history(B, cin, cout, K, S, T, elu):
+    """One 80 ms frame of the SEANet encoder layers (rows = 1920 / 480 / 96 / 16 per stream) with a history buffer in front: the
+    medium-M launches split K over workgroups (rst_gemm_win_split_plan > 1), the few-row ones go through the skinny GEMM with its
+    own split; both against the oracle convolution of [history ; chunk]."""
+    g = torch.Generator().manual_seed(T + cout)
+    P = K - S
+    full = torch.rand(B, cin, P + T, generator=g) * 2 - 1
+    w = synth._xavier(g, cout, cin, K)
+    b = 0.1 * torch.randn(cout, generator=g)
+    hist, x = full[:, :, :P], full[:, :, P:]
+    xin = F.elu(full) if elu else full
+    ref = F.conv1d(xin, w, b, stride=S)
+    y = RF.conv1d(nlc(x), RF.pack_conv_weight(w).to(DEV), b.to(DEV), k_eff=K, stride=S, hist=nlc(hist), act_in=ops.ACT_ELU if elu else ops.ACT_NONE)
+    assert ncl(y).shape == ref.shape and rel_err(ncl(y), ref) < TOL
+
+
+def test_split_plans_cover_the_streaming_shapes():
+    from rstnet_amd import _lib
+    L = _lib.lib()
+    assert L.rst_gemm_win_split_plan(480, 128, 512) > 1 and L.rst_gemm_win_split_plan(1920, 64, 192) >= 1
+    assert L.rst_gemm_win_split_plan(640000, 128, 512) == 1                   # the batch path is untouched
+    assert L.rst_skinny_f32_split_plan(2, 1024, 8192) >= 4 and L.rst_skinny_f32_split_plan(16, 512, 3072) >= 4
+    assert L.rst_skinny_f32_split_plan(2, 32768, 512) == 1
+
+
+@pytest.mark.parametrize("M,N,K", [(2, 1024, 8192), (16, 512, 3072), (96, 256, 1280), (1, 512, 2048), (64, 4096, 2048), (33, 100, 1000)])
+def test_few_row_linear_split_k(M, N, K):
+    """The few-row skinny GEMM with K split across workgroups (the 33 MB 512 -> 1024 k16 layer and friends) vs F.linear, with the
+    residual / LayerScale / GELU epilogue; twice in a row (the arrival counters must re-arm)."""
+    g = torch.Generator().manual_seed(M + N)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    res, scale = torch.randn(M, N, generator=g), torch.rand(N, generator=g)
+    ref = F.linear(x, w)
+    for _ in range(2):
+        assert rel_err(ops.linear(x.to(DEV), w.to(DEV)), ref) < TOL
+        y = ops.linear(x.to(DEV), w.to(DEV), res=res.to(DEV), scale=scale.to(DEV), act_out=ops.ACT_GELU)
+        assert rel_err(y, res + scale * F.gelu(ref)) < TOL
