@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--fp8", action="store_true", help="gpt: fp8 (e4m3, per-row scales) matrix-core path for the global blocks")
     ap.add_argument("--lm-context", type=int, default=0, help="lm: start the timed frames at this ring offset (e.g. 3000 = every "
                     "temporal attention reads the full 3000-slot KV ring; the ring content is zeros, the bytes are the same)")
+    ap.add_argument("--kv-dtype", choices=["bf16", "f32"], default="bf16", help="lm / e2e: precision of the temporal KV rings (bf16 = the "
+                    "reference's cache precision, the default; f32 = the fp32 parity setting)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch GEMM table (shape, ms, TFLOP/s, GB/s) to stderr")
     ap.add_argument("--no-check", action="store_true", help="codec: skip the parity sample (2 clips through the CPU oracle: code "
@@ -244,7 +246,7 @@ def build_lm(args, rank, world, dev):
         from rstnet_amd.parallel import broadcast_state_dict
         sd = broadcast_state_dict(sd, dev, src=0)
     n_params = sum(v.numel() for v in sd.values())
-    return cfg, LMModel.from_state_dict(sd, cfg), n_params
+    return cfg, LMModel.from_state_dict(sd, cfg, kv_dtype=torch.bfloat16 if args.kv_dtype == "bf16" else torch.float32), n_params
 
 
 def run_lm(args, rank, world, dev, lm=None, steps=None, warmup=None, cpu=True):

@@ -313,10 +313,13 @@ int rst_lm_rope_append_f32(const float* qkv, float* q, float* k, float* v, const
  * ring holds the same values once.  rope_dims: leading head dims that rotate (config.rope_n_elem; 0 -> D).
  * out_packed (optional, then out may be NULL; D = 64 / 128): the result is written as the packed bf16 hi / lo operand
  * [2][ceil(B/32)*32][H*D] of rst_gemm_skinny_bf16_f32 (the out-projection that follows) instead of fp32 -- one launch less per
- * layer; rows past B of the buffer are not touched (keep them zero). */
-int rst_lm_attn_decode_f32(const float* qkv, float* k, float* v, float* ws, uint32_t* counters, float* out,
+ * layer; rows past B of the buffer are not touched (keep them zero).
+ * kv_bf16 != 0 (long-ring form only): k / v are bf16 rings -- the reference's own cache precision (RingKVCache dtype,
+ * modules/transformer.py:228 with the model in bf16, moshi/models/loaders.py:144): appended keys / values are rounded to
+ * nearest-even, the new step attends to its own key / value at that precision, reads are widened to fp32. */
+int rst_lm_attn_decode_f32(const float* qkv, void* k, void* v, float* ws, uint32_t* counters, float* out,
                            const int64_t* pos_dev, int B, int H, int D, int cap, int context, int splits, int ldqkv, int rope,
-                           float rope_coef, int kv_heads, int rope_dims, uint16_t* out_packed, rst_stream_t stream);
+                           float rope_coef, int kv_heads, int rope_dims, uint16_t* out_packed, int kv_bf16, rst_stream_t stream);
 
 /* The few-query form of rst_attention_f32(ring = 1) for streaming steps of the codec transformers (T <= a few new steps per
  * call): q [B][H][T][D] already rotated and k / v already appended by rst_rope_split_f32; every (b, t, h) query is split

@@ -86,16 +86,19 @@ def rope_interleaved_1(x: torch.Tensor, pos: int, max_period: float) -> torch.Te
 class RingKV:
     """RingKVCache (modules/transformer.py:198-278) for T = 1 appends."""
 
-    def __init__(self, B: int, H: int, D: int, capacity: int):
+    def __init__(self, B: int, H: int, D: int, capacity: int, dtype: torch.dtype = torch.float32):
+        """``dtype``: the precision the cache stores at (the reference allocates it in the model's dtype, bf16 for the released
+        checkpoints: modules/transformer.py:228); values are kept here as fp32 numbers that are exactly representable in it."""
         self.capacity = capacity
+        self.dtype = dtype
         self.k = torch.zeros(B, H, capacity, D)
         self.v = torch.zeros(B, H, capacity, D)
         self.end_offset = 0
 
     def complete(self, k: torch.Tensor, v: torch.Tensor):
         idx = self.end_offset % self.capacity
-        self.k[:, :, idx] = k[:, :, 0]
-        self.v[:, :, idx] = v[:, :, 0]
+        self.k[:, :, idx] = k[:, :, 0].to(self.dtype).float()
+        self.v[:, :, idx] = v[:, :, 0].to(self.dtype).float()
         self.end_offset += 1
         slots = torch.arange(self.capacity)
         end_index = self.end_offset % self.capacity

@@ -46,7 +46,58 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const LmRopeAppendPara
 // key (the workgroup whose slot range holds the ring slot of this step, which also appends k / v to the ring).
 // Slots are split over gridDim.x workgroups; each writes (m, l, o[D]) to the workspace and the last one to arrive combines.
 // Lane groups of D/16 lanes own one slot per iteration (each lane 16 contiguous floats of the K / V row: coalesced).
-template <int D>
+// KV16: the ring holds bf16 (the reference's cache precision: RingKVCache(..., dtype=torch.bfloat16), modules/transformer.py:228,
+// loaders.py:144) -- keys / values are rounded to nearest-even when appended, the new step's own key / value take part in its
+// attention at that precision too (the reference reads them back from the cache), and the long-context frame reads half the bytes.
+__device__ __forceinline__ unsigned short df_bf16_rne(float f) {
+    const unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);   // NaN stays NaN
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float df_bf16_round(float f) { return __uint_as_float((unsigned)df_bf16_rne(f) << 16); }
+
+template <bool KV16> struct KvRow;
+template <> struct KvRow<false> {       // fp32 ring: 16 floats of a row
+    static __device__ __forceinline__ void load(const void* base, long elem, float (&o)[16]) {
+        const float* q = static_cast<const float*>(base) + elem;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(q + 4 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[4 * i + e] = t[e];
+        }
+    }
+    static __device__ __forceinline__ void store(void* base, long elem, const float (&v)[16]) {
+        float* q = static_cast<float*>(base) + elem;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(q + 4 * i) = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+    }
+    static __device__ __forceinline__ float round(float f) { return f; }
+};
+template <> struct KvRow<true> {        // bf16 ring: the same 16 elements in 32 bytes
+    static __device__ __forceinline__ void load(const void* base, long elem, float (&o)[16]) {
+        const unsigned short* q = static_cast<const unsigned short*>(base) + elem;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(q + 8 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[8 * i + 2 * e] = bf16_lo(t[e]); o[8 * i + 2 * e + 1] = bf16_hi(t[e]); }
+        }
+    }
+    static __device__ __forceinline__ void store(void* base, long elem, const float (&v)[16]) {
+        unsigned short* q = static_cast<unsigned short*>(base) + elem;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = (unsigned)df_bf16_rne(v[8 * i + 2 * e]) | ((unsigned)df_bf16_rne(v[8 * i + 2 * e + 1]) << 16);
+            *reinterpret_cast<u32x4*>(q + 8 * i) = t;
+        }
+    }
+    static __device__ __forceinline__ float round(float f) { return df_bf16_round(f); }
+};
+
+template <int D, bool KV16 = false>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) {
     constexpr int LPS = D / 16;            // lanes per slot
     constexpr int SPW = 64 / LPS;          // slots per wave iteration
@@ -102,48 +153,50 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     float o[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = 0.f;
-    float* kb = p.k + ((b * p.G + g) * p.cap) * (long)D + sub * 16;
-    float* vb = p.v + ((b * p.G + g) * p.cap) * (long)D + sub * 16;
+    const long kv_row0 = ((b * p.G + g) * p.cap) * (long)D + sub * 16;      // element offset of this lane's 16 dims in slot 0
 
-    for (int s0 = s_lo + wave * SPW; s0 < s_hi; s0 += 4 * SPW) {
-        const int slot = s0 + grp;
-        const bool ok = slot < s_hi && ring_visible(slot, pos_q, p.cap, p.context, end_offset);
-        float kv[16], vv[16];
+    // UNR slots per lane group and iteration: the K / V rows of all of them are requested before the first score is formed (a
+    // wave that waits out one memory latency per slot streams the ring at a fraction of the bandwidth).  The scores are folded
+    // into the running softmax one slot at a time, in slot order, as before.
+    constexpr int UNR = 2;
+    for (int s0 = s_lo + wave * SPW; s0 < s_hi; s0 += 4 * SPW * UNR) {
+        float kv[UNR][16], vv[UNR][16];
+        bool ok[UNR];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { kv[i] = 0.f; vv[i] = 0.f; }
-        if (slot < s_hi && slot == slot_cur) {       // the new step: from qkv, and appended to the ring
+        for (int u = 0; u < UNR; ++u) {
+            const int slot = s0 + u * 4 * SPW + grp;
+            ok[u] = slot < s_hi && ring_visible(slot, pos_q, p.cap, p.context, end_offset);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { kv[i] = kcur[i]; vv[i] = vn[i]; }
-            if (appender) {
+            for (int i = 0; i < 16; ++i) { kv[u][i] = 0.f; vv[u][i] = 0.f; }
+            if (slot < s_hi && slot == slot_cur) {       // the new step: from qkv (at the ring's precision), and appended to the ring
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    *reinterpret_cast<f32x4*>(kb + (long)slot * D + 4 * i) = f32x4{kv[4 * i], kv[4 * i + 1], kv[4 * i + 2], kv[4 * i + 3]};
-                    *reinterpret_cast<f32x4*>(vb + (long)slot * D + 4 * i) = f32x4{vv[4 * i], vv[4 * i + 1], vv[4 * i + 2], vv[4 * i + 3]};
+                for (int i = 0; i < 16; ++i) { kv[u][i] = KvRow<KV16>::round(kcur[i]); vv[u][i] = KvRow<KV16>::round(vn[i]); }
+                if (appender) {
+                    KvRow<KV16>::store(p.k, kv_row0 + (long)slot * D, kv[u]);
+                    KvRow<KV16>::store(p.v, kv_row0 + (long)slot * D, vv[u]);
                 }
-            }
-        } else if (ok) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 k4 = *reinterpret_cast<const f32x4*>(kb + (long)slot * D + 4 * i);
-                const f32x4 v4 = *reinterpret_cast<const f32x4*>(vb + (long)slot * D + 4 * i);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { kv[4 * i + e] = k4[e]; vv[4 * i + e] = v4[e]; }
+            } else if (ok[u]) {
+                KvRow<KV16>::load(p.k, kv_row0 + (long)slot * D, kv[u]);
+                KvRow<KV16>::load(p.v, kv_row0 + (long)slot * D, vv[u]);
             }
         }
-        float d = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) d = fmaf(kv[i], q[i], d);
+        for (int u = 0; u < UNR; ++u) {
+            float d = 0.f;
 #pragma unroll
-        for (int off = LPS / 2; off > 0; off >>= 1) d += __shfl_xor(d, off);   // all lanes take part (ok is per group)
-        const float sc = ok ? d * scale : -INFINITY;
-        const float m_new = fmaxf(m_run, sc);
-        if (m_new != -INFINITY) {
-            const float alpha = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
-            const float pw = sc == -INFINITY ? 0.f : expf(sc - m_new);
-            l_run = l_run * alpha + pw;
+            for (int i = 0; i < 16; ++i) d = fmaf(kv[u][i], q[i], d);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) o[i] = o[i] * alpha + pw * vv[i];
-            m_run = m_new;
+            for (int off = LPS / 2; off > 0; off >>= 1) d += __shfl_xor(d, off);   // all lanes take part (ok is per group)
+            const float sc = ok[u] ? d * scale : -INFINITY;
+            const float m_new = fmaxf(m_run, sc);
+            if (m_new != -INFINITY) {
+                const float alpha = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
+                const float pw = sc == -INFINITY ? 0.f : expf(sc - m_new);
+                l_run = l_run * alpha + pw;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[i] = o[i] * alpha + pw * vv[u][i];
+                m_run = m_new;
+            }
         }
     }
     // merge the lane groups of the wave (same `sub`), then the 4 waves, into one (m, l, o[D])
@@ -253,8 +306,8 @@ __global__ __launch_bounds__(64) void attn_small_kernel(const LmAttnParams p) {
     const float* qkv = p.qkv + b * p.ldqkv + (long)h * D + c * DPL;
     const float* knp = p.qkv + b * p.ldqkv + ((long)p.H + kvh) * D + c * DPL;
     const float* vnp = knp + (long)p.G * D;
-    float* kc = p.k + ((b * p.G + kvh) * cap) * (long)D + c * DPL;
-    float* vc = p.v + ((b * p.G + kvh) * cap) * (long)D + c * DPL;
+    float* kc = static_cast<float*>(p.k) + ((b * p.G + kvh) * cap) * (long)D + c * DPL;
+    float* vc = static_cast<float*>(p.v) + ((b * p.G + kvh) * cap) * (long)D + c * DPL;
     const int npass = (cap + 7) >> 3;
     float q[DPL], kn[DPL], vn[DPL];
 #pragma unroll
@@ -374,6 +427,7 @@ int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream) {
     RST_REQUIRE(T >= 1 && (long)p.B * T <= 65535 && p.H <= 65535 && p.D % 2 == 0, "lm_attn: bad sizes");
     RST_REQUIRE(p.G >= 1 && p.H % p.G == 0 && p.rope_dims >= 0 && p.rope_dims <= p.D && p.rope_dims % 2 == 0,
                 "lm_attn: bad kv head count %d for %d heads or rope_dims %d", p.G, p.H, p.rope_dims);
+    RST_REQUIRE(!p.kv_bf16 || (!p.q_pre && !(p.cap <= 64 && p.splits == 1)), "lm_attn: bf16 rings are served by the long-ring single-step form only");
     if (!p.q_pre && p.cap <= 64 && p.splits == 1) {
         switch (p.D) {
             case 32: hipLaunchKernelGGL(attn_small_kernel<32>, dim3(p.H, p.B), dim3(64), 0, stream, p); break;
@@ -387,6 +441,16 @@ int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream) {
     }
     RST_REQUIRE(p.splits == 1 || (p.ws && p.counters), "lm_attn: splits > 1 need the workspace and the (zeroed) counters");
     const dim3 grid(p.splits, p.H, p.B * T);
+    if (p.kv_bf16) {
+        switch (p.D) {
+            case 64: hipLaunchKernelGGL((attn_decode_kernel<64, true>), grid, dim3(256), 0, stream, p); break;
+            case 128: hipLaunchKernelGGL((attn_decode_kernel<128, true>), grid, dim3(256), 0, stream, p); break;
+            default:
+                rst_set_error("lm_attn: head dim %d unsupported for long rings (64, 128)", p.D);
+                return RST_ERR_UNSUPPORTED;
+        }
+        return rst_check_launch("lm_attn_kv16");
+    }
     switch (p.D) {
         case 64: hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, stream, p); break;
         case 128: hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, stream, p); break;

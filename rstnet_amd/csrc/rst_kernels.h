@@ -212,8 +212,9 @@ struct LmAttnParams {
     const float* qkv;     // [B][ldqkv]: [q (H*D) | k (G*D) | v (G*D)] of the new step (un-rotated); or nullptr with q_pre
     const float* q_pre;   // optional [B][H][T][D]: rotated queries of T new steps whose keys are already in the ring
     int T;
-    float* k;             // [B][G][cap][D] ring (the new step is appended)
-    float* v;
+    void* k;              // [B][G][cap][D] ring (the new step is appended): fp32, or bf16 when kv_bf16
+    void* v;
+    int kv_bf16;
     float* ws;            // [B][H][splits][D+2] workspace: (m, l, o[D]) per split (splits > 1)
     unsigned* counters;   // [B][H] arrival counters, zero before the first launch (re-armed by the kernel)
     float* out;           // [B][H*D]

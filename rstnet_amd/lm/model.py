@@ -115,8 +115,13 @@ class StreamingTransformer(StreamingModule[_StepState]):
     causal, rope or no positional embedding, optional per-step weights)."""
 
     def __init__(self, d_model: int, num_heads: int, num_layers: int, dim_feedforward: int, context: Optional[int],
-                 positional_embedding: str, max_period: float = 10000.0, weights_per_step: int = 0, device=None, dtype=None):
+                 positional_embedding: str, max_period: float = 10000.0, weights_per_step: int = 0, device=None, dtype=None,
+                 kv_dtype: torch.dtype = torch.float32):
         super().__init__()
+        # precision of the KV rings: bf16 = what the reference caches (RingKVCache in the model's dtype); rings of <= 64 slots
+        # (the depth transformer, tiny test models) always stay fp32 -- their bytes do not matter and their kernel is fp32
+        assert kv_dtype in (torch.float32, torch.bfloat16)
+        self.kv_dtype = kv_dtype
         assert d_model % num_heads == 0
         if positional_embedding not in ("rope", "none"):
             raise NotImplementedError(f"positional_embedding={positional_embedding!r}")
@@ -142,7 +147,9 @@ class StreamingTransformer(StreamingModule[_StepState]):
             splits = max(1, min(16, cap // 128, 1024 // max(1, batch_size * self.num_heads)))
             scratch = (torch.empty(batch_size, self.num_heads, splits, shape[3] + 2, device=dev),
                        torch.zeros(batch_size, self.num_heads, device=dev, dtype=torch.int32))
-        return _StepState([torch.zeros(shape, device=dev) for _ in self.layers], [torch.zeros(shape, device=dev) for _ in self.layers],
+        kvd = self.kv_dtype if cap > 64 else torch.float32
+        return _StepState([torch.zeros(shape, device=dev, dtype=kvd) for _ in self.layers],
+                          [torch.zeros(shape, device=dev, dtype=kvd) for _ in self.layers],
                           torch.zeros(1, device=dev, dtype=torch.long), scratch)
 
     def step(self, x: Optional[torch.Tensor], step_index: Optional[int] = None, pos: Optional[torch.Tensor] = None,
@@ -208,8 +215,9 @@ class LMModel(StreamingContainer):
                  bias_proj: bool = False, depformer_dim: int = 256, depformer_dim_feedforward=None,
                  depformer_multi_linear: bool = False, depformer_weights_per_step: bool = False, depformer_pos_emb: str = "sin",
                  existing_text_padding_id: Optional[int] = None, context: Optional[int] = None, device=None,
-                 dtype=torch.bfloat16, **kwargs):
+                 dtype=torch.bfloat16, kv_dtype: torch.dtype = torch.bfloat16, **kwargs):
         super().__init__()
+        self.kv_dtype = kv_dtype      # temporal KV rings: bf16 like the reference's cache (fp32 on request, e.g. fp32 parity runs)
         if norm != "rms_norm_f32" or norm_emb or bias_proj:
             raise NotImplementedError("the decode path implements norm='rms_norm_f32', norm_emb=False, bias_proj=False")
         if kwargs.get("gating", "silu") != "silu" or kwargs.get("depformer_gating", "silu") != "silu":
@@ -227,7 +235,8 @@ class LMModel(StreamingContainer):
         self.text_emb = ScaledEmbedding(text_card + 1, dim, **fk)
         self.text_linear = _Weight(text_card + (1 if existing_text_padding_id is None else 0), dim, **fk)
         self.transformer = StreamingTransformer(dim, num_heads, kwargs["num_layers"], int(hidden_scale * dim), context,
-                                                kwargs.get("positional_embedding", "sin"), kwargs.get("max_period", 10000.0), **fk)
+                                                kwargs.get("positional_embedding", "sin"), kwargs.get("max_period", 10000.0),
+                                                kv_dtype=kv_dtype, **fk)
         self.out_norm = RMSNorm(dim, **fk)
         self.depformer_multi_linear = depformer_multi_linear
         self.depformer_in = nn.ModuleList([_Weight(depformer_dim, dim, **fk) for _ in range(dep_q)])
@@ -345,10 +354,10 @@ class LMModel(StreamingContainer):
         return ops.lm_linear(y, self.linears[k].weight)
 
     @classmethod
-    def from_state_dict(cls, sd: Dict[str, torch.Tensor], cfg: dict) -> "LMModel":
+    def from_state_dict(cls, sd: Dict[str, torch.Tensor], cfg: dict, kv_dtype: torch.dtype = torch.bfloat16) -> "LMModel":
         """Model for ``cfg`` (keys of ``rstnet_amd.synth.LM_*``) with weights taken from ``sd`` WITHOUT copying them
-        (a 7.7 B-parameter state dict stays a single 15 GB allocation)."""
-        model = cls(causal=True, layer_scale=None, gating="silu", norm="rms_norm_f32", positional_embedding="rope",
+        (a 7.7 B-parameter state dict stays a single 15 GB allocation).  ``kv_dtype``: precision of the temporal KV rings."""
+        model = cls(kv_dtype=kv_dtype, causal=True, layer_scale=None, gating="silu", norm="rms_norm_f32", positional_embedding="rope",
                     depformer_causal=True, depformer_layer_scale=None, depformer_multi_linear=True, depformer_context=8,
                     depformer_gating="silu", depformer_pos_emb="none", depformer_weights_per_step=True, device="meta", **cfg)
         params = dict(model.named_parameters())

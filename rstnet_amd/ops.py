@@ -103,22 +103,34 @@ def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32) -> None:
 _gemm_scratch: dict = {}
 
 
+def _scratch(cache: dict, device, shape_key: tuple, build):
+    """Per-(device, stream, shape) scratch with a twin for graph capture.  A buffer that is first allocated INSIDE a capture is
+    zero-filled by a node of the graph, i.e. by one more launch on every replay (measured: 19 such fills per codec frame); so the
+    first eager use of a shape also creates the entry captures will look up (key "graph": all captured graphs of a device share
+    it -- their replays must not overlap, see the module docstring)."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (device, "graph" if capturing else _stream()) + shape_key
+    sc = cache.get(key)
+    if sc is None:
+        sc = cache[key] = build()
+        if not capturing and (device, "graph") + shape_key not in cache:
+            cache[(device, "graph") + shape_key] = build()
+    return sc
+
+
 def _gemm_split_scratch(device, M: int, N: int, K: int):
     """Split-K plan + scratch of the few- / medium-row (streaming step) GEMMs, cached per (stream, shape); launches on one stream
     are ordered and the counters re-arm themselves, so layers of equal shape share the buffers."""
     if M > 4096 or M == 0:
         return 1, None, None
-    key = (device, _stream(), M, N, K)
-    sc = _gemm_scratch.get(key)
-    if sc is None:
+
+    def build():
         sk = int(_lib.lib().rst_gemm_win_split_plan(M, N, K))
         if sk > 1:
-            sc = (sk, torch.empty(sk, M, N, device=device, dtype=torch.float32),
-                  torch.zeros(int(_lib.lib().rst_gemm_win_split_tiles(M, N)), device=device, dtype=torch.int32))
-        else:
-            sc = (1, None, None)
-        _gemm_scratch[key] = sc
-    return sc
+            return (sk, torch.empty(sk, M, N, device=device, dtype=torch.float32),
+                    torch.zeros(int(_lib.lib().rst_gemm_win_split_tiles(M, N)), device=device, dtype=torch.int32))
+        return (1, None, None)
+    return _scratch(_gemm_scratch, device, ("gemm_win", M, N, K), build)
 
 
 _skinny_f32_weights = _PackedWeights()
@@ -144,12 +156,11 @@ def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, 
     xp = torch.empty(32 if M <= 32 else (64 if M <= 64 else 128), wp.shape[1], device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().rst_skinny_f32_pack_win(_ptr(x), _ptr(hist), _ptr(xp), B, T_in, T_out, C_, K, S, P, pad_mode, T_in * C_, act_in,
                                                  _stream()))
-    key = (x.device, _stream(), "skinny", M, N, K)
-    sc = _gemm_scratch.get(key)
-    if sc is None:
+    def build():
         sk = int(_lib.lib().rst_skinny_f32_split_plan(M, N, K))
-        sc = _gemm_scratch[key] = (sk, torch.empty(sk, M, N, device=x.device, dtype=torch.float32),
-                                   torch.zeros((N + 31) // 32, device=x.device, dtype=torch.int32)) if sk > 1 else (1, None, None)
+        return (sk, torch.empty(sk, M, N, device=x.device, dtype=torch.float32),
+                torch.zeros((N + 31) // 32, device=x.device, dtype=torch.int32)) if sk > 1 else (1, None, None)
+    sc = _scratch(_gemm_scratch, x.device, ("skinny", M, N, K), build)
     _lib.check(_lib.lib().rst_gemm_skinny_f32(_ptr(xp), _ptr(wp), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, N, K, N, act_out,
                                              sc[0], _ptr(sc[1]), _ptr(sc[2]), _stream()))
 
@@ -336,11 +347,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, pos0: int = 
         # streaming step with a handful of new queries: split every query over the occupied ring slots instead of walking
         # the ring tile by tile with one wave per head
         splits = max(1, min(4, cap // 64))
-        key = (q.device, _stream(), B * T, H, splits, D)
-        sc = _attn_scratch.get(key)
-        if sc is None:
-            sc = _attn_scratch[key] = (torch.empty(B * T, H, splits, D + 2, device=q.device, dtype=torch.float32),
-                                       torch.zeros(B * T, H, device=q.device, dtype=torch.int32))
+        sc = _scratch(_attn_scratch, q.device, (B * T, H, splits, D),
+                      lambda: (torch.empty(B * T, H, splits, D + 2, device=q.device, dtype=torch.float32),
+                               torch.zeros(B * T, H, device=q.device, dtype=torch.int32)))
         _lib.check(_lib.lib().rst_attn_decode_multi_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(sc[0]), _ptr(sc[1]), _ptr(out), _ptr(pos_dev),
                                                        B, T, H, D, cap, int(context) if context else 0, splits, G, _stream()))
         return out
@@ -375,14 +384,12 @@ def rvq_search(x: torch.Tensor, emb: torch.Tensor, packed: torch.Tensor, e2: tor
     L, n_codes, D = emb.shape
     M = B * F
     assert x.shape == (M, len(groups) * D), (tuple(x.shape), M, len(groups), D)
-    codes = torch.zeros(B, L, F, device=x.device, dtype=torch.int64)
+    covered = sorted(l for g0, n in groups for l in range(g0, g0 + n)) == list(range(L))
+    codes = (torch.empty if covered else torch.zeros)(B, L, F, device=x.device, dtype=torch.int64)
     dist = torch.zeros(L, M, device=x.device, dtype=torch.float32) if return_dist else None
     keys = None
     if 0 < M <= 64:     # streaming step: the few-frame form (codes spread over workgroups)
-        kk = (x.device, _stream(), L, M)
-        keys = _rvq_keys.get(kk)
-        if keys is None:
-            keys = _rvq_keys[kk] = torch.full((L, M), -1, device=x.device, dtype=torch.int64)
+        keys = _scratch(_rvq_keys, x.device, (L, M), lambda: torch.full((L, M), -1, device=x.device, dtype=torch.int64))
     _lib.check(_lib.lib().rst_rvq_search_f32(_ptr(x), _ptr(emb), _ptr(packed), _ptr(e2), _ptr(codes), _ptr(dist), _ptr(keys), M, max(F, 1),
                                              x.shape[1], D, n_codes, L, len(groups), _int_array([g[0] for g in groups]),
                                              _int_array([g[1] for g in groups]), _stream()))
@@ -637,11 +644,7 @@ def _packed_buffer(device, B: int, K: int, role: str = "in") -> torch.Tensor:
     """Persistent, zero-initialised operand buffer per (stream, shape): producers write rows < B only, so the pad rows stay zero;
     layers of equal shape share it (launches on one stream are ordered).  ``role`` keeps the output of a GEMM that emits a packed
     operand apart from the operand it reads."""
-    key = (device, _stream(), B, K, role)
-    buf = _packed_out.get(key)
-    if buf is None:
-        buf = _packed_out[key] = torch.zeros(2, (B + 31) // 32 * 32, K, device=device, dtype=torch.bfloat16)
-    return buf
+    return _scratch(_packed_out, device, (B, K, role), lambda: torch.zeros(2, (B + 31) // 32 * 32, K, device=device, dtype=torch.bfloat16))
 
 
 def gemm_skinny(x, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
@@ -804,12 +807,16 @@ def lm_attn_decode(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     reduction over slot splits in ONE launch) -> ``[B, H*D]``; the ring is ``[B,G,cap,D]`` (``heads`` = H when G < H).
     ``scratch = (ws [B,H,splits,D+2] fp32, counters [B,H] int32 zeros)`` may be passed to reuse buffers (the counters re-arm
     themselves).  ``rope_dims``: leading head dims that rotate (0 = all; the frequencies then span ``rope_dims``)."""
-    for t, n in ((qkv, "qkv"), (k_cache, "k_cache"), (v_cache, "v_cache")):
-        _chk(t, n)
+    _chk(qkv, "qkv")
+    kv16 = k_cache.dtype == torch.bfloat16          # bf16 rings: the reference's cache precision (long-ring form)
+    _chk(k_cache, "k_cache", k_cache.dtype if kv16 else torch.float32)
+    _chk(v_cache, "v_cache", k_cache.dtype)
     _chk(pos_dev, "pos_dev", torch.int64)
     B, G, cap, D = k_cache.shape
     H = heads or G
     assert qkv.shape[1] == (H + 2 * G) * D, (tuple(qkv.shape), H, G, D)
+    if kv16 and cap <= 64:
+        raise NotImplementedError("bf16 KV rings are served by the long-ring attention (capacity > 64)")
     if splits is None:
         splits = 1 if cap <= 64 else max(1, min(16, cap // 128, 1024 // max(1, B * H)))
     ws = counters = None
@@ -826,7 +833,7 @@ def lm_attn_decode(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     xp = _packed_buffer(qkv.device, B, H * D) if packed else None
     _lib.check(_lib.lib().rst_lm_attn_decode_f32(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(ws), _ptr(counters), _ptr(out),
                                                 _ptr(pos_dev), B, H, D, cap, int(context) if context else 0, splits, qkv.shape[1],
-                                                int(rope), rope_coef(max_period, rope_dims or D), G, rope_dims, _ptr(xp), _stream()))
+                                                int(rope), rope_coef(max_period, rope_dims or D), G, rope_dims, _ptr(xp), int(kv16), _stream()))
     return PackedAct(xp, B, H * D) if packed else out
 
 
@@ -928,11 +935,9 @@ def depth_decode_frame(tables, h_all: torch.Tensor, tokens: torch.Tensor, noise:
         if noise is None or not noise.is_cuda or noise.dtype != torch.float32 or noise.dim() != 2 or noise.stride(1) != 1 or \
                 noise.shape[0] != B or noise.shape[1] < t.dep_q * top_k:
             raise ValueError("rstnet_amd.ops: `noise` must be float32 CUDA/HIP [B, >= dep_q * top_k] with unit column stride")
-    key = (h_all.device, _stream(), B, t.E, t.Hd, t.card)
-    ws = _depth_ws.get(key)
-    if ws is None:
-        nbytes = int(_lib.lib().rst_depth_frame_workspace_bytes(B, t.E, t.Hd, t.card))
-        ws = _depth_ws[key] = torch.zeros(nbytes // 8, device=h_all.device, dtype=torch.int64)
+    ws = _scratch(_depth_ws, h_all.device, (B, t.E, t.Hd, t.card),
+                  lambda: torch.zeros(int(_lib.lib().rst_depth_frame_workspace_bytes(B, t.E, t.Hd, t.card)) // 8, device=h_all.device,
+                                      dtype=torch.int64))
     _lib.check(_lib.lib().rst_depth_decode_frame(
         t.in_proj, t.out_proj, t.norm1, t.norm2, t.gate_in, t.gate_out, t.heads, t.head_bias, t.emb, t.emb_rows,
         _ptr(h_all), _ptr(tokens), _ptr(noise) if sampling else None, _ptr(limits), _ptr(ws), _ptr(t.status),

@@ -143,12 +143,24 @@ def test_embed_sum_and_rmsnorm():
 @pytest.mark.parametrize("H,D,cap,context,steps,rope", [(4, 64, 8, None, 8, False), (2, 128, 10, 10, 25, True), (32, 128, 300, 300, 40, True),
                                                         (4, 64, 300, 250, 320, True), (16, 64, 8, None, 8, False)])
 def test_rope_append_and_ring_attention(H, D, cap, context, steps, rope):
+    _ring_attention_case(H, D, cap, context, steps, rope, torch.float32)
+
+
+@pytest.mark.parametrize("H,D,cap,context,steps", [(32, 128, 300, 300, 40), (4, 64, 300, 250, 320), (8, 128, 3000, 3000, 12)])
+def test_ring_attention_bf16_kv(H, D, cap, context, steps):
+    """bf16 KV rings (the reference's cache precision, modules/transformer.py:228): against the oracle ring that rounds what it
+    stores to bf16 -- same rounded keys / values on both sides, so the fp32 attention over them must agree like the fp32 ring does;
+    the ring contents must be bit-identical bf16."""
+    _ring_attention_case(H, D, cap, context, steps, True, torch.bfloat16)
+
+
+def _ring_attention_case(H, D, cap, context, steps, rope, kv_dtype):
     """Step-by-step against the oracle's RingKV (slot->position map of RingKVCache.complete incl. SURVEY Q1)."""
     g = torch.Generator().manual_seed(H * D)
     B = 2
-    ring = L.RingKV(B, H, D, cap)
-    kc = torch.zeros(B, H, cap, D, device=DEV)
-    vc = torch.zeros(B, H, cap, D, device=DEV)
+    ring = L.RingKV(B, H, D, cap, dtype=kv_dtype)
+    kc = torch.zeros(B, H, cap, D, device=DEV, dtype=kv_dtype)
+    vc = torch.zeros(B, H, cap, D, device=DEV, dtype=kv_dtype)
     pos = torch.zeros(1, dtype=torch.long, device=DEV)
     for s in range(steps):
         qkv = torch.randn(B, 3 * H * D, generator=g)
@@ -163,8 +175,14 @@ def test_rope_append_and_ring_attention(H, D, cap, context, steps, rope):
         ref = F.scaled_dot_product_attention(q, keys, vals, mask.view(1, -1)).permute(0, 2, 1, 3).reshape(B, H * D)
         out = ops.lm_attn_decode(qkv.to(DEV), kc, vc, pos, rope=rope, context=context)
         pos.add_(1)
-        assert rel_err(out, ref) < 1e-4, f"step {s}"
-    assert rel_err(kc, ring.k) < 1e-4   # rotated keys: fp32 sin/cos of angles up to ~300 rad
+        assert rel_err(out, ref) < (1e-4 if kv_dtype == torch.float32 else 3e-3), f"step {s}"
+    if kv_dtype == torch.float32:
+        assert rel_err(kc, ring.k) < 1e-4   # rotated keys: fp32 sin/cos of angles up to ~300 rad
+    else:
+        # values are copied, so their bf16 images must be identical; rotated keys may differ by one bf16 ulp where the fp32
+        # rotation (sin / cos of large angles) lands on the other side of a rounding boundary
+        assert torch.equal(vc.float().cpu(), ring.v)
+        assert rel_err(kc.float(), ring.k) < 1e-2
 
 
 @pytest.mark.parametrize("V,k", [(2048, 250), (32, 7), (32000, 25), (50, 25), (4000, 250), (151936, 25), (40000, 300), (151936, 1000)])
