@@ -186,6 +186,23 @@ int rst_hist_update_f32(const float* x, const float* hist_in, float* hist_out, i
 int rst_hist_update_batch_f32(const float* const* x, float* const* hist, const int* T_in, const int* P, const int* C, int n, int B,
                               rst_stream_t stream);
 
+/* rst_codec_transformer_frame -- ONE streaming step of a Mimi transformer (ProjectedTransformer / StreamingTransformer with all its
+ * StreamingTransformerLayers, modules/transformer.py:434-750, as MimiModel calls it per 80 ms frame: compression.py:368-419) as one
+ * persistent launch, for B streams x T new positions with B * T <= 4 rows: per layer LayerNorm(eps) -> in_proj [3E][E] ->
+ * interleaved RoPE on q, k at positions *pos_dev + t (modules/rope.py) -> append to the ring k_cache / v_cache [B][H][cap][D]
+ * (slot (pos + t) % cap) -> attention of every new query over the ring with RingKVCache.complete's slot -> position map and the
+ * causal / context mask (:254-278, 404-414) -> out_proj [E][E] -> x + scale1 * . -> LayerNorm -> linear1 [F][E] -> exact GELU ->
+ * linear2 [E][F] -> x + scale2 * .   Tables are HOST arrays of L device pointers (scale1 / scale2 may be NULL: no LayerScale).
+ * x, y fp32 [B][T][E]; workspace of rst_codec_transformer_workspace_bytes(B * T, E, F) bytes (zeroed by the call on `stream`);
+ * *status is OR-ed with a non-zero code if an in-launch hand-off timed out (bounded spins; see rst_depth_decode_frame). */
+int rst_codec_transformer_workspace_bytes(int rows, int E, int F);
+int rst_codec_transformer_frame(const float* const* in_proj, const float* const* out_proj, const float* const* linear1,
+                                const float* const* linear2, const float* const* norm1_w, const float* const* norm1_b,
+                                const float* const* norm2_w, const float* const* norm2_b, const float* const* scale1,
+                                const float* const* scale2, float* const* k_cache, float* const* v_cache, const float* x, float* y,
+                                const int64_t* pos_dev, void* workspace, uint32_t* status, int B, int T, int E, int H, int F, int L,
+                                int cap, int context, int rope, float rope_coef, float eps, rst_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * RQ-Transformer decode step (T = 1 per call, small batch).  bf16 weights, fp32 activations / accumulation.
  * Reference files below are relative to MLLM_v2/.

@@ -43,6 +43,8 @@ SIGNATURES = {
     "rst_skinny_f32_split_plan": [_i, _i, _i],
     "rst_gemm_skinny_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "rst_mask_tail_f32": [_p, _p, _i, _i, _i, _i, _p],
+    "rst_codec_transformer_workspace_bytes": [_i, _i, _i],
+    "rst_codec_transformer_frame": [C.POINTER(_p)] * 12 + [_p, _p, _p, _p, _p] + [_i] * 9 + [_f, _f, _p],
     "rst_gemv_f32": [_p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "rst_gemv_bf16_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "rst_gemv_attn_bf16_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -256,9 +256,52 @@ class StreamingTransformer(StreamingModule[_TransformerState]):
         device = next(self.parameters()).device
         return _TransformerState(offset=torch.zeros(1, device=device, dtype=torch.long))
 
+    def _frame_layers(self, x: torch.Tensor):
+        """The per-layer tensors of ``ops.codec_transformer_frame`` if this streaming step can run as ONE persistent launch (a few
+        rows, plain layers with attention + GELU FFN + LayerNorm, all of them streaming), else None."""
+        state = self._streaming_state
+        if state is None or not x.is_cuda or x.dtype != torch.float32 or not self.layers:
+            return None
+        out = []
+        for layer in self.layers:
+            att = getattr(layer, "self_attn", None)
+            if (type(layer) is not StreamingTransformerLayer or att is None or att._streaming_state is None or att.weights_per_step
+                    or not isinstance(layer.norm1, LayerNorm) or not isinstance(layer.norm2, LayerNorm) or layer.norm1.eps != layer.norm2.eps):
+                return None
+            ms = att._streaming_state
+            out.append({"in_proj": att.in_proj_weight, "out_proj": att.out_proj.weight, "linear1": layer.linear1.weight,
+                        "linear2": layer.linear2.weight, "norm1_w": layer.norm1.weight, "norm1_b": layer.norm1.bias,
+                        "norm2_w": layer.norm2.weight, "norm2_b": layer.norm2.bias, "scale1": layer._scale(layer.layer_scale_1),
+                        "scale2": layer._scale(layer.layer_scale_2), "k_cache": ms.k_cache, "v_cache": ms.v_cache})
+        l0 = self.layers[0]
+        att = l0.self_attn
+        B, T, E = x.shape
+        if any(t.dtype != torch.float32 for ly in out for t in ly.values() if t is not None):
+            return None
+        if (out[0]["scale1"] is None) != (out[0]["scale2"] is None) or any((ly["scale1"] is None) != (out[0]["scale1"] is None) for ly in out):
+            return None
+        if not ops.codec_transformer_frame_supported(B, T, E, att.num_heads, l0.linear1.out_features, len(out), out[0]["k_cache"].shape[2]):
+            return None
+        return out
+
     def forward(self, x: torch.Tensor, *args, **kwargs) -> torch.Tensor:
         T = x.shape[1]
         state = self._streaming_state
+        frame = self._frame_layers(x) if not args and not kwargs else None
+        if frame is not None:
+            # one 80 ms frame of a few streams: all layers in ONE persistent launch (csrc/codec_tr.hip)
+            att = self.layers[0].self_attn
+            y = ops.codec_transformer_frame(x.contiguous(), frame, state.offset, H=att.num_heads, context=att.context,
+                                            rope=att.rope is not None, max_period=att.rope.max_period if att.rope is not None else 10000.0,
+                                            eps=self.layers[0].norm1.eps)
+            for layer in self.layers:
+                ms = layer.self_attn._streaming_state
+                ms.shared = state.offset
+                ms.offset_cpu += T
+                if layer._streaming_state is not None:
+                    layer._streaming_state.offset_cpu += T
+            state.offset.add_(T)
+            return y
         for layer in self.layers:
             att = getattr(layer, "self_attn", None)
             if att is not None and att._streaming_state is not None:

@@ -270,6 +270,30 @@ int rst_depth_decode_frame(const uint16_t* const* in_proj, const uint16_t* const
     return rst_launch_depth_frame(p, (hipStream_t)stream);
 }
 
+int rst_codec_transformer_workspace_bytes(int rows, int E, int F) { return (int)(rst_codec_tr_workspace_granules(rows, E, F) * 8); }
+
+int rst_codec_transformer_frame(const float* const* in_proj, const float* const* out_proj, const float* const* linear1,
+                                const float* const* linear2, const float* const* norm1_w, const float* const* norm1_b,
+                                const float* const* norm2_w, const float* const* norm2_b, const float* const* scale1,
+                                const float* const* scale2, float* const* k_cache, float* const* v_cache, const float* x, float* y,
+                                const int64_t* pos_dev, void* workspace, uint32_t* status, int B, int T, int E, int H, int F, int L,
+                                int cap, int context, int rope, float rope_coef, float eps, rst_stream_t stream) {
+    RST_REQUIRE(in_proj && out_proj && linear1 && linear2 && norm1_w && norm1_b && norm2_w && norm2_b && k_cache && v_cache,
+                "codec_transformer_frame: null table");
+    RST_REQUIRE(L >= 1 && L <= RST_CTR_MAX_L && H > 0 && E % H == 0, "codec_transformer_frame: L=%d (<= %d), H=%d, E=%d", L, RST_CTR_MAX_L, H, E);
+    CodecTrParams p = {};
+    for (int l = 0; l < L; ++l) {
+        p.in_proj[l] = in_proj[l]; p.out_proj[l] = out_proj[l]; p.lin1[l] = linear1[l]; p.lin2[l] = linear2[l];
+        p.n1g[l] = norm1_w[l]; p.n1b[l] = norm1_b[l]; p.n2g[l] = norm2_w[l]; p.n2b[l] = norm2_b[l];
+        p.ls1[l] = scale1 ? scale1[l] : nullptr; p.ls2[l] = scale2 ? scale2[l] : nullptr;
+        p.kc[l] = k_cache[l]; p.vc[l] = v_cache[l];
+    }
+    p.x = x; p.y = y; p.pos_dev = reinterpret_cast<const long*>(pos_dev); p.gran = static_cast<unsigned long long*>(workspace); p.status = status;
+    p.B = B; p.T = T; p.E = E; p.H = H; p.D = E / H; p.F = F; p.L = L; p.cap = cap; p.context = context; p.rope = rope;
+    p.rope_coef = rope_coef; p.eps = eps;
+    return rst_launch_codec_tr(p, (hipStream_t)stream);
+}
+
 int rst_gemv_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* w, const float* bias,
                  const float* res, const float* scale, float* y, int B, int N, int K, int act_out, rst_stream_t stream) {
     RST_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "gemv_f32: LayerNorm needs both gamma and beta");

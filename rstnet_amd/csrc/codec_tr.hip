@@ -1,0 +1,327 @@
+// One streaming step of a Mimi transformer (encoder_transformer / decoder_transformer: 8 layers of LayerNorm -> fused-QKV attention
+// with interleaved RoPE and a ring KV cache -> LayerScale residual -> LayerNorm -> GELU FFN -> LayerScale residual, fp32;
+// modules/transformer.py:376-423,434-592,595-690) for the few rows of one 80 ms frame (R = streams x positions <= 4) as ONE
+// persistent launch.  As separate launches a layer is 6 dependent kernels of 1-4 MB each (LN + in-proj GEMV | rope / split |
+// ring attention | out-proj GEMV | LN + linear1 GEMV | linear2 GEMV), ~5-7 us apiece whatever their size; here the 5 op
+// boundaries of a layer are in-launch hand-offs (persist.h) and the weights of the next op are requested before each wait.
+//
+// Work split: G workgroups x 4 waves, weight row r of an op belongs to wave (r mod 4G); every workgroup keeps the residual stream
+// x [R][E] in LDS and recomputes the LayerNorms itself.  Attention of (stream b, head h) is owned by workgroup b * H + h: it
+// gathers the head's q / k / v of the new steps, rotates q and k (modules/rope.py:37-62, position = *pos_dev + t), appends k / v to
+// the ring in HBM (slot (pos + t) % cap: the ring persists across frames; only this workgroup index ever touches the head's
+// ring inside a launch) and runs the T queries against the ring with the slot -> position map and mask of
+// RingKVCache.complete (transformer.py:254-278,404-414, incl. the `delta <= 0` slot), one wave per query.
+#include "persist.h"
+
+namespace {
+
+// ---- rows of an fp32 weight matrix: RU rows x CU chunks of 512 k (8 floats = two 16-byte loads per lane and chunk)
+template <int RU, int CU> struct CtPre { f32x4 wv[RU][CU][2]; };
+
+template <int RU, int CU>
+__device__ __forceinline__ void ct_rows_load(CtPre<RU, CU>& pre, const float* w, int N, int K, int r0, int kb, int W, int lane) {
+#pragma unroll
+    for (int j = 0; j < RU; ++j)
+#pragma unroll
+        for (int c = 0; c < CU; ++c) {
+            const int r = r0 + j * W, kk = kb + c * 512 + lane * 8;
+            pre.wv[j][c][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pre.wv[j][c][1] = pre.wv[j][c][0];
+            if (r < N && kk < K) {
+                const float* q = w + (long)r * K + kk;
+                pre.wv[j][c][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
+                pre.wv[j][c][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q + 4));
+            }
+        }
+}
+
+template <int RU, int CU>
+__device__ __forceinline__ void ct_rows_issue(CtPre<RU, CU>& pre, const float* w, int N, int K, int gw, int W, int lane) {
+    ct_rows_load<RU, CU>(pre, w, N, K, gw, 0, W, lane);
+}
+
+// y[r][0..R) for rows r = gw, gw + W, ...; the first block (rows gw + j W, k < CU * 512) was requested by ct_rows_issue
+template <int R, int RU, int CU, typename Epi>
+__device__ __forceinline__ void ct_rows(CtPre<RU, CU>& pre, const float* w, int N, int K, const float* xs, int gw, int W, int lane, Epi epi) {
+    for (int r0 = gw; r0 < N; r0 += RU * W) {
+        float acc[RU][R];
+#pragma unroll
+        for (int j = 0; j < RU; ++j)
+#pragma unroll
+            for (int b = 0; b < R; ++b) acc[j][b] = 0.f;
+        for (int kb = 0; kb < K; kb += CU * 512) {
+            if (r0 != gw || kb != 0) ct_rows_load<RU, CU>(pre, w, N, K, r0, kb, W, lane);
+#pragma unroll
+            for (int c = 0; c < CU; ++c) {
+                const int kk = kb + c * 512 + lane * 8;
+                if (kk < K) {
+#pragma unroll
+                    for (int b = 0; b < R; ++b) {
+                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + b * K + kk);
+                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs + b * K + kk + 4);
+#pragma unroll
+                        for (int j = 0; j < RU; ++j) {
+                            const f32x4 a0 = pre.wv[j][c][0], a1 = pre.wv[j][c][1];
+                            float a = acc[j][b];
+                            a = fmaf(a0[0], x0[0], a); a = fmaf(a0[1], x0[1], a); a = fmaf(a0[2], x0[2], a); a = fmaf(a0[3], x0[3], a);
+                            a = fmaf(a1[0], x1[0], a); a = fmaf(a1[1], x1[1], a); a = fmaf(a1[2], x1[2], a); a = fmaf(a1[3], x1[3], a);
+                            acc[j][b] = a;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RU; ++j) {
+            const int r = r0 + j * W;
+            float s[R];
+#pragma unroll
+            for (int b = 0; b < R; ++b) s[b] = wave_sum(acc[j][b]);
+            if (lane == 0 && r < N) epi(r, s);
+        }
+    }
+}
+
+// nn.LayerNorm(E, eps) with affine gamma / beta over every row of x [R][E] -> xs (two-pass statistics, biased variance: the
+// arithmetic of gemv_kernel's prologue 3)
+template <int R>
+__device__ __forceinline__ void ct_layernorm(const float* x, const float* gamma, const float* beta, float eps, int E, float* xs, DfShared& sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int b = 0; b < R; ++b) {
+        float s = 0.f;
+        for (int i = tid; i < E; i += DF_THREADS) s += x[b * E + i];
+        s = wave_sum(s);
+        __syncthreads();
+        if (lane == 0) sh.red[wave] = s;
+        __syncthreads();
+        const float mean = (sh.red[0] + sh.red[1] + sh.red[2] + sh.red[3]) / (float)E;
+        float v = 0.f;
+        for (int i = tid; i < E; i += DF_THREADS) { const float d = x[b * E + i] - mean; v = fmaf(d, d, v); }
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) sh.red[wave] = v;
+        __syncthreads();
+        const float var = sh.red[0] + sh.red[1] + sh.red[2] + sh.red[3];
+        const float rstd = 1.0f / sqrtf(var / (float)E + eps);
+        for (int i = tid; i < E; i += DF_THREADS) xs[b * E + i] = (x[b * E + i] - mean) * rstd * gamma[i] + beta[i];
+    }
+    __syncthreads();
+}
+
+template <int R>
+__global__ __launch_bounds__(DF_THREADS) void codec_tr_kernel(const CodecTrParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    DfShared& sh = *reinterpret_cast<DfShared*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wg = blockIdx.x, G = gridDim.x;
+    const int gw = wg * DF_WAVES + wave, W = G * DF_WAVES;
+    const int E = p.E, F = p.F, D = p.D, H = p.H, T = p.T, cap = p.cap;
+    const int XW = E > F ? E : F;
+    // LDS carve (floats): header | xs [R][max(E, F)] | xres [R][E] | qh [T][3][D]
+    float* xs = lds + DF_HDR_FLOATS;
+    float* xres = xs + R * XW;
+    float* qh = xres + R * E;
+    u64* gX = p.gran;
+    u64* gQKV = gX + (long)R * E;
+    u64* gATT = gQKV + (long)R * 3 * E;
+    u64* gH = gATT + (long)R * E;
+    if (tid == 0) sh.dead = 0;
+    CtPre<2, 1> pq;         // in-projection rows of this wave
+    CtPre<1, 1> po;         // out-projection
+    CtPre<2, 1> p1;         // linear1
+    CtPre<1, 4> p2;         // linear2
+    ct_rows_issue<2, 1>(pq, p.in_proj[0], 3 * E, E, gw, W, lane);
+    for (int i = tid; i < R * E; i += DF_THREADS) xres[i] = p.x[i];
+    const long pos = *p.pos_dev;
+    __syncthreads();
+    unsigned eX = 0, eQKV = 0, eATT = 0, eH = 0;
+
+    for (int l = 0; l < p.L; ++l) {
+        // ---- in-projection of the normed rows
+        ct_layernorm<R>(xres, p.n1g[l], p.n1b[l], p.eps, E, xs, sh);
+        ++eQKV;
+        ct_rows<R, 2, 1>(pq, p.in_proj[l], 3 * E, E, xs, gw, W, lane, [&](int r, float (&s)[R]) {
+#pragma unroll
+            for (int b = 0; b < R; ++b) df_publish(gQKV + (long)b * 3 * E + r, eQKV, s[b]);
+        });
+        ct_rows_issue<1, 1>(po, p.out_proj[l], E, E, gw, W, lane);
+        // ---- attention of (stream, head) = workgroup index
+        ++eATT;
+        if (wg < p.B * H) {
+            const int b = wg / H, h = wg - b * H;
+            // q / k / v of the head for the T new steps of stream b: item i = (t, part, d)
+            df_gather<2>(gQKV, T * 3 * D, eQKV, qh, [&](int i) { const int t = i / (3 * D), j = i - t * 3 * D, part = j / D;
+                                                              return ((long)(b * T + t) * 3 + part) * E + h * D + (j - part * D); }, sh, p.status, 2u);
+            // interleaved RoPE on q and k at position pos + t (modules/rope.py:37-62), then the ring append
+            for (int i = tid; i < T * D; i += DF_THREADS) {      // item = (t, which in {q, k}, pair)
+                const int t = i / D, j = i - t * D, which = j / (D / 2), pr = j - which * (D / 2);
+                if (p.rope) {
+                    const float ang = expf((float)pr * p.rope_coef) * ((float)pos + (float)t);
+                    const float c = cosf(ang), sn = sinf(ang);
+                    float* v2 = qh + (t * 3 + which) * D + 2 * pr;
+                    const float re = v2[0], im = v2[1];
+                    v2[0] = re * c - im * sn;
+                    v2[1] = re * sn + im * c;
+                }
+            }
+            __syncthreads();
+            float* kring = p.kc[l] + ((long)(b * H + h) * cap) * D;
+            float* vring = p.vc[l] + ((long)(b * H + h) * cap) * D;
+            for (int i = tid; i < T * D; i += DF_THREADS) {
+                const int t = i / D, d = i - t * D;
+                const int slot = (int)((pos + t) % cap);
+                kring[(long)slot * D + d] = qh[(t * 3 + 1) * D + d];
+                vring[(long)slot * D + d] = qh[(t * 3 + 2) * D + d];
+            }
+            // one wave per query: lane group `grp` (LPS = D / 16 lanes, 16 dims each) owns slot s0 + grp of a pass
+            if (wave < T) {
+                const int t = wave;
+                const int LPS = D >> 4, SPW = 64 / LPS;
+                const int sub = lane % LPS, grp = lane / LPS;
+                const long pos_q = pos + t, end_offset = pos + T;
+                const int n_used = (int)min((long)cap, end_offset);
+                const float scale = 1.0f / sqrtf((float)D);
+                float q[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) q[i] = qh[(t * 3) * D + sub * 16 + i];
+                float m_run = -INFINITY, l_run = 0.f, o[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[i] = 0.f;
+                for (int s0 = 0; s0 < n_used; s0 += SPW) {
+                    const int slot = s0 + grp;
+                    const bool ok = slot < n_used && ring_visible(slot, pos_q, cap, p.context, end_offset);
+                    float kv[16], vv[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { kv[i] = 0.f; vv[i] = 0.f; }
+                    // a slot written by this very step comes from LDS (the stores above may not have landed for this wave's loads)
+                    int tn = -1;
+                    for (int t2 = 0; t2 < T; ++t2) tn = (int)((pos + t2) % cap) == slot ? t2 : tn;
+                    if (ok && tn >= 0) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { kv[i] = qh[(tn * 3 + 1) * D + sub * 16 + i]; vv[i] = qh[(tn * 3 + 2) * D + sub * 16 + i]; }
+                    } else if (ok) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 k4 = *reinterpret_cast<const f32x4*>(kring + (long)slot * D + sub * 16 + 4 * i);
+                            const f32x4 v4 = *reinterpret_cast<const f32x4*>(vring + (long)slot * D + sub * 16 + 4 * i);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { kv[4 * i + e] = k4[e]; vv[4 * i + e] = v4[e]; }
+                        }
+                    }
+                    float d = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) d = fmaf(kv[i], q[i], d);
+                    for (int off = LPS / 2; off > 0; off >>= 1) d += __shfl_xor(d, off);
+                    const float sc = ok ? d * scale : -INFINITY;
+                    const float m_new = fmaxf(m_run, sc);
+                    if (m_new != -INFINITY) {
+                        const float alpha = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
+                        const float pw = sc == -INFINITY ? 0.f : expf(sc - m_new);
+                        l_run = l_run * alpha + pw;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) o[i] = o[i] * alpha + pw * vv[i];
+                        m_run = m_new;
+                    }
+                }
+                // merge the lane groups of the wave (same `sub`)
+                float m_w = m_run;
+                for (int off = LPS; off < 64; off <<= 1) m_w = fmaxf(m_w, __shfl_xor(m_w, off));
+                const float f = (m_run == -INFINITY) ? 0.f : expf(m_run - m_w);
+                float l_w = l_run * f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[i] *= f;
+                for (int off = LPS; off < 64; off <<= 1) {
+                    l_w += __shfl_xor(l_w, off);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[i] += __shfl_xor(o[i], off);
+                }
+                if (grp == 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        df_publish(gATT + (long)(b * T + t) * E + h * D + sub * 16 + i, eATT, l_w > 0.f ? o[i] / l_w : 0.f);
+                }
+            }
+        }
+        // ---- out-projection, LayerScale, residual
+        df_gather<4>(gATT, R * E, eATT, xs, [](int i) { return i; }, sh, p.status, 4u);
+        ++eX;
+        ct_rows<R, 1, 1>(po, p.out_proj[l], E, E, xs, gw, W, lane, [&](int r, float (&s)[R]) {
+            const float sc1 = p.ls1[l] ? p.ls1[l][r] : 1.0f;
+#pragma unroll
+            for (int b = 0; b < R; ++b) df_publish(gX + (long)b * E + r, eX, xres[b * E + r] + sc1 * s[b]);
+        });
+        ct_rows_issue<2, 1>(p1, p.lin1[l], F, E, gw, W, lane);
+        df_gather<4>(gX, R * E, eX, xres, [](int i) { return i; }, sh, p.status, 8u);
+        // ---- FFN: x + scale2 * W2 gelu(W1 LN(x))
+        ct_layernorm<R>(xres, p.n2g[l], p.n2b[l], p.eps, E, xs, sh);
+        ++eH;
+        ct_rows<R, 2, 1>(p1, p.lin1[l], F, E, xs, gw, W, lane, [&](int r, float (&s)[R]) {
+#pragma unroll
+            for (int b = 0; b < R; ++b) df_publish(gH + (long)b * F + r, eH, rst_gelu(s[b]));
+        });
+        ct_rows_issue<1, 4>(p2, p.lin2[l], E, F, gw, W, lane);
+        df_gather<8>(gH, R * F, eH, xs, [](int i) { return i; }, sh, p.status, 16u);
+        ++eX;
+        ct_rows<R, 1, 4>(p2, p.lin2[l], E, F, xs, gw, W, lane, [&](int r, float (&s)[R]) {
+            const float sc2 = p.ls2[l] ? p.ls2[l][r] : 1.0f;
+#pragma unroll
+            for (int b = 0; b < R; ++b) df_publish(gX + (long)b * E + r, eX, xres[b * E + r] + sc2 * s[b]);
+        });
+        if (l + 1 < p.L) ct_rows_issue<2, 1>(pq, p.in_proj[l + 1], 3 * E, E, gw, W, lane);
+        df_gather<4>(gX, R * E, eX, xres, [](int i) { return i; }, sh, p.status, 32u);
+    }
+    if (wg == 0)
+        for (int i = tid; i < R * E; i += DF_THREADS) p.y[i] = xres[i];
+}
+
+int ct_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+}  // namespace
+
+long rst_codec_tr_workspace_granules(int R, int E, int F) { return (long)R * (5L * E + F); }
+
+int rst_launch_codec_tr(const CodecTrParams& p, hipStream_t stream) {
+    const int R = p.B * p.T;
+    RST_REQUIRE(p.B >= 1 && p.T >= 1 && p.T <= DF_WAVES && R <= 4, "codec_tr: %d streams x %d new positions (at most 4 rows, 4 positions)", p.B, p.T);
+    RST_REQUIRE(p.E > 0 && p.E % 8 == 0 && p.F > 0 && p.F % 8 == 0 && p.H > 0 && p.D >= 16 && p.D % 16 == 0 && p.D <= 256 && p.H * p.D == p.E &&
+                    (64 % (p.D / 16)) == 0 && p.L >= 1 && p.L <= RST_CTR_MAX_L && p.cap >= p.T,
+                "codec_tr: unsupported shape (E=%d F=%d H=%d D=%d L=%d cap=%d)", p.E, p.F, p.H, p.D, p.L, p.cap);
+    RST_REQUIRE(p.x && p.y && p.pos_dev && p.gran && p.status, "codec_tr: null buffers");
+    for (int l = 0; l < p.L; ++l)
+        RST_REQUIRE(p.in_proj[l] && p.out_proj[l] && p.lin1[l] && p.lin2[l] && p.n1g[l] && p.n1b[l] && p.n2g[l] && p.n2b[l] && p.kc[l] && p.vc[l],
+                    "codec_tr: layer %d pointers", l);
+    const int G = ct_cu_count();
+    RST_REQUIRE(p.B * p.H <= G, "codec_tr: %d (stream, head) pairs > %d workgroups", p.B * p.H, G);
+    const int XW = p.E > p.F ? p.E : p.F;
+    const size_t lds = ((size_t)DF_HDR_FLOATS + (size_t)R * XW + (size_t)R * p.E + (size_t)p.T * 3 * p.D) * sizeof(float);
+    RST_REQUIRE(lds <= 150 * 1024, "codec_tr: %zu bytes of LDS", lds);
+    if (hipMemsetAsync(p.gran, 0, (size_t)rst_codec_tr_workspace_granules(R, p.E, p.F) * 8, stream) != hipSuccess) {
+        rst_set_error("codec_tr: workspace memset failed");
+        return RST_ERR_LAUNCH;
+    }
+    auto go = [&](auto kern) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipGetLastError();
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(G), dim3(DF_THREADS), lds, stream, p);
+    };
+    switch (R) {
+        case 1: go(codec_tr_kernel<1>); break;
+        case 2: go(codec_tr_kernel<2>); break;
+        case 3: go(codec_tr_kernel<3>); break;
+        default: go(codec_tr_kernel<4>); break;
+    }
+    return rst_check_launch("codec_tr");
+}

@@ -266,6 +266,32 @@ struct DepthFrameParams {
 long rst_depth_frame_workspace_granules(int B, int E, int Hd, int card);
 int rst_launch_depth_frame(const DepthFrameParams& p, hipStream_t stream);
 
+// ---- codec_tr.hip: one streaming step of a Mimi transformer (all layers) as one persistent launch
+#define RST_CTR_MAX_L 8
+struct CodecTrParams {
+    const float* in_proj[RST_CTR_MAX_L];    // fp32 [3E][E]
+    const float* out_proj[RST_CTR_MAX_L];   // fp32 [E][E]
+    const float* lin1[RST_CTR_MAX_L];       // fp32 [F][E]
+    const float* lin2[RST_CTR_MAX_L];       // fp32 [E][F]
+    const float* n1g[RST_CTR_MAX_L];        // LayerNorm gamma / beta [E]
+    const float* n1b[RST_CTR_MAX_L];
+    const float* n2g[RST_CTR_MAX_L];
+    const float* n2b[RST_CTR_MAX_L];
+    const float* ls1[RST_CTR_MAX_L];        // LayerScale [E] or nullptr
+    const float* ls2[RST_CTR_MAX_L];
+    float* kc[RST_CTR_MAX_L];               // KV rings [B][H][cap][D] (the new steps are appended)
+    float* vc[RST_CTR_MAX_L];
+    const float* x;                         // [B][T][E]
+    float* y;                               // [B][T][E]
+    const long* pos_dev;                    // position of the first new step (device scalar)
+    unsigned long long* gran;               // rst_codec_tr_workspace_granules(B * T, E, F) 8-byte words
+    unsigned* status;
+    int B, T, E, H, D, F, L, cap, context, rope;
+    float rope_coef, eps;
+};
+long rst_codec_tr_workspace_granules(int R, int E, int F);
+int rst_launch_codec_tr(const CodecTrParams& p, hipStream_t stream);
+
 // ---- lm_ring.hip: LMGen's token ring / delay pattern
 struct LmRingParams {
     long* cache;                // [B][K][CT] int64

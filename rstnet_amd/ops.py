@@ -946,11 +946,67 @@ def depth_decode_frame(tables, h_all: torch.Tensor, tokens: torch.Tensor, noise:
         int(context) if context else 0, int(ring_cap) if ring_cap else t.dep_q, _stream()))
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# One streaming step of a Mimi transformer as ONE persistent launch (rst_codec_transformer_frame)
+# ----------------------------------------------------------------------------------------------------------------------
+_ctr_ws: dict = {}
+_ctr_status: dict = {}
+
+
+def codec_transformer_frame_supported(B: int, T: int, E: int, H: int, F: int, L: int, cap: int) -> bool:
+    """Shapes the persistent launch serves (else the launch-per-op layer loop runs): at most 4 rows and 4 new positions, <= 8
+    layers, head dim a multiple of 16 that divides 1024."""
+    if not (depth_frame_enabled() and B >= 1 and 1 <= T <= 4 and B * T <= 4 and E % 8 == 0 and F % 8 == 0 and H >= 1 and E % H == 0):
+        return False
+    D = E // H
+    return 1 <= L <= 8 and D % 16 == 0 and D <= 256 and 64 % (D // 16) == 0 and cap >= T and B * H <= 64 and \
+        4 * (512 + B * T * max(E, F) + B * T * E + T * 3 * D) <= 150 * 1024
+
+
+def codec_transformer_status(device) -> torch.Tensor:
+    """The device status word the persistent codec-transformer launches of ``device`` OR their time-out codes into (0 = all fine)."""
+    st = _ctr_status.get(device)
+    if st is None:
+        st = _ctr_status[device] = torch.zeros(1, device=device, dtype=torch.int32)
+    return st
+
+
+def codec_transformer_frame(x: torch.Tensor, layers: Sequence[dict], pos_dev: torch.Tensor, *, H: int, context: Optional[int], rope: bool,
+                            max_period: float, eps: float) -> torch.Tensor:
+    """x fp32 ``[B, T, E]`` (the new positions of every stream) -> ``[B, T, E]`` through all ``layers``: each a dict of fp32 device
+    tensors ``in_proj [3E, E], out_proj [E, E], linear1 [F, E], linear2 [E, F], norm1_w/b, norm2_w/b [E], scale1/scale2 [E] or None,
+    k_cache / v_cache [B, H, cap, D]`` (rings: the new steps are appended).  ``pos_dev``: int64 device scalar, position of x[:, 0]."""
+    _chk(x, "x")
+    _chk(pos_dev, "pos_dev", torch.int64)
+    B, T, E = x.shape
+    L = len(layers)
+    F_ = layers[0]["linear1"].shape[0]
+    cap = layers[0]["k_cache"].shape[2]
+    for ly in layers:
+        for name in ("in_proj", "out_proj", "linear1", "linear2", "norm1_w", "norm1_b", "norm2_w", "norm2_b", "k_cache", "v_cache"):
+            _chk(ly[name], name)
+        _chk(ly.get("scale1"), "scale1"); _chk(ly.get("scale2"), "scale2")
+
+    def table(name):
+        return (C.c_void_p * L)(*[_ptr(ly.get(name)) for ly in layers])
+    has_scale = layers[0].get("scale1") is not None
+    y = torch.empty_like(x)
+    ws = _scratch(_ctr_ws, x.device, (B * T, E, F_),
+                  lambda: torch.zeros(int(_lib.lib().rst_codec_transformer_workspace_bytes(B * T, E, F_)) // 8, device=x.device, dtype=torch.int64))
+    D = E // H
+    _lib.check(_lib.lib().rst_codec_transformer_frame(
+        table("in_proj"), table("out_proj"), table("linear1"), table("linear2"), table("norm1_w"), table("norm1_b"), table("norm2_w"),
+        table("norm2_b"), table("scale1") if has_scale else None, table("scale2") if has_scale else None, table("k_cache"), table("v_cache"),
+        _ptr(x), _ptr(y), _ptr(pos_dev), _ptr(ws), _ptr(codec_transformer_status(x.device)), B, T, E, H, F_, L, cap,
+        int(context) if context else 0, int(rope), rope_coef(max_period, D), float(eps), _stream()))
+    return y
+
+
 # every public entry point runs under the device guard of its first tensor argument
 for _name in ("skinny_f32_pack_weight", "gemm_win", "linear", "seanet_resblock", "layernorm", "rope_split", "attention", "rvq_pack",
               "rvq_search", "rvq_gather", "convtr_depthwise", "activation", "transpose12", "mask_tail", "hist_update", "gemv_bf16",
               "gemv_attn", "gemv_embed", "skinny_pack_weight", "skinny_pack_act", "gemm_skinny", "skinny_pack_weight_fp8", "gemm_skinny_fp8", "lm_gated_pair",
               "lm_linear", "embed_sum", "rmsnorm", "lm_rope_append", "lm_attn_decode", "lm_sample", "lm_ring_begin", "lm_ring_commit",
-              "depth_decode_frame"):
+              "depth_decode_frame", "codec_transformer_frame"):
     globals()[_name] = _on_tensor_device(globals()[_name])
 del _name

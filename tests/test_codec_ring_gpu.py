@@ -78,9 +78,12 @@ def test_projected_transformer_matches_reference_fixture():
     assert rel_err(y, O.projected_transformer(sd, "encoder_transformer", O.MimiConfig(), x)) < 1e-3
 
 
-@pytest.mark.parametrize("chunk", [2, 1, 5, 16])
-def test_projected_transformer_streamed_across_the_wrap(chunk):
-    """Streamed in chunks for 300 positions (the ring wraps at 250) vs the oracle's TransformerStream."""
+@pytest.mark.parametrize("chunk,persistent", [(2, True), (1, True), (2, False), (1, False), (5, True), (16, True)])
+def test_projected_transformer_streamed_across_the_wrap(chunk, persistent, monkeypatch):
+    """Streamed in chunks for 300 positions (the ring wraps at 250) vs the oracle's TransformerStream.  Chunks of 1 / 2 positions
+    (x 2 streams = 2 / 4 rows) run all 8 layers as ONE persistent launch (rst_codec_transformer_frame) unless RST_DEPTH_FRAME=0
+    selects the launch-per-op layer loop; longer chunks always take the loop."""
+    monkeypatch.setenv("RST_DEPTH_FRAME", "1" if persistent else "0")
     sd = synth.mimi_state_dict(cases.MIMI_SEED, layer_scale=cases.TRANSFORMER_LAYER_SCALE)
     model, tr = _transformer(sd)
     x = cases.transformer_input(batch=2)
@@ -94,6 +97,26 @@ def test_projected_transformer_streamed_across_the_wrap(chunk):
             y = tr(xc.to(DEV))[0]
             worst = max(worst, rel_err(y, ref))
     assert worst < 1e-3, worst
+    assert int(ops.codec_transformer_status(torch.device(DEV)).item()) == 0, "a hand-off of the persistent transformer launch timed out"
+
+
+def test_codec_transformer_frame_mixed_with_layer_loop():
+    """One session that alternates between the persistent launch (chunks of 2 positions) and the layer loop (a chunk of 7): both
+    append to the same rings and advance the same position counter."""
+    sd = synth.mimi_state_dict(cases.MIMI_SEED, layer_scale=cases.TRANSFORMER_LAYER_SCALE)
+    model, tr = _transformer(sd, "decoder_transformer")
+    x = cases.transformer_input(batch=1, frames=40)
+    ts = O.TransformerStream(sd, "decoder_transformer", O.MimiConfig(), 1)
+    worst, i = 0.0, 0
+    with tr.streaming(1):
+        for n in (2, 2, 7, 2, 1, 7, 2, 2, 3, 2, 4, 6):
+            xc = x[:, :, i:i + n].contiguous()
+            i += n
+            with torch.no_grad():
+                ref = ts.step(xc)
+            worst = max(worst, rel_err(tr(xc.to(DEV))[0], ref))
+    assert i == 40 and worst < 1e-3, worst
+    assert int(ops.codec_transformer_status(torch.device(DEV)).item()) == 0
 
 
 def test_mimi_long_stream_matches_moshi_fixture():
@@ -129,3 +152,4 @@ def test_mimi_long_stream_matches_moshi_fixture():
     assert excused <= n_near
     assert rel_err(wav[:, :, :1920 * 4], torch.from_numpy(g["wav_head"])) < 1e-3
     assert rel_err(wav[:, :, -1920 * tail:], torch.from_numpy(g["wav_tail"])) < 1e-3
+    assert int(ops.codec_transformer_status(torch.device(DEV)).item()) == 0
