@@ -938,12 +938,20 @@ def depth_decode_frame(tables, h_all: torch.Tensor, tokens: torch.Tensor, noise:
     ws = _scratch(_depth_ws, h_all.device, (B, t.E, t.Hd, t.card),
                   lambda: torch.zeros(int(_lib.lib().rst_depth_frame_workspace_bytes(B, t.E, t.Hd, t.card)) // 8, device=h_all.device,
                                       dtype=torch.int64))
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.lib().rst_depth_decode_frame(
         t.in_proj, t.out_proj, t.norm1, t.norm2, t.gate_in, t.gate_out, t.heads, t.head_bias, t.emb, t.emb_rows,
         _ptr(h_all), _ptr(tokens), _ptr(noise) if sampling else None, _ptr(limits), _ptr(ws), _ptr(t.status),
         B, t.E, t.H, t.Hd, t.card, t.dep_q, t.L, h_all.stride(0) if B > 1 else h_all.shape[1], tokens.stride(0) if B > 1 else tokens.shape[1],
         noise.stride(0) if (sampling and B > 1) else (noise.shape[1] if sampling else 0), int(top_k), int(sampling), float(temp), float(eps),
         int(context) if context else 0, int(ring_cap) if ring_cap else t.dep_q, _stream()))
+    if prof is not None:
+        e1.record()
+        n_w = t.dep_q * (t.L * (3 * t.E * t.E + t.E * t.E + 3 * t.Hd * t.E) + t.card * t.E)      # weight elements read once per frame
+        prof.append(("depth_frame", e0, e1, 2.0 * B * n_w, 2 * n_w + 4 * h_all.numel(), (B, t.dep_q, t.L)))
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -3,7 +3,7 @@
 #   bench JSON lines, rocprofv3 kernel traces (--kernel-trace --stats) and the two PMC passes (FETCH_SIZE / WRITE_SIZE) per
 #   workload.  The raw rocprof outputs are reduced on the box (tools/rocpd_summary.py, tools/pmc_traffic.py) to the small
 #   files that are then copied into profiles/ and committed; only those travel back (gpurun_out/ is capped at 64 MiB).
-TAG=${1:-r01f}
+TAG=${1:-r02}
 WHAT=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG
@@ -15,19 +15,21 @@ prof() { local n=$1; shift
   run "${n}_trace" rocprofv3 --kernel-trace --stats -d "$RAW/${n}_trace" -o t -- "$@"
   local db; db=$(find "$RAW/${n}_trace" -name "*.db" | head -1)
   [ -n "$db" ] && python tools/rocpd_summary.py "$db" "$O/${n}" | tail -1
-  NO_CUDA_GRAPH=1 run "${n}_fetch" rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$RAW/${n}_fetch" -o f -- "$@"
-  NO_CUDA_GRAPH=1 run "${n}_write" rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$RAW/${n}_write" -o w -- "$@"
+  # counter passes: eager launches, and the launch-per-op depth phase (the persistent frame kernels need every CU resident at once,
+  # which a counter-collecting profiler does not promise; the traffic figures are those of the GEMV / GEMM kernels anyway)
+  RST_DEPTH_FRAME=0 NO_CUDA_GRAPH=1 run "${n}_fetch" rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$RAW/${n}_fetch" -o f -- "$@"
+  RST_DEPTH_FRAME=0 NO_CUDA_GRAPH=1 run "${n}_write" rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$RAW/${n}_write" -o w -- "$@"
   local fc wc; fc=$(find "$RAW/${n}_fetch" -name "*counter_collection.csv" | head -1); wc=$(find "$RAW/${n}_write" -name "*counter_collection.csv" | head -1)
   [ -n "$fc" ] && [ -n "$wc" ] && python tools/pmc_traffic.py "$fc" "$wc" "$O/${n}_pmc_traffic.json" | head -6
   rm -f "$O/${n}_trace.out" "$O/${n}_fetch.out" "$O/${n}_write.out"
 }
 if [ "$WHAT" = all ] || [ "$WHAT" = codec ]; then
-  run codec_bench python bench.py --steps 5 --warmup 2 --check
-  prof codec python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+  run codec_bench python bench.py --steps 20 --warmup 5
+  prof codec python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sub --no-check --timing-samples 1
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = codec ] || [ "$WHAT" = mfma ]; then
   # MFMA-pipe busy cycles of the codec step (its own PMC pass; tools/pmc_mfma.py)
-  NO_CUDA_GRAPH=1 run codec_mfma rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$RAW/codec_mfma" -o m -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline
+  NO_CUDA_GRAPH=1 run codec_mfma rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$RAW/codec_mfma" -o m -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-sub --no-check --timing-samples 1
   mc=$(find "$RAW/codec_mfma" -name "*counter_collection.csv" | head -1)
   [ -n "$mc" ] && python tools/pmc_mfma.py "$mc" "$O/codec_mfma.json" | head -8
   rm -f "$O/codec_mfma.out"
@@ -36,17 +38,21 @@ if [ "$WHAT" = all ] || [ "$WHAT" = lm ]; then
   run lm_bench python bench.py --workload lm --steps 60 --warmup 5
   run lm_ctx3000_bench python bench.py --workload lm --steps 60 --warmup 5 --lm-context 3000 --no-cpu-baseline
   run lm32_bench python bench.py --workload lm --lm-batch 32 --steps 30 --warmup 5 --no-cpu-baseline
-  prof lm python bench.py --workload lm --steps 6 --warmup 2 --no-cpu-baseline
+  prof lm python bench.py --workload lm --steps 6 --warmup 2 --no-cpu-baseline --timing-samples 2
+  db=$(find "$RAW/lm_trace" -name "*.db" | head -1); [ -n "$db" ] && python tools/frame_timeline.py "$db" "$O/lm_timeline.csv" lm_ring_begin_kernel 2
+  BENCH_DEPTH_CHAINS=1 python tools/bench_depth.py 2>&1 | grep -v amdgpu > "$O/depth_phase.txt"
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = gpt ]; then
   run gpt_bench python bench.py --workload gpt --steps 40 --warmup 5
+  run gpt1_bench python bench.py --workload gpt --lm-batch 1 --steps 60 --warmup 5 --no-cpu-baseline
   prof gpt python bench.py --workload gpt --steps 6 --warmup 2 --no-cpu-baseline
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = e2e ]; then
   run e2e1_bench python bench.py --workload e2e --lm-batch 1 --steps 60 --warmup 6
   run e2e32_bench python bench.py --workload e2e --lm-batch 32 --steps 30 --warmup 5
-  run e2e1_trace rocprofv3 --kernel-trace --stats -d "$RAW/e2e1_trace" -o t -- python bench.py --workload e2e --lm-batch 1 --steps 30 --warmup 4
+  run e2e1_trace rocprofv3 --kernel-trace --stats -d "$RAW/e2e1_trace" -o t -- python bench.py --workload e2e --lm-batch 1 --steps 30 --warmup 4 --no-cpu-baseline --timing-samples 2
   db=$(find "$RAW/e2e1_trace" -name "*.db" | head -1); [ -n "$db" ] && python tools/rocpd_summary.py "$db" "$O/e2e1" | tail -1
+  [ -n "$db" ] && python tools/frame_timeline.py "$db" "$O/e2e1_timeline.csv" lm_ring_begin_kernel 2
   rm -f "$O/e2e1_trace.out"
 fi
 du -sh "$O"; ls "$O"
