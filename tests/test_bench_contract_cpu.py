@@ -54,7 +54,23 @@ def test_default_workload_line_has_roofline_and_cpu_baseline():
     d = _last_json(os.path.join(ROOT, "profiles", f"{TAG}_codec_bench.json"))
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["peak"] == 157.3 and d["dtype"] == "f32"
     assert d["cpu_baseline"]["kind"] == "port" and "configs[1]" in d["config"]["workload"]
-    assert d["code_exact_match_vs_cpu_oracle"] == 1.0
+    assert d["code_exact_match_vs_cpu_oracle"] == 1.0 and d["wav_rel_err_vs_cpu_oracle"] < 1e-3      # the parity sample rides on the default line
+    assert d["timing"]["samples"] >= 50 and d["timing"]["median_ms"] <= d["timing"]["p95_ms"]
+
+
+def test_default_line_carries_the_north_star_sub_benchmarks():
+    """the driver-run line times the batch-1 LM step and the batch-1 end-to-end frame too, each with its own
+    roofline and CPU baseline, median + p95 over >= 50 frames."""
+    d = _last_json(os.path.join(ROOT, "profiles", f"{TAG}_codec_bench.json"))
+    for key, what in (("lm_b1", "configs[2]"), ("e2e_b1", "configs[3]")):
+        sub = d[key]
+        assert what in sub["config"]["workload"] and sub["unit"] == "frames/s" and sub["value"] > 0
+        assert sub["timing"]["samples"] >= 50 and sub["steps"] >= 50 and sub["ms_per_step"] > 0
+        r = sub["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+        c = sub["cpu_baseline"]
+        assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert d["e2e_b1"]["x_realtime_per_stream"] >= 10.0            # the north-star target: >= 10x real time end to end at batch 1
 
 
 # ---- host logic of bench.py itself (no GPU needed)
