@@ -302,9 +302,11 @@ int rst_gemm_skinny_fp8_f32(const uint8_t* xp, const float* xscale, const uint8_
                             const float* bias, float* y, int B, int N, int K, int ldy, rst_stream_t stream);
 
 /* out[b] = (add ? add[b] : 0) + sum_i table_i[tokens[b][tok_index[i]]]: the ScaledEmbedding sums of
- * LMModel.forward_text / forward_depformer (models/model.py:67-91, 372-380, 413-419): id -1 -> zero row, ids clamped
- * at 0, tables bf16 [rows][D], summed in table order in fp32.  `tables` / `tok_index` are HOST arrays (n_tables <= 24). */
-int rst_embed_sum_bf16(const int64_t* tokens, const uint16_t* const* tables, const int* tok_index, int n_tables,
+ * LMModel.forward_text / forward_depformer (models/model.py:67-91, 372-380, 413-419): id -1 -> zero row; tables bf16
+ * [rows][D], summed in table order in fp32.  Ids outside a table are clamped into it (other negative ids -> row 0, ids >=
+ * table_rows[i] -> the last row; the reference's F.embedding raises -- use LMGen(check=True) for that behaviour; table_rows
+ * may be NULL: no upper check).  `tables` / `tok_index` / `table_rows` are HOST arrays (n_tables <= 24). */
+int rst_embed_sum_bf16(const int64_t* tokens, const uint16_t* const* tables, const int* tok_index, const int* table_rows, int n_tables,
                        const float* add, float* out, int B, int D, int tok_stride, rst_stream_t stream);
 
 /* RMSNorm rows (rms_norm_f32, modules/transformer.py:34-46): out_norm of LMModel.forward_text. */

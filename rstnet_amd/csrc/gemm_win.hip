@@ -265,6 +265,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 
                         __hip_atomic_store(wsb + (long)m * p.N + n, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
         }
+        // publish form: `sc1` write-through stores drained by every storing wave (asm wait), one relaxed agent-scope counter bump,
+        // `sc1` loads on the reading side -- valid without a fence pair per MI355X_MICROARCH.md (handoff-flag / splitk-seam rows)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {

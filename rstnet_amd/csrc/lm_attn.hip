@@ -260,6 +260,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     // counter; the LAST arriver of (b, h) reads the partials with agent-scope (L1-bypassing) loads, combines, and re-arms the
     // counter for the next launch.  No dispatch-order / placement assumption.
     __shared__ int sm_last;
+    // publish form: relaxed agent-scope stores are `sc1` write-through stores (they leave the XCD's L2), every storing wave drains
+    // them with the asm wait below (inline asm: the compiler cannot drop it), ONE lane then bumps the counter; the reader uses
+    // relaxed agent-scope (`sc1`, L1-bypassing) loads -- the "sc1 payload -> asm vmcnt(0) -> sc1 flag / sc1 loads" form that
+    // MI355X_MICROARCH.md lists as valid without a release / acquire fence pair (its cost rows: handoff-flag, splitk-seam).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {

@@ -417,7 +417,10 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(const EmbedSumParams p) 
         for (int i = 0; i < p.n_tables; ++i) {
             const long tok = p.tokens[(long)b * p.tok_stride + p.tok_index[i]];
             if (tok != -1) {
-                const long row = tok < 0 ? 0 : tok;
+                // ids outside the table are clamped into it (the reference's F.embedding raises; a kernel cannot, and must not
+                // read out of bounds): other negative ids -> row 0, ids >= rows -> the last row
+                long row = tok < 0 ? 0 : tok;
+                if (p.rows[i] > 0 && row >= p.rows[i]) row = p.rows[i] - 1;
                 s += __uint_as_float((unsigned)p.tables[i][row * p.D + d] << 16);
             }
         }

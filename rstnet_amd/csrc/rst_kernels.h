@@ -190,6 +190,7 @@ struct EmbedSumParams {
     const long* tokens;                          // [B][tok_stride]
     const unsigned short* tables[RST_MAX_TABLES];  // bf16 [rows][D]
     int tok_index[RST_MAX_TABLES];               // token column feeding table i
+    int rows[RST_MAX_TABLES];                    // rows of table i (ids are clamped into it; 0 = unknown: not checked)
     const float* add;                            // optional fp32 [B][D] added first
     float* out;                                  // [B][D]
     int B, D, n_tables, tok_stride;

@@ -770,8 +770,8 @@ def embed_sum(tokens: torch.Tensor, tables: Sequence[torch.Tensor], tok_index: S
     B, D = tokens.shape[0], tables[0].shape[1]
     out = torch.empty(B, D, device=tokens.device, dtype=torch.float32)
     tabs = (C.c_void_p * len(tables))(*[t.data_ptr() for t in tables])
-    _lib.check(_lib.lib().rst_embed_sum_bf16(_ptr(tokens), tabs, _int_array(list(tok_index)), len(tables), _ptr(add), _ptr(out), B, D,
-                                            tokens.shape[1], _stream()))
+    _lib.check(_lib.lib().rst_embed_sum_bf16(_ptr(tokens), tabs, _int_array(list(tok_index)), _int_array([t.shape[0] for t in tables]),
+                                            len(tables), _ptr(add), _ptr(out), B, D, tokens.shape[1], _stream()))
     return out
 
 

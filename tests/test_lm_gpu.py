@@ -135,6 +135,15 @@ def test_embed_sum_and_rmsnorm():
         e = L.scaled_embedding(tabs[i], toks[:, col])
         ref = e if ref is None else ref + e
     assert torch.equal(out.cpu(), ref)
+    # ids outside a table never read out of bounds: >= rows -> the last row, other negative ids -> row 0 (the reference raises)
+    bad = torch.tensor([[33, -5, 1000000, 0, 7], [2, 2, 2, 2, 2]])
+    out = ops.embed_sum(bad.to(DEV), [t.to(DEV) for t in tabs], [1, 2, 3, 4, 0])
+    clamped = torch.tensor([[32, 0, 32, 0, 7], [2, 2, 2, 2, 2]])
+    ref = None
+    for i, col in enumerate([1, 2, 3, 4, 0]):
+        e = L.scaled_embedding(tabs[i], clamped[:, col])
+        ref = e if ref is None else ref + e
+    assert torch.equal(out.cpu(), ref)
     x = torch.randn(3, 1000, generator=g)
     a = 1 + 0.1 * torch.randn(1000, generator=g)
     assert rel_err(ops.rmsnorm(x.to(DEV), a.to(DEV), 1e-8), L.rms_norm(x, a)) < 1e-6
