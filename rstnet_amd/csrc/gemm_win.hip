@@ -23,8 +23,46 @@ namespace {
 
 constexpr int BK = 32;
 
-template <int TM, int TN, int WM, int WN, bool VEC, bool ELU, int KB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 3 : 1, KB == 16 ? 3 : 2))) void gemm_win_kernel(const GemmWinParams p) {
+// ---- epilogue of one tile: bias -> GELU? -> (residual + scale *) -> ELU? -> store; 32 consecutive columns per half wave.
+// The residual loads of a 32 x 32 block are issued back to back (predicated, no branches) before any of them is consumed.
+template <int TM, int TN, bool FULL = false>
+__device__ __forceinline__ void gw_epilogue(const GemmWinParams& p, const f32x16 (&acc)[TM][TN], int m0w, int n0w, int M, int lane) {
+    // FULL: every row / column of the tile exists (the tile-streaming kernel's interior tiles) -- no predicates, no branches
+    const bool has_res = p.res != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0w + j * 32 + (lane & 31);
+        const bool n_ok = FULL || n < p.N;
+        const float bias = (p.bias && n_ok) ? p.bias[n] : 0.0f;
+        const float scale = (p.scale && n_ok) ? p.scale[n] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0w + i * 32 + 4 * (lane >> 5);
+            const long o = (long)mb * p.ldy + n;        // element e of the accumulator sits (e & 3) + 8 * (e >> 2) rows further down
+            float r[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int dm = (e & 3) + 8 * (e >> 2);
+                r[e] = (has_res && n_ok && (FULL || mb + dm < M)) ? p.res[o + (long)dm * p.ldy] : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int dm = (e & 3) + 8 * (e >> 2);
+                float v = acc[i][j][e] + bias;
+                if (p.act_out == 1) v = rst_gelu(v);
+                if (has_res) v = r[e] + scale * v;
+                if (p.act_out == 2) v = rst_elu(v);
+                if (n_ok && (FULL || mb + dm < M)) p.y[o + (long)dm * p.ldy] = v;
+            }
+        }
+    }
+}
+
+// One output tile, start to finish (staging coordinates, K loop, split-K reduction, epilogue).  FAST compiles the one-basic-block
+// K loop of interior tiles and the split-K protocol in; the tile-streaming kernel below calls it with FAST = false for the few
+// tiles that touch an utterance edge.
+template <int TM, int TN, int WM, int WN, bool VEC, bool ELU, int KB, bool FAST>
+__device__ __forceinline__ void gw_tile(const GemmWinParams& p, const int tile, const int m0, const int n0, float* smem) {
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
     constexpr int LDS_LD = KB + 4;      // floats per LDS row
@@ -32,7 +70,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 
     constexpr int RA = BM / RP;         // A rows staged per thread
     constexpr int RB = BN / RP;
     static_assert(BM % RP == 0 && BN % RP == 0, "tile smaller than one staging pass");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                     // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;   // [2][BN][LDS_LD]
 
@@ -40,16 +77,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-
-    // XCD-aware tile order: blocks that land on one XCD (bid % 8) walk consecutive tiles, n fastest, so
-    // the A rows they share stay in that XCD's L2.
-    const int nblk = gridDim.x;
-    const int bid = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int m0 = (tile / tiles_n) * BM;
-    const int n0 = (tile % tiles_n) * BN;
 
     const int M = p.B * p.T_out;
     const int TC = p.T_in * p.C;
@@ -169,8 +196,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 
 
     // split-K (few-row streaming steps): workgroup blockIdx.y owns k-tiles [kt0, kt1)
     const int nk_all = (p.K + KB - 1) / KB;
-    const int per_split = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int kt0 = blockIdx.y * per_split;
+    const int nsplit = FAST ? (int)gridDim.y : 1;
+    const int per_split = (nk_all + nsplit - 1) / nsplit;
+    const int kt0 = FAST ? blockIdx.y * per_split : 0;
     const int nk = min(nk_all, kt0 + per_split);
     if (kt0 < nk) {
         load_tiles(kt0);
@@ -205,10 +233,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 
     // first / last tile of an utterance): the K loop is ONE basic block of unconditional 16-byte loads, so the scheduler can
     // spread the global loads and the LDS writes of the next k-tile between the MFMAs of this one instead of running them
     // as separate phases with the matrix pipe idle.
-    bool interior = VEC && gridDim.y == 1 && m0 + BM <= M && n0 + BN <= p.N && p.K % KB == 0;
+    bool interior = FAST && VEC && gridDim.y == 1 && m0 + BM <= M && n0 + BN <= p.N && p.K % KB == 0;
 #pragma unroll
     for (int j = 0; j < RA; ++j) interior = interior && a_klo[j] == 0 && a_khi[j] == p.K;
-    if (__syncthreads_and(interior)) {
+    if (FAST && __syncthreads_and(interior)) {
         const float* ap[RA];
         const float* bp[RB];
 #pragma unroll
@@ -250,7 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 
 
     // ---- split-K reduction: write-through partials + arrival counter; the last workgroup of the tile sums them in a
     // fixed order (deterministic) and runs the epilogue (cdna_hip_programming.md G16, counter form)
-    if (gridDim.y > 1) {
+    if (FAST && gridDim.y > 1) {
         __shared__ int sm_last;
         float* wsb = p.ws + (long)blockIdx.y * M * p.N;
 #pragma unroll
@@ -293,33 +321,206 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 
         }
     }
 
-    // ---- epilogue: bias -> GELU? -> (residual + scale *) -> ELU? -> store; 32 consecutive columns per half wave.
-    // The residual loads of a tile are issued back to back (predicated, no branches) before any of them is consumed.
+    gw_epilogue<TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, M, lane);
+}
+
+// XCD-aware tile order: blocks that land on one XCD (bid % 8) walk consecutive tiles, n fastest, so the A rows they share stay
+// in that XCD's L2: XCD x owns tiles [xcd_first(x), xcd_first(x + 1)).
+__device__ __forceinline__ int gw_xcd_first(int tiles, int x) {
+    const int q = tiles >> 3, r = tiles & 7;
+    return x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+}
+
+template <int TM, int TN, int WM, int WN, bool VEC, bool ELU, int KB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 3 : 1, KB == 16 ? 3 : 2))) void gemm_win_kernel(const GemmWinParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tile = gw_xcd_first(gridDim.x, blockIdx.x & 7) + (blockIdx.x >> 3);
+    const int tiles_n = (p.N + 32 * TN * WN - 1) / (32 * TN * WN);
+    gw_tile<TM, TN, WM, WN, VEC, ELU, KB, true>(p, tile, (tile / tiles_n) * (32 * TM * WM), (tile % tiles_n) * (32 * TN * WN), smem);
+}
+
+// ---- tile-streaming form of the 128 x 128 configuration -------------------------------------------------------------------
+// The launches that carry the codec's FLOPs have 10^3 .. 10^5 tiles of 8 .. 192 k-tiles each; with one workgroup per tile the matrix
+// pipe idles through every tile's first load round trip, its index arithmetic, its epilogue and the dispatch of its successor,
+// and the workgroups of a CU (dispatched together, same K) go through those phases together.  Here a workgroup is resident
+// (two / three per CU) and walks its share of the tiles as ONE stream of k-tiles: the loads of the next tile's first k-tile are
+// issued under the MFMAs of this tile's last one and land in the free LDS buffer, so the only per-tile cost left is the
+// epilogue itself.  Tiles that touch an utterance edge (padding / history / ragged rows) take the general routine.
+template <bool ELU, int KB, int DBG = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 3 : 1, KB == 16 ? 3 : 2))) void gemm_win_stream_kernel(const GemmWinParams p, const int tiles) {
+    constexpr int TM = 2, TN = 2, WM = 2, WN = 2;
+    constexpr int BM = 128, BN = 128;
+    constexpr int LDS_LD = KB + 4;
+    constexpr int RP = 1024 / KB;
+    constexpr int RA = BM / RP, RB = BN / RP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDS_LD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = tid / (KB / 4);
+    const int lk = (tid % (KB / 4)) * 4;
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 4;
+
+    const int M = p.B * p.T_out;
+    const int TC = p.T_in * p.C;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nk = p.K / KB;                       // fast path only when K % KB == 0 (checked per tile)
+    const bool k_ok = p.K % KB == 0;
+
+    // this workgroup's tiles: XCD x owns a contiguous range, its resident workgroups stride through it together
+    const int xcd = blockIdx.x & 7;
+    const int first = gw_xcd_first(tiles, xcd);
+    const int count = gw_xcd_first(tiles, xcd + 1) - first;
+    const int stride = ((int)gridDim.x + 7 - xcd) >> 3;
+    int l = blockIdx.x >> 3;
+    if (l >= count) return;
+
+    struct Ctx {                     // staging pointers of a tile (this thread's RA rows of A, RB rows of W)
+        const float* ap[RA];
+        unsigned bo[RB];             // float offset from p.w
+    };
+    // staging pointers of a tile + "every window inside its utterance, full tile" (all threads vote: one barrier)
+    auto setup = [&](int m0, int n0, Ctx& c) -> bool {
+        bool interior = k_ok && m0 + BM <= M && n0 + BN <= p.N;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-        const bool n_ok = n < p.N;
-        const float bias = (p.bias && n_ok) ? p.bias[n] : 0.0f;
-        const float scale = (p.scale && n_ok) ? p.scale[n] : 1.0f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + (wm * TM + i) * 32;
-            float r[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + rst_mfma32_row(e, lane);
-                r[e] = (p.res && n_ok && m < M) ? p.res[(long)m * p.ldy + n] : 0.0f;
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + rst_mfma32_row(e, lane);
-                float v = acc[i][j][e] + bias;
-                if (p.act_out == 1) v = rst_gelu(v);
-                if (p.res) v = r[e] + scale * v;
-                if (p.act_out == 2) v = rst_elu(v);
-                if (n_ok && m < M) p.y[(long)m * p.ldy + n] = v;
-            }
+        for (int j = 0; j < RA; ++j) {
+            const int m = min(m0 + lrow + RP * j, M - 1);
+            const int b = m / p.T_out;
+            const int t = m - b * p.T_out;
+            const int f0 = (t * p.S - p.P) * p.C;
+            interior = interior && f0 >= 0 && f0 + p.K <= TC;
+            c.ap[j] = p.x + (long)b * p.x_bstride + f0 + lk;
         }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) c.bo[j] = (unsigned)min(n0 + lrow + RP * j, p.N - 1) * (unsigned)p.K + lk;
+        return __syncthreads_and(interior);
+    };
+
+    f32x4 ra[RA], rb[RB];
+    auto issue = [&](const Ctx& c, int kt) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) ra[j] = *reinterpret_cast<const f32x4*>(c.ap[j] + kt * KB);
+#pragma unroll
+        for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(p.w + c.bo[j] + kt * KB);
+    };
+    auto store_tiles = [&](int buf) {
+        float* a = As + buf * BM * LDS_LD;
+        float* b = Bs + buf * BN * LDS_LD;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            f32x4 v = ra[j];
+            if (ELU) {
+                v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]);
+            }
+            *reinterpret_cast<f32x4*>(a + (lrow + RP * j) * LDS_LD + lk) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+            *reinterpret_cast<f32x4*>(b + (lrow + RP * j) * LDS_LD + lk) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+    auto clear = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    };
+    auto mma_tile = [&](int buf, int ks0, int ks1) {
+        const float* a = As + buf * BM * LDS_LD + (wm * TM * 32 + frag_row) * LDS_LD + frag_k;
+        const float* b = Bs + buf * BN * LDS_LD + (wn * TN * 32 + frag_row) * LDS_LD + frag_k;
+#pragma unroll
+        for (int ks = ks0; ks < ks1; ++ks) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS_LD + ks * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS_LD + ks * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+    };
+    // One k-tile of the stream.  Registers hold the k-tile that follows the one in LDS (requested a whole step ago, so a loaded-HBM
+    // round trip of ~2 us is covered by a step's worth of the CU's MFMAs -- with the loads requested and consumed inside the same
+    // step the matrix pipe measured 11 % idle on them): they go to the other LDS buffer first, the registers are refilled with the
+    // k-tile after that (`c`, `kt`: possibly the next tile's), then the MFMAs of this k-tile run.
+    auto step = [&](const Ctx& c, int kt, int buf) {
+        if (DBG == 5) {      // MFMA only (ceiling measurement)
+#pragma unroll
+            for (int e = 0; e < 4 * (KB / 8); ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[0][e & 3], rb[0][e & 3], acc[i][j], 0, 0, 0);
+            return;
+        }
+        store_tiles(buf ^ 1);
+        if (DBG != 1) issue(c, kt);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(buf, 0, KB / 8);
+        __syncthreads();
+    };
+    // start of a run of interior tiles: k-tile 0 to LDS, k-tile 1 to the registers
+    auto prime = [&](const Ctx& c, int buf) {
+        issue(c, 0);
+        store_tiles(buf);
+        issue(c, 1);
+        __syncthreads();
+    };
+
+    Ctx c, cn;
+    int tile = first + l;
+    int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    bool fast = nk >= 2 && setup(m0, n0, c);
+    int buf = 0;
+    if (fast) prime(c, 0);
+    for (;;) {
+        const bool has_next = l + stride < count;
+        const int tile_n = tile + stride;
+        const int m0n = (tile_n / tiles_n) * BM, n0n = (tile_n % tiles_n) * BN;
+        bool fast_n = false;
+        if (fast) {
+            clear();
+            int lkt = 2;                 // k-tile the next request fetches
+            for (int kt = 0; kt < nk; ++kt) {
+                if (lkt == nk) {
+                    // the request stream crosses into the next tile: its pointers take the place of this tile's (before an edge
+                    // tile / at the end: harmless re-loads of this tile's first k-tiles)
+                    lkt = 0;
+                    if (has_next) {
+                        fast_n = setup(m0n, n0n, cn);
+                        if (fast_n) c = cn;
+                    }
+                }
+                step(c, lkt, buf);
+                ++lkt;
+                buf ^= 1;
+            }
+            gw_epilogue<TM, TN, true>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, M, lane);
+        } else {
+            gw_tile<TM, TN, WM, WN, true, ELU, KB, false>(p, tile, m0, n0, smem);
+            if (has_next) fast_n = nk >= 2 && setup(m0n, n0n, c);
+        }
+        if (!has_next) break;
+        if (fast_n && !fast) prime(c, buf);     // after a general tile
+        fast = fast_n;
+        l += stride;
+        tile = tile_n;
+        m0 = m0n;
+        n0 = n0n;
     }
 }
 
@@ -349,6 +550,46 @@ int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
     else if (vec) go(gemm_win_kernel<TM, TN, WM, WN, true, false, KB>);
     else if (elu) go(gemm_win_kernel<TM, TN, WM, WN, false, true, KB>);
     else go(gemm_win_kernel<TM, TN, WM, WN, false, false, KB>);
+    return rst_check_launch("gemm_win");
+}
+
+static int gw_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// the 128 x 128 configuration on 16-byte-aligned operands: resident workgroups streaming through the tiles
+template <int KB>
+int launch_stream(const GemmWinParams& p, long tiles, hipStream_t stream) {
+    if (tiles > 0x7fffffffL) {
+        rst_set_error("gemm_win: too many tiles (%ld)", tiles);
+        return RST_ERR_UNSUPPORTED;
+    }
+    const size_t lds = 2 * (128 + 128) * (KB + 4) * sizeof(float);
+    static const int per_cu_env = getenv("RST_GEMM_STREAM_WGS") ? atoi(getenv("RST_GEMM_STREAM_WGS")) : 0;
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (KB == 16 ? 3 : 2);
+    const long resident = (long)per_cu * gw_cu_count();
+    const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
+    auto go = [&](auto kern) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipGetLastError();
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p, (int)tiles);
+    };
+    static const int dbg = getenv("RST_GEMM_DBG") ? atoi(getenv("RST_GEMM_DBG")) : 0;
+    if (KB == 16 && dbg == 1) go(gemm_win_stream_kernel<false, 16, 1>);
+    else if (KB == 16 && dbg == 5) go(gemm_win_stream_kernel<false, 16, 5>);
+    else if (p.act_in == 1) go(gemm_win_stream_kernel<true, KB>);
+    else go(gemm_win_stream_kernel<false, KB>);
     return rst_check_launch("gemm_win");
 }
 
@@ -399,6 +640,12 @@ int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
             const long tiles = ((M + 127) / 128) * ((p.N + 127) / 128);
             // RST_GEMM_KB32 (any value) forces the 32-wide chunks: the calibration knob of the PMC traffic numbers
             static const bool kb32_only = getenv("RST_GEMM_KB32") != nullptr;
+            // RST_GEMM_STREAM=0: one workgroup per tile (the pre-streaming form, kept for A/B measurements)
+            static const bool stream_off = getenv("RST_GEMM_STREAM") && atoi(getenv("RST_GEMM_STREAM")) == 0;
+            if (vec && !stream_off && p.split_k <= 1) {
+                if (tiles >= 768 && !kb32_only) return launch_stream<16>(p, tiles, stream);
+                return launch_stream<32>(p, tiles, stream);
+            }
             if (tiles >= 768 && !kb32_only) return launch_cfg<2, 2, 2, 2, 16>(p, vec, stream);
             return launch_cfg<2, 2, 2, 2>(p, vec, stream);
         }

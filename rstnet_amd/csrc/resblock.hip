@@ -12,6 +12,8 @@
 // Both GEMMs run on v_mfma_f32_32x32x2_f32 with the b128 k-permutation of gemm_win.hip; W1 streams through a
 // double-buffered LDS ring, W2 is prefetched into registers during GEMM1 and parked in the LDS bytes of the
 // (then dead) input tile.
+#include <cstdlib>
+#include <type_traits>
 #include "rst_common.h"
 #include "rst_kernels.h"
 
@@ -42,8 +44,12 @@ struct Carve {
     }
 };
 
-template <int C, int BM, int WM, int WN, bool PRE, bool POST>
-__global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
+// One tile.  FULL: every row of the X tile and of the output tile lies inside the utterance (all but the first / last tile of an
+// utterance) -- no per-lane conditions, so no load or store sits in a branch of its own.  (A load under a per-lane condition is
+// branched around and waited for on the spot, a conditional store whose value needs a load waits for every outstanding memory
+// operation: the edge form of this kernel serialises ~9 HBM and ~32 L2 round trips plus its own stores per tile.)
+template <int C, int BM, int WM, int WN, bool PRE, bool POST, bool FULL>
+__device__ __forceinline__ void resblock_tile(const ResblockParams& p, float* smem, const long b, const int t0) {
     constexpr int H = C / 2;
     constexpr int XLD = C + 4, HLD = H + 4;
     constexpr int NT1 = H / 32 / WN;      // GEMM1 column tiles per wave
@@ -54,7 +60,6 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
     static_assert(BM == 32 * WM && WM * WN == 4 && NT1 >= 1 && W1CH >= 1 && W2CH >= 1, "tile config");
     static_assert(!POST || BM == 128, "the fused last conv maps two lanes to each of the BM output rows");
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const Carve<C, BM> cv(p.Kw, PRE, POST);
     float* Xs = smem;                    // [(BM+Kw-1)][XLD] ELU(x); later W2s [C][HLD] (+ Hs); later (POST) Ys [BM][XLD]
     float* Hs = smem + cv.hs_off;        // [BM][HLD]
@@ -67,10 +72,6 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const int Kw = p.Kw, T = p.T;
     const int halo = POST ? p.Kf - 1 : 0;
-    const int BMo = BM - halo;                         // output rows produced per tile
-    const int tiles = (T + BMo - 1) / BMo;
-    const long b = blockIdx.x / tiles;
-    const int t0 = (blockIdx.x % tiles) * BMo - halo;  // time of tile row 0
     const int XR = BM + Kw - 1;
 
     // ---- W2 prefetch (lands during GEMM1)
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
         const int tA0 = t0 - (Kw - 1) - (K0 - 1);
         for (int i = tid; i < BM + 24; i += 256) {   // the whole carve (incl. the tail read with zero weights) is defined
             const int t = tA0 + i;
-            As[i] = (i < XR + K0 - 1 && t >= 0 && t < T) ? p.x[b * T + t] : 0.f;
+            const float v = p.x[b * T + min(max(t, 0), T - 1)];
+            As[i] = (i < XR + K0 - 1 && (FULL || (t >= 0 && t < T))) ? v : 0.f;
         }
         for (int i = tid; i < C * K0; i += 256) W0s[(i / K0) * (MAXK0 + 1) + i % K0] = p.w0[i];
         __syncthreads();
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
                     float v = b0r;
 #pragma unroll
                     for (int k = 0; k < MAXK0; ++k) v = fmaf(w0r[k], av[q + k], v);
-                    if (rx < XR) Xs[rx * XLD + c] = (t >= 0 && t < T) ? rst_elu(v) : 0.f;
+                    if (rx < XR) Xs[rx * XLD + c] = (FULL || (t >= 0 && t < T)) ? rst_elu(v) : 0.f;
                 }
             }
         }
@@ -123,13 +125,16 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
             const int idx = tid + 256 * i;
             const int rx = idx / (C / 4), c4 = (idx - rx * (C / 4)) * 4;
             const int t = t0 - (Kw - 1) + rx;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (rx < XR) {
-                if (t >= 0) {
-                    if (t < T) v = *reinterpret_cast<const f32x4*>(p.x + (b * T + t) * C + c4);
-                } else if (p.hist && t >= -(Kw - 1)) {
-                    v = *reinterpret_cast<const f32x4*>(p.hist + (b * (Kw - 1) + (Kw - 1) + t) * C + c4);
-                }
+            f32x4 v;
+            if (FULL) {
+                v = *reinterpret_cast<const f32x4*>(p.x + (b * T + min(t, t0 + BM - 1)) * C + c4);     // rows past the tile: unused
+            } else {
+                // clamped address (x, or the streaming history for t < 0), zeroed afterwards where the row does not exist
+                const bool from_hist = p.hist && t < 0 && t >= -(Kw - 1);
+                const float* src = from_hist ? p.hist + (b * (Kw - 1) + (Kw - 1) + t) * C + c4
+                                             : p.x + (b * T + min(max(t, 0), T - 1)) * C + c4;
+                v = *reinterpret_cast<const f32x4*>(src);
+                if (!(rx < XR && ((t >= 0 && t < T) || from_hist))) v = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             xv[i] = v;
         }
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int t = t0 + wm * 32 + rst_mfma32_row(e, lane);
-                xres[j][e] = (t >= 0 && t < T) ? p.x[(b * T + t) * C + col] : 0.f;
+                xres[j][e] = p.x[(b * T + (FULL ? t : min(max(t, 0), T - 1))) * C + col];   // used only where the row exists
             }
         }
     }
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
         for (int e = 0; e < 16; ++e) {
             const int r = wm * 32 + rst_mfma32_row(e, lane);
             const int t = t0 + r;
-            const bool valid = t >= 0 && t < T;
+            const bool valid = FULL || (t >= 0 && t < T);
             float xr = 0.f;
             if (PRE) {
                 if ((e & 3) == 0) {   // rows e..e+3 of this lane are consecutive: one K0+3 window serves all four
@@ -310,9 +315,22 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
             s += __shfl_xor(s, 1);
             s += __shfl_xor(s, 2);
             const int t = t0 + r;
-            if (q == 0 && r < BM && t >= 0 && t < T) p.y[b * T + t] = s + p.bf[0];
+            if (q == 0 && r < BM && (FULL || (t >= 0 && t < T))) p.y[b * T + t] = s + p.bf[0];
         }
     }
+}
+
+template <int C, int BM, int WM, int WN, bool PRE, bool POST>
+__global__ __launch_bounds__(256) void resblock_kernel(const ResblockParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int halo = POST ? p.Kf - 1 : 0;
+    const int BMo = BM - halo;                         // output rows produced per tile
+    const int tiles = (p.T + BMo - 1) / BMo;
+    const long b = blockIdx.x / tiles;
+    const int t0 = (blockIdx.x % tiles) * BMo - halo;  // time of tile row 0
+    const bool full = t0 - (p.Kw - 1) - (PRE ? p.K0 - 1 : 0) >= 0 && t0 + BM <= p.T;
+    if (full) resblock_tile<C, BM, WM, WN, PRE, POST, true>(p, smem, b, t0);
+    else resblock_tile<C, BM, WM, WN, PRE, POST, false>(p, smem, b, t0);
 }
 
 template <int C, int BM, int WM, int WN, bool PRE, bool POST>
@@ -329,6 +347,311 @@ int launch(const ResblockParams& p, hipStream_t stream) {
         attr_set = true;
     }
     hipLaunchKernelGGL((resblock_kernel<C, BM, WM, WN, PRE, POST>), dim3((unsigned)tiles), dim3(256), lds, stream, p);
+    return rst_check_launch("resblock");
+}
+
+// ---- C = 64 (24 kHz level), Kw = 3: resident workgroups, weights in registers -----------------------------------------------
+// A tile of this level is only 128 MFMAs per wave (3.5 us of matrix pipe) between one HBM round trip for x, two weight stagings
+// and ~10 barriers, so the launch-per-tile form above spends most of its time in exposed latencies.  Here a workgroup is
+// resident (two per CU) and walks its tiles:
+//   * W1 (32 x 192) is loaded ONCE into registers as MFMA B fragments (96 VGPRs) and W2 (64 x 32) once into LDS: no weight
+//     traffic, no k-tile barriers -- GEMM1 is 24 A-fragment ds_reads + 96 MFMAs, GEMM2 12 reads + 32 MFMAs;
+//   * every load of a tile is unconditional (interior tiles: no per-lane conditions at all; edge tiles: clamped addresses) so
+//     they are all in flight at once -- a load under a per-lane condition is branched around and waited for on the spot;
+//   * a wave owns 32 rows through both GEMMs (WN = 1), so the hidden tile is wave-private: two workgroup barriers per tile
+//     (X tile staged / X tile free; the fused last conv parks ELU(y) in the freed X tile and adds one for its taps).
+constexpr int RS_C = 64, RS_H = 32, RS_BM = 128, RS_KW = 3, RS_LD = 68, RS_HLD = 36, RS_XR = RS_BM + RS_KW - 1, RS_MAXK0 = 8, RS_MAXKF = 4;
+constexpr int RS_XS = RS_XR * RS_LD;                 // ELU(x) tile; POST: ELU(y) tile after GEMM1
+constexpr int RS_HS = RS_BM * RS_HLD;                // hidden tile
+constexpr int RS_W2 = RS_C * RS_HLD;                 // W2 [C][H]
+constexpr int RS_AS = RS_BM + 24;                    // PRE: audio samples of a tile
+constexpr int RS_LDS_FLOATS = RS_XS + RS_HS + RS_W2 + RS_AS + RS_C * (RS_MAXK0 + 1) + RS_MAXKF * RS_C + RS_MAXKF * RS_BM;
+
+template <bool PRE, bool POST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void resblock64_stream_kernel(const ResblockParams p, const int tiles_u, const int total) {
+    constexpr int C = RS_C, LD = RS_LD, HLD = RS_HLD, BM = RS_BM, XR = RS_XR, KW = RS_KW;
+    constexpr int XCH = (XR * (C / 4) + 255) / 256;     // float4 chunks of the x tile per thread (9)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;
+    float* Hs = Xs + RS_XS;
+    float* W2s = Hs + RS_HS;
+    float* As = W2s + RS_W2;
+    float* W0s = As + RS_AS;                            // [C][MAXK0 + 1]
+    float* Wfs = W0s + C * (RS_MAXK0 + 1);              // [Kf][C]
+    float* Ds = Wfs + RS_MAXKF * C;                     // [Kf][BM] per-row tap dots of the fused last conv
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    const int T = p.T;
+    const int halo = POST ? p.Kf - 1 : 0;
+    const int BMo = BM - halo;
+    const int K0 = p.K0;
+
+    // ---- weights for the lifetime of the workgroup: W1 as B fragments in registers, W2 in LDS
+    f32x4 fb1[KW * C / 8];
+#pragma unroll
+    for (int ks = 0; ks < KW * C / 8; ++ks) fb1[ks] = *reinterpret_cast<const f32x4*>(p.w1 + frow * (KW * C) + ks * 8 + fk);
+    for (int i = tid; i < C * RS_H / 4; i += 256)
+        *reinterpret_cast<f32x4*>(W2s + (i >> 3) * HLD + (i & 7) * 4) = *reinterpret_cast<const f32x4*>(p.w2 + (size_t)i * 4);
+    const float bias1 = p.b1[frow];
+    const float bias2[2] = {p.b2[frow], p.b2[32 + frow]};
+    if (PRE)
+        for (int i = tid; i < C * K0; i += 256) W0s[(i / K0) * (RS_MAXK0 + 1) + i % K0] = p.w0[i];
+    if (POST)
+        for (int i = tid; i < p.Kf * C; i += 256) Wfs[i] = p.wf[i];
+
+    // ---- input requests of a tile (registers): x rows t0-2 .. t0+127, or the audio samples the fused first conv needs
+    f32x4 xv[PRE ? 1 : XCH];
+    auto request = [&](int idx) {
+        const long b = idx / tiles_u;
+        const int t0 = (idx - (int)b * tiles_u) * BMo - halo;
+        // Raw, unconditional loads from addresses clamped into the utterance; rows that do not exist are zeroed where the tile is
+        // staged (after a barrier, so the compiler cannot sink the load back under the condition: a load under a per-lane condition
+        // is waited for on the spot -- one exposed round trip per load).
+        if (PRE) {
+            const int t = t0 - (KW - 1) - (K0 - 1) + tid;
+            xv[0][0] = p.x[b * T + min(max(t, 0), T - 1)];
+        } else {
+#pragma unroll
+            for (int i = 0; i < XCH; ++i) {
+                const int ch = tid + 256 * i;
+                const int rx = ch >> 4, c4 = (ch & 15) * 4;
+                const int t = t0 - (KW - 1) + rx;
+                xv[i] = *reinterpret_cast<const f32x4*>(p.x + (b * T + min(max(t, 0), T - 1)) * C + c4);
+            }
+        }
+    };
+
+    // One tile.  FULL: every row of the X tile and of the output tile lies inside the utterance (all but the first and last tile
+    // of an utterance) -- no per-lane conditions anywhere, so no branches around loads / stores and counted waits only.
+    auto tile_body = [&](auto full_tag, const int idx, const long b, const int t0) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        request(idx);       // all of the tile's loads in flight at once (the other resident workgroup covers the round trip)
+
+        // ---- stage ELU(x) of this tile from the registers, then request the next tile's input
+        if (PRE) {
+            {
+                const int t = t0 - (KW - 1) - (K0 - 1) + tid;
+                if (tid < RS_AS) As[tid] = (tid < XR + K0 - 1 && (FULL || (t >= 0 && t < T))) ? xv[0][0] : 0.f;
+            }
+            __syncthreads();
+            // conv0 + ELU: a thread owns one channel (weights in registers) and walks groups of 4 consecutive rows
+            constexpr int G = 256 / C;
+            const int c = tid & (C - 1), g = tid / C;
+            float w0r[RS_MAXK0];
+#pragma unroll
+            for (int k = 0; k < RS_MAXK0; ++k) w0r[k] = k < K0 ? W0s[c * (RS_MAXK0 + 1) + k] : 0.f;
+            const float b0r = p.b0[c];
+            for (int rx0 = g * 4; rx0 < XR; rx0 += 4 * G) {
+                float av[RS_MAXK0 + 3];
+#pragma unroll
+                for (int k = 0; k < RS_MAXK0 + 3; ++k) av[k] = As[rx0 + k];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rx = rx0 + q;
+                    const int t = t0 - (KW - 1) + rx;
+                    float v = b0r;
+#pragma unroll
+                    for (int k = 0; k < RS_MAXK0; ++k) v = fmaf(w0r[k], av[q + k], v);
+                    if (rx < XR) Xs[rx * LD + c] = (FULL || (t >= 0 && t < T)) ? rst_elu(v) : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XCH; ++i) {
+                const int ch = tid + 256 * i;
+                const int rx = ch >> 4, c4 = (ch & 15) * 4;
+                const int t = t0 - (KW - 1) + rx;
+                if (rx < XR) {
+                    f32x4 v = xv[i];
+                    v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]);
+                    if (!FULL && (t < 0 || t >= T)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(Xs + rx * LD + c4) = v;
+                }
+            }
+        }
+        __syncthreads();                                 // X tile staged
+
+        // ---- GEMM1: acc1[32 x 32] = Xwin[32 x 192] * W1^T
+        f32x16 acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+        {
+            const float* a = Xs + (wave * 32 + frow) * LD + fk;
+#pragma unroll
+            for (int ks = 0; ks < KW * C / 8; ++ks) {
+                const f32x4 fa = *reinterpret_cast<const f32x4*>(a + (ks / 8) * LD + (ks % 8) * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb1[ks][e], acc1, 0, 0, 0);
+            }
+        }
+        // ---- epilogue 1: hidden rows of this wave (wave-private: no workgroup barrier)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            Hs[(wave * 32 + rst_mfma32_row(e, lane)) * HLD + frow] = rst_elu(acc1[e] + bias1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- skip-connection operand in the row-major layout of the output pass below: lane -> (row it*8 + lane/8, 4 channels),
+        // 16-byte loads requested now, landing under GEMM2.  (The accumulator layout gives a lane one column of 16 rows: 32 + 32
+        // dword loads / stores per lane, and the address path of the CU -- not HBM -- becomes what the tile waits for.)
+        const int orow = lane >> 3, oc4 = (lane & 7) * 4;
+        f32x4 xres[2][4];
+        if (!PRE) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int t = t0 + wave * 32 + it * 8 + orow;
+                    xres[j][it] = *reinterpret_cast<const f32x4*>(p.x + (b * T + (FULL ? t : min(max(t, 0), T - 1))) * C + j * 32 + oc4);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- GEMM2: acc2[32 x 64] = H[32 x 32] * W2^T
+        f32x16 acc2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[j][e] = 0.f;
+        {
+            const float* a = Hs + (wave * 32 + frow) * HLD + fk;
+            const float* bw = W2s + frow * HLD + fk;
+#pragma unroll
+            for (int ks = 0; ks < RS_H / 8; ++ks) {
+                const f32x4 fa = *reinterpret_cast<const f32x4*>(a + ks * 8);
+                f32x4 fb[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4*>(bw + j * 32 * HLD + ks * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[j][e], acc2[j], 0, 0, 0);
+            }
+        }
+
+        // ---- epilogue 2: y = x + acc2 + b2, 32 columns at a time through this wave's (now dead) hidden rows: accumulator layout in,
+        // row-major 16-byte pieces out (wave-private: no workgroup barrier)
+        float dk[4][RS_MAXKF];                  // POST: per-row tap dots of the fused last conv, 8 lanes per row
+        if (POST) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int k = 0; k < RS_MAXKF; ++k) dk[it][k] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j * 32 + frow;
+            float w0c[RS_MAXK0], awin[RS_MAXK0 + 3];
+            float b0c = 0.f;
+            if (PRE) {
+                b0c = p.b0[col];
+#pragma unroll
+                for (int k = 0; k < RS_MAXK0; ++k) w0c[k] = k < K0 ? W0s[col * (RS_MAXK0 + 1) + k] : 0.f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // GEMM2 reads / the previous pass's reads of these rows are done
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = wave * 32 + rst_mfma32_row(e, lane);
+                float v = acc2[j][e] + bias2[j];
+                if (PRE) {                  // the skip operand is conv0(audio), recomputed from the audio tile
+                    if ((e & 3) == 0) {     // rows e..e+3 of this lane are consecutive: one K0+3 window serves all four
+#pragma unroll
+                        for (int k = 0; k < RS_MAXK0 + 3; ++k) awin[k] = As[r + (KW - 1) + k];
+                    }
+                    float xr = b0c;
+#pragma unroll
+                    for (int k = 0; k < RS_MAXK0; ++k) xr = fmaf(w0c[k], awin[(e & 3) + k], xr);
+                    v = xr + v;
+                }
+                Hs[r * HLD + frow] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = wave * 32 + it * 8 + orow;
+                const int t = t0 + r;
+                const bool valid = FULL || (t >= 0 && t < T);
+                f32x4 v = *reinterpret_cast<const f32x4*>(Hs + r * HLD + oc4);
+                if (!PRE) { v[0] = xres[j][it][0] + v[0]; v[1] = xres[j][it][1] + v[1]; v[2] = xres[j][it][2] + v[2]; v[3] = xres[j][it][3] + v[3]; }
+                if (POST || p.elu_out) { v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]); }
+                if (POST) {
+                    if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < RS_MAXKF; ++k) {
+                        if (k < p.Kf) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(Wfs + k * C + j * 32 + oc4);
+                            dk[it][k] = fmaf(wv[0], v[0], dk[it][k]); dk[it][k] = fmaf(wv[1], v[1], dk[it][k]);
+                            dk[it][k] = fmaf(wv[2], v[2], dk[it][k]); dk[it][k] = fmaf(wv[3], v[3], dk[it][k]);
+                        }
+                    }
+                } else if (valid) {
+                    *reinterpret_cast<f32x4*>(p.y + (b * T + t) * C + j * 32 + oc4) = v;
+                }
+            }
+        }
+        if (POST) {
+            // final Conv1d C -> 1, kernel Kf: out[t] = bf + sum_k d_k[t - Kf + 1 + k],  d_k[r] = sum_c wf[k][c] * ELU(y[r][c]):
+            // the 8 lanes of a row meet, then the taps meet across rows / waves through Ds
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int k = 0; k < RS_MAXKF; ++k) {
+                    float d = dk[it][k];
+                    d += __shfl_xor(d, 1);
+                    d += __shfl_xor(d, 2);
+                    d += __shfl_xor(d, 4);
+                    if ((lane & 7) == 0 && k < p.Kf) Ds[k * BM + wave * 32 + it * 8 + orow] = d;
+                }
+            __syncthreads();                             // taps of all rows present; every wave is also past GEMM1: X tile free
+            if (tid < BM && tid >= halo) {
+                const int t = t0 + tid;
+                float s = p.bf[0];
+                for (int k = 0; k < p.Kf; ++k) s += Ds[k * BM + tid - halo + k];
+                if (FULL || (t >= 0 && t < T)) p.y[b * T + t] = s;
+            }
+        } else {
+            __syncthreads();                             // every wave is past GEMM1: the X tile may be overwritten
+        }
+    };
+
+    for (int idx = blockIdx.x; idx < total; idx += gridDim.x) {
+        const long b = idx / tiles_u;
+        const int t0 = (idx - (int)b * tiles_u) * BMo - halo;
+        const bool full = t0 - (KW - 1) - (PRE ? K0 - 1 : 0) >= 0 && t0 + BM <= T;
+        if (full) tile_body(std::true_type{}, idx, b, t0);
+        else tile_body(std::false_type{}, idx, b, t0);
+    }
+}
+
+template <bool PRE, bool POST>
+int launch64_stream(const ResblockParams& p, hipStream_t stream) {
+    const int halo = POST ? p.Kf - 1 : 0;
+    const long tiles_u = (p.T + (RS_BM - halo) - 1) / (RS_BM - halo);
+    const long total = (long)p.B * tiles_u;
+    if (total > 0x7fffffffL) { rst_set_error("resblock: grid too large"); return RST_ERR_UNSUPPORTED; }
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resblock64_stream_kernel<PRE, POST>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const long resident = 2L * cus;
+    const unsigned grid = (unsigned)(total < resident ? total : resident);
+    hipLaunchKernelGGL((resblock64_stream_kernel<PRE, POST>), dim3(grid), dim3(256), RS_LDS_FLOATS * sizeof(float), stream, p,
+                       (int)tiles_u, (int)total);
     return rst_check_launch("resblock");
 }
 
@@ -352,6 +675,16 @@ int rst_launch_resblock(const ResblockParams& p, hipStream_t stream) {
     RST_REQUIRE(!p.pre || (p.w0 && p.b0), "resblock: PRE needs w0/b0");
     RST_REQUIRE(!p.post || (p.wf && p.bf), "resblock: POST needs wf/bf");
     RST_REQUIRE(!(p.hist && (p.pre || p.post)), "resblock: streaming history is only supported by the plain variant");
+    // RST_RESBLOCK_STREAM=0: the launch-per-tile form for every shape (A/B measurements)
+    static const bool stream_off = getenv("RST_RESBLOCK_STREAM") && atoi(getenv("RST_RESBLOCK_STREAM")) == 0;
+    // the fused last conv measured faster in the launch-per-tile form (0.92 vs 1.00 ms at 16 x 10 s): three workgroups per CU
+    // against two, and its output is one float per row either way; RST_RESBLOCK_STREAM=2 forces the resident form for it too
+    static const bool stream_post = getenv("RST_RESBLOCK_STREAM") && atoi(getenv("RST_RESBLOCK_STREAM")) == 2;
+    if (p.C == 64 && p.Kw == RS_KW && !p.hist && !stream_off && !(p.pre && p.post) && (!p.post || stream_post)) {
+        if (p.pre) return launch64_stream<true, false>(p, stream);
+        if (p.post) return launch64_stream<false, true>(p, stream);
+        return launch64_stream<false, false>(p, stream);
+    }
     if (p.C == 64) {
         if (p.pre && p.post) return launch<64, 128, 4, 1, true, true>(p, stream);
         if (p.pre) return launch<64, 128, 4, 1, true, false>(p, stream);

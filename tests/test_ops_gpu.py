@@ -89,7 +89,8 @@ def test_resblock(name):
     assert rel_err(ncl(y), gold) < TOL
 
 
-@pytest.mark.parametrize("C,B,T", [(64, 2, 300), (64, 1, 128), (64, 3, 129), (128, 2, 200), (128, 1, 63)])
+# (64, 5, 20011): 785 tiles -- more than the resident workgroups of the tile-streaming C = 64 kernel, so every one walks several
+@pytest.mark.parametrize("C,B,T", [(64, 2, 300), (64, 1, 128), (64, 3, 129), (64, 5, 20011), (128, 2, 200), (128, 1, 63)])
 def test_fused_resblock(C, B, T):
     """rst_seanet_resblock_f32 (plain) == the oracle's resnet_block."""
     assert ops.resblock_supported(C, C // 2, 3)
@@ -103,7 +104,7 @@ def test_fused_resblock(C, B, T):
     assert rel_err(ncl(y), O.resnet_block(sd, "p", x)) < TOL
 
 
-@pytest.mark.parametrize("B,T", [(2, 500), (1, 126), (1, 127), (3, 253)])
+@pytest.mark.parametrize("B,T", [(2, 500), (1, 126), (1, 127), (3, 253), (5, 20011)])
 def test_fused_resblock_with_first_and_last_conv(B, T):
     """pre: encoder.model.0 (Conv1d 1->64 k7) folded in;  post: ELU + decoder.model.14 (Conv1d 64->1 k3) folded in."""
     C = 64

@@ -1,6 +1,7 @@
 """Micro-benchmarks of individual C-ABI kernels (HIP-event timing); also the workload for rocprofv3 --pmc passes.
 
-    python tools/bench_kernels.py [case ...]        cases: res64 res64pre res64post res128 gemm:<M>x<N>x<K>[:elu] ...
+    python tools/bench_kernels.py [case ...]        cases: res64 res64pre res64post res128 gemm:<M>x<N>x<K>[:elu]
+                                                           conv:<B>x<T>x<Cin>x<N>x<Kw>x<S>[:elu][:res] ...
 """
 import os
 import sys
@@ -70,6 +71,21 @@ def gemm_case(M, N, K, elu=False, res=False):
     r = torch.randn(M, N, generator=g).to(DEV) if res else None
     ms = timeit(lambda: ops.gemm_win(x, w, B=1, T_in=M, T_out=M, C_=K, S=1, P=0, N=N, res=r, act_in=int(elu)))
     return ms, 2.0 * M * N * K
+
+
+def conv_case(B, T, Cin, N, Kw, S, elu=False, res=False):
+    """gemm_win in its window form: conv Cin -> N, kernel Kw, stride S over [B, T, Cin] (a transposed conv k = q*S of Cout
+    channels is conv:B x T x Cin x (S*Cout) x q x 1).  Causal left padding Kw - S, zeros."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, T, Cin, generator=g).to(DEV)
+    w = (torch.randn(N, Kw * Cin, generator=g) * 0.05).to(DEV)
+    T_out = T // S
+    r = torch.randn(B, T_out, N, generator=g).to(DEV) if res else None
+    bias = torch.zeros(N, device=DEV)
+    out = torch.empty(B, T_out, N, device=DEV)
+    ms = timeit(lambda: ops.gemm_win(x, w, B=B, T_in=T, T_out=T_out, C_=Cin, S=S, P=Kw - S, N=N, bias=bias, res=r,
+                                     act_in=int(elu), out=out), iters=8, warm=2)
+    return ms, 2.0 * B * T_out * N * Kw * Cin
 
 
 def sample_case(V, k, sampling=True):
@@ -145,6 +161,11 @@ def main():
             Bq, N, K = [int(v) for v in parts[1].split("x")]
             ms, nbytes = skinny_case(Bq, N, K, gate="gate" in parts[2:])
             print(f"{c:32s} {ms * 1e3:8.1f} us  {nbytes / ms / 1e6:8.1f} GB/s", flush=True)
+            continue
+        if c.startswith("conv:"):
+            parts = c.split(":")
+            ms, fl = conv_case(*[int(v) for v in parts[1].split("x")], elu="elu" in parts[2:], res="res" in parts[2:])
+            print(f"{c:40s} {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TFLOP/s", flush=True)
             continue
         if c.startswith("res"):
             C = 128 if "128" in c else 64
