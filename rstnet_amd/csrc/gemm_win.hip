@@ -121,52 +121,66 @@ __device__ __forceinline__ void gw_tile(const GemmWinParams& p, const int tile, 
         return v;
     };
 
+    // 16-byte pieces of the general path: the source ADDRESS is chosen per lane (activations / history / replicated edge, or a dummy
+    // when the piece is padding), the load itself is unconditional, and padding is cleared with a mask the compiler cannot see
+    // through.  A load under a per-lane condition (or one feeding a select it can fold back into a condition) is branched around
+    // and waited for on the spot, which turns a k-tile into RA + RB exposed round trips -- the streaming steps live on this path.
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    auto masked_load = [&](const float* src, bool ok) -> f32x4 {
+        int m = ok ? -1 : 0;
+        asm volatile("" : "+v"(m));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? src : p.w);
+        const i32x4 b = __builtin_bit_cast(i32x4, v) & m;
+        return __builtin_bit_cast(f32x4, b);
+    };
     auto load_tiles = [&](int kt) {
         const int k = kt * KB + lk;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (VEC && k >= a_klo[j] && k < a_khi[j]) {
-                v = *reinterpret_cast<const f32x4*>(p.x + a_off[j] + a_f0[j] + k);   // interior: the common case
-            } else if (a_ok[j]) {
-                if (VEC) {
-                    if (k < p.K) {
-                        const int f = a_f0[j] + k;
-                        if (f >= 0) {
-                            if (f < TC) v = *reinterpret_cast<const f32x4*>(p.x + a_off[j] + f);
-                            else if (p.pad_mode == 1)  // F.pad(mode="replicate") also replicates the right extra padding
-                                v = *reinterpret_cast<const f32x4*>(p.x + a_off[j] + TC - p.C + f % p.C);
-                        } else if (p.hist) {
-                            v = *reinterpret_cast<const f32x4*>(p.hist + h_off[j] + PC + f);
-                        } else if (p.pad_mode == 1) {
-                            int c = f % p.C;
-                            if (c < 0) c += p.C;
-                            v = *reinterpret_cast<const f32x4*>(p.x + a_off[j] + c);
-                        }
+            if (VEC) {
+                const int f = a_f0[j] + k;
+                bool ok = a_ok[j] && k < p.K;
+                const float* src = p.x + a_off[j] + f;
+                if (f < 0) {
+                    if (p.hist) {
+                        src = p.hist + h_off[j] + PC + f;
+                    } else if (p.pad_mode == 1) {
+                        int c = f % p.C;
+                        if (c < 0) c += p.C;
+                        src = p.x + a_off[j] + c;
+                    } else {
+                        ok = false;
                     }
-                } else {
+                } else if (f >= TC) {
+                    if (p.pad_mode == 1) src = p.x + a_off[j] + TC - p.C + f % p.C;   // F.pad(mode="replicate") also replicates the right extra padding
+                    else ok = false;
+                }
+                ra[j] = masked_load(src, ok);
+            } else {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (a_ok[j]) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (k + e < p.K) v[e] = load_elem_a(j, a_f0[j] + k + e);
                 }
+                ra[j] = v;
             }
-            ra[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int n = n0 + lrow + RP * j;
-            if (n < p.N) {
-                const float* wp = p.w + (long)n * p.K + k;
-                if (VEC) {
-                    if (k < p.K) v = *reinterpret_cast<const f32x4*>(wp);
-                } else {
+            const float* wp = p.w + (long)n * p.K + k;
+            if (VEC) {
+                rb[j] = masked_load(wp, n < p.N && k < p.K);
+            } else {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < p.N) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (k + e < p.K) v[e] = wp[e];
                 }
+                rb[j] = v;
             }
-            rb[j] = v;
         }
     };
 
@@ -304,20 +318,29 @@ __device__ __forceinline__ void gw_tile(const GemmWinParams& p, const int tile, 
         }
         __syncthreads();
         if (!sm_last) return;
+        // the partials of a 32 x 32 block are read four splits at a time (64 loads in flight per lane) and summed in split order
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+            const int n = min(n0 + (wn * TN + j) * 32 + (lane & 31), p.N - 1);       // rows / columns past the edge: clamped, never stored
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + (wm * TM + i) * 32 + rst_mfma32_row(e, lane);
-                    float s = 0.f;
-                    if (n < p.N && m < M)
-                        for (unsigned ks = 0; ks < gridDim.y; ++ks)
-                            s += __hip_atomic_load(p.ws + ((long)ks * M + m) * p.N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    acc[i][j][e] = s;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int ks = 0; ks < (int)gridDim.y; ks += 4) {
+                    float t[16][4];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = min(m0 + (wm * TM + i) * 32 + rst_mfma32_row(e, lane), M - 1);
+                        rst_load_partials<4>(p.ws + (long)m * p.N + n, (long)M * p.N, ks, (int)gridDim.y, t[e]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (ks + u < (int)gridDim.y) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[i][j][e] += t[e][u];
+                        }
                 }
+            }
         }
     }
 

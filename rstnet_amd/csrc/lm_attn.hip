@@ -276,15 +276,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     if (!sm_last) return;
     if (tid < D) {
         const float* w0 = p.ws + (((long)blockIdx.z * p.H + h) * gridDim.x) * (long)(D + 2);
+        // eight splits at a time: their (max, sum, out[tid]) triples are all in flight before the first is used
         float M = -INFINITY;
-        for (int s2 = 0; s2 < active; ++s2) M = fmaxf(M, __hip_atomic_load(w0 + (long)s2 * (D + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        for (int s2 = 0; s2 < active; s2 += 8) {
+            float t[8];
+            rst_load_partials<8>(w0, D + 2, s2, active, t);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) M = fmaxf(M, t[u]);      // entries past `active` repeat the last one: harmless for a max
+        }
         float L = 0.f, O = 0.f;
-        for (int s2 = 0; s2 < active; ++s2) {
-            const float* w = w0 + (long)s2 * (D + 2);
-            const float ms = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float fw = ms == -INFINITY ? 0.f : expf(ms - M);
-            L = fmaf(__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fw, L);
-            O = fmaf(__hip_atomic_load(w + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fw, O);
+        for (int s2 = 0; s2 < active; s2 += 8) {
+            float ms[8], ls[8], os[8];
+            rst_load_partials<8>(w0, D + 2, s2, active, ms);
+            rst_load_partials<8>(w0 + 1, D + 2, s2, active, ls);
+            rst_load_partials<8>(w0 + 2 + tid, D + 2, s2, active, os);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (s2 + u < active) {
+                    const float fw = ms[u] == -INFINITY ? 0.f : expf(ms[u] - M);
+                    L = fmaf(ls[u], fw, L);
+                    O = fmaf(os[u], fw, O);
+                }
+            }
         }
         const float r = L > 0.f ? O / L : 0.f;
         if (p.out_packed) sm_o[0][tid] = r;

@@ -40,6 +40,23 @@ __global__ __launch_bounds__(1024) void sample_big_kernel(const LmSampleParams p
     auto to_key = [](float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
     auto from_key = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); };
     auto key_at = [&](int i) { return to_key(sampling ? lg[i] / p.temp : lg[i]); };
+    // fn(i, key) over this thread's ids i = tid, tid + NT, ... < V in ascending order, eight loads in flight at a time (index
+    // clamped, the keys past the end cleared to 0 -- below every real key -- through a mask the compiler cannot turn back into a
+    // condition on the load).  One load per loop iteration is one exposed L2 round trip per id: 148 of them per pass at V = 151 936.
+    auto scan = [&](auto fn) {
+        for (int i0 = tid; i0 < V; i0 += NT * 8) {
+            float f[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) f[u] = lg[min(i0 + u * NT, V - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * NT;
+                unsigned msk = i < V ? 0xffffffffu : 0u;
+                asm volatile("" : "+v"(msk));
+                fn(i, to_key(sampling ? f[u] / p.temp : f[u]) & msk);
+            }
+        }
+    };
     int slot = 0;
     auto block_count = [&](int c) {            // sum of a per-thread count over the block (fresh LDS row per call)
 #pragma unroll
@@ -59,11 +76,10 @@ __global__ __launch_bounds__(1024) void sample_big_kernel(const LmSampleParams p
     // (1) arg-max over all ids (lowest index on ties) + this thread's maximum over the ids that may be drawn
     unsigned bk = 0u, tk = 0u;
     int bi = 0x7fffffff;
-    for (int i = tid; i < V; i += NT) {
-        const unsigned u = key_at(i);
+    scan([&](int i, unsigned u) {
         if (u > bk) { bk = u; bi = i; }
         if (i < limit && u > tk) tk = u;
-    }
+    });
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned ok = __shfl_xor(bk, o);
@@ -83,7 +99,7 @@ __global__ __launch_bounds__(1024) void sample_big_kernel(const LmSampleParams p
     // (2) softmax denominator over all ids
     const float mx = from_key(bk);
     float s = 0.f;
-    for (int i = tid; i < V; i += NT) s += expf(from_key(key_at(i)) - mx);
+    scan([&](int, unsigned u) { s += u ? expf(from_key(u) - mx) : 0.f; });
     s = wave_sum(s);
     if (lane == 0) red_v[wave] = s;
     __syncthreads();
@@ -104,13 +120,12 @@ __global__ __launch_bounds__(1024) void sample_big_kernel(const LmSampleParams p
     auto take = [&](unsigned u, int i) { return i < limit && u != 0u && (u > thr || (u == thr && i <= idx_lim)); };
     // (3) collect
     auto collect = [&]() {
-        for (int i = tid; i < V; i += NT) {
-            const unsigned u = key_at(i);
+        scan([&](int i, unsigned u) {
             if (take(u, i)) {
                 const int at = atomicAdd(&n_cand, 1);
                 if (at < SAMPLE_BIG_CAP) comp[at] = ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - i);
             }
-        }
+        });
         __syncthreads();
         return n_cand;
     };

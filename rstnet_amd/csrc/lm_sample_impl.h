@@ -55,12 +55,19 @@ __device__ __forceinline__ int sample_row(const float* lg, const float* noise_ro
     // keys of the (scaled) logits, element j of this thread is index j * NT + tid; key 0 (below every real key) pads the tail
     unsigned bk = 0u;
     int bi = 0x7fffffff;
+    // (all EPT loads are unconditional -- index clamped, tail keys cleared through a mask the compiler cannot fold back into a
+    // condition: a load under `i < V` is branched around and waited for on the spot, EPT exposed round trips per row)
+    float fl[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) fl[j] = lg[min(j * NT + tid, V - 1)];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         const int i = j * NT + tid;
-        float f = i < V ? lg[i] : 0.f;
+        unsigned msk = i < V ? 0xffffffffu : 0u;
+        asm volatile("" : "+v"(msk));
+        float f = fl[j];
         if (sampling) f = f / temp;
-        key[j] = i < V ? to_key(f) : 0u;
+        key[j] = to_key(f) & msk;
         if (key[j] > bk) { bk = key[j]; bi = i; }          // ascending i: the first maximum is kept
     }
 #pragma unroll

@@ -151,12 +151,14 @@ __device__ __forceinline__ void resblock_tile(const ResblockParams& p, float* sm
     }
 
     // ---- phase 1: GEMM1  acc1[BM x H] = Xwin[BM x Kw*C] * W1^T
+    // Two accumulator chains per column tile (even / odd k-steps, summed in epilogue 1): with one, every MFMA waits for its
+    // predecessor's 64-cycle result, and any instruction the wave issues in between (the fragment reads) adds to that.
     const int nk = Kw * C / BK;
-    f32x16 acc1[NT1];
+    f32x16 acc1[NT1], acc1b[NT1];
 #pragma unroll
     for (int j = 0; j < NT1; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) { acc1[j][e] = 0.f; acc1b[j][e] = 0.f; }
     const int frow = lane & 31, fk = (lane >> 5) * 4;
     {
         f32x4 w1r[W1CH];
@@ -191,7 +193,10 @@ __device__ __forceinline__ void resblock_tile(const ResblockParams& p, float* sm
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int j = 0; j < NT1; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[j][e], acc1[j], 0, 0, 0);
+                    for (int j = 0; j < NT1; ++j) {
+                        if (e & 1) acc1b[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[j][e], acc1b[j], 0, 0, 0);
+                        else acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[j][e], acc1[j], 0, 0, 0);
+                    }
             }
             if (kt + 1 < nk) store_w1((kt + 1) & 1);
             __syncthreads();
@@ -204,7 +209,7 @@ __device__ __forceinline__ void resblock_tile(const ResblockParams& p, float* sm
         const int col = (wn * NT1 + j) * 32 + (lane & 31);
         const float bias = p.b1[col];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) Hs[(wm * 32 + rst_mfma32_row(e, lane)) * HLD + col] = rst_elu(acc1[j][e] + bias);
+        for (int e = 0; e < 16; ++e) Hs[(wm * 32 + rst_mfma32_row(e, lane)) * HLD + col] = rst_elu((acc1[j][e] + acc1b[j][e]) + bias);
     }
     float* W2s = Xs;
 #pragma unroll
@@ -473,22 +478,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();                                 // X tile staged
 
         // ---- GEMM1: acc1[32 x 32] = Xwin[32 x 192] * W1^T
-        f32x16 acc1;
+        f32x16 acc1, acc1b;                              // two chains (even / odd k-steps): see resblock_tile
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+        for (int e = 0; e < 16; ++e) { acc1[e] = 0.f; acc1b[e] = 0.f; }
         {
             const float* a = Xs + (wave * 32 + frow) * LD + fk;
 #pragma unroll
             for (int ks = 0; ks < KW * C / 8; ++ks) {
                 const f32x4 fa = *reinterpret_cast<const f32x4*>(a + (ks / 8) * LD + (ks % 8) * 8);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb1[ks][e], acc1, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) {
+                    if (e & 1) acc1b = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb1[ks][e], acc1b, 0, 0, 0);
+                    else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb1[ks][e], acc1, 0, 0, 0);
+                }
             }
         }
         // ---- epilogue 1: hidden rows of this wave (wave-private: no workgroup barrier)
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-            Hs[(wave * 32 + rst_mfma32_row(e, lane)) * HLD + frow] = rst_elu(acc1[e] + bias1);
+            Hs[(wave * 32 + rst_mfma32_row(e, lane)) * HLD + frow] = rst_elu((acc1[e] + acc1b[e]) + bias1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

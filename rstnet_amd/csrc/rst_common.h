@@ -42,3 +42,15 @@ __device__ __forceinline__ float rst_gelu(float v) {
 __device__ __forceinline__ int rst_mfma32_row(int r, int lane) {
     return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 }
+
+// U write-through partials ws[(k0 + u) * stride], u < U, read with relaxed agent-scope (L1-bypassing) loads that are all in flight at
+// once; entries at k0 + u >= n repeat the last valid one (callers skip them).  A `for (k) s += atomic_load(...)` loop is compiled as
+// one exposed round trip per term -- the last arriver of a split reduction then spends longer summing than the splits spent
+// computing.
+template <int U>
+__device__ __forceinline__ void rst_load_partials(const float* ws, long stride, int k0, int n, float (&t)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        t[u] = __hip_atomic_load(ws + (long)min(k0 + u, n - 1) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+

@@ -47,29 +47,44 @@ __global__ __launch_bounds__(256) void f32_pack_win_kernel(const SkinnyF32PackPa
         const int h = (int)(idx & 1);
         const int q = (int)((idx >> 1) % (p.Kp / 8));
         const int m = (int)((idx >> 1) / (p.Kp / 8));
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m < M) {
-            const int b = m / p.T_out, t = m - b * p.T_out;
+        // the four loads are unconditional (source address chosen per lane, padding cleared by a mask the compiler cannot fold back
+        // into a condition): a load under a per-lane condition is waited for on the spot, four round trips instead of one
+        f32x4 v;
+        {
+            const int mm = min(m, M - 1);
+            const int b = mm / p.T_out, t = mm - b * p.T_out;
             const long xo = (long)b * p.x_bstride, ho = (long)b * PC;
             const int f0 = (t * p.S - p.P) * p.C;
+            const float* src[4];
+            int msk[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int k = 8 * q + 2 * e + h;
-                float a = 0.f;
-                if (k < p.K) {
-                    const int f = f0 + k;
-                    if (f >= 0) {
-                        if (f < TC) a = p.x[xo + f];
-                        else if (p.pad_mode == 1) a = p.x[xo + TC - p.C + f % p.C];
-                    } else if (p.hist) {
-                        a = p.hist[ho + PC + f];
+                const int f = f0 + k;
+                bool ok = m < M && k < p.K;
+                const float* s = p.x + xo + f;
+                if (f < 0) {
+                    if (p.hist) {
+                        s = p.hist + ho + PC + f;
                     } else if (p.pad_mode == 1) {
                         int c = f % p.C;
                         if (c < 0) c += p.C;
-                        a = p.x[xo + c];
+                        s = p.x + xo + c;
+                    } else {
+                        ok = false;
                     }
-                    if (p.act_in == 1) a = rst_elu(a);
+                } else if (f >= TC) {
+                    if (p.pad_mode == 1) s = p.x + xo + TC - p.C + f % p.C;
+                    else ok = false;
                 }
+                src[e] = ok ? s : p.xp;        // any valid address: the value is masked away
+                msk[e] = ok ? -1 : 0;
+                asm volatile("" : "+v"(msk[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = __builtin_bit_cast(float, __builtin_bit_cast(int, *src[e]) & msk[e]);
+                if (p.act_in == 1) a = rst_elu(a);     // ELU(0) = 0: padding stays zero
                 v[e] = a;
             }
         }
@@ -180,9 +195,14 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
         for (int idx = tid; idx < NB * 32 * 32; idx += 64 * SF_WAVES) {
             const int m = idx >> 5, n = n0 + (idx & 31);
             if (m < M && n < p.N) {
-                float v = 0.f;
-                for (int ks = 0; ks < nsplit; ++ks)
-                    v += __hip_atomic_load(p.ws + ((long)ks * M + m) * p.N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float v = 0.f;                      // summed in split order (deterministic), eight partials in flight at a time
+                for (int ks = 0; ks < nsplit; ks += 8) {
+                    float t[8];
+                    rst_load_partials<8>(p.ws + (long)m * p.N + n, (long)M * p.N, ks, nsplit, t);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (ks + u < nsplit) v += t[u];
+                }
                 epilogue(v, m, n);
             }
         }
