@@ -149,13 +149,16 @@ def test_embed_sum_and_rmsnorm():
     assert rel_err(ops.rmsnorm(x.to(DEV), a.to(DEV), 1e-8), L.rms_norm(x, a)) < 1e-6
 
 
+# (2, 64, 2048, 2048, 600): 16 slot splits, more than 8 of them holding keys from step 512 on (the combine reads them 8 at a time)
 @pytest.mark.parametrize("H,D,cap,context,steps,rope", [(4, 64, 8, None, 8, False), (2, 128, 10, 10, 25, True), (32, 128, 300, 300, 40, True),
-                                                        (4, 64, 300, 250, 320, True), (16, 64, 8, None, 8, False)])
+                                                        (4, 64, 300, 250, 320, True), (16, 64, 8, None, 8, False),
+                                                        (2, 64, 2048, 2048, 600, True)])
 def test_rope_append_and_ring_attention(H, D, cap, context, steps, rope):
     _ring_attention_case(H, D, cap, context, steps, rope, torch.float32)
 
 
-@pytest.mark.parametrize("H,D,cap,context,steps", [(32, 128, 300, 300, 40), (4, 64, 300, 250, 320), (8, 128, 3000, 3000, 12)])
+@pytest.mark.parametrize("H,D,cap,context,steps", [(32, 128, 300, 300, 40), (4, 64, 300, 250, 320), (8, 128, 3000, 3000, 12),
+                                                   (2, 128, 2048, 2048, 600)])
 def test_ring_attention_bf16_kv(H, D, cap, context, steps):
     """bf16 KV rings (the reference's cache precision, modules/transformer.py:228): against the oracle ring that rounds what it
     stores to bf16 -- same rounded keys / values on both sides, so the fp32 attention over them must agree like the fp32 ring does;

@@ -355,6 +355,53 @@ def test_gemm_win_kb16_linear_epilogues():
     assert rel_err(y, res + scale * F.gelu(ref)) < TOL
 
 
+# ---- the tile-streaming form of the 128 x 128 configuration (gemm_win_stream_kernel): resident workgroups walk several tiles each,
+# interior tiles take the streamed K loop, edge tiles the general routine -- every way the two can alternate inside one workgroup
+
+@pytest.mark.parametrize("M,N,K", [
+    (16640, 512, 96),      # 520 tiles of 32-wide k-chunks: more than the resident workgroups (2 per CU), 3 k-tiles per tile
+    (16640, 512, 32),      # one k-tile per tile: no second k-tile to keep in registers -> general routine for every tile
+    (16640, 512, 40),      # K not a multiple of the k-chunk -> general routine
+    (100000, 200, 64),     # >= 768 tiles of 16-wide chunks; the second column tile is ragged (N = 200): fast / general alternate
+    (131073 + 5, 128, 48), # ragged last row tile at the end of a workgroup's run
+    (4100, 128, 4096),     # barely past the medium-M split route: 33 tiles, fewer than the resident workgroups
+])
+def test_gemm_win_stream_linear_shapes(M, N, K):
+    g = torch.Generator().manual_seed(M % 1000 + N + K)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    b, res, scale = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.rand(N, generator=g)
+    ref = F.linear(x.double(), w.double(), b.double())
+    assert rel_err(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV)), ref.float()) < TOL
+    y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), res=res.to(DEV), scale=scale.to(DEV), act_out=ops.ACT_GELU)
+    assert rel_err(y, (res.double() + scale.double() * F.gelu(ref)).float()) < TOL
+
+
+def test_gemm_win_stream_short_utterances():
+    """Conv k3 s1 over 40 utterances of 700 steps (T_out = 700: every row tile of 128 straddles or touches an utterance edge somewhere
+    in the run, windows reach 2 steps back): interior and edge tiles interleave tile by tile inside each resident workgroup."""
+    g = torch.Generator().manual_seed(35)
+    B, cin, cout, T = 40, 64, 256, 700
+    x = torch.rand(B, cin, T, generator=g) * 2 - 1
+    w = synth._xavier(g, cout, cin, 3)
+    b = 0.1 * torch.randn(cout, generator=g)
+    y = RF.conv1d(nlc(x), RF.pack_conv_weight(w).to(DEV), b.to(DEV), k_eff=3, act_in=ops.ACT_ELU)
+    ref = O.causal_conv1d(F.elu(x), w, b)
+    assert rel_err(ncl(y), ref) < TOL
+
+
+def test_gemm_win_deep_split():
+    """160 rows x 128 columns x K = 4096: five 32-row tiles, K split 32 ways -- the last arriver reads the partials four splits at a
+    time (eight batches), summed in split order."""
+    from rstnet_amd import _lib
+    M, N, K = 160, 128, 4096
+    assert _lib.lib().rst_gemm_win_split_plan(M, N, K) >= 16
+    g = torch.Generator().manual_seed(36)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    ref = F.linear(x.double(), w.double()).float()
+    for _ in range(2):          # the arrival counters re-arm
+        assert rel_err(ops.linear(x.to(DEV), w.to(DEV)), ref) < TOL
+
+
 # ---- streaming-step shapes: split-K across workgroups (medium-M gemm_win, few-row skinny GEMM)
 
 @pytest.mark.parametrize("B,cin,cout,K,S,T,elu", [(1, 64, 128, 8, 4, 1920, True), (1, 128, 64, 3, 1, 480, True), (2, 64, 32, 3, 1, 1920, True),
