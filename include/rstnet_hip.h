@@ -287,7 +287,13 @@ int rst_skinny_pack_weight_bf16(const uint16_t* w, uint16_t* wp, int N, int K, i
 int rst_skinny_pack_act_f32(const float* x, const float* alpha, uint16_t* xp, int B, int K, int ldx, int mode, float eps,
                             rst_stream_t stream);
 int rst_gemm_skinny_bf16_f32(const uint16_t* xp, const uint16_t* wp, const float* res, const float* bias, float* y, int B, int N,
-                             int K, int ldy, uint16_t* gate_out, rst_stream_t stream);
+                             int K, int ldy, uint16_t* gate_out, int split_k, float* ws, uint32_t* counters, rst_stream_t stream);
+/* split_k = rst_skinny_bf16_split_plan(B, N, K) (> 1 only for K >= 2048): K is also split over workgroups, each taking four (two
+ * above 32 rows) adjacent column tiles, so that the packed activations are pulled through a CU's load path once per four weight
+ * tiles and ~256-384 workgroups stream; ws [split_k][ceil(B/32)*32][N] fp32 and counters [ceil(N/32)] (zero before the first
+ * launch, self re-arming) are caller-owned scratch; the last workgroup of a column group sums the partials in split order
+ * (deterministic).  split_k <= 1 (ws / counters may be NULL): one workgroup per column tile(s) over all of K, as before. */
+int rst_skinny_bf16_split_plan(int B, int N, int K);
 
 /* Opt-in fp8 form of the three entry points above (BASELINE.json configs[4]: fp8 MFMA GEMMs on the temporal blocks at batch
  * 32): OCP e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8, weights with one scale per row (amax / 448, quantised once),

@@ -313,11 +313,14 @@ int rst_skinny_pack_act_f32(const float* x, const float* alpha, uint16_t* xp, in
     return rst_launch_skinny_pack_act(x, alpha, xp, B, K, ldx, mode, eps, (hipStream_t)stream);
 }
 
+int rst_skinny_bf16_split_plan(int B, int N, int K) { return rst_skinny_bf16_split_plan_impl(B, N, K); }
+
 int rst_gemm_skinny_bf16_f32(const uint16_t* xp, const uint16_t* wp, const float* res, const float* bias, float* y, int B, int N,
-                             int K, int ldy, uint16_t* gate_out, rst_stream_t stream) {
+                             int K, int ldy, uint16_t* gate_out, int split_k, float* ws, uint32_t* counters, rst_stream_t stream) {
     SkinnyParams p;
     p.xp = xp; p.w = wp; p.res = res; p.bias = bias; p.y = y; p.B = B; p.N = N; p.K = K; p.ldy = ldy;
     p.gate_out = gate_out; p.gate_plane = (long)((B + 31) / 32 * 32) * (N / 2);
+    p.split_k = split_k; p.ws = ws; p.counters = counters;
     return rst_launch_gemm_skinny(p, (hipStream_t)stream);
 }
 

@@ -86,15 +86,27 @@ constexpr int SKINNY_WAVES = 8;
 // barrier in the main loop.  The activations are the MFMA "A" side, so an accumulator is C[b = row(e, lane)][n = lane & 31]
 // and the global stores are 128-byte coalesced.  The 8 partial tiles meet in LDS and are summed in wave order
 // (deterministic); there is no cross-workgroup reduction.
+//
+// What bounds a launch is the CU's load path, not HBM: a wave-step pulls 1 KB of weights AND 2 KB of packed activations (L2 hits)
+// through the L1, which sustains ~60 GB/s per CU -- measured: time = 4-6 us + 3.2 ns x K per workgroup, whatever N (33.5 MB as
+// 1024 x 16384 takes 57 us, as 16384 x 1024 10 us).  Hence (rst_skinny_bf16_split_plan_impl / rst_launch_gemm_skinny): where enough
+// workgroups remain a workgroup takes CT = 4 adjacent column tiles (the activations of a step feed four weight tiles: 1.5 bytes through the L1 per
+// weight byte instead of 3) and, for the longest K, only a slice of it (gridDim.y splits, so that ~256-384 workgroups exist); the partial tiles go to
+// `ws` with write-through stores, one arrival counter per column group, and the LAST workgroup to arrive sums them in split order
+// (deterministic) and runs the epilogue (the protocol of the fp32 few-row GEMM, csrc/skinny_f32.hip).
 template <int NB, int CT>   // batch tiles of 32, weight-row tiles per workgroup
 __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const SkinnyParams p) {
     __shared__ float red[SKINNY_WAVES][NB * 32][33];
+    __shared__ int sm_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = (p.N + 31) / 32;
     const int tile0 = blockIdx.x * CT;
     const int steps = p.K / 16;
-    const int per = (steps + SKINNY_WAVES - 1) / SKINNY_WAVES;
-    const int s0 = wave * per, s1 = min(steps, s0 + per);
+    const int nsplit = gridDim.y;
+    const int per_split = (steps + nsplit - 1) / nsplit;
+    const int st_lo = blockIdx.y * per_split, st_hi = min(steps, st_lo + per_split);
+    const int per = (max(st_hi - st_lo, 0) + SKINNY_WAVES - 1) / SKINNY_WAVES;
+    const int s0 = st_lo + wave * per, s1 = min(st_hi, s0 + per);
     const long xplane = (long)NB * 32 * p.K;                        // elements of the hi plane
     const unsigned short* xh = p.xp + (long)lane * 8;
     const unsigned short* xl = xh + xplane;
@@ -108,6 +120,21 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
         for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
+    // residual / bias of this thread's outputs: requested before the K loop (clamped addresses), used after it -- in the epilogue
+    // each would be one more exposed round trip of a launch that lasts a handful of them
+    constexpr int EP = NB * 32 * 32 / (64 * SKINNY_WAVES);          // output elements per thread and column tile
+    float rpre[CT][EP], bpre[CT][EP];
+    if (!p.gate_out) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int q = 0; q < EP; ++q) {
+                const int idx = tid + q * 64 * SKINNY_WAVES;
+                const int b = min(idx >> 5, p.B - 1), n = min((tile0 + c) * 32 + (idx & 31), p.N - 1);
+                rpre[c][q] = p.res ? p.res[(long)b * p.ldy + n] : 0.f;
+                bpre[c][q] = p.bias ? p.bias[n] : 0.f;
+            }
+    }
     constexpr int UN = (NB * 2 + CT) <= 4 ? 4 : 2;
     for (int s = s0; s < s1; s += UN) {
         bf16x8 a[UN][CT], bh[UN][NB], bl[UN][NB];
@@ -135,14 +162,16 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
                 }
     }
     const int i = lane & 31;
+    bool single = false;            // red[slot] alone holds the tile (the summed splits) instead of one partial per wave
+    int slot = 0;
+    auto tsum = [&](int b, int col) {
+        if (single) return red[slot][b][col];
+        float v = red[0][b][col];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        if (c) __syncthreads();
-#pragma unroll
-        for (int t = 0; t < NB; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) red[wave][t * 32 + rst_mfma32_row(e, lane)][i] = acc[t][c][e];
-        __syncthreads();
+        for (int w = 1; w < SKINNY_WAVES; ++w) v += red[w][b][col];
+        return v;
+    };
+    auto emit = [&](int c) {        // epilogue of column tile c from the tile in `red`
         const int n0 = (tile0 + c) * 32;
         if (p.gate_out) {
             // interleaved gated layer: columns 0..15 of the tile are u, 16..31 the matching v; emit silu(u) * v as the packed
@@ -155,29 +184,117 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
                     float v[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        float u = 0.f, g = 0.f;
-#pragma unroll
-                        for (int w = 0; w < SKINNY_WAVES; ++w) { u += red[w][b][j8 + j]; g += red[w][b][16 + j8 + j]; }
+                        float u = tsum(b, j8 + j), g = tsum(b, 16 + j8 + j);
                         if (p.bias) { u += p.bias[kout + j]; g += p.bias[half + kout + j]; }
                         v[j] = b < p.B ? silu(u) * g : 0.f;
                     }
                     store_packed8(p.gate_out, p.gate_plane, b, kout, half, v);
                 }
             }
-            continue;
+            return;
         }
-        for (int idx = tid; idx < NB * 32 * 32; idx += 64 * SKINNY_WAVES) {
+#pragma unroll
+        for (int q = 0; q < EP; ++q) {
+            const int idx = tid + q * 64 * SKINNY_WAVES;
             const int b = idx >> 5, nl = idx & 31;
             const int n = n0 + nl;
             if (b < p.B && n < p.N) {
-                float s = 0.f;
-#pragma unroll
-                for (int w = 0; w < SKINNY_WAVES; ++w) s += red[w][b][nl];
+                float s = tsum(b, nl);
                 const long o = (long)b * p.ldy + n;
-                if (p.bias) s += p.bias[n];
-                p.y[o] = p.res ? p.res[o] + s : s;
+                if (p.bias) s += bpre[c][q];
+                p.y[o] = p.res ? rpre[c][q] + s : s;
             }
         }
+    };
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (c) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wave][t * 32 + rst_mfma32_row(e, lane)][i] = acc[t][c][e];
+        __syncthreads();
+        if (nsplit == 1) {
+            emit(c);
+        } else {
+            // this split's partial tile (the 8 waves summed in wave order) -> ws, write-through.  16-byte pieces: a 4-byte `sc1`
+            // store is a fabric write of its own (MI355X_MICROARCH.md: ~6x the time per byte of a 16-byte one), and a tile is 1024
+            // of them per workgroup
+            const int n0 = (tile0 + c) * 32;
+            if ((p.N & 3) == 0) {
+                if (tid < NB * 32 * 8) {
+                    const int b = tid >> 3, q4 = (tid & 7) * 4;
+                    if (b < p.B && n0 + q4 < p.N) {
+                        const f32x4 v = {tsum(b, q4), tsum(b, q4 + 1), tsum(b, q4 + 2), tsum(b, q4 + 3)};
+                        float* dst = p.ws + ((long)blockIdx.y * (NB * 32) + b) * p.N + n0 + q4;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < EP; ++q) {
+                    const int idx = tid + q * 64 * SKINNY_WAVES;
+                    const int b = idx >> 5, n = n0 + (idx & 31);
+                    if (b < p.B && n < p.N)
+                        __hip_atomic_store(p.ws + ((long)blockIdx.y * (NB * 32) + b) * p.N + n, tsum(b, idx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+    if (nsplit == 1) return;
+    // every storing wave drains its write-through stores, ONE lane bumps the group's counter; the last arriver combines
+    // (publish form: `sc1` stores, asm wait, relaxed agent-scope counter and loads -- MI355X_MICROARCH.md handoff-flag / splitk-seam)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(p.counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sm_last = prev == (unsigned)nsplit - 1;
+        if (sm_last) __hip_atomic_store(p.counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!sm_last) return;
+    // the partials of ALL CT tiles are requested together (a round trip to memory each way: the writers' stores left their L2) and
+    // summed into red[c] -- the eight per-wave slots double as per-tile slots here -- then the epilogues run
+    single = true;
+    static_assert(CT <= SKINNY_WAVES, "one LDS slot per column tile");
+    {
+        float v[CT][EP];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int q = 0; q < EP; ++q) v[c][q] = 0.f;
+        for (int ks = 0; ks < nsplit; ks += 4) {          // split order, CT * EP * 4 partials in flight
+            float t[CT][EP][4];
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int q = 0; q < EP; ++q) {
+                    const int idx = tid + q * 64 * SKINNY_WAVES;
+                    const int bc = min(idx >> 5, p.B - 1), nc = min((tile0 + c) * 32 + (idx & 31), p.N - 1);   // pad: clamped, unused
+                    rst_load_partials<4>(p.ws + (long)bc * p.N + nc, (long)(NB * 32) * p.N, ks, nsplit, t[c][q]);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ks + u < nsplit) {
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+#pragma unroll
+                        for (int q = 0; q < EP; ++q) v[c][q] += t[c][q][u];
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int q = 0; q < EP; ++q) {
+                const int idx = tid + q * 64 * SKINNY_WAVES;
+                red[c][idx >> 5][idx & 31] = v[c][q];
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        slot = c;
+        emit(c);
     }
 }
 
@@ -199,19 +316,48 @@ int rst_launch_skinny_pack_act(const float* x, const float* alpha, unsigned shor
     return rst_check_launch("skinny_pack_act");
 }
 
+// Column tiles per workgroup.  Long K (>= 2048) with the split scratch available: as many as the kernel has (the activations of a
+// step are then shared by 4 / 2 weight tiles); otherwise by tile count alone, as before the split form existed.
+static int skinny_ct(int B, int tiles, int K, int split) {
+    const int max_ct = B <= 32 ? 4 : 2;
+    if (K >= 2048 && (split > 1 || tiles >= 192 * max_ct)) return tiles >= max_ct ? max_ct : (tiles >= 2 ? 2 : 1);
+    if (B <= 32) return tiles >= 2048 ? 4 : (tiles >= 512 ? 2 : 1);
+    return tiles >= 512 ? 2 : 1;
+}
+
+// K splits of a launch (1: none).  The in-launch hand-off costs ~8 us (drained write-through stores, the counter round trip, the
+// partials read back from memory, measured: 8 MB as 1024 x 4096 takes 14.7 us split 16 ways), so only long K pays: K >= 8192 for one
+// batch tile (the 4096 x 11264 gated projection: 47 -> 33 us), K >= 4096 for two (64 x 4096 x 4096: 25 -> 20 us); at K = 4096 and
+// <= 32 rows the split and the plain form measured equal (17 us), below that the split form loses.  Then: split until ~256-384
+// workgroups exist, every wave keeping >= 2 MFMA steps.
+int rst_skinny_bf16_split_plan_impl(int B, int N, int K) {
+    if (B < 1 || B > 64 || N < 1 || K < (B <= 32 ? 8192 : 4096) || K % 16) return 1;
+    const int tiles = (N + 31) / 32, steps = K / 16;
+    const int max_ct = B <= 32 ? 4 : 2;
+    const int ct = tiles >= max_ct ? max_ct : (tiles >= 2 ? 2 : 1);
+    const int groups = (tiles + ct - 1) / ct;
+    int s = 1;
+    while (groups * s * 2 <= 384 && steps / (s * 2 * SKINNY_WAVES) >= 2 && s < 16) s *= 2;
+    return s;
+}
+
 int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B >= 1 && p.B <= 64 && p.N > 0 && p.K > 0 && p.K % 16 == 0, "gemm_skinny: need 1 <= B <= 64 and K %% 16 == 0 (B=%d K=%d)", p.B, p.K);
     RST_REQUIRE(p.xp && p.w && (p.y || p.gate_out), "gemm_skinny: null pointer");
     RST_REQUIRE(!p.gate_out || (p.N % 32 == 0 && !p.res), "gemm_skinny: the gated epilogue needs N %% 32 == 0 and takes no residual");
     const int tiles = (p.N + 31) / 32;
     const int threads = 64 * SKINNY_WAVES;
+    const int split = p.split_k > 1 ? p.split_k : 1;
+    RST_REQUIRE(split == 1 || (p.ws && p.counters && split <= 64), "gemm_skinny: split-K needs the scratch buffers (split <= 64)");
+    const int ct = skinny_ct(p.B, tiles, p.K, split);
+    const dim3 grid((tiles + ct - 1) / ct, split);
     if (p.B <= 32) {
-        if (tiles >= 2048) hipLaunchKernelGGL((gemm_skinny_kernel<1, 4>), dim3((tiles + 3) / 4), dim3(threads), 0, stream, p);
-        else if (tiles >= 512) hipLaunchKernelGGL((gemm_skinny_kernel<1, 2>), dim3((tiles + 1) / 2), dim3(threads), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_skinny_kernel<1, 1>), dim3(tiles), dim3(threads), 0, stream, p);
+        if (ct == 4) hipLaunchKernelGGL((gemm_skinny_kernel<1, 4>), grid, dim3(threads), 0, stream, p);
+        else if (ct == 2) hipLaunchKernelGGL((gemm_skinny_kernel<1, 2>), grid, dim3(threads), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<1, 1>), grid, dim3(threads), 0, stream, p);
     } else {
-        if (tiles >= 512) hipLaunchKernelGGL((gemm_skinny_kernel<2, 2>), dim3((tiles + 1) / 2), dim3(threads), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_skinny_kernel<2, 1>), dim3(tiles), dim3(threads), 0, stream, p);
+        if (ct == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, 2>), grid, dim3(threads), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<2, 1>), grid, dim3(threads), 0, stream, p);
     }
     return rst_check_launch("gemm_skinny");
 }

@@ -317,8 +317,12 @@ struct SkinnyParams {
     int B, N, K, ldy;
     unsigned short* gate_out;   // optional instead of y (weights packed with interleave): silu(u) * v as packed hi / lo planes, K = N/2
     long gate_plane;            // elements per plane of gate_out
+    int split_k;                // > 1: K also split over gridDim.y workgroups (rst_skinny_bf16_split_plan_impl), partials in ws
+    float* ws;                  // [split_k][ceil(B/32)*32][N]
+    unsigned* counters;         // [ceil(N/32)], zero before the first launch (self re-arming)
 };
 int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream);
+int rst_skinny_bf16_split_plan_impl(int B, int N, int K);
 struct SkinnyFp8Params {
     const unsigned char* xp;    // packed fp8 activations [ceil(B/32)][K/32][64][16]
     const float* xscale;        // [ceil(B/32)*32] per-row scales of the activations

@@ -672,7 +672,13 @@ def gemm_skinny(x, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Opt
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.lib().rst_gemm_skinny_bf16_f32(_ptr(xp), _ptr(wp), _ptr(res), _ptr(bias), _ptr(out), B, N, K, N, _ptr(gp), _stream()))
+    def build():         # split-K scratch of this shape: partial tiles + arrival counters (zero once, the kernel re-arms them)
+        sk = int(_lib.lib().rst_skinny_bf16_split_plan(B, N, K))
+        return (sk, torch.empty(sk, (B + 31) // 32 * 32, N, device=xp.device, dtype=torch.float32),
+                torch.zeros((N + 31) // 32, device=xp.device, dtype=torch.int32)) if sk > 1 else (1, None, None)
+    sc = _scratch(_gemm_scratch, xp.device, ("skinny_bf16", B, N, K), build)
+    _lib.check(_lib.lib().rst_gemm_skinny_bf16_f32(_ptr(xp), _ptr(wp), _ptr(res), _ptr(bias), _ptr(out), B, N, K, N, _ptr(gp),
+                                                  sc[0], _ptr(sc[1]), _ptr(sc[2]), _stream()))
     if prof is not None:
         e1.record()
         prof.append(("gemm_skinny", e0, e1, 2.0 * B * N * K, 2 * N * K + 4 * (x.numel() + B * N), (B, N, K)))

@@ -23,8 +23,10 @@ prof() { local n=$1; shift
   [ -n "$fc" ] && [ -n "$wc" ] && python tools/pmc_traffic.py "$fc" "$wc" "$O/${n}_pmc_traffic.json" | head -6
   rm -f "$O/${n}_trace.out" "$O/${n}_fetch.out" "$O/${n}_write.out"
 }
+# the bench lines quote the trace / counter summaries of the SAME code: each workload is profiled first, its summaries are copied
+# into this box's profiles/ under the tag, and only then the bench line is taken
+publish() { for f in "$O"/$1_*; do case "$f" in *.out|*.err|*_bench.json) ;; *) cp "$f" "profiles/${TAG}_$(basename "$f")";; esac; done; }
 if [ "$WHAT" = all ] || [ "$WHAT" = codec ]; then
-  run codec_bench python bench.py --steps 20 --warmup 5
   prof codec python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sub --no-check --timing-samples 1
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = codec ] || [ "$WHAT" = mfma ]; then
@@ -34,18 +36,24 @@ if [ "$WHAT" = all ] || [ "$WHAT" = codec ] || [ "$WHAT" = mfma ]; then
   [ -n "$mc" ] && python tools/pmc_mfma.py "$mc" "$O/codec_mfma.json" | head -8
   rm -f "$O/codec_mfma.out"
 fi
+if [ "$WHAT" = all ] || [ "$WHAT" = codec ]; then
+  publish codec
+  run codec_bench python bench.py --steps 20 --warmup 5
+fi
 if [ "$WHAT" = all ] || [ "$WHAT" = lm ]; then
+  prof lm python bench.py --workload lm --steps 6 --warmup 2 --no-cpu-baseline --timing-samples 2
+  db=$(find "$RAW/lm_trace" -name "*.db" | head -1); [ -n "$db" ] && python tools/frame_timeline.py "$db" "$O/lm_timeline.csv" lm_ring_begin_kernel 2
+  publish lm
   run lm_bench python bench.py --workload lm --steps 60 --warmup 5
   run lm_ctx3000_bench python bench.py --workload lm --steps 60 --warmup 5 --lm-context 3000 --no-cpu-baseline
   run lm32_bench python bench.py --workload lm --lm-batch 32 --steps 30 --warmup 5 --no-cpu-baseline
-  prof lm python bench.py --workload lm --steps 6 --warmup 2 --no-cpu-baseline --timing-samples 2
-  db=$(find "$RAW/lm_trace" -name "*.db" | head -1); [ -n "$db" ] && python tools/frame_timeline.py "$db" "$O/lm_timeline.csv" lm_ring_begin_kernel 2
   BENCH_DEPTH_CHAINS=1 python tools/bench_depth.py 2>&1 | grep -v amdgpu > "$O/depth_phase.txt"
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = gpt ]; then
+  prof gpt python bench.py --workload gpt --steps 6 --warmup 2 --no-cpu-baseline
+  publish gpt
   run gpt_bench python bench.py --workload gpt --steps 40 --warmup 5
   run gpt1_bench python bench.py --workload gpt --lm-batch 1 --steps 60 --warmup 5 --no-cpu-baseline
-  prof gpt python bench.py --workload gpt --steps 6 --warmup 2 --no-cpu-baseline
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = e2e ]; then
   run e2e1_bench python bench.py --workload e2e --lm-batch 1 --steps 60 --warmup 6
