@@ -318,7 +318,8 @@ __device__ __forceinline__ void gw_tile(const GemmWinParams& p, const int tile, 
         }
         __syncthreads();
         if (!sm_last) return;
-        // the partials of a 32 x 32 block are read four splits at a time (64 loads in flight per lane) and summed in split order
+        // the partials of a 32 x 32 block are read UB splits at a time (64 / 128 loads in flight per lane) and summed in split order
+        constexpr int UB = TM * TN == 1 ? 8 : 4;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = min(n0 + (wn * TN + j) * 32 + (lane & 31), p.N - 1);       // rows / columns past the edge: clamped, never stored
@@ -326,15 +327,15 @@ __device__ __forceinline__ void gw_tile(const GemmWinParams& p, const int tile, 
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-                for (int ks = 0; ks < (int)gridDim.y; ks += 4) {
-                    float t[16][4];
+                for (int ks = 0; ks < (int)gridDim.y; ks += UB) {
+                    float t[16][UB];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int m = min(m0 + (wm * TM + i) * 32 + rst_mfma32_row(e, lane), M - 1);
-                        rst_load_partials<4>(p.ws + (long)m * p.N + n, (long)M * p.N, ks, (int)gridDim.y, t[e]);
+                        rst_load_partials<UB>(p.ws + (long)m * p.N + n, (long)M * p.N, ks, (int)gridDim.y, t[e]);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < UB; ++u)
                         if (ks + u < (int)gridDim.y) {
 #pragma unroll
                             for (int e = 0; e < 16; ++e) acc[i][j][e] += t[e][u];

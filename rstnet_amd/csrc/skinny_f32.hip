@@ -122,6 +122,20 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
         for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
+    // epilogue operands of this thread's outputs (EP per column tile): requested before the K loop from clamped addresses, used after it
+    // -- fetched in the epilogue each group of them is one more exposed round trip of a launch that lasts a handful
+    constexpr int EP = NB * 32 * 32 / (64 * SF_WAVES);
+    float rpre[CT][EP], bpre[CT][EP], spre[CT][EP];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int q = 0; q < EP; ++q) {
+            const int idx = tid + q * 64 * SF_WAVES;
+            const int m = min(idx >> 5, p.M - 1), n = min((tile0 + c) * 32 + (idx & 31), p.N - 1);
+            rpre[c][q] = p.res ? p.res[(long)m * p.ldy + n] : 0.f;
+            bpre[c][q] = p.bias ? p.bias[n] : 0.f;
+            spre[c][q] = p.scale ? p.scale[n] : 1.0f;
+        }
     constexpr int UN = NB * CT <= 2 ? 4 : 2;
     for (int s = s0; s < s1; s += UN) {
         f32x4 a[UN][CT], bx[UN][NB];
@@ -149,11 +163,11 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
     // activations are the MFMA "A" side: acc[t][c][e] = C[m = 32 t + row(e, lane)][n = 32 (tile0 + c) + (lane & 31)]
     const int i = lane & 31;
     const int M = p.M;
-    auto epilogue = [&](float v, int m, int n) {
-        if (p.bias) v += p.bias[n];
+    auto epilogue = [&](float v, int m, int n, int c, int q) {
+        if (p.bias) v += bpre[c][q];
         if (p.act_out == 1) v = rst_gelu(v);
         const long o = (long)m * p.ldy + n;
-        if (p.res) v = p.res[o] + (p.scale ? p.scale[n] : 1.0f) * v;
+        if (p.res) v = rpre[c][q] + spre[c][q] * v;
         if (p.act_out == 2) v = rst_elu(v);
         p.y[o] = v;
     };
@@ -166,14 +180,16 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
             for (int e = 0; e < 16; ++e) red[wave][t * 32 + rst_mfma32_row(e, lane)][i] = acc[t][c][e];
         __syncthreads();
         const int n0 = (tile0 + c) * 32;
-        for (int idx = tid; idx < NB * 32 * 32; idx += 64 * SF_WAVES) {
+#pragma unroll
+        for (int q = 0; q < EP; ++q) {
+            const int idx = tid + q * 64 * SF_WAVES;
             const int m = idx >> 5, nl = idx & 31;
             const int n = n0 + nl;
             if (m < M && n < p.N) {
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < SF_WAVES; ++w) v += red[w][m][nl];
-                if (nsplit == 1) epilogue(v, m, n);
+                if (nsplit == 1) epilogue(v, m, n, c, q);
                 else __hip_atomic_store(p.ws + ((long)blockIdx.y * M + m) * p.N + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -189,24 +205,40 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
     }
     __syncthreads();
     if (!sm_last) return;
+    // the partials of ALL of this thread's outputs are requested together (the writers' stores left their L2: a round trip to memory)
+    // and summed in split order (deterministic), four splits at a time
+    float v[CT][EP];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        const int n0 = (tile0 + c) * 32;
-        for (int idx = tid; idx < NB * 32 * 32; idx += 64 * SF_WAVES) {
-            const int m = idx >> 5, n = n0 + (idx & 31);
-            if (m < M && n < p.N) {
-                float v = 0.f;                      // summed in split order (deterministic), eight partials in flight at a time
-                for (int ks = 0; ks < nsplit; ks += 8) {
-                    float t[8];
-                    rst_load_partials<8>(p.ws + (long)m * p.N + n, (long)M * p.N, ks, nsplit, t);
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (ks + u < nsplit) v += t[u];
-                }
-                epilogue(v, m, n);
+        for (int q = 0; q < EP; ++q) v[c][q] = 0.f;
+    for (int ks = 0; ks < nsplit; ks += 4) {
+        float t[CT][EP][4];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int q = 0; q < EP; ++q) {
+                const int idx = tid + q * 64 * SF_WAVES;
+                const int m = min(idx >> 5, M - 1), n = min((tile0 + c) * 32 + (idx & 31), p.N - 1);      // past the edge: clamped, unused
+                rst_load_partials<4>(p.ws + (long)m * p.N + n, (long)M * p.N, ks, nsplit, t[c][q]);
             }
-        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ks + u < nsplit) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int q = 0; q < EP; ++q) v[c][q] += t[c][q][u];
+            }
     }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int q = 0; q < EP; ++q) {
+            const int idx = tid + q * 64 * SF_WAVES;
+            const int m = idx >> 5, n = (tile0 + c) * 32 + (idx & 31);
+            if (m < M && n < p.N) epilogue(v[c][q], m, n, c, q);
+        }
 }
 
 inline unsigned sf_grid(long total, long cap) {
