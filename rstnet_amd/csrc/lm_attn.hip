@@ -162,22 +162,34 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     for (int s0 = s_lo + wave * SPW; s0 < s_hi; s0 += 4 * SPW * UNR) {
         float kv[UNR][16], vv[UNR][16];
         bool ok[UNR];
+        // every K / V row of the iteration is requested unconditionally (slot clamped into the ring) before any is looked at; rows
+        // that do not take part are cleared afterwards through a mask the compiler cannot fold back into a condition on the load
+        // (a load under a per-lane condition is waited for inside its branch: one exposed round trip per slot instead of per iteration)
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int slot = min(s0 + u * 4 * SPW + grp, p.cap - 1);
+            KvRow<KV16>::load(p.k, kv_row0 + (long)slot * D, kv[u]);
+            KvRow<KV16>::load(p.v, kv_row0 + (long)slot * D, vv[u]);
+        }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int slot = s0 + u * 4 * SPW + grp;
+            const bool cur = slot < s_hi && slot == slot_cur;
             ok[u] = slot < s_hi && ring_visible(slot, pos_q, p.cap, p.context, end_offset);
+            unsigned msk = (ok[u] && !cur) ? 0xffffffffu : 0u;
+            asm volatile("" : "+v"(msk));
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { kv[u][i] = 0.f; vv[u][i] = 0.f; }
-            if (slot < s_hi && slot == slot_cur) {       // the new step: from qkv (at the ring's precision), and appended to the ring
+            for (int i = 0; i < 16; ++i) {
+                kv[u][i] = __uint_as_float(__float_as_uint(kv[u][i]) & msk);
+                vv[u][i] = __uint_as_float(__float_as_uint(vv[u][i]) & msk);
+            }
+            if (cur) {       // the new step: from qkv (at the ring's precision), and appended to the ring
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { kv[u][i] = KvRow<KV16>::round(kcur[i]); vv[u][i] = KvRow<KV16>::round(vn[i]); }
                 if (appender) {
                     KvRow<KV16>::store(p.k, kv_row0 + (long)slot * D, kv[u]);
                     KvRow<KV16>::store(p.v, kv_row0 + (long)slot * D, vv[u]);
                 }
-            } else if (ok[u]) {
-                KvRow<KV16>::load(p.k, kv_row0 + (long)slot * D, kv[u]);
-                KvRow<KV16>::load(p.v, kv_row0 + (long)slot * D, vv[u]);
             }
         }
 #pragma unroll
