@@ -318,8 +318,8 @@ __device__ __forceinline__ void gw_tile(const GemmWinParams& p, const int tile, 
         }
         __syncthreads();
         if (!sm_last) return;
-        // the partials of a 32 x 32 block are read UB splits at a time (64 / 128 loads in flight per lane) and summed in split order
-        constexpr int UB = TM * TN == 1 ? 8 : 4;
+        // the partials of a 32 x 32 block are read UB splits at a time (128 / 64 loads in flight per lane) and summed in split order
+        constexpr int UB = TM * TN == 1 ? 8 : (TM * TN == 2 ? 4 : 1);    // the 2 x 2 configuration is never split (M <= 4096 takes 32-row tiles)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = min(n0 + (wn * TN + j) * 32 + (lane & 31), p.N - 1);       // rows / columns past the edge: clamped, never stored
