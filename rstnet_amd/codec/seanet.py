@@ -208,13 +208,19 @@ class SEANetResnetBlock(StreamingContainer):
         u = x if isinstance(self.shortcut, nn.Identity) else self.shortcut.forward_nlc(x)
         convs = [m for m in self.block if isinstance(m, StreamingConv1d)]
         h = x
-        for conv in convs[:-1]:
-            h = conv.forward_nlc(h, act_in=ops.ACT_ELU)
+        # x also feeds the skip, so its ELU is applied on the first conv's operand load; a hidden activation whose only consumer
+        # is a kernel-1 conv (no streaming history of it is kept) gets its ELU once, in the producer's epilogue
+        pending = ops.ACT_ELU
+        for i, conv in enumerate(convs[:-1]):
+            nxt = convs[i + 1]
+            in_producer = nxt._effective_kernel_size == 1 and nxt._stride == 1
+            h = conv.forward_nlc(h, act_in=pending, act_out=ops.ACT_ELU_OUT if in_producer else ops.ACT_NONE)
+            pending = ops.ACT_NONE if in_producer else ops.ACT_ELU
         last = convs[-1]
         if h.shape[1] == u.shape[1] and last._stride == 1 and last._effective_kernel_size == 1:
             # skip-add (and the caller's ELU) fused into the epilogue
-            return last.forward_nlc(h, act_in=ops.ACT_ELU, res=u, act_out=ops.ACT_ELU_OUT if elu_out else ops.ACT_NONE)
-        v = last.forward_nlc(h, act_in=ops.ACT_ELU)
+            return last.forward_nlc(h, act_in=pending, res=u, act_out=ops.ACT_ELU_OUT if elu_out else ops.ACT_NONE)
+        v = last.forward_nlc(h, act_in=pending)
         y = _to_nlc(self.add(_to_ncl(u), _to_ncl(v)))
         return ops.activation(y, "elu") if elu_out else y
 

@@ -69,10 +69,8 @@ __global__ __launch_bounds__(64) void attention_kernel(const AttentionParams p) 
 
     f32x4 qf[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        qf[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (q0 + j < p.T) qf[s] = *reinterpret_cast<const f32x4*>(qb + (long)(q0 + j) * D + 8 * s + 4 * h);
-    }
+    for (int s = 0; s < KS; ++s)     // rows past T: a clamped (valid) row, never stored -- unconditional loads, all in flight at once
+        qf[s] = *reinterpret_cast<const f32x4*>(qb + (long)min(q0 + j, p.T - 1) * D + 8 * s + 4 * h);
 
     // slots that can be visible to this query tile
     int lo = 0, hi = p.cap - 1;
@@ -93,18 +91,23 @@ __global__ __launch_bounds__(64) void attention_kernel(const AttentionParams p) 
 
     for (int s0 = (lo / 32) * 32; s0 <= hi; s0 += 32) {
         __syncthreads();
-        // stage K / V tile (32 slots x D), zero beyond cap
+        // stage K / V tile (32 slots x D).  Slots beyond cap read the last slot again (finite data): their scores are masked to -inf
+        // below, so the duplicate takes weight 0 -- and all 2 x 8 loads of the tile are unconditional, i.e. in flight together (a load
+        // under `s0 + row < cap` is waited for inside its branch: 8 round trips per tile instead of one)
+        f32x4 kreg[(32 * D / 4) / 64], vreg[(32 * D / 4) / 64];
+#pragma unroll
+        for (int i = 0; i < (32 * D / 4) / 64; ++i) {
+            const int idx = lane + 64 * i;
+            const int row = min(s0 + idx / (D / 4), p.cap - 1), c4 = (idx % (D / 4)) * 4;
+            kreg[i] = *reinterpret_cast<const f32x4*>(kb + (long)row * D + c4);
+            vreg[i] = *reinterpret_cast<const f32x4*>(vb + (long)row * D + c4);
+        }
 #pragma unroll
         for (int i = 0; i < (32 * D / 4) / 64; ++i) {
             const int idx = lane + 64 * i;
             const int row = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (s0 + row < p.cap) {
-                kv = *reinterpret_cast<const f32x4*>(kb + (long)(s0 + row) * D + c4);
-                vv = *reinterpret_cast<const f32x4*>(vb + (long)(s0 + row) * D + c4);
-            }
-            *reinterpret_cast<f32x4*>(Ks + row * KLD + c4) = kv;
-            *reinterpret_cast<f32x4*>(Vs + row * D + c4) = vv;
+            *reinterpret_cast<f32x4*>(Ks + row * KLD + c4) = kreg[i];
+            *reinterpret_cast<f32x4*>(Vs + row * D + c4) = vreg[i];
         }
         __syncthreads();
 
