@@ -50,7 +50,10 @@ def test_gemv_bf16_prologues(B, N, K):
             assert y.shape == (B, N // 2) and rel_err(y, F.silu(h[:, :N // 2]) * h[:, N // 2:]) < 2e-5
 
 
-@pytest.mark.parametrize("B,N,K", [(32, 4096, 4096), (5, 1000, 1024), (17, 37, 2816), (64, 2048, 1024), (33, 12288, 4096), (8, 96, 64)])
+# K >= 8192 (>= 4096 above 32 rows): K is also split across workgroups (rst_skinny_bf16_split_plan > 1), four / two column tiles per
+# workgroup; N = 1001: ragged last tile and the 4-byte partial stores (N % 4 != 0)
+@pytest.mark.parametrize("B,N,K", [(32, 4096, 4096), (5, 1000, 1024), (17, 37, 2816), (64, 2048, 1024), (33, 12288, 4096), (8, 96, 64),
+                                   (32, 1000, 8192), (7, 1001, 8192), (3, 4096, 11264), (48, 200, 4096)])
 def test_gemm_skinny_bf16(B, N, K):
     """bf16-MFMA skinny GEMM with hi/lo-split activations: fp32-class accuracy against the fp32 oracle product."""
     g = torch.Generator().manual_seed(B + N + K)
@@ -71,7 +74,8 @@ def test_gemm_skinny_bf16(B, N, K):
 
 
 @pytest.mark.parametrize("B,I,K,bias", [(1, 11264, 4096, False), (2, 2816, 1024, True), (1, 24, 16, True), (3, 1408, 512, False),
-                                        (32, 11264, 4096, False), (33, 4864, 896, True), (64, 96, 64, True)])
+                                        (32, 11264, 4096, False), (33, 4864, 896, True), (64, 96, 64, True),
+                                        (40, 2816, 4096, True)])      # the gated epilogue behind a K split (two batch tiles)
 def test_gated_pair_epilogue_fusion(B, I, K, bias):
     """Batch > 2: the first GEMM of the gated MLP applies silu(u) * v in its epilogue and hands the packed hi/lo operand
     to the second (weights packed with the two halves interleaved).  fp32-class accuracy against the fp64 product."""
