@@ -214,6 +214,12 @@ def merge_lora_weights(model: "GPT") -> None:
     return None
 
 
+def _lora_bases(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Copies of the un-adapted weights of every linear that carries adapters in ``sd`` (key = ``<name>.linear.weight``)."""
+    return {k[: -len(".lora_A")] + ".linear.weight": sd[k[: -len(".lora_A")] + ".linear.weight"].detach().clone()
+            for k in sd if k.endswith(".lora_A")}
+
+
 def _qkv_row_order(cfg: Config) -> torch.Tensor:
     """Row permutation of the fused QKV weight: GQA-interleaved [group: q_0..q_{qpk-1}, k, v] -> [Q heads | K heads | V heads],
     and within each q / k head the rotary dims from rotate-half order to interleaved pairs:
@@ -410,6 +416,7 @@ class GPT(StreamingModule[_GPTState]):
         self.config = config
         fk = {"device": device, "dtype": dtype}
         self.lm_head = _Linear(config.n_embd, config.padded_vocab_size, config.lm_head_bias, **fk)
+        self._lora_base: Optional[Dict[str, torch.Tensor]] = None      # from_state_dict(..., keep_lora_base=True)
         self.dep_q = config.dep_q
         self.transformer = LLAMAStreamingTransformer(config, **fk)
         self.max_seq_length = config.block_size
@@ -598,15 +605,49 @@ class GPT(StreamingModule[_GPTState]):
 
     # ---- loading
     @classmethod
-    def from_state_dict(cls, sd: Dict[str, torch.Tensor], config: Config) -> "GPT":
+    def from_state_dict(cls, sd: Dict[str, torch.Tensor], config: Config, keep_lora_base: bool = False) -> "GPT":
         """Model for ``config`` with weights taken from ``sd`` (reference key names, legacy base-checkpoint names accepted,
-        LoRA adapters merged) without copying the dense tensors."""
+        LoRA adapters merged) without copying the dense tensors.  ``keep_lora_base``: also keep a copy of the un-adapted weight
+        of every adapted linear, so that ``load_adapters`` can swap adapter sets later (the reference keeps adapters unmerged
+        for that, llama_streaming.py:113-143; here a swap re-merges in place)."""
         sd = _remap_legacy(dict(sd))
         sd = {k: v for k, v in sd.items() if not k.endswith(("cos", "sin", "_lora_ind"))}
+        bases = None
         if any(k.endswith(".lora_A") for k in sd):
             if config.lora_r <= 0:
                 raise RuntimeError("state dict carries LoRA adapters but config.lora_r == 0")
+            if keep_lora_base:
+                bases = _lora_bases(sd)
             sd = merge_lora_state_dict(sd, config)
+        model = cls._from_merged(sd, config)
+        model._lora_base = bases
+        return model
+
+    def load_adapters(self, adapters: Optional[Dict[str, torch.Tensor]]) -> None:
+        """Swap the LoRA adapter set of a model built with ``keep_lora_base=True``: every adapted linear becomes
+        ``W_base + (B A) * alpha / r`` of the new ``<name>.lora_A`` / ``<name>.lora_B`` tensors, written IN PLACE into the live
+        weights (same fp32 accumulate + rounding as at load, incl. the fused-QKV row scatter); linears of the base set that the new
+        set does not adapt -- or all of them, ``adapters=None`` -- return to their base weights.  The kernel-side packed copies
+        follow the weights' ``_version``, so the next call re-packs what changed; captured decode graphs hold the OLD packed
+        copies, hence swaps are only allowed between sessions (outside ``streaming()`` / ``GPTGen.begin``)."""
+        if self._lora_base is None:
+            raise RuntimeError("load_adapters needs a model built with from_state_dict(..., keep_lora_base=True) from a state dict with adapters")
+        if self._streaming_state is not None or self.transformer._streaming_state is not None:
+            raise RuntimeError("load_adapters: swap adapters between sessions, not inside streaming()")
+        adapters = {} if adapters is None else {k: v for k, v in adapters.items() if k.endswith((".lora_A", ".lora_B"))}
+        unknown = [k for k in adapters if k.endswith(".lora_A") and k[: -len(".lora_A")] + ".linear.weight" not in self._lora_base]
+        if unknown:
+            raise RuntimeError(f"load_adapters: no base weight kept for {unknown[:3]} (adapt the same linears as the set the model was built with)")
+        params = dict(self.named_parameters())
+        tmp = dict(adapters)
+        tmp.update({k: v for k, v in self._lora_base.items()})
+        merged = merge_lora_state_dict({k: v.to(self._lora_base[next(iter(self._lora_base))].device) for k, v in tmp.items()}, self.config)
+        with torch.no_grad():
+            for name in self._lora_base:
+                params[name].copy_(merged[name])
+
+    @classmethod
+    def _from_merged(cls, sd: Dict[str, torch.Tensor], config: Config) -> "GPT":
         model = cls(config, device="meta")
         params = dict(model.named_parameters())
         missing = [k for k in params if k not in sd]

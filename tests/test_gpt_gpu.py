@@ -280,3 +280,39 @@ def test_fp8_blocks_stay_close_to_the_oracle(name):
             assert rel_err(lg, lg_o) < 0.15, t
             agree += int((lg.argmax(-1).cpu() == lg_o.argmax(-1)).sum())
     assert agree >= 0.8 * 5 * B
+
+
+def test_load_adapters_repacks_kernel_side_copies():
+    """Adapter swap on a live model (GPT.load_adapters): the weights change in place, the kernels' packed copies (QKV row order,
+    stacked gate, skinny operand order) must follow -- logits of the swapped model == logits of a model built from [base ; new set],
+    for the full-sequence forward and for graph-captured T = 1 steps of a new session."""
+    cfg_d = dict(CFGS["gqa"])
+    cfg = Config.from_dict(cfg_d)
+    is_lora = lambda k: k.endswith((".lora_A", ".lora_B"))
+    sd1 = {k: v.to(DEV) for k, v in synth.gpt_state_dict(cfg_d, 21).items()}
+    ad2 = {k: v.to(DEV) for k, v in synth.gpt_state_dict(cfg_d, 22).items() if is_lora(k)}
+    base = {k: v for k, v in sd1.items() if not is_lora(k)}
+    toks = cases.gpt_tokens(cfg_d)[:, :, :cases.GPT_T_FULL].to(DEV)
+    model = GPT.from_state_dict({k: v.clone() for k, v in sd1.items()}, cfg, keep_lora_base=True)
+
+    def logits_of(m):
+        h, lg = m.forward_global(toks)
+        with m.streaming(toks.shape[0]):
+            steps = [m.forward_global(toks[:, :, t:t + 1])[1] for t in range(4)]
+        return lg, torch.cat(steps, 1)
+
+    first = logits_of(model)                                  # packs (and captures) everything once with adapter set 1
+    ref1 = logits_of(GPT.from_state_dict({k: v.clone() for k, v in sd1.items()}, cfg))
+    assert torch.equal(first[0], ref1[0]) and torch.equal(first[1], ref1[1])
+    model.load_adapters(ad2)
+    ref2 = logits_of(GPT.from_state_dict({**{k: v.clone() for k, v in base.items()}, **ad2}, cfg))
+    got2 = logits_of(model)
+    assert torch.equal(got2[0], ref2[0]) and torch.equal(got2[1], ref2[1])
+    assert not torch.equal(got2[0], first[0])
+    model.load_adapters(None)
+    ref0 = logits_of(GPT.from_state_dict({k: v.clone() for k, v in base.items()}, cfg))
+    got0 = logits_of(model)
+    assert torch.equal(got0[0], ref0[0]) and torch.equal(got0[1], ref0[1])
+    with model.streaming(2):
+        with pytest.raises(RuntimeError):
+            model.load_adapters(ad2)

@@ -80,3 +80,42 @@ def test_qkv_row_order_is_the_rotate_half_to_interleaved_permutation(cfg_d):
     s = (rot_i(q).view(Gq, qpk, hs) * rot_i(k)[:, None]).sum(-1)
     assert torch.allclose(s, s_ref, rtol=1e-5, atol=1e-5)
     assert torch.equal(v, v_ref)
+
+
+@pytest.mark.parametrize("cfg_d", [synth.GPT_TINY_GQA, synth.GPT_TINY_MHA], ids=["gqa", "mha"])
+def test_load_adapters_swaps_in_place(cfg_d):
+    """GPT.load_adapters: a model built with keep_lora_base=True takes another adapter set (or none) and ends up with exactly the
+    weights of a model built from [base ; that set] -- the reference keeps adapters unmerged for this (llama_streaming.py:113-143),
+    here the swap re-merges in place (same tensors: the kernels' packed copies follow their `_version`)."""
+    cfg = G.Config.from_dict(cfg_d)
+    sd1 = synth.gpt_state_dict(cfg_d, 11)
+    is_lora = lambda k: k.endswith((".lora_A", ".lora_B"))
+    base = {k: v for k, v in sd1.items() if not is_lora(k)}
+    ad2 = {k: v for k, v in synth.gpt_state_dict(cfg_d, 12).items() if is_lora(k)}
+    assert ad2 and any(not torch.equal(ad2[k], sd1[k]) for k in ad2)
+
+    model = G.GPT.from_state_dict({k: v.clone() for k, v in sd1.items()}, cfg, keep_lora_base=True)
+    ptrs = {n: p.data_ptr() for n, p in model.named_parameters()}
+    vers = {n: p._version for n, p in model.named_parameters()}
+
+    def same_as(ref_sd):
+        ref = G.GPT.from_state_dict({k: v.clone() for k, v in ref_sd.items()}, cfg)
+        for (n, p), (n2, q) in zip(model.named_parameters(), ref.named_parameters()):
+            assert n == n2 and torch.equal(p, q), n
+
+    same_as(sd1)
+    model.load_adapters(ad2)
+    same_as({**base, **ad2})
+    adapted = [n for n in ptrs if n in model._lora_base]
+    assert adapted and all(dict(model.named_parameters())[n].data_ptr() == ptrs[n] for n in ptrs)          # in place
+    assert all(dict(model.named_parameters())[n]._version > vers[n] for n in adapted)                       # packed copies will rebuild
+    model.load_adapters(None)
+    same_as(base if cfg.lora_r == 0 else {**base})           # back to the un-adapted weights
+    model.load_adapters({k: v for k, v in sd1.items() if is_lora(k)})
+    same_as(sd1)
+
+    plain = G.GPT.from_state_dict({k: v.clone() for k, v in sd1.items()}, cfg)
+    with pytest.raises(RuntimeError):
+        plain.load_adapters(ad2)                              # built without keep_lora_base
+    with pytest.raises(RuntimeError):
+        model.load_adapters({"transformer.h.0.nope.lora_A": torch.zeros(1, 1), "transformer.h.0.nope.lora_B": torch.zeros(1, 1)})
