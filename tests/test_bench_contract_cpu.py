@@ -56,6 +56,13 @@ def test_default_workload_line_has_roofline_and_cpu_baseline():
     assert d["cpu_baseline"]["kind"] == "port" and "configs[1]" in d["config"]["workload"]
     assert d["code_exact_match_vs_cpu_oracle"] == 1.0 and d["wav_rel_err_vs_cpu_oracle"] < 1e-3      # the parity sample rides on the default line
     assert d["timing"]["samples"] >= 50 and d["timing"]["median_ms"] <= d["timing"]["p95_ms"]
+    # the trace / counter cross-checks quote the streamed kernel of the same round, and the matrix pipe's busy fraction at the
+    # clock the power budget allowed sits next to the nominal-peak fraction
+    r = d["roofline"]
+    assert r["rocprof"]["source"].startswith(f"profiles/{TAG}_") and abs(r["rocprof"]["frac"] - r["frac"]) < 0.05
+    assert r["traffic"]["source"].startswith(f"profiles/{TAG}_") and r["traffic"]["bytes_per_launch"] > 0
+    m = r["mfma_pipe"]
+    assert 0.3 < m["busy_frac"] <= 1.0 and 1.5 < m["shader_clock_ghz"] < 2.6 and m["peak_at_that_clock_tflops"] <= 160
 
 
 def test_default_line_carries_the_north_star_sub_benchmarks():
