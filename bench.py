@@ -166,9 +166,19 @@ def cpu_baseline(sd, seconds_per_clip: float, batch: int = 4):
                 dt = time.perf_counter() - t0
                 if best is None or dt < best:
                     best, best_threads = dt, threads
+    # SURVEY 8(d) also asks for the single-thread figure: one 2 s clip, one thread
+    torch.set_num_threads(1)
+    one = synth.synth_audio(1, 2 * 24000, seed=11)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        c1 = O.encode(sd, cfg, one)
+        O.decode(sd, cfg, c1)
+        dt1 = time.perf_counter() - t0
     torch.set_num_threads(default_threads)
     frames = codes.shape[0] * codes.shape[2]
     return {"value": round(frames / best, 2), "unit": "frames/s", "cores": best_threads, "kind": "port",
+            "single_thread": {"value": round(c1.shape[0] * c1.shape[2] / dt1, 2), "unit": "frames/s", "cores": 1,
+                              "sample": f"oracle encode+decode of one 2 s clip, 1 thread ({dt1:.2f} s)"},
             "sample": f"oracle encode+decode of {batch} x {seconds_per_clip:g} s clips, fp32, torch CPU, best of "
                       f"{{{min(32, default_threads)}, {default_threads}}} threads x 2 runs ({best:.2f} s); host has "
                       f"{os.cpu_count()} logical cores"}
@@ -386,19 +396,28 @@ def gpt_cpu_baseline(cfg_d, frames: int = 3):
                       f"32), greedy, fp32, LoRA pre-merged"}
 
 
-def bench_gpt(args, rank, world, dev):
-    """BASELINE configs[4]: Qwen-0.5B-shaped litgpt backbone (LoRA adapters merged at load) + codecformer, B streams; one step =
-    one frame: text sample + dep_q depth steps with sampling (one graph) + the global T = 1 step of the completed frame (one
-    graph)."""
-    from rstnet_amd import ops, synth
-    from rstnet_amd.lm.generate import GPTGen
+def build_gpt(args, dev):
+    from rstnet_amd import synth
     from rstnet_amd.lm.gpt import GPT, Config
     cfg_d = dict(synth.GPT_QWEN_0_5B if args.lm_config != "tiny" else synth.GPT_TINY_GQA)
-    B = args.lm_batch
     sd = synth.gpt_state_dict(cfg_d, seed=0, device=str(dev))
-    model = GPT.from_state_dict(sd, Config.from_dict(cfg_d)).use_fp8(args.fp8)
+    model = GPT.from_state_dict(sd, Config.from_dict(cfg_d))
     del sd
-    n_params = sum(v.numel() for v in model.state_dict().values())
+    return cfg_d, model, sum(v.numel() for v in model.state_dict().values())
+
+
+def run_gpt(args, rank, world, dev, gpt=None, fp8=None, steps=None, warmup=None, cpu=True):
+    """BASELINE configs[4]: Qwen-0.5B-shaped litgpt backbone (LoRA adapters merged at load) + codecformer, B streams; one step =
+    one frame: text sample + dep_q depth steps with sampling (one graph) + the global T = 1 step of the completed frame (one
+    graph).  Returns the result dict on rank 0 (None elsewhere)."""
+    from rstnet_amd import ops
+    from rstnet_amd.lm.generate import GPTGen
+    cfg_d, model, n_params = gpt if gpt is not None else build_gpt(args, dev)
+    fp8 = args.fp8 if fp8 is None else fp8
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    model.use_fp8(fp8)
+    B = args.lm_batch
     n_codes = cfg_d["audio_card"] - 2
     gen = GPTGen(model, use_sampling=not args.greedy, temp=0.8, temp_text=0.7, top_k=250, top_k_text=25, n_audio_codes=n_codes)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -412,7 +431,7 @@ def bench_gpt(args, rank, world, dev):
     def frame(h, logits):
         text, audio = gen.frame(h.contiguous(), logits.contiguous())
         return gen.advance(text, audio)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         h, logits = frame(h, logits)
     torch.cuda.synchronize()
     if world > 1:
@@ -420,20 +439,27 @@ def bench_gpt(args, rank, world, dev):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         h, logits = frame(h, logits)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    samples = []
+    for _ in range(max(args.timing_samples, 1) if world == 1 else 0):      # median / p95 of individually synchronised frames
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        h, logits = frame(h, logits)
+        torch.cuda.synchronize()
+        samples.append((time.perf_counter() - ts) * 1e3)
     gen.end()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank != 0:
-        return
+        return None
     # roofline of the weight-streaming GEMMs: one extra eager frame with HIP events per launch
     gen2 = GPTGen(model, use_sampling=not args.greedy, n_audio_codes=n_codes, noise=None)
     os.environ["NO_CUDA_GRAPH"] = "1"
@@ -457,31 +483,46 @@ def bench_gpt(args, rank, world, dev):
             d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += nb
         for shp, (n, t, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             print(f"  gemm B,N,K={shp}: {n:4d} launches {t:8.3f} ms  {nb / t / 1e6:8.1f} GB/s", file=sys.stderr)
-    ms_frame = elapsed / args.steps * 1e3
+    ms_frame = elapsed / steps * 1e3
+    # every weight byte a frame streams once: global blocks + LM head (bf16, or e4m3 + scales for the fp8 blocks), the stacked
+    # codecformer_in, dep_q x (depth layers + head)
+    c = cfg_d
+    blk = c["n_layer"] * ((c["n_embd"] + 2 * c["n_query_groups"] * (c["n_embd"] // c["n_head"])) * c["n_embd"] + c["n_embd"] * c["n_embd"]
+                          + 3 * c["intermediate_size"] * c["n_embd"])
+    dE, dH = c["codecformer_dim"], (21 * c["codecformer_dim"]) // 8 if c["codecformer_dim_feedforward"] == 4 * c["codecformer_dim"] \
+        else (2 * c["codecformer_dim_feedforward"]) // 3
+    dep = c["dep_q"] * (c["codecformer_layers"] * (4 * dE * dE + 3 * dH * dE) + c["audio_card"] * dE + dE * c["n_embd"])
+    frame_bytes = blk * (1 if fp8 else 2) + 2 * (c["padded_vocab_size"] * c["n_embd"] + dep)
     result = {
         "metric": METRIC,
-        "value": round(B * world * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_frame, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16 weights, f32 activations (bf16 hi+lo split on the matrix cores)", "data": "synthetic",
+        "value": round(B * world * steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(ms_frame, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": ("fp8 e4m3 block GEMMs, " if fp8 else "") + "bf16 weights, f32 activations (bf16 hi+lo split on the matrix cores)",
+        "data": "synthetic",
         "config": {"workload": "GPT (Qwen-1.5-0.5B-shaped litgpt backbone, LoRA r=32 merged) + codecformer: streamed frame = global "
                                "step + text sample + 8 depth steps with sampling, BASELINE.json configs[4]",
                    "batch_per_gpu": B, "params": n_params, "sampling": "greedy" if args.greedy else "temp 0.8/0.7 top-k 250/25",
                    "hip_graphs": True,
-                   "gemm_precision": "fp8 e4m3 (per-row scales) in the global blocks, bf16 hi+lo elsewhere" if args.fp8 else "bf16 hi+lo",
+                   "gemm_precision": "fp8 e4m3 (per-row scales) in the global blocks, bf16 hi+lo elsewhere" if fp8 else "bf16 hi+lo",
                    "parallelism": f"replica x{world}"},
-        "x_realtime_per_stream": round(args.steps / elapsed / 12.5, 2),
+        "x_realtime_per_stream": round(steps / elapsed / 12.5, 2),
         "roofline": {"bound": "hbm", "kernel": ("gemv_kernel / gemv_norm_kernel" if B <= 2 else "gemm_skinny_kernel") + " (bf16 weight streaming)",
                      "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                      "traffic": pmc_traffic("gemv_" if B <= 2 else "gemm_skinny_kernel", "gpt"),
                      "algorithmic_bytes_per_launch": round(nbytes / max(1, len(gemm))), "launches_per_step": len(gemm),
                      "avg_launch_ms": round(ms / max(1, len(gemm)), 5), "kernel_ms_per_step": round(ms, 3),
-                     "algorithmic_gb_per_step": round(nbytes / 1e9, 3), "share_of_step_eager": round(ms / ms_frame, 3)},
+                     "algorithmic_gb_per_step": round(nbytes / 1e9, 3), "share_of_step_eager": round(ms / ms_frame, 3),
+                     # the whole frame against the HBM roofline: every weight byte of the frame once / the frame time
+                     "frame": {"algorithmic_gb": round(frame_bytes / 1e9, 3), "achieved": round(frame_bytes / ms_frame / 1e6, 1),
+                               "frac": round(frame_bytes / ms_frame / 1e6 / HBM_PEAK_GBS, 4)}},
     }
-    _with_rocprof(result["roofline"], "gemv_" if B <= 2 else "gemm_skinny_kernel", "gpt", nbytes / max(1, len(gemm)), HBM_PEAK_GBS)
-    if not args.no_cpu_baseline and world == 1:    # the CPU leg is timed on rank 0 of the single-GPU run only
+    if samples:
+        result["timing"] = _timing(samples)
+    _with_rocprof(result["roofline"], "gemv_" if B <= 2 else "gemm_skinny_kernel", "gpt_fp8" if fp8 else "gpt", nbytes / max(1, len(gemm)), HBM_PEAK_GBS)
+    if cpu and not args.no_cpu_baseline and world == 1:    # the CPU leg is timed on rank 0 of the single-GPU run only
         result["cpu_baseline"] = gpt_cpu_baseline(cfg_d)
-    print(json.dumps(result), flush=True)
+    return result
 
 
 def run_e2e(args, rank, world, dev, lm=None, steps=None, warmup=None, lm_result=None):
@@ -577,7 +618,9 @@ def main():
 
     if args.workload in ("lm", "e2e", "gpt"):
         if args.workload == "gpt":
-            bench_gpt(args, rank, world, dev)
+            res = run_gpt(args, rank, world, dev)
+            if rank == 0:
+                print(json.dumps(res), flush=True)
         else:
             lm = build_lm(args, rank, world, dev)
             res = run_lm(args, rank, world, dev, lm=lm) if args.workload == "lm" else run_e2e(args, rank, world, dev, lm=lm)
@@ -687,10 +730,32 @@ def main():
         if not args.no_cpu_baseline and "cpu_baseline" in lm_res:
             e2e_res["cpu_baseline"] = e2e_cpu_baseline(lm_res["cpu_baseline"])
             lm_res["cpu_baseline"].pop("_seconds_per_frame", None)
-        for sub in (lm_res, e2e_res):      # sub-objects: drop what the enclosing line already states
+        subs = {"lm_b1": lm_res, "e2e_b1": e2e_res}
+        lm_cpu, e2e_cpu = lm_res.get("cpu_baseline"), e2e_res.get("cpu_baseline")
+
+        def shared_cpu(leg, of):
+            return dict(leg, note=f"the CPU leg of {of} (one stream; not re-timed for this sub-object)") if leg else None
+        # configs[2] with every temporal attention reading a full 3000-slot ring; configs[3] at its per-GPU size (32 streams)
+        args.lm_context = 3000
+        subs["lm_ctx3000"] = run_lm(args, rank, world, dev, lm=lm, steps=args.sub_steps, warmup=10, cpu=False)
+        args.lm_context, args.lm_batch = 0, 32
+        subs["lm_b32"] = run_lm(args, rank, world, dev, lm=lm, steps=args.sub_steps, warmup=10, cpu=False)
+        subs["e2e_b32"] = run_e2e(args, rank, world, dev, lm=lm, steps=args.sub_steps, warmup=10, lm_result=subs["lm_b32"])
+        for name, leg, of in (("lm_ctx3000", lm_cpu, "lm_b1"), ("lm_b32", lm_cpu, "lm_b1"), ("e2e_b32", e2e_cpu, "e2e_b1")):
+            if leg:
+                subs[name]["cpu_baseline"] = shared_cpu(leg, of)
+        del lm
+        torch.cuda.empty_cache()
+        # configs[4]: Qwen-0.5B-shaped GPT + LoRA, 32 streams, bf16 hi+lo and the fp8 block GEMMs
+        gpt = build_gpt(args, dev)
+        subs["gpt_b32"] = run_gpt(args, rank, world, dev, gpt=gpt, fp8=False, steps=args.sub_steps, warmup=10)
+        subs["gpt_b32_fp8"] = run_gpt(args, rank, world, dev, gpt=gpt, fp8=True, steps=args.sub_steps, warmup=10, cpu=False)
+        if "cpu_baseline" in subs["gpt_b32"]:
+            subs["gpt_b32_fp8"]["cpu_baseline"] = shared_cpu(subs["gpt_b32"]["cpu_baseline"], "gpt_b32")
+        for sub in subs.values():      # sub-objects: drop what the enclosing line already states
             for k in ("metric", "n_gpus", "higher_is_better", "scaling", "vs_baseline", "data"):
                 sub.pop(k, None)
-        result["lm_b1"], result["e2e_b1"] = lm_res, e2e_res
+        result.update(subs)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

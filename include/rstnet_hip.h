@@ -194,8 +194,12 @@ int rst_hist_update_batch_f32(const float* const* x, float* const* hist, const i
  * causal / context mask (:254-278, 404-414) -> out_proj [E][E] -> x + scale1 * . -> LayerNorm -> linear1 [F][E] -> exact GELU ->
  * linear2 [E][F] -> x + scale2 * .   Tables are HOST arrays of L device pointers (scale1 / scale2 may be NULL: no LayerScale).
  * x, y fp32 [B][T][E]; workspace of rst_codec_transformer_workspace_bytes(B * T, E, F) bytes (zeroed by the call on `stream`);
- * *status is OR-ed with a non-zero code if an in-launch hand-off timed out (bounded spins; see rst_depth_decode_frame). */
+ * status: 4 device words with the protocol of rst_depth_decode_frame (a timed-out hand-off is repaired in-stream by the
+ * one-workgroup launch the call enqueues behind the persistent one; status[1] counts repaired steps).
+ * rst_codec_transformer_supported: > 0 (the grid of the persistent launch) when the shape is served and one workgroup of its
+ * footprint fits a CU (occupancy query), else 0 -- callers then run the launch-per-op layer loop. */
 int rst_codec_transformer_workspace_bytes(int rows, int E, int F);
+int rst_codec_transformer_supported(int B, int T, int E, int H, int F, int L, int cap);
 int rst_codec_transformer_frame(const float* const* in_proj, const float* const* out_proj, const float* const* linear1,
                                 const float* const* linear2, const float* const* norm1_w, const float* const* norm1_b,
                                 const float* const* norm2_w, const float* const* norm2_b, const float* const* scale1,
@@ -258,10 +262,19 @@ int rst_gemv_embed_bf16_f32(const float* add, const uint16_t* table, const int64
  * are never drawn at step k (the id blanking of sample_token_audio / _2048).  context <= 0: none (the depth transformer's).
  * The KV ring of the depth transformer (ring_cap >= dep_q slots: dep_q for LMGen -- RingKVCache.complete's positions then hide
  * step 0 at the last step, the `delta <= 0` slot -- or dep_q + 1 for a caller that sized its ring so) lives in the LDS of the launch; ops hand their output vectors over in `workspace` (rst_depth_frame_workspace_bytes bytes, 8-byte
- * {epoch, value} granules, zeroed by the call itself on `stream`).  *status is OR-ed with a non-zero code if a hand-off timed
- * out (bounded spins: the launch always terminates; the frame's tokens are then undefined).  One launch = grid of one workgroup
- * per CU, all of which must be resident: nothing else may run on the device concurrently with it. */
+ * {epoch, value} granules, zeroed by the call itself on `stream`).
+ * Residency and what happens without it: the persistent launch is a grid of up to one workgroup per CU (sized so that every
+ * workgroup owns rows in the all-to-all ops; refused -- rst_depth_frame_supported == 0 -- when the occupancy query says a CU
+ * cannot take one), all of which must be resident at once.  A device shared with other work may not grant that: every spin is
+ * bounded (~0.2 s), a timed-out hand-off ORs a code into status[0] and the launch drains.  The call enqueues, right behind it, the
+ * same kernel as ONE workgroup: it returns at once while status[0] == 0 and otherwise recomputes the frame alone (it depends on no
+ * other workgroup, so it cannot time out), overwrites the tokens, increments status[1] (frames repaired), ORs the codes into
+ * status[2] and clears status[0] -- as with the reference's depformer_step (models/model.py:564-597) wrong tokens never leave the
+ * stream.  `status`: 4 device words, zero before the first call; hosts read status[1] now and then and move a device that keeps
+ * repairing to the launch-per-op chain (a repaired frame costs the time-outs + ~30 ms).
+ * rst_depth_frame_supported: the grid (> 0) when the shape is served, else 0. */
 int rst_depth_frame_workspace_bytes(int B, int E, int Hd, int card);
+int rst_depth_frame_supported(int B, int E, int H, int Hd, int card, int dep_q, int L, int top_k);
 int rst_depth_decode_frame(const uint16_t* const* in_proj, const uint16_t* const* out_proj, const float* const* norm1,
                            const float* const* norm2, const uint16_t* const* gate_in, const uint16_t* const* gate_out,
                            const uint16_t* const* heads, const float* const* head_bias, const uint16_t* const* emb, const int* emb_rows,

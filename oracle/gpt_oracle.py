@@ -164,6 +164,37 @@ def lora_qkv_forward(x: torch.Tensor, sd: SD, prefix: str, cfg: GPTConfig) -> to
 
 
 # ----------------------------------------------------------------------------------------------------------- primitives
+def fp8_e4m3_rows(t: torch.Tensor) -> torch.Tensor:
+    """Per-row symmetric e4m3 quantisation as the product's opt-in fp8 path applies it (one scale = amax / 448 per weight row, one
+    dynamic scale per activation row; csrc/lm_skinny.hip rst_skinny_pack_{weight,act}_fp8), returned de-quantised in fp32."""
+    sc = t.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30) / 448.0
+    return (t / sc).to(torch.float8_e4m3fn).float() * sc
+
+
+def fp8_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 product of the e4m3-quantised operands (+ the unquantised bias): what BASELINE.json configs[4]'s "fp8 MFMA GEMMs" compute."""
+    return F.linear(fp8_e4m3_rows(x.float()), fp8_e4m3_rows(w.float()), b)
+
+
+_block_linear = F.linear      # the linears inside the global blocks (merged weights); swapped by `fp8_blocks()`
+
+
+class fp8_blocks:
+    """``with fp8_blocks():`` -- the block linears of ``forward_global(..., merged=True)`` run as ``fp8_linear`` (the oracle side of
+    ``GPT.use_fp8()``: fused QKV, attention projection, fc_1 / fc_2, MLP projection; embeddings, norms, attention and the LM head
+    stay fp32 exactly as in the product)."""
+
+    def __enter__(self):
+        global _block_linear
+        self._saved, _block_linear = _block_linear, fp8_linear
+        return self
+
+    def __exit__(self, *exc):
+        global _block_linear
+        _block_linear = self._saved
+        return False
+
+
 def lit_rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     """lit_model.RMSNorm.forward (:707-714) without the unit offset."""
     x = x.float()
@@ -224,7 +255,7 @@ def attention(x: torch.Tensor, sd: SD, p: str, cfg: GPTConfig, cos: torch.Tensor
     G, hs = cfg.n_query_groups, cfg.head_size
     q_per_kv = cfg.n_head // G
     if merged:
-        qkv = F.linear(x, sd[f"{p}.attn.linear.weight"].float(), sd.get(f"{p}.attn.linear.bias"))
+        qkv = _block_linear(x, sd[f"{p}.attn.linear.weight"].float(), sd.get(f"{p}.attn.linear.bias"))
     else:
         qkv = lora_qkv_forward(x, sd, f"{p}.attn", cfg)
     qkv = qkv.view(B, T, G, q_per_kv + 2, hs).permute(0, 2, 3, 1, 4)
@@ -252,13 +283,16 @@ def attention(x: torch.Tensor, sd: SD, p: str, cfg: GPTConfig, cos: torch.Tensor
     y = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=0.0, scale=1.0 / hs ** 0.5)
     y = y.transpose(1, 2).reshape(B, T, hs * cfg.n_head)
     if merged:
-        return F.linear(y, sd[f"{p}.proj.linear.weight"].float(), sd.get(f"{p}.proj.linear.bias"))
+        return _block_linear(y, sd[f"{p}.proj.linear.weight"].float(), sd.get(f"{p}.proj.linear.bias"))
     return lora_linear_forward(y, sd, f"{p}.proj", cfg.lora_r if cfg.lora_projection else 0, cfg.lora_alpha)
 
 
 def mlp(x: torch.Tensor, sd: SD, p: str, cfg: GPTConfig, merged: bool) -> torch.Tensor:
     """LLaMAMLP.forward (lit_model.py:399-403) over (LoRA) linears."""
-    r = 0 if merged or not cfg.lora_mlp else cfg.lora_r
+    if merged:
+        lin = lambda t, name: _block_linear(t, sd[f"{p}.{name}.linear.weight"].float(), sd.get(f"{p}.{name}.linear.bias"))     # noqa: E731
+        return lin(F.silu(lin(x, "fc_1")) * lin(x, "fc_2"), "proj")
+    r = cfg.lora_r if cfg.lora_mlp else 0
     a = lora_linear_forward(x, sd, f"{p}.fc_1", r, cfg.lora_alpha)
     b = lora_linear_forward(x, sd, f"{p}.fc_2", r, cfg.lora_alpha)
     return lora_linear_forward(F.silu(a) * b, sd, f"{p}.proj", r, cfg.lora_alpha)

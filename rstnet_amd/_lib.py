@@ -44,12 +44,14 @@ SIGNATURES = {
     "rst_gemm_skinny_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "rst_mask_tail_f32": [_p, _p, _i, _i, _i, _i, _p],
     "rst_codec_transformer_workspace_bytes": [_i, _i, _i],
+    "rst_codec_transformer_supported": [_i, _i, _i, _i, _i, _i, _i],
     "rst_codec_transformer_frame": [C.POINTER(_p)] * 12 + [_p, _p, _p, _p, _p] + [_i] * 9 + [_f, _f, _p],
     "rst_gemv_f32": [_p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "rst_gemv_bf16_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "rst_gemv_attn_bf16_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rst_gemv_embed_bf16_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "rst_depth_frame_workspace_bytes": [_i, _i, _i, _i],
+    "rst_depth_frame_supported": [_i, _i, _i, _i, _i, _i, _i, _i],
     "rst_depth_decode_frame": [C.POINTER(_p)] * 9 + [C.POINTER(_i), _p, _p, _p, _p, _p, _p] + [_i] * 12 + [_f, _f, _i, _i, _p],
     "rst_skinny_pack_weight_bf16": [_p, _p, _i, _i, _i, _p],
     "rst_skinny_pack_act_f32": [_p, _p, _p, _i, _i, _i, _i, _f, _p],

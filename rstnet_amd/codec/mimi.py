@@ -30,6 +30,7 @@ class _MimiState:
     """Per-streaming-session graph wrappers (one per input shape) of the encode / decode step."""
     enc: dict = field(default_factory=dict)
     dec: dict = field(default_factory=dict)
+    calls: int = 0
 
     def reset(self) -> None:
         self.enc.clear()
@@ -122,9 +123,15 @@ class MimiCodec(StreamingModule[_MimiState]):
         if state is None or not audio_data.is_cuda:
             return self.quantizer.encode_nlc(self.encode_latent(audio_data))
         # streaming: after two eager frames every step has the same shapes and buffer addresses -> replay a HIP graph
-        g = state.enc.get(tuple(audio_data.shape))
+        # (keyed by ops.persistent_epoch too: a device whose persistent transformer launches needed repairs -- polled here every 64
+        # steps, without synchronising -- moves to the layer loop, which is another graph)
+        if state.calls % 64 == 0:
+            ops.persistent_poll(audio_data.device)
+        state.calls += 1
+        key = tuple(audio_data.shape) + (ops.persistent_epoch(audio_data.device),)
+        g = state.enc.get(key)
         if g is None:
-            g = state.enc[tuple(audio_data.shape)] = Graphed(lambda a: self.quantizer.encode_nlc(self.encode_latent(a)), warmup=2)
+            g = state.enc[key] = Graphed(lambda a: self.quantizer.encode_nlc(self.encode_latent(a)), warmup=2)
         return g(audio_data.contiguous()).clone()
 
     @torch.no_grad()
@@ -135,9 +142,10 @@ class MimiCodec(StreamingModule[_MimiState]):
         state = self._streaming_state
         if state is None or not codes.is_cuda:
             return self._decode(codes)
-        g = state.dec.get(tuple(codes.shape))
+        key = tuple(codes.shape) + (ops.persistent_epoch(codes.device),)
+        g = state.dec.get(key)
         if g is None:
-            g = state.dec[tuple(codes.shape)] = Graphed(self._decode, warmup=2)
+            g = state.dec[key] = Graphed(self._decode, warmup=2)
         return g(codes.contiguous()).clone()
 
     def _decode(self, codes: torch.Tensor) -> torch.Tensor:

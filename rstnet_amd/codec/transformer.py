@@ -280,7 +280,8 @@ class StreamingTransformer(StreamingModule[_TransformerState]):
             return None
         if (out[0]["scale1"] is None) != (out[0]["scale2"] is None) or any((ly["scale1"] is None) != (out[0]["scale1"] is None) for ly in out):
             return None
-        if not ops.codec_transformer_frame_supported(B, T, E, att.num_heads, l0.linear1.out_features, len(out), out[0]["k_cache"].shape[2]):
+        if not ops.codec_transformer_frame_supported(B, T, E, att.num_heads, l0.linear1.out_features, len(out), out[0]["k_cache"].shape[2],
+                                                     device=x.device):
             return None
         return out
 

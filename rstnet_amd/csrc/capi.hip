@@ -239,8 +239,13 @@ int rst_gemv_embed_bf16_f32(const float* add, const uint16_t* table, const int64
     return rst_launch_gemv(p, (hipStream_t)stream);
 }
 
-int rst_depth_frame_workspace_bytes(int B, int E, int Hd, int card) {
-    return (int)(rst_depth_frame_workspace_granules(B, E, Hd, card) * 8);
+int rst_depth_frame_workspace_bytes(int B, int E, int Hd, int card) { return (int)rst_depth_frame_workspace_bytes_impl(B, E, Hd, card); }
+
+int rst_depth_frame_supported(int B, int E, int H, int Hd, int card, int dep_q, int L, int top_k) {
+    if (H <= 0 || E % H) return 0;
+    DepthFrameParams p = {};
+    p.B = B; p.E = E; p.H = H; p.D = E / H; p.Hd = Hd; p.card = card; p.dep_q = dep_q; p.L = L; p.top_k = top_k;
+    return rst_depth_frame_grid(p);
 }
 
 int rst_depth_decode_frame(const uint16_t* const* in_proj, const uint16_t* const* out_proj, const float* const* norm1,
@@ -265,12 +270,15 @@ int rst_depth_decode_frame(const uint16_t* const* in_proj, const uint16_t* const
     }
     p.h_all = h_all; p.tokens = reinterpret_cast<long*>(tokens); p.noise = noise; p.v_limit = v_limit_dev;
     p.gran = static_cast<unsigned long long*>(workspace); p.status = status;
+    p.hist_solo = workspace ? reinterpret_cast<float*>(p.gran + 2 * rst_depth_frame_workspace_granules(B, E, Hd, card)) : nullptr;
     p.B = B; p.E = E; p.H = H; p.D = E / H; p.Hd = Hd; p.card = card; p.dep_q = dep_q; p.L = L; p.ld_h = ld_h; p.tok_stride = tok_stride;
     p.noise_stride = noise_stride; p.top_k = top_k; p.use_sampling = use_sampling; p.context = context; p.ring_cap = ring_cap; p.eps = eps; p.temp = temp;
     return rst_launch_depth_frame(p, (hipStream_t)stream);
 }
 
-int rst_codec_transformer_workspace_bytes(int rows, int E, int F) { return (int)(rst_codec_tr_workspace_granules(rows, E, F) * 8); }
+int rst_codec_transformer_workspace_bytes(int rows, int E, int F) { return (int)(rst_codec_tr_workspace_granules(rows, E, F) * 16); }
+
+int rst_codec_transformer_supported(int B, int T, int E, int H, int F, int L, int cap) { return rst_codec_tr_grid(B, T, E, H, F, L, cap); }
 
 int rst_codec_transformer_frame(const float* const* in_proj, const float* const* out_proj, const float* const* linear1,
                                 const float* const* linear2, const float* const* norm1_w, const float* const* norm1_b,

@@ -108,8 +108,12 @@ __device__ __forceinline__ void ct_layernorm(const float* x, const float* gamma,
     __syncthreads();
 }
 
-template <int R>
+// SOLO: the one-workgroup repair launch enqueued behind the persistent one (persist.h): a no-op unless a hand-off of that launch timed
+// out, else the whole step recomputed by this workgroup alone (every (stream, head) pair in turn; the ring slots of the new steps are
+// rewritten with the right values before anything reads them -- reads of a new step's own slots come from LDS either way).
+template <int R, bool SOLO>
 __global__ __launch_bounds__(DF_THREADS) void codec_tr_kernel(const CodecTrParams p) {
+    if (SOLO && __hip_atomic_load(p.status, DF_RLX) == 0u) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     DfShared& sh = *reinterpret_cast<DfShared*>(lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(DF_THREADS) void codec_tr_kernel(const CodecTrParam
     float* xs = lds + DF_HDR_FLOATS;
     float* xres = xs + R * XW;
     float* qh = xres + R * E;
-    u64* gX = p.gran;
+    u64* gX = p.gran + (SOLO ? (long)R * (5L * E + F) : 0L);
     u64* gQKV = gX + (long)R * E;
     u64* gATT = gQKV + (long)R * 3 * E;
     u64* gH = gATT + (long)R * E;
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(DF_THREADS) void codec_tr_kernel(const CodecTrParam
         ct_rows_issue<1, 1>(po, p.out_proj[l], E, E, gw, W, lane);
         // ---- attention of (stream, head) = workgroup index
         ++eATT;
-        if (wg < p.B * H) {
-            const int b = wg / H, h = wg - b * H;
+        for (int bh = wg; bh < p.B * H; bh += G) {
+            const int b = bh / H, h = bh - b * H;
             // q / k / v of the head for the T new steps of stream b: item i = (t, part, d)
             df_gather<2>(gQKV, T * 3 * D, eQKV, qh, [&](int i) { const int t = i / (3 * D), j = i - t * 3 * D, part = j / D;
                                                               return ((long)(b * T + t) * 3 + part) * E + h * D + (j - part * D); }, sh, p.status, 2u);
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(DF_THREADS) void codec_tr_kernel(const CodecTrParam
     }
     if (wg == 0)
         for (int i = tid; i < R * E; i += DF_THREADS) p.y[i] = xres[i];
+    if (SOLO) df_solo_done(p.status);
 }
 
 int ct_cu_count() {
@@ -289,39 +294,63 @@ int ct_cu_count() {
 
 long rst_codec_tr_workspace_granules(int R, int E, int F) { return (long)R * (5L * E + F); }
 
+// Workgroups of the persistent launch for a shape, 0 if it is not served: every workgroup must own a row of the in-projection
+// (3E rows) and of linear1 (F rows) -- the all-to-all ops between two writes of a hand-off buffer (persist.h) -- every (stream,
+// head) pair needs a workgroup and one workgroup of that LDS footprint must fit a CU.
+int rst_codec_tr_grid(int B, int T, int E, int H, int F, int L, int cap) {
+    const int R = B * T;
+    if (!(B >= 1 && T >= 1 && T <= DF_WAVES && R <= 4 && E > 0 && E % 8 == 0 && F > 0 && F % 8 == 0 && H > 0 && E % H == 0 && L >= 1 &&
+          L <= RST_CTR_MAX_L && cap >= T))
+        return 0;
+    const int D = E / H;
+    if (!(D >= 16 && D % 16 == 0 && D <= 256 && (64 % (D / 16)) == 0)) return 0;
+    const int XW = E > F ? E : F;
+    const size_t lds = ((size_t)DF_HDR_FLOATS + (size_t)R * XW + (size_t)R * E + (size_t)T * 3 * D) * sizeof(float);
+    if (lds > 150 * 1024) return 0;
+    const int G = df_grid_for_rows(ct_cu_count(), min(3 * E, F));
+    if (B * H > G) return 0;
+    static int fits = -1;
+    if (fits < 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(codec_tr_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        int nb = 0;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, codec_tr_kernel<4, false>, DF_THREADS, 150 * 1024);
+        (void)hipGetLastError();
+        fits = (e == hipSuccess && nb >= 1) ? 1 : 0;
+    }
+    return fits ? G : 0;
+}
+
 int rst_launch_codec_tr(const CodecTrParams& p, hipStream_t stream) {
     const int R = p.B * p.T;
-    RST_REQUIRE(p.B >= 1 && p.T >= 1 && p.T <= DF_WAVES && R <= 4, "codec_tr: %d streams x %d new positions (at most 4 rows, 4 positions)", p.B, p.T);
-    RST_REQUIRE(p.E > 0 && p.E % 8 == 0 && p.F > 0 && p.F % 8 == 0 && p.H > 0 && p.D >= 16 && p.D % 16 == 0 && p.D <= 256 && p.H * p.D == p.E &&
-                    (64 % (p.D / 16)) == 0 && p.L >= 1 && p.L <= RST_CTR_MAX_L && p.cap >= p.T,
-                "codec_tr: unsupported shape (E=%d F=%d H=%d D=%d L=%d cap=%d)", p.E, p.F, p.H, p.D, p.L, p.cap);
+    const int G = rst_codec_tr_grid(p.B, p.T, p.E, p.H, p.F, p.L, p.cap);
+    RST_REQUIRE(G > 0 && p.H * p.D == p.E, "codec_tr: unsupported shape (B=%d T=%d E=%d F=%d H=%d D=%d L=%d cap=%d) or no resident grid for it", p.B, p.T,
+                p.E, p.F, p.H, p.D, p.L, p.cap);
     RST_REQUIRE(p.x && p.y && p.pos_dev && p.gran && p.status, "codec_tr: null buffers");
     for (int l = 0; l < p.L; ++l)
         RST_REQUIRE(p.in_proj[l] && p.out_proj[l] && p.lin1[l] && p.lin2[l] && p.n1g[l] && p.n1b[l] && p.n2g[l] && p.n2b[l] && p.kc[l] && p.vc[l],
                     "codec_tr: layer %d pointers", l);
-    const int G = ct_cu_count();
-    RST_REQUIRE(p.B * p.H <= G, "codec_tr: %d (stream, head) pairs > %d workgroups", p.B * p.H, G);
     const int XW = p.E > p.F ? p.E : p.F;
     const size_t lds = ((size_t)DF_HDR_FLOATS + (size_t)R * XW + (size_t)R * p.E + (size_t)p.T * 3 * p.D) * sizeof(float);
-    RST_REQUIRE(lds <= 150 * 1024, "codec_tr: %zu bytes of LDS", lds);
-    if (hipMemsetAsync(p.gran, 0, (size_t)rst_codec_tr_workspace_granules(R, p.E, p.F) * 8, stream) != hipSuccess) {
+    // both granule sets (persistent launch | repair launch) start at zero in every call
+    if (hipMemsetAsync(p.gran, 0, (size_t)rst_codec_tr_workspace_granules(R, p.E, p.F) * 16, stream) != hipSuccess) {
         rst_set_error("codec_tr: workspace memset failed");
         return RST_ERR_LAUNCH;
     }
-    auto go = [&](auto kern) {
-        static bool attr_set = false;
+    auto go = [&](auto kern, int grid) {
+        static bool attr_set = false;       // one flag per kernel instance
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             (void)hipGetLastError();
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(G), dim3(DF_THREADS), lds, stream, p);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(DF_THREADS), lds, stream, p);
     };
+    // the persistent launch, then its one-workgroup repair launch (a no-op unless a hand-off timed out: persist.h)
     switch (R) {
-        case 1: go(codec_tr_kernel<1>); break;
-        case 2: go(codec_tr_kernel<2>); break;
-        case 3: go(codec_tr_kernel<3>); break;
-        default: go(codec_tr_kernel<4>); break;
+        case 1: go(codec_tr_kernel<1, false>, G); go(codec_tr_kernel<1, true>, 1); break;
+        case 2: go(codec_tr_kernel<2, false>, G); go(codec_tr_kernel<2, true>, 1); break;
+        case 3: go(codec_tr_kernel<3, false>, G); go(codec_tr_kernel<3, true>, 1); break;
+        default: go(codec_tr_kernel<4, false>, G); go(codec_tr_kernel<4, true>, 1); break;
     }
     return rst_check_launch("codec_tr");
 }

@@ -15,7 +15,6 @@
 // slots -> conflict free).
 // K order inside a BK chunk is permuted (lane half h owns k = 8s + 4h .. +3) so that fragments are read with
 // one ds_read_b128 per four MFMAs; both operands use the same permutation so the product is unchanged.
-#include <cstdlib>
 #include "rst_common.h"
 #include "rst_kernels.h"
 
@@ -596,7 +595,7 @@ int launch_stream(const GemmWinParams& p, long tiles, hipStream_t stream) {
         return RST_ERR_UNSUPPORTED;
     }
     const size_t lds = 2 * (128 + 128) * (KB + 4) * sizeof(float);
-    static const int per_cu_env = getenv("RST_GEMM_STREAM_WGS") ? atoi(getenv("RST_GEMM_STREAM_WGS")) : 0;
+    static const int per_cu_env = rst_knob("RST_GEMM_STREAM_WGS", 0);      // tools build only
     const int per_cu = per_cu_env > 0 ? per_cu_env : (KB == 16 ? 3 : 2);
     const long resident = (long)per_cu * gw_cu_count();
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
@@ -609,10 +608,14 @@ int launch_stream(const GemmWinParams& p, long tiles, hipStream_t stream) {
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p, (int)tiles);
     };
-    static const int dbg = getenv("RST_GEMM_DBG") ? atoi(getenv("RST_GEMM_DBG")) : 0;
-    if (KB == 16 && dbg == 1) go(gemm_win_stream_kernel<false, 16, 1>);
-    else if (KB == 16 && dbg == 5) go(gemm_win_stream_kernel<false, 16, 5>);
-    else if (p.act_in == 1) go(gemm_win_stream_kernel<true, KB>);
+#ifdef RST_ABLATION
+    // ceiling measurements: instances that skip the loads / run the MFMAs only -- WRONG RESULTS by construction, which
+    // is why they are compiled into the tools build alone
+    static const int dbg = rst_knob("RST_GEMM_DBG", 0);
+    if (KB == 16 && dbg == 1) { go(gemm_win_stream_kernel<false, 16, 1>); return rst_check_launch("gemm_win"); }
+    if (KB == 16 && dbg == 5) { go(gemm_win_stream_kernel<false, 16, 5>); return rst_check_launch("gemm_win"); }
+#endif
+    if (p.act_in == 1) go(gemm_win_stream_kernel<true, KB>);
     else go(gemm_win_stream_kernel<false, KB>);
     return rst_check_launch("gemm_win");
 }
@@ -662,10 +665,10 @@ int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
         case 0: {                                                            // 128 x 128
             // >= 3 tiles per CU: k-chunks of 16 (40 KB of LDS, accumulators in VGPRs) put three workgroups on a CU instead of two
             const long tiles = ((M + 127) / 128) * ((p.N + 127) / 128);
-            // RST_GEMM_KB32 (any value) forces the 32-wide chunks: the calibration knob of the PMC traffic numbers
-            static const bool kb32_only = getenv("RST_GEMM_KB32") != nullptr;
-            // RST_GEMM_STREAM=0: one workgroup per tile (the pre-streaming form, kept for A/B measurements)
-            static const bool stream_off = getenv("RST_GEMM_STREAM") && atoi(getenv("RST_GEMM_STREAM")) == 0;
+            // tools build only -- RST_GEMM_KB32=1 forces the 32-wide chunks (the calibration knob of the PMC traffic numbers, DESIGN.md
+            // 3.1), RST_GEMM_STREAM=0 one workgroup per tile (the pre-streaming form, for A/B measurements)
+            static const bool kb32_only = rst_knob("RST_GEMM_KB32", 0) != 0;
+            static const bool stream_off = rst_knob("RST_GEMM_STREAM", 1) == 0;
             if (vec && !stream_off && p.split_k <= 1) {
                 if (tiles >= 768 && !kb32_only) return launch_stream<16>(p, tiles, stream);
                 return launch_stream<32>(p, tiles, stream);

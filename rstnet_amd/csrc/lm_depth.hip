@@ -123,8 +123,18 @@ __device__ __forceinline__ void df_rows(DfPre<RU, CU, PAIR>& pre, const unsigned
     }
 }
 
-template <int B>
+// The KV history of the frame's earlier steps: LDS of the head's owner; in the SOLO (repair) launch one workgroup owns every head and
+// the history of all of them lives in a global scratch, read and written with agent-scope (L1-bypassing) accesses.
+template <bool SOLO> struct DfHist {
+    float* base;
+    __device__ __forceinline__ float rd(long i) const { return SOLO ? __hip_atomic_load(base + i, DF_RLX) : base[i]; }
+    __device__ __forceinline__ void wr(long i, float v) const { if (SOLO) __hip_atomic_store(base + i, v, DF_RLX); else base[i] = v; }
+};
+
+template <int B, bool SOLO>
 __global__ __launch_bounds__(DF_THREADS) void depth_frame_kernel(const DepthFrameParams p) {
+    // SOLO: the repair launch behind the persistent one (persist.h) -- a no-op unless a hand-off of that launch timed out
+    if (SOLO && __hip_atomic_load(p.status, DF_RLX) == 0u) return;
     // all LDS is carved from the dynamic region (static objects in front of it would shift its 16-byte alignment: G17)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     DfShared& sh = *reinterpret_cast<DfShared*>(lds);
@@ -139,12 +149,13 @@ __global__ __launch_bounds__(DF_THREADS) void depth_frame_kernel(const DepthFram
     float* xres = xs + B * XW;
     float* lg = xres + B * E;
     float* qh = lg + B * card;
-    float* hist = qh + B * 3 * D;
+    const long hist_head = (long)p.L * dep_q * B * 2 * D;       // history floats of one head
+    const DfHist<SOLO> hist{SOLO ? p.hist_solo : qh + B * 3 * D};
     long off = DF_HDR_FLOATS + (long)B * XW + (long)B * E + (long)B * card + (long)B * 3 * D + (long)p.L * dep_q * B * 2 * D;
     off += off & 1;
     u64* comp = reinterpret_cast<u64*>(lds + off);
-    // granule workspace
-    u64* gX = p.gran;
+    // granule workspace (the repair launch has its own zeroed copy behind the persistent launch's)
+    u64* gX = p.gran + (SOLO ? (long)B * (5L * E + Hd + card + 1) : 0L);
     u64* gQKV = gX + (long)B * E;
     u64* gATT = gQKV + (long)B * 3 * E;
     u64* gH = gATT + (long)B * E;
@@ -195,23 +206,24 @@ __global__ __launch_bounds__(DF_THREADS) void depth_frame_kernel(const DepthFram
             df_rows_issue<1, 2, false>(po, p.out_proj[l] + (long)k * E * E, E, E, gw, W, lane);
             // ---- attention of head `wg` (modules/transformer.py:376-416 on a ring of ring_cap slots, no rope)
             ++eATT;
-            if (wg < p.H) {
-                const int h = wg;
+            for (int h = wg; h < p.H; h += G) {
+                const long hb = SOLO ? h * hist_head : 0;
                 df_gather<2>(gQKV, B * 3 * D, eQKV, qh, [&](int i) { const int b = i / (3 * D), j = i - b * 3 * D, part = j / D;
                                                                   return b * 3 * E + part * E + h * D + (j - part * D); }, sh, p.status, 2u);
-                float* hk = hist + (((long)l * dep_q + k) * B) * 2 * D;       // [B][2][D] of this (layer, step)
+                const long hk = hb + (((long)l * dep_q + k) * B) * 2 * D;       // [B][2][D] of this (layer, step)
                 for (int i = tid; i < B * 2 * D; i += DF_THREADS) {
                     const int b = i / (2 * D), j = i - b * 2 * D;
-                    hk[i] = qh[b * 3 * D + D + j];
+                    hist.wr(hk + i, qh[b * 3 * D + D + j]);
                 }
+                if (SOLO) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the write-through stores have landed before the reads below
                 __syncthreads();
                 if (wave == 0) {
                     for (int b = 0; b < B; ++b) {
                         float sc[RST_DEPTH_MAX_Q], m = -INFINITY;
                         for (int s = 0; s <= k; ++s) {
-                            const float* ks = hist + ((((long)l * dep_q + s) * B + b) * 2) * D;
+                            const long ks = hb + ((((long)l * dep_q + s) * B + b) * 2) * D;
                             float d = 0.f;
-                            for (int dd = lane; dd < D; dd += 64) d = fmaf(ks[dd], qh[b * 3 * D + dd], d);
+                            for (int dd = lane; dd < D; dd += 64) d = fmaf(hist.rd(ks + dd), qh[b * 3 * D + dd], d);
                             d = wave_sum(d);
                             sc[s] = ring_visible(s, k, p.ring_cap, p.context, (long)k + 1) ? d / att_div : -INFINITY;
                             m = fmaxf(m, sc[s]);
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(DF_THREADS) void depth_frame_kernel(const DepthFram
                         for (int s = 0; s <= k; ++s) { sc[s] = sc[s] == -INFINITY ? 0.f : expf(sc[s] - m); lsum += sc[s]; }
                         for (int dd = lane; dd < D; dd += 64) {
                             float o = 0.f;
-                            for (int s = 0; s <= k; ++s) o = fmaf(sc[s], hist[((((long)l * dep_q + s) * B + b) * 2 + 1) * D + dd], o);
+                            for (int s = 0; s <= k; ++s) o = fmaf(sc[s], hist.rd(hb + ((((long)l * dep_q + s) * B + b) * 2 + 1) * D + dd), o);
                             df_publish(gATT + (long)b * E + h * D + dd, eATT, o / lsum);
                         }
                     }
@@ -281,6 +293,7 @@ __global__ __launch_bounds__(DF_THREADS) void depth_frame_kernel(const DepthFram
             }
         }
     }
+    if (SOLO) df_solo_done(p.status);
 }
 
 int df_cu_count() {
@@ -307,36 +320,68 @@ size_t df_lds_bytes(const DepthFrameParams& p) {
 
 long rst_depth_frame_workspace_granules(int B, int E, int Hd, int card) { return (long)B * (5L * E + Hd + card + 1); }
 
+// workspace: granules of the persistent launch | granules of the repair launch | KV history of the repair launch (fp32, all heads)
+long rst_depth_frame_workspace_bytes_impl(int B, int E, int Hd, int card) {
+    return 2 * rst_depth_frame_workspace_granules(B, E, Hd, card) * 8 + (long)RST_DEPTH_MAX_L * RST_DEPTH_MAX_Q * B * 2 * E * 4;
+}
+
+// Workgroups of the persistent launch for a shape, 0 if it is not served: every workgroup must own a row of the in-projection
+// (3E rows), the gated FFN-in (Hd row pairs) and the head (card rows) -- the all-to-all ops between two writes of a hand-off buffer
+// (persist.h) -- every head needs a workgroup, and one workgroup of that LDS footprint must fit a CU (occupancy query).
+int rst_depth_frame_grid(const DepthFrameParams& p) {
+    if (!(p.B >= 1 && p.B <= 2 && p.E > 0 && p.E % 8 == 0 && p.Hd > 0 && p.Hd % 8 == 0 && p.H > 0 && p.D > 0 && p.H * p.D == p.E && p.card > 0 &&
+          p.card <= 16 * DF_THREADS && p.dep_q >= 1 && p.dep_q <= RST_DEPTH_MAX_Q && p.L >= 1 && p.L <= RST_DEPTH_MAX_L))
+        return 0;
+    const size_t lds = df_lds_bytes(p);
+    if (lds > 150 * 1024) return 0;
+    const int rows = min(min(3 * p.E, p.Hd), p.card);
+    const int G = df_grid_for_rows(df_cu_count(), rows);
+    if (p.H > G) return 0;
+    // residency: all G workgroups must run at once, one per CU -- ask the runtime whether a CU takes a workgroup of this footprint
+    static int fits[2][2] = {{-1, -1}, {-1, -1}};        // [B - 1][lds > 64 KB]: the answer does not change within a footprint class
+    int& f = fits[p.B - 1][lds > 64 * 1024];
+    if (f < 0) {
+        const void* kern = p.B == 1 ? reinterpret_cast<const void*>(depth_frame_kernel<1, false>) : reinterpret_cast<const void*>(depth_frame_kernel<2, false>);
+        (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        int nb = 0;
+        const size_t probe = lds > 64 * 1024 ? 150 * 1024 : 64 * 1024;
+        const hipError_t e = p.B == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, depth_frame_kernel<1, false>, DF_THREADS, probe)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, depth_frame_kernel<2, false>, DF_THREADS, probe);
+        (void)hipGetLastError();
+        f = (e == hipSuccess && nb >= 1) ? 1 : 0;
+    }
+    return f ? G : 0;
+}
+
 int rst_launch_depth_frame(const DepthFrameParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B >= 1 && p.B <= 2, "depth_frame: batch %d (the persistent form serves 1 and 2)", p.B);
-    RST_REQUIRE(p.E > 0 && p.E % 8 == 0 && p.Hd > 0 && p.Hd % 8 == 0 && p.H > 0 && p.D > 0 && p.H * p.D == p.E && p.card > 0 &&
-                    p.card <= 16 * DF_THREADS && p.dep_q >= 1 && p.dep_q <= RST_DEPTH_MAX_Q && p.L >= 1 && p.L <= RST_DEPTH_MAX_L,
-                "depth_frame: unsupported shape (E=%d Hd=%d H=%d D=%d card=%d dep_q=%d L=%d)", p.E, p.Hd, p.H, p.D, p.card, p.dep_q, p.L);
-    RST_REQUIRE(p.h_all && p.tokens && p.gran && p.status && p.ld_h >= p.dep_q * p.E && p.tok_stride >= p.dep_q + 1, "depth_frame: null / short buffers");
+    RST_REQUIRE(p.h_all && p.tokens && p.gran && p.hist_solo && p.status && p.ld_h >= p.dep_q * p.E && p.tok_stride >= p.dep_q + 1, "depth_frame: null / short buffers");
     RST_REQUIRE(!p.use_sampling || p.temp <= 0.f || (p.noise && p.noise_stride >= p.dep_q * p.top_k), "depth_frame: sampling needs dep_q * top_k noise values per row");
+    const int G = rst_depth_frame_grid(p);
+    RST_REQUIRE(G > 0, "depth_frame: unsupported shape (E=%d Hd=%d H=%d D=%d card=%d dep_q=%d L=%d) or no resident grid for it", p.E, p.Hd, p.H, p.D,
+                p.card, p.dep_q, p.L);
     for (int l = 0; l < p.L; ++l) {
         RST_REQUIRE(p.in_proj[l] && p.out_proj[l] && p.norm1[l] && p.norm2[l], "depth_frame: layer %d pointers", l);
         for (int k = 0; k < p.dep_q; ++k) RST_REQUIRE(p.gate_in[l][k] && p.gate_out[l][k], "depth_frame: gating pointers of layer %d step %d", l, k);
     }
     for (int k = 0; k < p.dep_q; ++k) RST_REQUIRE(p.heads[k] && p.emb[k] && p.emb_rows[k] >= 1, "depth_frame: head / embedding of step %d", k);
-    const int G = df_cu_count();
-    RST_REQUIRE(p.H <= G, "depth_frame: %d heads > %d workgroups", p.H, G);
     const size_t lds = df_lds_bytes(p);
-    RST_REQUIRE(lds <= 150 * 1024, "depth_frame: %zu bytes of LDS", lds);
-    // every polled word starts at zero in EVERY launch (a memset node when captured): epochs count from 1 inside the launch
-    if (hipMemsetAsync(p.gran, 0, (size_t)rst_depth_frame_workspace_granules(p.B, p.E, p.Hd, p.card) * 8, stream) != hipSuccess) {
+    // every polled word (both granule sets) starts at zero in EVERY launch (a memset node when captured): epochs count from 1
+    if (hipMemsetAsync(p.gran, 0, (size_t)rst_depth_frame_workspace_granules(p.B, p.E, p.Hd, p.card) * 16, stream) != hipSuccess) {
         rst_set_error("depth_frame: workspace memset failed");
         return RST_ERR_LAUNCH;
     }
-    auto go = [&](auto kern) {
-        static bool attr_set = false;
+    auto go = [&](auto kern, int grid) {
+        static bool attr_set = false;       // one flag per kernel instance (the lambda is instantiated per `kern` type)
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             (void)hipGetLastError();
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(G), dim3(DF_THREADS), lds, stream, p);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(DF_THREADS), lds, stream, p);
     };
-    if (p.B == 1) go(depth_frame_kernel<1>); else go(depth_frame_kernel<2>);
+    // the persistent launch, then its one-workgroup repair launch (a no-op unless a hand-off timed out: persist.h)
+    if (p.B == 1) { go(depth_frame_kernel<1, false>, G); go(depth_frame_kernel<1, true>, 1); }
+    else { go(depth_frame_kernel<2, false>, G); go(depth_frame_kernel<2, true>, 1); }
     return rst_check_launch("depth_frame");
 }

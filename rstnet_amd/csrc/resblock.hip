@@ -683,11 +683,11 @@ int rst_launch_resblock(const ResblockParams& p, hipStream_t stream) {
     RST_REQUIRE(!p.pre || (p.w0 && p.b0), "resblock: PRE needs w0/b0");
     RST_REQUIRE(!p.post || (p.wf && p.bf), "resblock: POST needs wf/bf");
     RST_REQUIRE(!(p.hist && (p.pre || p.post)), "resblock: streaming history is only supported by the plain variant");
-    // RST_RESBLOCK_STREAM=0: the launch-per-tile form for every shape (A/B measurements)
-    static const bool stream_off = getenv("RST_RESBLOCK_STREAM") && atoi(getenv("RST_RESBLOCK_STREAM")) == 0;
+    // tools build only -- RST_RESBLOCK_STREAM=0: the launch-per-tile form for every shape (A/B measurements)
+    static const bool stream_off = rst_knob("RST_RESBLOCK_STREAM", 1) == 0;
     // the fused last conv measured faster in the launch-per-tile form (0.92 vs 1.00 ms at 16 x 10 s): three workgroups per CU
     // against two, and its output is one float per row either way; RST_RESBLOCK_STREAM=2 forces the resident form for it too
-    static const bool stream_post = getenv("RST_RESBLOCK_STREAM") && atoi(getenv("RST_RESBLOCK_STREAM")) == 2;
+    static const bool stream_post = rst_knob("RST_RESBLOCK_STREAM", 1) == 2;
     if (p.C == 64 && p.Kw == RS_KW && !p.hist && !stream_off && !(p.pre && p.post) && (!p.post || stream_post)) {
         if (p.pre) return launch64_stream<true, false>(p, stream);
         if (p.post) return launch64_stream<false, true>(p, stream);

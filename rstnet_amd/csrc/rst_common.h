@@ -20,6 +20,19 @@ int rst_check_launch(const char* what);
         }                                 \
     } while (0)
 
+// Measurement knobs (A/B switches between kernel forms, ablation variants that skip work) exist ONLY in the tools build
+// (`make ablation` -> librstnet_hip_ablation.so, -DRST_ABLATION, loaded by tools/ via RSTNET_LIB): the shipped library reads no
+// environment variable, so nothing outside its arguments can change what it computes.
+#ifdef RST_ABLATION
+#include <cstdlib>
+static inline int rst_knob(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+#else
+static inline constexpr int rst_knob(const char*, int dflt) { return dflt; }
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

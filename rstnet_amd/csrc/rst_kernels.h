@@ -258,13 +258,17 @@ struct DepthFrameParams {
     long* tokens;               // int64 [B][tok_stride]: column 0 = the text token (input), column k + 1 = token sampled at step k
     const float* noise;         // fp32 [B][noise_stride] Exp(1): step k uses columns [k * top_k, (k + 1) * top_k)   (sampling only)
     const int* v_limit;         // optional device int [dep_q]: ids >= v_limit[k] are never drawn at step k
-    unsigned long long* gran;   // granule workspace, rst_depth_frame_workspace_granules(B, E, Hd, card) 8-byte words
-    unsigned* status;           // device word: 0 = ok, else a bit per timed-out hand-off (the frame's tokens are then undefined)
+    unsigned long long* gran;   // granule workspace: 2 x rst_depth_frame_workspace_granules(B, E, Hd, card) 8-byte words (persistent + repair launch)
+    float* hist_solo;           // KV history of the repair launch: RST_DEPTH_MAX_L * RST_DEPTH_MAX_Q * B * 2 * E floats
+    unsigned* status;           // 4 device words: [0] time-out codes of the frame in flight (cleared by the repair launch), [1] frames
+                                // repaired so far, [2] OR of the codes of every repaired frame, [3] reserved
     int B, E, H, D, Hd, card, dep_q, L, ld_h, tok_stride, noise_stride, top_k, use_sampling, context;
     int ring_cap;               // capacity of the (virtual) KV ring: dep_q for LMGen, dep_q + 1 where the caller sized it so (no hidden slot)
     float eps, temp;
 };
 long rst_depth_frame_workspace_granules(int B, int E, int Hd, int card);
+long rst_depth_frame_workspace_bytes_impl(int B, int E, int Hd, int card);
+int rst_depth_frame_grid(const DepthFrameParams& p);       // workgroups of the persistent launch, 0 = shape not served
 int rst_launch_depth_frame(const DepthFrameParams& p, hipStream_t stream);
 
 // ---- codec_tr.hip: one streaming step of a Mimi transformer (all layers) as one persistent launch
@@ -285,12 +289,13 @@ struct CodecTrParams {
     const float* x;                         // [B][T][E]
     float* y;                               // [B][T][E]
     const long* pos_dev;                    // position of the first new step (device scalar)
-    unsigned long long* gran;               // rst_codec_tr_workspace_granules(B * T, E, F) 8-byte words
-    unsigned* status;
+    unsigned long long* gran;               // 2 x rst_codec_tr_workspace_granules(B * T, E, F) 8-byte words (persistent + repair launch)
+    unsigned* status;                       // 4 device words, as DepthFrameParams::status
     int B, T, E, H, D, F, L, cap, context, rope;
     float rope_coef, eps;
 };
 long rst_codec_tr_workspace_granules(int R, int E, int F);
+int rst_codec_tr_grid(int B, int T, int E, int H, int F, int L, int cap);      // workgroups of the persistent launch, 0 = shape not served
 int rst_launch_codec_tr(const CodecTrParams& p, hipStream_t stream);
 
 // ---- lm_ring.hip: LMGen's token ring / delay pattern

@@ -51,12 +51,20 @@ class DepthFrameTables:
         self.eps = float(dep.layers[0].norm1.eps)
         self.context = dep.context
         dev = heads[0].device
-        self.status = torch.zeros(1, device=dev, dtype=torch.int32)     # OR of the time-out codes of every launch so far
+        from .. import ops
+        # 4 words (csrc/persist.h): time-out codes of the frame in flight | frames repaired by the one-workgroup launch | OR of the
+        # repaired frames' codes | reserved; registered with ops.persistent_poll
+        self.status = ops.new_persistent_status(dev)
         self._keep = keep
 
+    def repairs(self) -> int:
+        """Frames whose hand-offs timed out and that the repair launch recomputed (reads the device words: synchronises)."""
+        return int(self.status[1].item())
+
     def check(self) -> None:
-        """Raises if any launch so far reported a timed-out hand-off (reads the device status word: synchronises)."""
-        code = int(self.status.item())
-        if code:
-            raise RuntimeError(f"rst_depth_decode_frame: a hand-off timed out (status {code:#x}); the device was shared with other work "
-                               "or the launch was not fully resident")
+        """Raises if any launch so far had a timed-out hand-off, repaired or not (reads the device status words: synchronises).  The
+        tokens of a repaired frame are right; the check exists for tests and ``LMGen(check=True)`` runs that want to know."""
+        st = self.status.tolist()
+        if st[0] or st[1]:
+            raise RuntimeError(f"rst_depth_decode_frame: hand-offs timed out ({st[1]} frame(s) repaired by the one-workgroup launch, codes "
+                               f"{st[2]:#x}, in flight {st[0]:#x}); the device was shared with other work or the launch was not fully resident")

@@ -75,6 +75,7 @@ class GPTGen:
         self._limits = torch.full((cfg.dep_q,), self.n_audio_codes + 1, device=dev, dtype=torch.int32)
         self._depth = _Graphed(self._depth_frame, disable=eager)
         self._regime, self.B, self._eager = None, batch_size, eager
+        self._frames, self._persist_epoch = 0, ops.persistent_epoch(dev)
 
     def end(self) -> None:
         m = self.model
@@ -100,14 +101,15 @@ class GPTGen:
         h_all = ops.lm_linear(h, m.codecformer_in_all())      # codecformer_in[k](h) of all dep_q steps in one launch
         E, H = dep.d_model, dep.num_heads
         Hd = dep.layers[0].gating[0].linear_out.weight.shape[1]
-        if ops.depth_frame_enabled() and ops.depth_frame_supported(B, E, H, Hd, cfg.audio_card, cfg.dep_q, len(dep.layers), k_eff):
+        if ops.depth_frame_enabled(text_token.device) and ops.depth_frame_supported(B, E, H, Hd, cfg.audio_card, cfg.dep_q, len(dep.layers), k_eff):
             # batch 1 / 2: the dep_q steps with their samplers are one persistent launch (csrc/lm_depth.hip)
             tokens = torch.empty(B, cfg.dep_q + 1, device=text_token.device, dtype=torch.long)
             tokens[:, 0] = text_token
             noise = None
             if self.use_sampling:
                 noise = torch.cat([self._exp_noise("audio", g_idx, l_idx, B, k_eff) for l_idx in range(cfg.dep_q)], 1)
-            ops.depth_decode_frame(m.depth_frame_tables(), h_all, tokens, noise, use_sampling=self.use_sampling, temp=self.temp, top_k=k_eff,
+            self._tables = m.depth_frame_tables()      # a captured frame embeds the tables' device pointers: kept alive with the graph
+            ops.depth_decode_frame(self._tables, h_all, tokens, noise, use_sampling=self.use_sampling, temp=self.temp, top_k=k_eff,
                                    eps=dep.layers[0].norm1.eps, context=dep.context, limits=self._limits,
                                    ring_cap=dep._streaming_state.k[0].shape[2])
             return tokens[:, 1:].contiguous()
@@ -134,6 +136,13 @@ class GPTGen:
     def frame(self, h: torch.Tensor, logits: torch.Tensor, g_idx: int = 0):
         """(h, logits) of the last position -> (text token [B], audio tokens [B, dep_q]) of the next frame."""
         B = h.shape[0]
+        if self._frames % 64 == 0 and h.is_cuda and not self._eager:
+            # health of the persistent depth launch (csrc/persist.h): a device that had to repair frames moves to the launch-per-op chain
+            ops.persistent_poll(h.device)
+            if self._persist_epoch != ops.persistent_epoch(h.device):
+                self._persist_epoch = ops.persistent_epoch(h.device)
+                self._depth = _Graphed(self._depth_frame)
+        self._frames += 1
         k_text = min(self.top_k_text, self.model.config.padded_vocab_size)
         text = ops.lm_sample(logits, use_sampling=self.use_sampling, temp=self.temp_text, top_k=k_text,
                              noise=self._exp_noise("text", g_idx, 0, B, k_text))

@@ -383,6 +383,8 @@ class _LMGenState:
     graphed_frame: _Graphed
     depth: Optional[_StepState] = None     # the depth transformer's KV rings of THIS session (a captured frame points at them)
     offset: int = 0
+    persist_epoch: int = 0                 # ops.persistent_epoch(device) when the frame graph was captured
+    tables: object = None                  # the DepthFrameTables the captured frame points at (kept alive with the graph)
 
     def reset(self) -> None:
         self.offset = 0
@@ -412,7 +414,8 @@ class LMGen(StreamingModule[_LMGenState]):
                            dtype=torch.long)
         disable = lm.device.type != "cuda"
         return _LMGenState(cache, lm._get_initial_token(), torch.zeros(1, device=lm.device, dtype=torch.long),
-                           _Graphed(self._frame, disable=disable), depth=lm.depformer._init_streaming_state(batch_size))
+                           _Graphed(self._frame, disable=disable), depth=lm.depformer._init_streaming_state(batch_size),
+                           persist_epoch=ops.persistent_epoch(lm.device))
 
     def _noise(self, B: int, k: int) -> Optional[torch.Tensor]:
         if not self.use_sampling:
@@ -450,10 +453,13 @@ class LMGen(StreamingModule[_LMGenState]):
         h_all = ops.lm_linear(h_t, lm.depformer_in_all())
         E, H = dep.d_model, dep.num_heads
         Hd = dep.layers[0].gating[0].linear_out.weight.shape[1]
-        if ops.depth_frame_enabled() and h_t.is_cuda and ops.depth_frame_supported(B, E, H, Hd, lm.card, lm.dep_q, len(dep.layers), self.top_k):
+        if ops.depth_frame_enabled(h_t.device) and h_t.is_cuda and ops.depth_frame_supported(B, E, H, Hd, lm.card, lm.dep_q, len(dep.layers), self.top_k):
             # batch 1 / 2: the whole phase (dep_q x (L layers + head + sampler)) is ONE persistent launch whose ops hand their
             # vectors over in-kernel; the depth KV ring lives in its LDS
-            ops.depth_decode_frame(lm.depth_frame_tables(), h_all, tokens, noise, use_sampling=self.use_sampling, temp=self.temp,
+            tables = lm.depth_frame_tables()
+            if self._streaming_state is not None:
+                self._streaming_state.tables = tables       # a captured frame embeds the tables' device pointers: they live as long as it does
+            ops.depth_decode_frame(tables, h_all, tokens, noise, use_sampling=self.use_sampling, temp=self.temp,
                                    top_k=self.top_k, eps=dep.layers[0].norm1.eps, context=dep.context)
             return
         state = self._streaming_state
@@ -479,6 +485,13 @@ class LMGen(StreamingModule[_LMGenState]):
         assert S == 1, "Only support being given steps one by one."
         needed = lm.num_codebooks - lm.dep_q - 1
         assert Ki == needed, f"We expect {needed} tokens from the user stream, got {Ki}."
+        if state.offset % 64 == 0 and lm.device.type == "cuda":
+            # health of the persistent depth launch (no synchronisation): a device that had to repair frames moves to the
+            # launch-per-op chain, which needs a fresh capture
+            ops.persistent_poll(lm.device)
+            if state.persist_epoch != ops.persistent_epoch(lm.device):
+                state.persist_epoch = ops.persistent_epoch(lm.device)
+                state.graphed_frame = _Graphed(self._frame)
         out, input_ = state.graphed_frame(input_tokens.reshape(B, Ki).contiguous())
         if self.check:
             if lm._depth_tables._val is not None:

@@ -189,11 +189,17 @@ def gemm_win(x: torch.Tensor, w: torch.Tensor, *, B: int, T_in: int, T_out: int,
         assert res.numel() == out.numel()
     if hist is not None:
         assert hist.numel() == B * P * C_, (tuple(hist.shape), B, P, C_)
-    if _few_rows(B * T_out, N, K) and PROFILE is None:
+    prof = PROFILE
+    if _few_rows(B * T_out, N, K):        # the same route with and without instrumentation: profiles describe the shipped path
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, S, P, pad_mode, act_in, act_out)
+        if prof is not None:
+            e1.record()
+            prof.append(("gemm_skinny_f32", e0, e1, 2.0 * B * T_out * N * K, 4 * (w.numel() + x.numel() + out.numel()), (B * T_out, N, K)))
         return out
     split_k, ws, cnt = _gemm_split_scratch(x.device, B * T_out, N, K)
-    prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -228,11 +234,17 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         return out
     if ln is not None:
         x = layernorm(x, ln[0], ln[1], ln[2])
-    if _few_rows(M, N, K) and PROFILE is None:
+    prof = PROFILE
+    if _few_rows(M, N, K):
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _gemm_few_rows(x, None, w, bias, res, scale, out, 1, M, M, K, K, N, 1, 0, 0, ACT_NONE, act_out)
+        if prof is not None:
+            e1.record()
+            prof.append(("gemm_skinny_f32", e0, e1, 2.0 * M * N * K, 4 * (w.numel() + x.numel() + out.numel()), (M, N, K)))
         return out
     split_k, ws, cnt = _gemm_split_scratch(x.device, M, N, K)
-    prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -901,25 +913,106 @@ def lm_ring_commit(cache: torch.Tensor, tokens: torch.Tensor, delays: torch.Tens
 DEPTH_FRAME_MAX_L, DEPTH_FRAME_MAX_Q = 8, 8
 _depth_ws: dict = {}
 
+# ---- health of the persistent launches (csrc/persist.h).  A launch whose workgroups are not all resident (device shared with other
+# work) times out and is repaired in-stream by its one-workgroup twin: outputs stay right, but a repaired frame costs ~0.2 s.  Every
+# launcher's status words are registered here; `persistent_poll` reads their repair counters WITHOUT synchronising (async copy into
+# pinned memory, evaluated on the next poll) and retires the persistent path on a device that had to repair -- sessions then
+# re-capture their frame graphs on the launch-per-op chain (`persistent_epoch` changes).
+PERSISTENT_MAX_REPAIRS = 0          # repairs tolerated per device before the launch-per-op chain takes over
+_persist_status: dict = {}          # device -> list of weakrefs of status tensors (int32 [4])
+_persist_off: dict = {}             # device -> reason string
+_persist_epoch: dict = {}           # device -> int, bumped when the device's persistent path is retired
+_persist_pending: dict = {}         # device -> (event, [pinned int32 [4] copies])
 
-def depth_frame_enabled() -> bool:
-    """RST_DEPTH_FRAME=0 keeps the launch-per-op depth phase (A/B measurements, or a device shared with other work: the persistent
-    launch needs every CU)."""
+
+def new_persistent_status(device) -> torch.Tensor:
+    """The 4 status words of a persistent launcher (time-out codes in flight | frames repaired | OR of repaired codes | reserved),
+    registered for `persistent_poll`."""
+    import weakref
+    device = torch.device(device)
+    st = torch.zeros(4, device=device, dtype=torch.int32)
+    _persist_status.setdefault(device, []).append(weakref.ref(st))
+    return st
+
+
+def persistent_epoch(device) -> int:
+    return _persist_epoch.get(torch.device(device), 0)
+
+
+def persistent_repairs(device, synchronize: bool = True) -> int:
+    """Frames / codec steps of `device` that the repair launches had to recompute so far (reads the device words: synchronises)."""
+    device = torch.device(device)
+    alive = [r() for r in _persist_status.get(device, [])]
+    return int(sum(int(t[1].item()) for t in alive if t is not None))
+
+
+def _retire_persistent(device, reason: str) -> None:
+    import warnings
+    if device not in _persist_off:
+        _persist_off[device] = reason
+        _persist_epoch[device] = _persist_epoch.get(device, 0) + 1
+        warnings.warn(f"rstnet_amd: persistent frame launches retired on {device}: {reason}; the launch-per-op chain takes over "
+                      "(outputs were repaired in-stream, nothing wrong left the device)", RuntimeWarning)
+
+
+def persistent_poll(device, synchronize: bool = False) -> None:
+    """Looks at the repair counters of `device` (the copy requested by the PREVIOUS call unless `synchronize`), retires the persistent
+    path beyond PERSISTENT_MAX_REPAIRS repairs and requests the next copy.  Cheap enough for once every few dozen frames; never
+    called inside a graph capture."""
+    device = torch.device(device)
+    if device.type != "cuda" or device in _persist_off or torch.cuda.is_current_stream_capturing():
+        return
+    if synchronize:
+        n = persistent_repairs(device)
+        if n > PERSISTENT_MAX_REPAIRS:
+            _retire_persistent(device, f"{n} frame(s) needed the one-workgroup repair launch (hand-offs timed out: not all workgroups were resident)")
+        return
+    pend = _persist_pending.get(device)
+    if pend is not None:
+        ev, copies = pend
+        if not ev.query():
+            return
+        n = int(sum(int(c[1]) for c in copies))
+        _persist_pending.pop(device, None)
+        if n > PERSISTENT_MAX_REPAIRS:
+            _retire_persistent(device, f"{n} frame(s) needed the one-workgroup repair launch (hand-offs timed out: not all workgroups were resident)")
+            return
+    refs = _persist_status.get(device, [])
+    alive = [t for t in (r() for r in refs) if t is not None]
+    _persist_status[device] = [r for r in refs if r() is not None]
+    if not alive:
+        return
+    with torch.cuda.device(device):
+        copies = [torch.empty(4, dtype=torch.int32).pin_memory() for _ in alive]
+        for c, t in zip(copies, alive):
+            c.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+    _persist_pending[device] = (ev, copies)
+
+
+def depth_frame_enabled(device=None) -> bool:
+    """RST_DEPTH_FRAME=0 keeps the launch-per-op depth phase / codec transformer layers (A/B measurements, or a device known to be
+    shared with other work); a device whose persistent launches needed repairs is retired automatically (`persistent_poll`)."""
     import os
-    return os.environ.get("RST_DEPTH_FRAME", "1") not in ("0", "")
+    if os.environ.get("RST_DEPTH_FRAME", "1") in ("0", ""):
+        return False
+    return device is None or torch.device(device) not in _persist_off
+
+
+@functools.lru_cache(maxsize=256)
+def _depth_frame_grid(B: int, E: int, H: int, Hd: int, card: int, dep_q: int, L: int, top_k: int) -> int:
+    return int(_lib.lib().rst_depth_frame_supported(B, E, H, Hd, card, dep_q, L, top_k))
 
 
 def depth_frame_supported(B: int, E: int, H: int, Hd: int, card: int, dep_q: int, L: int, top_k: int) -> bool:
-    """Shapes ``rst_depth_decode_frame`` serves (the checks of rst_launch_depth_frame, so that callers can pick the per-op path
-    instead of catching an error): batch 1 / 2, E and Hd multiples of 8, card <= 4096, at most 8 layers and 8 steps."""
-    if not (1 <= B <= 2 and E % 8 == 0 and Hd % 8 == 0 and H >= 1 and E % H == 0 and 0 < card <= 4096):
+    """Shapes ``rst_depth_decode_frame`` serves -- the library's own answer (rst_depth_frame_supported: batch 1 / 2, E and Hd multiples
+    of 8, card <= 4096, at most 8 layers and 8 steps, the LDS footprint, a grid in which every workgroup owns rows of every
+    all-to-all op and that still has a workgroup per head, and the occupancy query), so that callers can pick the per-op path
+    instead of catching an error."""
+    if not (1 <= B <= 2 and 1 <= dep_q <= DEPTH_FRAME_MAX_Q and 1 <= L <= DEPTH_FRAME_MAX_L and H >= 1 and E % max(H, 1) == 0):
         return False
-    if not (1 <= dep_q <= DEPTH_FRAME_MAX_Q and 1 <= L <= DEPTH_FRAME_MAX_L and H <= 64):
-        return False
-    D = E // H
-    k = top_k if 0 < top_k < card else card
-    lds = 4 * (512 + B * max(E, Hd) + B * E + B * card + B * 3 * D + L * dep_q * B * 2 * D + 1) + 8 * ((k + 7) // 8 * 8)
-    return lds <= 150 * 1024
+    return _depth_frame_grid(B, E, H, Hd, card, dep_q, L, top_k if 0 < top_k < card else card) > 0
 
 
 def depth_decode_frame(tables, h_all: torch.Tensor, tokens: torch.Tensor, noise: Optional[torch.Tensor], *, use_sampling: bool,
@@ -967,21 +1060,27 @@ _ctr_ws: dict = {}
 _ctr_status: dict = {}
 
 
-def codec_transformer_frame_supported(B: int, T: int, E: int, H: int, F: int, L: int, cap: int) -> bool:
-    """Shapes the persistent launch serves (else the launch-per-op layer loop runs): at most 4 rows and 4 new positions, <= 8
-    layers, head dim a multiple of 16 that divides 1024."""
-    if not (depth_frame_enabled() and B >= 1 and 1 <= T <= 4 and B * T <= 4 and E % 8 == 0 and F % 8 == 0 and H >= 1 and E % H == 0):
+@functools.lru_cache(maxsize=256)
+def _codec_tr_grid(B: int, T: int, E: int, H: int, F: int, L: int, cap: int) -> int:
+    return int(_lib.lib().rst_codec_transformer_supported(B, T, E, H, F, L, cap))
+
+
+def codec_transformer_frame_supported(B: int, T: int, E: int, H: int, F: int, L: int, cap: int, device=None) -> bool:
+    """Shapes the persistent launch serves (else the launch-per-op layer loop runs) -- the library's own answer
+    (rst_codec_transformer_supported: at most 4 rows and 4 new positions, <= 8 layers, head dim a multiple of 16 that divides 1024, a
+    grid with rows for every workgroup and a workgroup per (stream, head), the occupancy query)."""
+    if not (depth_frame_enabled(device) and B >= 1 and 1 <= T <= 4 and B * T <= 4 and H >= 1 and E % max(H, 1) == 0):
         return False
-    D = E // H
-    return 1 <= L <= 8 and D % 16 == 0 and D <= 256 and 64 % (D // 16) == 0 and cap >= T and B * H <= 64 and \
-        4 * (512 + B * T * max(E, F) + B * T * E + T * 3 * D) <= 150 * 1024
+    return _codec_tr_grid(B, T, E, H, F, L, cap) > 0
 
 
 def codec_transformer_status(device) -> torch.Tensor:
-    """The device status word the persistent codec-transformer launches of ``device`` OR their time-out codes into (0 = all fine)."""
+    """The 4 device status words of the persistent codec-transformer launches of ``device`` (persist.h: [0] time-out codes of the step in
+    flight, [1] steps repaired by the one-workgroup launch, [2] OR of the repaired codes)."""
+    device = torch.device(device)
     st = _ctr_status.get(device)
     if st is None:
-        st = _ctr_status[device] = torch.zeros(1, device=device, dtype=torch.int32)
+        st = _ctr_status[device] = new_persistent_status(device)
     return st
 
 

@@ -97,7 +97,7 @@ def test_projected_transformer_streamed_across_the_wrap(chunk, persistent, monke
             y = tr(xc.to(DEV))[0]
             worst = max(worst, rel_err(y, ref))
     assert worst < 1e-3, worst
-    assert int(ops.codec_transformer_status(torch.device(DEV)).item()) == 0, "a hand-off of the persistent transformer launch timed out"
+    assert ops.codec_transformer_status(torch.device(DEV)).tolist()[:3] == [0, 0, 0], "a hand-off of the persistent transformer launch timed out"
 
 
 def test_codec_transformer_frame_mixed_with_layer_loop():
@@ -116,7 +116,7 @@ def test_codec_transformer_frame_mixed_with_layer_loop():
                 ref = ts.step(xc)
             worst = max(worst, rel_err(tr(xc.to(DEV))[0], ref))
     assert i == 40 and worst < 1e-3, worst
-    assert int(ops.codec_transformer_status(torch.device(DEV)).item()) == 0
+    assert ops.codec_transformer_status(torch.device(DEV)).tolist()[:3] == [0, 0, 0]
 
 
 def test_mimi_long_stream_matches_moshi_fixture():
@@ -152,4 +152,4 @@ def test_mimi_long_stream_matches_moshi_fixture():
     assert excused <= n_near
     assert rel_err(wav[:, :, :1920 * 4], torch.from_numpy(g["wav_head"])) < 1e-3
     assert rel_err(wav[:, :, -1920 * tail:], torch.from_numpy(g["wav_tail"])) < 1e-3
-    assert int(ops.codec_transformer_status(torch.device(DEV)).item()) == 0
+    assert ops.codec_transformer_status(torch.device(DEV)).tolist()[:3] == [0, 0, 0]

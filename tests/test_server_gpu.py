@@ -1,11 +1,15 @@
 """The websocket loop on the GPU: 20 frames of PCM through rstnet_amd.server.ServerState (real Mimi codec + the tiny 16-stream LM,
-greedy) must give the audio the StreamingPipeline gives for the same input -- the server adds transport and framing, no arithmetic."""
+greedy) must give (1) the audio the composed CPU oracles give for the same input -- oracle Mimi encode -> oracle LMGen -> oracle Mimi
+decode, the parity statement (moshi/server.py:122-136 is exactly that composition) -- and (2) sample for sample what the
+StreamingPipeline gives: the server adds transport and framing, no arithmetic."""
 import asyncio
 
 import numpy as np
 import pytest
 import torch
 
+from oracle import lm_oracle as L
+from oracle import mimi_oracle as O
 from rstnet_amd import server as S
 from rstnet_amd import synth
 from rstnet_amd.codec.loaders import get_mimi
@@ -65,5 +69,17 @@ def test_server_session_equals_pipeline():
     finally:
         loop.close()
     assert len(got) == len(want) == frames - 1
+    # (1) against the composed oracles (the session starts from reset states: the warm-up frames leave no trace)
+    mcfg = O.MimiConfig()
+    with torch.no_grad():
+        codes = O.encode(mimi_sd, mcfg, pcm)
+        og = L.LMGenOracle({k: v.float() for k, v in lm_sd.items()}, L.LMConfig(**cfg), 1)
+        toks = [og.step(codes[:, :, f:f + 1]) for f in range(frames)]
+        ref = O.decode(mimi_sd, mcfg, torch.cat([t[:, 1:] for t in toks[1:]], -1))[0, 0].numpy()
+    stream = np.concatenate(got)
+    assert stream.shape == ref.shape
+    err = float(np.abs(stream - ref).max() / np.abs(ref).max())
+    assert err < 1e-3, err
+    # (2) against the pipeline
     for f, (a, b) in enumerate(zip(got, want)):
         assert a.shape == (FRAME,) and float(np.abs(a - b).max()) <= 1e-5 * max(1.0, float(np.abs(b).max())), f"frame {f}"
