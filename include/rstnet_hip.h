@@ -301,6 +301,12 @@ int rst_skinny_pack_act_f32(const float* x, const float* alpha, uint16_t* xp, in
                             rst_stream_t stream);
 int rst_gemm_skinny_bf16_f32(const uint16_t* xp, const uint16_t* wp, const float* res, const float* bias, float* y, int B, int N,
                              int K, int ldy, uint16_t* gate_out, int split_k, float* ws, uint32_t* counters, rst_stream_t stream);
+/* The same GEMM taking the fp32 activations x [B][ldx] directly (no rst_skinny_pack_act_f32 launch in front of it): every lane forms
+ * the hi / lo operand of its (batch row, 8 k) piece in registers; mode 1 (RMSNorm) puts x * alpha into the operand and applies
+ * 1 / sqrt(eps + mean(x^2)) to the accumulators (the factor commutes with the contraction).  No K split; meant for K <= 2048 (the
+ * depth transformer and the GPT blocks, whose launches are latency chains: one launch less per linear), ldx % 4 == 0. */
+int rst_gemm_skinny_x32_bf16_f32(const float* x, const float* alpha, float eps, int mode, int ldx, const uint16_t* wp, const float* res,
+                                 const float* bias, float* y, int B, int N, int K, int ldy, uint16_t* gate_out, rst_stream_t stream);
 /* split_k = rst_skinny_bf16_split_plan(B, N, K) (> 1 only for K >= 2048): K is also split over workgroups, each taking four (two
  * above 32 rows) adjacent column tiles, so that the packed activations are pulled through a CU's load path once per four weight
  * tiles and ~256-384 workgroups stream; ws [split_k][ceil(B/32)*32][N] fp32 and counters [ceil(N/32)] (zero before the first
@@ -372,10 +378,18 @@ int rst_attn_decode_multi_f32(const float* q, const float* k, const float* v, fl
  * argmax_j p_j / noise_j with caller-provided Exp(1) noise [B][noise_stride] (the reference draws it with
  * Tensor.exponential_, :44-46).  tokens[b * tok_stride] = result.  v_limit (0 = V; v_limit_dev, when given, is a device
  * int32 that overrides it): ids >= limit are never drawn -- the probability blanking of sample_token_audio (2049) and
- * sample_token_audio_2048 (2048), utils/sampling.py:107-158, applied after the softmax like there; greedy ignores it. */
+ * sample_token_audio_2048 (2048), utils/sampling.py:107-158, applied after the softmax like there; greedy ignores it.
+ * top_p > 0: nucleus sampling instead of top-k, as sample_token prefers it (:96-99) -- sample_top_p (:66-82): probabilities
+ * sorted descending (ties: lowest id first), entries kept while the exclusive prefix sum is <= top_p, survivors renormalised,
+ * token = idx[argmax_j q_j / noise_j] with ONE noise value per sorted position: noise then needs V values per row
+ * (noise_stride >= V).  Ids >= limit are left out of the nucleus (the reference's own combination of blanking and top_p yields NaN).
+ * workspace: rst_lm_sample_workspace_bytes(B, V, top_k, top_p > 0) bytes (0 when none is needed): the sort buffer of top_p, and for
+ * V > 32768 the chunk records of the two-level form (one 256-thread workgroup per 10 240 ids selects the chunk's exact top-k, one
+ * workgroup per row merges them: same tokens as the one-level kernel, which runs when workspace is NULL). */
+int64_t rst_lm_sample_workspace_bytes(int B, int V, int top_k, int top_p_mode);
 int rst_lm_sample_f32(const float* logits, const float* noise, int64_t* tokens, int B, int V, int ld, int top_k,
                       int noise_stride, int tok_stride, int use_sampling, float temp, int v_limit, const int32_t* v_limit_dev,
-                      rst_stream_t stream);
+                      float top_p, void* workspace, int64_t workspace_bytes, rst_stream_t stream);
 
 /* LMGen.step's token ring and delay pattern (models/model.py:506-562) on the device.  cache int64 [B][K][CT] (CT = max_delay
  * + 2), delays int32 [K] and the frame counter offset_dev (int64 scalar) stay in HBM, so that a frame is one captured graph.

@@ -182,10 +182,18 @@ def forward_depformer(sd: SD, cfg: LMConfig, cb_index: int, prev_token: torch.Te
     return F.linear(y, sd[f"linears.{cb_index}.weight"].float())[:, None]
 
 
-def sample_token(logits: torch.Tensor, use_sampling: bool, temp: float, top_k: int, noise: Optional[torch.Tensor] = None):
-    """sample_token (utils/sampling.py:85-105) with the exponential noise of `multinomial` (:44-46) passed in."""
+def sample_token(logits: torch.Tensor, use_sampling: bool, temp: float, top_k: int, noise: Optional[torch.Tensor] = None,
+                 top_p: float = 0.0):
+    """sample_token (utils/sampling.py:85-105) with the exponential noise of `multinomial` (:44-46) passed in.  ``top_p > 0``:
+    sample_top_p (:66-82) -- ``noise`` then has one entry per SORTED vocabulary position (full width); ties sort lowest id first."""
     if use_sampling and temp > 0.0:
         probs = torch.softmax(logits / temp, dim=-1)
+        if top_p > 0.0:
+            ps, idx = torch.sort(probs, dim=-1, descending=True, stable=True)
+            mask = torch.cumsum(ps, dim=-1) - ps > top_p
+            ps = ps * (~mask).float()
+            ps = ps / ps.sum(dim=-1, keepdim=True)
+            return idx.gather(-1, (ps / noise).argmax(dim=-1, keepdim=True))[..., 0]
         p, idx = torch.topk(probs, top_k, dim=-1)
         choice = (p / noise).argmax(dim=-1, keepdim=True)
         return idx.gather(-1, choice)[..., 0]

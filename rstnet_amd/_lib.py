@@ -59,13 +59,14 @@ SIGNATURES = {
     "rst_skinny_pack_act_fp8": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "rst_gemm_skinny_fp8_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "rst_gemm_skinny_bf16_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p],
+    "rst_gemm_skinny_x32_bf16_f32": [_p, _p, _f, _i, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "rst_skinny_bf16_split_plan": [_i, _i, _i],
     "rst_embed_sum_bf16": [_p, C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), _i, _p, _p, _i, _i, _i, _p],
     "rst_rmsnorm_f32": [_p, _p, _p, _l, _i, _f, _p],
     "rst_lm_rope_append_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "rst_lm_attn_decode_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _i, _p],
     "rst_attn_decode_multi_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
-    "rst_lm_sample_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p, _p],
+    "rst_lm_sample_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p, _f, _p, _l, _p],
     "rst_lm_ring_begin_i64": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "rst_lm_ring_commit_i64": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }
@@ -94,6 +95,8 @@ def lib() -> C.CDLL:
         fn = getattr(handle, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = _i
+    handle.rst_lm_sample_workspace_bytes.restype = _l
+    handle.rst_lm_sample_workspace_bytes.argtypes = [_i, _i, _i, _i]
     handle.rst_version.restype = _i
     handle.rst_version.argtypes = []
     handle.rst_last_error.restype = C.c_char_p

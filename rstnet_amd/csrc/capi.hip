@@ -325,10 +325,22 @@ int rst_skinny_bf16_split_plan(int B, int N, int K) { return rst_skinny_bf16_spl
 
 int rst_gemm_skinny_bf16_f32(const uint16_t* xp, const uint16_t* wp, const float* res, const float* bias, float* y, int B, int N,
                              int K, int ldy, uint16_t* gate_out, int split_k, float* ws, uint32_t* counters, rst_stream_t stream) {
-    SkinnyParams p;
+    RST_REQUIRE(xp, "gemm_skinny_bf16: null packed activations");
+    SkinnyParams p = {};
     p.xp = xp; p.w = wp; p.res = res; p.bias = bias; p.y = y; p.B = B; p.N = N; p.K = K; p.ldy = ldy;
     p.gate_out = gate_out; p.gate_plane = (long)((B + 31) / 32 * 32) * (N / 2);
     p.split_k = split_k; p.ws = ws; p.counters = counters;
+    return rst_launch_gemm_skinny(p, (hipStream_t)stream);
+}
+
+int rst_gemm_skinny_x32_bf16_f32(const float* x, const float* alpha, float eps, int mode, int ldx, const uint16_t* wp, const float* res,
+                                 const float* bias, float* y, int B, int N, int K, int ldy, uint16_t* gate_out, rst_stream_t stream) {
+    RST_REQUIRE(x, "gemm_skinny_x32: null activations");
+    SkinnyParams p = {};
+    p.xf = x; p.alpha = alpha; p.eps = eps; p.xmode = mode; p.ldx = ldx;
+    p.w = wp; p.res = res; p.bias = bias; p.y = y; p.B = B; p.N = N; p.K = K; p.ldy = ldy;
+    p.gate_out = gate_out; p.gate_plane = (long)((B + 31) / 32 * 32) * (N / 2);
+    p.split_k = 1;
     return rst_launch_gemm_skinny(p, (hipStream_t)stream);
 }
 
@@ -396,11 +408,13 @@ int rst_attn_decode_multi_f32(const float* q, const float* k, const float* v, fl
     return rst_launch_lm_attn(p, (hipStream_t)stream);
 }
 
+int64_t rst_lm_sample_workspace_bytes(int B, int V, int top_k, int top_p_mode) { return rst_lm_sample_workspace_bytes_impl(B, V, top_k, top_p_mode); }
+
 int rst_lm_sample_f32(const float* logits, const float* noise, int64_t* tokens, int B, int V, int ld, int top_k,
                       int noise_stride, int tok_stride, int use_sampling, float temp, int v_limit, const int32_t* v_limit_dev,
-                      rst_stream_t stream) {
+                      float top_p, void* workspace, int64_t workspace_bytes, rst_stream_t stream) {
     LmSampleParams p;
-    p.v_limit = v_limit; p.v_limit_dev = v_limit_dev;
+    p.v_limit = v_limit; p.v_limit_dev = v_limit_dev; p.top_p = top_p; p.ws = workspace; p.ws_bytes = workspace ? workspace_bytes : 0;
     p.logits = logits; p.noise = noise; p.tokens = (long*)tokens; p.B = B; p.V = V; p.ld = ld; p.top_k = top_k;
     p.noise_stride = noise_stride; p.tok_stride = tok_stride; p.use_sampling = use_sampling; p.temp = temp;
     return rst_launch_lm_sample(p, (hipStream_t)stream);

@@ -20,10 +20,20 @@ template <int NT> struct SampleShared {
     int n_cand;
 };
 
+// What a SELECT call (first level of the two-level sampler for large vocabularies, lm_sample.hip) reports about its chunk of a row.
+struct SampleChunk {
+    unsigned max_key;       // order-preserving key of the chunk's largest (scaled) logit
+    int max_idx;            // its lowest id
+    float sum_exp;          // sum over the chunk of exp(logit - chunk max)
+    int n_cand;             // candidates written to comp (the chunk's top-k among the ids that may be drawn)
+};
+
 // One logits row `lg[0..V)` (global or LDS), all NT threads of the workgroup: returns the token (valid in thread 0).
-template <int NT, int EPT>
+// SELECT: `lg[0..V)` is a CHUNK of a row whose first id is `id0`; the call stops after the exact top-k selection -- the candidates
+// (composites carrying their GLOBAL ids) are left in comp[0 .. n_cand) and `*chunk` is filled (valid in every thread).
+template <int NT, int EPT, bool SELECT = false>
 __device__ __forceinline__ int sample_row(const float* lg, const float* noise_row, int V, int top_k, bool sampling, float temp, int limit_in,
-                                          unsigned long long* comp, SampleShared<NT>& sh) {
+                                          unsigned long long* comp, SampleShared<NT>& sh, int id0 = 0, SampleChunk* chunk = nullptr) {
     constexpr int NW = NT / 64;
     float (&red_v)[NW] = sh.red_v;
     int (&red_i)[NW] = sh.red_i;
@@ -82,6 +92,7 @@ __device__ __forceinline__ int sample_row(const float* lg, const float* noise_ro
 #pragma unroll
     for (int w = 1; w < NW; ++w)
         if ((unsigned)red_j[w] > bk || ((unsigned)red_j[w] == bk && red_i[w] < bi)) { bk = (unsigned)red_j[w]; bi = red_i[w]; }
+    if (SELECT) { chunk->max_key = bk; chunk->max_idx = id0 + bi; chunk->sum_exp = 0.f; chunk->n_cand = 0; }
     if (!sampling) return bi;
     // softmax denominator (fp32, max-subtracted like torch.softmax)
     const float mx = from_key(bk);
@@ -97,7 +108,10 @@ __device__ __forceinline__ int sample_row(const float* lg, const float* noise_ro
 
     // id blanking of sample_token_audio / sample_token_audio_2048 (utils/sampling.py:107-158): the probabilities of ids >= limit
     // are overwritten after the softmax over ALL ids, so the denominator above is untouched and the ids just leave the race
-    const int limit = limit_in > 0 && limit_in < V ? limit_in : V;
+    if (SELECT) chunk->sum_exp = denom;
+    // (SELECT: `limit_in` is the row's limit minus id0, already clamped to [0, V] by the caller; 0 = no id of this chunk may be drawn)
+    const int limit = SELECT ? limit_in : (limit_in > 0 && limit_in < V ? limit_in : V);
+    if (SELECT && limit <= 0) return 0;
     if (limit < V) {
 #pragma unroll
         for (int j = 0; j < EPT; ++j) key[j] = j * NT + tid < limit ? key[j] : 0u;
@@ -143,10 +157,11 @@ __device__ __forceinline__ int sample_row(const float* lg, const float* noise_ro
         const bool take = key[j] > thr || (key[j] == thr && j * NT + tid <= idx_lim);
         const unsigned long long mk = __ballot(take);
         const int at = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-        if (take && at < k) comp[at] = ((unsigned long long)key[j] << 32) | (unsigned)(0x7fffffff - (j * NT + tid));
+        if (take && at < k) comp[at] = ((unsigned long long)key[j] << 32) | (unsigned)(0x7fffffff - (id0 + j * NT + tid));
         base += __popcll(mk);
     }
     __syncthreads();
+    if (SELECT) { chunk->n_cand = k; return 0; }
     float win = -INFINITY;
     int win_rank = 0x7fffffff, win_tok = 0;
     for (int c = tid; c < k; c += NT) {

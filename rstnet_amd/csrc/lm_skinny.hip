@@ -94,9 +94,17 @@ constexpr int SKINNY_WAVES = 8;
 // weight byte instead of 3) and, for the longest K, only a slice of it (gridDim.y splits, so that ~256-384 workgroups exist); the partial tiles go to
 // `ws` with write-through stores, one arrival counter per column group, and the LAST workgroup to arrive sums them in split order
 // (deterministic) and runs the epilogue (the protocol of the fp32 few-row GEMM, csrc/skinny_f32.hip).
-template <int NB, int CT>   // batch tiles of 32, weight-row tiles per workgroup
+//
+// XF (round 3): the activations arrive as fp32 rows and the launch forms its own MFMA operand -- per step a lane reads the 8 floats of
+// its (batch row, k-octet), multiplies by the RMSNorm gains, splits into bf16 hi + lo in registers (the same split as the packing
+// launch) and feeds all CT column tiles from it.  The row's 1 / rms factor commutes with the contraction, so it is applied to the
+// accumulators: the lanes sum the squares of what they load, the waves' partial sums meet in LDS next to the partial tiles.  This
+// removes the activation-packing launch in front of every normed / plain linear of the 1024-wide layers (depth transformer, GPT
+// blocks): ~150 of the ~530 launches of a batch-32 GPT frame, each a 3-4 us link of a latency-bound chain.
+template <int NB, int CT, bool XF = false>   // batch tiles of 32, weight-row tiles per workgroup
 __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const SkinnyParams p) {
     __shared__ float red[SKINNY_WAVES][NB * 32][33];
+    __shared__ float ssq_red[XF ? SKINNY_WAVES : 1][NB * 32];
     __shared__ int sm_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = (p.N + 31) / 32;
@@ -135,9 +143,23 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
                 bpre[c][q] = p.bias ? p.bias[n] : 0.f;
             }
     }
-    constexpr int UN = (NB * 2 + CT) <= 4 ? 4 : 2;
+    constexpr int UN = XF ? 2 : ((NB * 2 + CT) <= 4 ? 4 : 2);
+    // XF: this lane's batch rows (lane % 32 of every batch tile) and k-octet inside a step ((lane / 32) * 8); rows past B read row
+    // B - 1 and are cleared through a mask (no load under a per-lane condition: DESIGN.md 3.12)
+    float ssq[NB];
+    const float* xrow[NB];
+    unsigned xmask[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+        ssq[t] = 0.f;
+        const int b = t * 32 + (lane & 31);
+        xrow[t] = XF ? p.xf + (long)min(b, p.B - 1) * p.ldx + (lane >> 5) * 8 : nullptr;
+        xmask[t] = b < p.B ? 0xffffffffu : 0u;
+        asm volatile("" : "+v"(xmask[t]));
+    }
     for (int s = s0; s < s1; s += UN) {
         bf16x8 a[UN][CT], bh[UN][NB], bl[UN][NB];
+        f32x4 xv[XF ? UN : 1][NB][2], gv[XF ? UN : 1][2];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const bool ok = s + u < s1;
@@ -145,10 +167,43 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
 #pragma unroll
             for (int c = 0; c < CT; ++c)
                 a[u][c] = ok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wt[c] + so)) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (XF) {
+                const int ks = min(s + u, s1 - 1) * 16;         // a step past the wave's range re-reads its last one (masked below)
 #pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                bh[u][t] = ok ? *reinterpret_cast<const bf16x8*>(xh + (long)t * steps * 512 + so) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                bl[u][t] = ok ? *reinterpret_cast<const bf16x8*>(xl + (long)t * steps * 512 + so) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                for (int t = 0; t < NB; ++t) {
+                    xv[u][t][0] = *reinterpret_cast<const f32x4*>(xrow[t] + ks);
+                    xv[u][t][1] = *reinterpret_cast<const f32x4*>(xrow[t] + ks + 4);
+                }
+                if (p.xmode == 1) {
+                    gv[u][0] = *reinterpret_cast<const f32x4*>(p.alpha + ks + (lane >> 5) * 8);
+                    gv[u][1] = *reinterpret_cast<const f32x4*>(p.alpha + ks + (lane >> 5) * 8 + 4);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    bh[u][t] = ok ? *reinterpret_cast<const bf16x8*>(xh + (long)t * steps * 512 + so) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    bl[u][t] = ok ? *reinterpret_cast<const bf16x8*>(xl + (long)t * steps * 512 + so) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
+        }
+        if (XF) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const unsigned live = s + u < s1 ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float xj = __uint_as_float(__float_as_uint(xv[u][t][j >> 2][j & 3]) & xmask[t] & live);
+                        ssq[t] = fmaf(xj, xj, ssq[t]);
+                        v[j] = p.xmode == 1 ? xj * gv[u][j >> 2][j & 3] : xj;
+                    }
+                    u32x4 hi, lo;
+                    split_hi_lo8(v, hi, lo);
+                    bh[u][t] = __builtin_bit_cast(bf16x8, hi);
+                    bl[u][t] = __builtin_bit_cast(bf16x8, lo);
+                }
             }
         }
 #pragma unroll
@@ -162,14 +217,28 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
                 }
     }
     const int i = lane & 31;
+    if (XF) {        // this wave's share of every row's sum of squares (both k-octet halves of the lanes), summed in wave order below
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const float sq = ssq[t] + __shfl_xor(ssq[t], 32);
+            if (lane < 32) ssq_red[wave][t * 32 + lane] = sq;
+        }
+    }
     bool single = false;            // red[slot] alone holds the tile (the summed splits) instead of one partial per wave
     int slot = 0;
+    auto rinv = [&](int b) {        // XF + RMSNorm: 1 / sqrt(eps + mean(x[b]^2)), the factor the operand left out
+        if (!XF || p.xmode != 1) return 1.0f;
+        float q = ssq_red[0][b];
+#pragma unroll
+        for (int w = 1; w < SKINNY_WAVES; ++w) q += ssq_red[XF ? w : 0][b];
+        return 1.0f / sqrtf(p.eps + q / (float)p.K);
+    };
     auto tsum = [&](int b, int col) {
         if (single) return red[slot][b][col];
         float v = red[0][b][col];
 #pragma unroll
         for (int w = 1; w < SKINNY_WAVES; ++w) v += red[w][b][col];
-        return v;
+        return XF ? v * rinv(b) : v;
     };
     auto emit = [&](int c) {        // epilogue of column tile c from the tile in `red`
         const int n0 = (tile0 + c) * 32;
@@ -343,7 +412,10 @@ int rst_skinny_bf16_split_plan_impl(int B, int N, int K) {
 
 int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B >= 1 && p.B <= 64 && p.N > 0 && p.K > 0 && p.K % 16 == 0, "gemm_skinny: need 1 <= B <= 64 and K %% 16 == 0 (B=%d K=%d)", p.B, p.K);
-    RST_REQUIRE(p.xp && p.w && (p.y || p.gate_out), "gemm_skinny: null pointer");
+    RST_REQUIRE((p.xp || p.xf) && p.w && (p.y || p.gate_out), "gemm_skinny: null pointer");
+    const bool xf = p.xp == nullptr;
+    RST_REQUIRE(!xf || (p.ldx % 4 == 0 && p.ldx >= p.K && (uintptr_t)p.xf % 16 == 0 && (p.xmode == 0 || (p.xmode == 1 && p.alpha)) && p.split_k <= 1),
+                "gemm_skinny: the fp32-input form needs 16-byte aligned rows (ldx %% 4 == 0), mode 0 / 1 (with alpha) and no K split");
     RST_REQUIRE(!p.gate_out || (p.N % 32 == 0 && !p.res), "gemm_skinny: the gated epilogue needs N %% 32 == 0 and takes no residual");
     const int tiles = (p.N + 31) / 32;
     const int threads = 64 * SKINNY_WAVES;
@@ -351,6 +423,17 @@ int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream) {
     RST_REQUIRE(split == 1 || (p.ws && p.counters && split <= 64), "gemm_skinny: split-K needs the scratch buffers (split <= 64)");
     const int ct = skinny_ct(p.B, tiles, p.K, split);
     const dim3 grid((tiles + ct - 1) / ct, split);
+    if (xf) {
+        if (p.B <= 32) {
+            if (ct == 4) hipLaunchKernelGGL((gemm_skinny_kernel<1, 4, true>), grid, dim3(threads), 0, stream, p);
+            else if (ct == 2) hipLaunchKernelGGL((gemm_skinny_kernel<1, 2, true>), grid, dim3(threads), 0, stream, p);
+            else hipLaunchKernelGGL((gemm_skinny_kernel<1, 1, true>), grid, dim3(threads), 0, stream, p);
+        } else {
+            if (ct == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, 2, true>), grid, dim3(threads), 0, stream, p);
+            else hipLaunchKernelGGL((gemm_skinny_kernel<2, 1, true>), grid, dim3(threads), 0, stream, p);
+        }
+        return rst_check_launch("gemm_skinny_x32");
+    }
     if (p.B <= 32) {
         if (ct == 4) hipLaunchKernelGGL((gemm_skinny_kernel<1, 4>), grid, dim3(threads), 0, stream, p);
         else if (ct == 2) hipLaunchKernelGGL((gemm_skinny_kernel<1, 2>), grid, dim3(threads), 0, stream, p);

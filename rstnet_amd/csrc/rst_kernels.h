@@ -237,7 +237,11 @@ struct LmSampleParams {
     float temp;
     int v_limit;               // sampling only: ids >= v_limit are never drawn (probabilities blanked AFTER the softmax); 0 = V
     const int* v_limit_dev;    // optional device scalar overriding v_limit (lets one captured graph serve changing limits)
+    float top_p;               // > 0: nucleus sampling (sample_top_p) instead of top-k; noise then holds V values per row
+    void* ws;                  // scratch of rst_lm_sample_workspace_bytes_impl bytes: chunk records + candidates of the two-level form
+    long ws_bytes;             // for V > 32768, the sort buffer of top_p; NULL: one-level kernels only (top_p then refused)
 };
+long rst_lm_sample_workspace_bytes_impl(int B, int V, int top_k, int top_p_mode);
 int rst_launch_lm_sample(const LmSampleParams& p, hipStream_t stream);
 
 // ---- lm_depth.hip: the depth phase of a frame as one persistent launch
@@ -325,6 +329,11 @@ struct SkinnyParams {
     int split_k;                // > 1: K also split over gridDim.y workgroups (rst_skinny_bf16_split_plan_impl), partials in ws
     float* ws;                  // [split_k][ceil(B/32)*32][N]
     unsigned* counters;         // [ceil(N/32)], zero before the first launch (self re-arming)
+    // fp32-input form (xp == nullptr): the launch forms its own operand from x -- no activation-packing launch in front of it
+    const float* xf;            // [B][ldx] fp32
+    const float* alpha;         // xmode 1: RMSNorm gains [K]
+    int ldx, xmode;             // 0: x as is; 1: RMSNorm (x * alpha in the operand, 1 / rms applied to the accumulators)
+    float eps;
 };
 int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream);
 int rst_skinny_bf16_split_plan_impl(int B, int N, int K);

@@ -659,6 +659,11 @@ def _packed_buffer(device, B: int, K: int, role: str = "in") -> torch.Tensor:
     return _scratch(_packed_out, device, (B, K, role), lambda: torch.zeros(2, (B + 31) // 32 * 32, K, device=device, dtype=torch.bfloat16))
 
 
+# K up to which a plain / RMSNorm linear of 2 < B <= 64 rows takes the fp32 activations directly (rst_gemm_skinny_x32_bf16_f32: the
+# operand is formed inside the GEMM, no packing launch); above it the packing launch + packed GEMM (+ K split) stay
+SKINNY_X32_MAX_K = 2048
+
+
 def gemm_skinny(x, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Optional[torch.Tensor] = None,
                 eps: float = 1e-8, res: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, gate_out: bool = False):
     """``y[B,N] = (res +) (bias +) P(x) @ w.T`` for 2 < B <= 64 on the bf16 matrix cores: prologue + hi/lo split + packing of
@@ -669,6 +674,27 @@ def gemm_skinny(x, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Opt
     N, K = w.shape
     gate_out = gate_out and N % 32 == 0 and res is None
     wp = skinny_pack_weight(w, interleave_halves=gate_out)
+    if not isinstance(x, PackedAct) and prologue in (PROLOGUE_NONE, PROLOGUE_RMSNORM) and K <= SKINNY_X32_MAX_K and x.dim() == 2 and \
+            x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:      # (K this short is never split: split plan >= 4096)
+        # fp32 rows straight into the GEMM (one launch instead of two)
+        _chk(alpha, "alpha")
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise TypeError("rstnet_amd.ops: `x` must be a float32 CUDA/HIP matrix")
+        assert x.shape[1] == K, (tuple(x.shape), N, K, prologue)
+        B = x.shape[0]
+        out = None if gate_out else torch.empty(B, N, device=x.device, dtype=torch.float32)
+        gp = _packed_buffer(x.device, B, N // 2, "gate") if gate_out else None
+        prof = PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(_lib.lib().rst_gemm_skinny_x32_bf16_f32(_ptr(x), _ptr(alpha) if prologue == PROLOGUE_RMSNORM else None, float(eps),
+                                                          1 if prologue == PROLOGUE_RMSNORM else 0, x.stride(0) if B > 1 else K, _ptr(wp), _ptr(res),
+                                                          _ptr(bias), _ptr(out), B, N, K, N, _ptr(gp), _stream()))
+        if prof is not None:
+            e1.record()
+            prof.append(("gemm_skinny", e0, e1, 2.0 * B * N * K, 2 * N * K + 4 * (x.numel() + B * N), (B, N, K)))
+        return PackedAct(gp, B, N // 2) if gate_out else out
     if isinstance(x, PackedAct):
         assert prologue == PROLOGUE_NONE and x.K == K
         xp, B = x.xp, x.B
@@ -855,23 +881,38 @@ def lm_attn_decode(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     return PackedAct(xp, B, H * D) if packed else out
 
 
+_sample_ws: dict = {}
+
+
 def lm_sample(logits: torch.Tensor, *, use_sampling: bool, temp: float, top_k: int, noise: Optional[torch.Tensor] = None,
-              out: Optional[torch.Tensor] = None, limit: int = 0, limit_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, limit: int = 0, limit_dev: Optional[torch.Tensor] = None, top_p: float = 0.0,
+              two_level: bool = True) -> torch.Tensor:
     """logits fp32 ``[B, V]`` -> tokens int64 ``[B]`` (greedy, or top-k sampling with Exp(1) ``noise [B, top_k]``).  ``limit``
-    (or the int32 device scalar ``limit_dev``): ids >= limit are never drawn when sampling."""
+    (or the int32 device scalar ``limit_dev``): ids >= limit are never drawn when sampling.  ``top_p > 0``: nucleus sampling
+    (utils/sampling.py:66-82) instead of top-k; ``noise`` is then ``[B, V]`` (one draw per sorted position).  ``two_level=False``
+    keeps the one-workgroup-per-row kernel for vocabularies above 32768 (A/B measurements, tests)."""
     _chk(logits, "logits")
     _chk(limit_dev, "limit_dev", torch.int32)
     B, V = logits.shape
+    sampling = bool(use_sampling and temp > 0)
+    nucleus = sampling and top_p > 0.0
     if noise is not None:       # a [B, >= top_k] column slice of a wider noise buffer is fine (row stride is passed on)
         if not noise.is_cuda or noise.dtype != torch.float32 or noise.dim() != 2 or noise.stride(1) != 1 or noise.shape[0] != B:
             raise ValueError("rstnet_amd.ops: `noise` must be a float32 CUDA/HIP tensor [B, k] with unit column stride")
+        if nucleus and noise.shape[1] < V:
+            raise ValueError(f"rstnet_amd.ops: top_p sampling draws one noise value per vocabulary entry: noise [B, >= {V}] needed")
     if out is None:
         out = torch.empty(B, device=logits.device, dtype=torch.int64)
     elif not out.is_cuda or out.dtype != torch.int64 or out.dim() != 1 or out.shape[0] != B:   # may be a column of a [B, n] buffer
         raise ValueError("rstnet_amd.ops: `out` must be an int64 CUDA/HIP vector of length B")
+    ws, nbytes = None, 0
+    if nucleus or (two_level and V > 32768):
+        nbytes = int(_lib.lib().rst_lm_sample_workspace_bytes(B, V, top_k if sampling else 1, int(nucleus)))
+        if nbytes:
+            ws = _scratch(_sample_ws, logits.device, ("sample", nbytes), lambda: torch.empty((nbytes + 7) // 8, device=logits.device, dtype=torch.int64))
     _lib.check(_lib.lib().rst_lm_sample_f32(_ptr(logits), _ptr(noise), _ptr(out), B, V, V, top_k, noise.stride(0) if noise is not None else 0,
                                            out.stride(0) if B > 1 else 1, int(use_sampling), float(temp), int(limit), _ptr(limit_dev),
-                                           _stream()))
+                                           float(top_p) if nucleus else 0.0, _ptr(ws), nbytes, _stream()))
     return out
 
 

@@ -140,6 +140,33 @@ def sampling_logits(name: str) -> torch.Tensor:
     return lg
 
 
+# nucleus sampling (sample_token(..., top_p=p) -> sample_top_p, utils/sampling.py:66-82,96-97): name -> (B, V, top_p, temp, seed, logit
+# scale).  The noise is one Exp(1) draw per SORTED vocabulary position ([B, V]); it is not stored but re-drawn from the seed on the
+# CPU generator (`sampling_top_p_noise`), exactly as make_golden.py re-draws what the reference's multinomial drew.
+SAMPLING_TOP_P_CASES = {
+    "audio": (3, 2048, 0.9, 0.8, 21, 1.0),           # nuclei of ~1000 entries
+    "text": (2, 32000, 0.8, 0.7, 22, 1.5),           # several thousand
+    "qwen_vocab": (2, 151936, 0.6, 0.7, 23, 2.5),    # a few hundred of 151 936
+    "tight": (4, 2048, 0.3, 1.0, 24, 3.0),           # a handful
+}
+
+
+def sampling_top_p_logits(name: str) -> torch.Tensor:
+    B, V, top_p, temp, seed, scale = SAMPLING_TOP_P_CASES[name]
+    g = torch.Generator().manual_seed(930 + seed)
+    return scale * torch.randn(B, 1, 1, V, generator=g)
+
+
+def sampling_top_p_noise(name: str) -> torch.Tensor:
+    """The Exp(1) tensor `multinomial` draws for this case: global CPU generator seeded as make_golden.py seeds it (restores the state)."""
+    B, V, top_p, temp, seed, scale = SAMPLING_TOP_P_CASES[name]
+    state = torch.get_rng_state()
+    torch.manual_seed(seed)
+    noise = torch.empty(B, V).exponential_(1)
+    torch.set_rng_state(state)
+    return noise
+
+
 # ---- reverse_delay (infer_no_streaming.py:311-323): name -> shape; [8, L] as generated, [L, 8] exercises the transpose branch
 REVERSE_DELAY_CASES = {"k_major": (8, 13), "t_major": (21, 8), "two_frames": (8, 2)}
 

@@ -245,6 +245,16 @@ def gen_sampling():
         out[f"{name}.tokens"], out[f"{name}.noise"] = tok.numpy().astype(np.int32), noise.numpy()
         out[f"{name}.greedy"] = greedy.numpy().astype(np.int32)
         print("sampling", name, tuple(tok.shape), tok.flatten().tolist())
+    # nucleus sampling: sample_token(top_p=p) -> sample_top_p (:66-82); its multinomial draws [B, 1, 1, V] noise right after the seed
+    for name, (B, V, top_p, temp, seed, scale) in cases.SAMPLING_TOP_P_CASES.items():
+        lg = cases.sampling_top_p_logits(name)
+        torch.manual_seed(seed)
+        tok = S.sample_token(lg.clone(), use_sampling=True, temp=temp, top_k=0, top_p=top_p)
+        probs = torch.softmax(lg / temp, -1).sort(-1, descending=True).values
+        nucleus = ((probs.cumsum(-1) - probs) <= top_p).sum(-1).flatten()
+        out[f"top_p.{name}.tokens"] = tok.numpy().astype(np.int32)
+        out[f"top_p.{name}.nucleus"] = nucleus.numpy().astype(np.int32)
+        print("sampling top_p", name, tuple(tok.shape), tok.flatten().tolist(), "nucleus sizes", nucleus.tolist())
     np.savez(os.path.join(HERE, "sampling.npz"), **out)
 
 

@@ -331,6 +331,61 @@ def test_sampler_matches_reference_fixture(name):
     assert torch.equal(tok.cpu(), torch.from_numpy(g[f"{name}.greedy"]).long().view(B))
 
 
+@pytest.mark.parametrize("name", list(cases.SAMPLING_TOP_P_CASES))
+def test_top_p_sampler_matches_reference_fixture(name):
+    """rst_lm_sample_f32(top_p > 0) against the tokens the REFERENCE's sample_token(top_p=...) returned (sampling.npz, nuclei of
+    1 .. ~3000 entries, the 151 936-entry vocabulary) for the full-width noise its multinomial drew, and against the oracle on a row
+    with exact ties (sorted lowest id first) and with id blanking."""
+    g = np.load(os.path.join(G, "sampling.npz"))
+    B, V, top_p, temp, seed, scale = cases.SAMPLING_TOP_P_CASES[name]
+    lg = cases.sampling_top_p_logits(name).view(B, V)
+    noise = cases.sampling_top_p_noise(name)
+    tok = ops.lm_sample(lg.to(DEV), use_sampling=True, temp=temp, top_k=0, noise=noise.to(DEV), top_p=top_p)
+    assert torch.equal(tok.cpu(), torch.from_numpy(g[f"top_p.{name}.tokens"]).long().view(B))
+    # top_p wins over top_k when both are given (utils/sampling.py:96-99); greedy ignores both
+    tok = ops.lm_sample(lg.to(DEV), use_sampling=True, temp=temp, top_k=25, noise=noise.to(DEV), top_p=top_p)
+    assert torch.equal(tok.cpu(), torch.from_numpy(g[f"top_p.{name}.tokens"]).long().view(B))
+    assert torch.equal(ops.lm_sample(lg.to(DEV), use_sampling=False, temp=temp, top_k=0, top_p=top_p).cpu(), lg.argmax(-1))
+    # ties: quantised logits -> plateaus inside the nucleus
+    lq = (lg * 2).round() / 2
+    ref = L.sample_token(lq, True, temp, 0, noise, top_p=top_p)
+    assert torch.equal(ops.lm_sample(lq.to(DEV), use_sampling=True, temp=temp, top_k=0, noise=noise.to(DEV), top_p=top_p).cpu(), ref)
+    # id blanking: ids >= limit leave the nucleus, the softmax denominator stays that of the full row (as the top-k path blanks)
+    limit = V // 2
+    probs = torch.softmax(lq / temp, -1)
+    probs[:, limit:] = 0.0
+    ps, idx = torch.sort(probs, dim=-1, descending=True, stable=True)
+    ps = ps * (~(torch.cumsum(ps, -1) - ps > top_p)).float()
+    ref = idx.gather(-1, (ps / noise).argmax(-1, keepdim=True))[:, 0]
+    got = ops.lm_sample(lq.to(DEV), use_sampling=True, temp=temp, top_k=0, noise=noise.to(DEV), top_p=top_p, limit=limit)
+    assert torch.equal(got.cpu(), ref) and int(got.max()) < limit
+
+
+@pytest.mark.parametrize("V,k", [(151936, 25), (65536, 50), (40000, 100), (151936, 1)])
+def test_two_level_sampler_equals_one_level(V, k):
+    """Vocabularies above 32768: the chunked two-level sampler (sample_split_kernel + sample_merge_kernel) against the one-workgroup-per-row
+    kernel it replaces and the oracle -- random rows, an exact tie, massive plateaus, id blanking, greedy."""
+    g = torch.Generator().manual_seed(V + k)
+    B = 5
+    logits = torch.randn(B, V, generator=g) * 3
+    logits[0, 70000 % V] = logits[0, 3] = logits[0].max() + 1.0                # a tie for the first place across chunks
+    logits[1] = torch.randint(0, 3, (V,), generator=g).float()                   # plateaus
+    logits[2] = 1.5
+    noise = torch.empty(B, k).exponential_(1, generator=g)
+    for limit in (0, 30000, 11):
+        if limit and limit < k:
+            continue
+        two = ops.lm_sample(logits.to(DEV), use_sampling=True, temp=0.8, top_k=k, noise=noise.to(DEV), limit=limit)
+        one = ops.lm_sample(logits.to(DEV), use_sampling=True, temp=0.8, top_k=k, noise=noise.to(DEV), limit=limit, two_level=False)
+        assert torch.equal(two, one), limit
+        if not limit:
+            probs = torch.softmax(logits / 0.8, -1)
+            order = torch.argsort(probs, dim=-1, descending=True, stable=True)[:, :k]
+            ref = order.gather(1, (probs.gather(1, order) / noise).argmax(-1, keepdim=True))[:, 0]
+            assert torch.equal(two.cpu(), ref)
+    assert torch.equal(ops.lm_sample(logits.to(DEV), use_sampling=False, temp=0.8, top_k=k).cpu(), logits.argmax(-1))
+
+
 def test_lm_state_dict_keys():
     cfg, sd, model = _tiny()
     assert set(model.state_dict().keys()) == set(sd.keys())

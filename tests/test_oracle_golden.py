@@ -217,6 +217,19 @@ def test_sampling_oracle_matches_reference(name):
         assert torch.equal(L.sample_token(lg.clone(), True, temp, k, noise), want)
 
 
+@pytest.mark.parametrize("name", list(cases.SAMPLING_TOP_P_CASES))
+def test_top_p_oracle_matches_reference(name):
+    """Nucleus sampling: oracle/lm_oracle.py:sample_token(top_p=...) against the tokens the reference's sample_token(top_p=...) ->
+    sample_top_p (utils/sampling.py:66-82) returned, with the full-width Exp(1) noise its multinomial drew re-drawn from the seed."""
+    from oracle import lm_oracle as L
+    g = np.load(os.path.join(G, "sampling.npz"))
+    B, V, top_p, temp, seed, scale = cases.SAMPLING_TOP_P_CASES[name]
+    lg = cases.sampling_top_p_logits(name)
+    noise = cases.sampling_top_p_noise(name).view(B, 1, 1, V)
+    want = torch.from_numpy(g[f"top_p.{name}.tokens"]).long()
+    assert torch.equal(L.sample_token(lg, True, temp, 0, noise, top_p=top_p), want)
+
+
 @pytest.mark.parametrize("name", list(cases.REVERSE_DELAY_CASES))
 def test_reverse_delay_matches_reference(name):
     """Oracle and product `reverse_delay` against the reference function's own outputs (tests/golden/reverse_delay.npz)."""
