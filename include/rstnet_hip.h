@@ -386,7 +386,7 @@ int rst_attn_decode_multi_f32(const float* q, const float* k, const float* v, fl
  * workspace: rst_lm_sample_workspace_bytes(B, V, top_k, top_p > 0) bytes (0 when none is needed): the sort buffer of top_p, and for
  * V > 32768 the chunk records of the two-level form (one 256-thread workgroup per 10 240 ids selects the chunk's exact top-k, one
  * workgroup per row merges them: same tokens as the one-level kernel, which runs when workspace is NULL). */
-int64_t rst_lm_sample_workspace_bytes(int B, int V, int top_k, int top_p_mode);
+int rst_lm_sample_workspace_bytes(int B, int V, int top_k, int top_p_mode);
 int rst_lm_sample_f32(const float* logits, const float* noise, int64_t* tokens, int B, int V, int ld, int top_k,
                       int noise_stride, int tok_stride, int use_sampling, float temp, int v_limit, const int32_t* v_limit_dev,
                       float top_p, void* workspace, int64_t workspace_bytes, rst_stream_t stream);

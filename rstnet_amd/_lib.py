@@ -66,6 +66,7 @@ SIGNATURES = {
     "rst_lm_rope_append_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "rst_lm_attn_decode_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _i, _p],
     "rst_attn_decode_multi_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rst_lm_sample_workspace_bytes": [_i, _i, _i, _i],
     "rst_lm_sample_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p, _f, _p, _l, _p],
     "rst_lm_ring_begin_i64": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "rst_lm_ring_commit_i64": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
@@ -95,8 +96,6 @@ def lib() -> C.CDLL:
         fn = getattr(handle, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = _i
-    handle.rst_lm_sample_workspace_bytes.restype = _l
-    handle.rst_lm_sample_workspace_bytes.argtypes = [_i, _i, _i, _i]
     handle.rst_version.restype = _i
     handle.rst_version.argtypes = []
     handle.rst_last_error.restype = C.c_char_p

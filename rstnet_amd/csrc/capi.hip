@@ -408,7 +408,10 @@ int rst_attn_decode_multi_f32(const float* q, const float* k, const float* v, fl
     return rst_launch_lm_attn(p, (hipStream_t)stream);
 }
 
-int64_t rst_lm_sample_workspace_bytes(int B, int V, int top_k, int top_p_mode) { return rst_lm_sample_workspace_bytes_impl(B, V, top_k, top_p_mode); }
+int rst_lm_sample_workspace_bytes(int B, int V, int top_k, int top_p_mode) {
+    const long n = rst_lm_sample_workspace_bytes_impl(B, V, top_k, top_p_mode);
+    return n > 0x7fffffffL ? -1 : (int)n;
+}
 
 int rst_lm_sample_f32(const float* logits, const float* noise, int64_t* tokens, int B, int V, int ld, int top_k,
                       int noise_stride, int tok_stride, int use_sampling, float temp, int v_limit, const int32_t* v_limit_dev,
