@@ -37,7 +37,7 @@ __global__ __launch_bounds__(1024) void sample_big_kernel(const LmSampleParams p
     const float* lg = p.logits + b * p.ld;
     const bool sampling = p.use_sampling && p.temp > 0.f;
     const int V = p.V;
-    auto to_key = [](float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+    auto to_key = [](float f) { unsigned u = __float_as_uint(f + 0.0f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
     auto from_key = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); };
     auto key_at = [&](int i) { return to_key(sampling ? lg[i] / p.temp : lg[i]); };
     // fn(i, key) over this thread's ids i = tid, tid + NT, ... < V in ascending order, eight loads in flight at a time (index
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const LmSampleParams
     const float* lg = p.logits + b * p.ld;
     const int V = p.V;
     unsigned long long* a = reinterpret_cast<unsigned long long*>(p.ws) + b * vpad;
-    auto to_key = [](float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+    auto to_key = [](float f) { unsigned u = __float_as_uint(f + 0.0f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
     auto from_key = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); };
     int limit = p.v_limit_dev ? *p.v_limit_dev : p.v_limit;
     limit = limit > 0 && limit < V ? limit : V;

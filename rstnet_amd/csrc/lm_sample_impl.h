@@ -42,7 +42,7 @@ __device__ __forceinline__ int sample_row(const float* lg, const float* noise_ro
     int& n_cand = sh.n_cand;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    auto to_key = [](float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+    auto to_key = [](float f) { unsigned u = __float_as_uint(f + 0.0f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
     auto from_key = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); };
     unsigned key[EPT];
     int slot = 0;                                  // every block-wide count uses a fresh row of per-wave LDS cells

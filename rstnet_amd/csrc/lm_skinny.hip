@@ -143,7 +143,11 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
                 bpre[c][q] = p.bias ? p.bias[n] : 0.f;
             }
     }
-    constexpr int UN = XF ? 2 : ((NB * 2 + CT) <= 4 ? 4 : 2);
+    // MFMA steps whose loads are all requested before the first is consumed.  The loop body is loads -> wait -> MFMAs, i.e. one exposed
+    // memory round trip (2-3 us for HBM weights under load) per iteration: the 1024-wide layers (8 steps per wave) run as ONE
+    // iteration where the registers allow it (one batch tile, one column tile), measured: the fp32-input form with 2 steps per
+    // iteration cost what the packing launch it removed had cost.
+    constexpr int UN = (NB == 1 && CT == 1) ? 8 : (XF ? (NB == 1 && CT == 2 ? 4 : 2) : ((NB * 2 + CT) <= 4 ? 4 : 2));
     // XF: this lane's batch rows (lane % 32 of every batch tile) and k-octet inside a step ((lane / 32) * 8); rows past B read row
     // B - 1 and are cleared through a mask (no load under a per-lane condition: DESIGN.md 3.12)
     float ssq[NB];
