@@ -266,7 +266,7 @@ int rst_gemv_embed_bf16_f32(const float* add, const uint16_t* table, const int64
  * Residency and what happens without it: the persistent launch is a grid of up to one workgroup per CU (sized so that every
  * workgroup owns rows in the all-to-all ops; refused -- rst_depth_frame_supported == 0 -- when the occupancy query says a CU
  * cannot take one), all of which must be resident at once.  A device shared with other work may not grant that: every spin is
- * bounded (~0.2 s), a timed-out hand-off ORs a code into status[0] and the launch drains.  The call enqueues, right behind it, the
+ * bounded (0.1 s), a timed-out hand-off ORs a code into status[0] and the launch drains.  The call enqueues, right behind it, the
  * same kernel as ONE workgroup: it returns at once while status[0] == 0 and otherwise recomputes the frame alone (it depends on no
  * other workgroup, so it cannot time out), overwrites the tokens, increments status[1] (frames repaired), ORs the codes into
  * status[2] and clears status[0] -- as with the reference's depformer_step (models/model.py:564-597) wrong tokens never leave the
@@ -303,8 +303,9 @@ int rst_gemm_skinny_bf16_f32(const uint16_t* xp, const uint16_t* wp, const float
                              int K, int ldy, uint16_t* gate_out, int split_k, float* ws, uint32_t* counters, rst_stream_t stream);
 /* The same GEMM taking the fp32 activations x [B][ldx] directly (no rst_skinny_pack_act_f32 launch in front of it): every lane forms
  * the hi / lo operand of its (batch row, 8 k) piece in registers; mode 1 (RMSNorm) puts x * alpha into the operand and applies
- * 1 / sqrt(eps + mean(x^2)) to the accumulators (the factor commutes with the contraction).  No K split; meant for K <= 2048 (the
- * depth transformer and the GPT blocks, whose launches are latency chains: one launch less per linear), ldx % 4 == 0. */
+ * 1 / sqrt(eps + mean(x^2)) to the accumulators (the factor commutes with the contraction); the rows are read coalesced and transposed
+ * into operand order through a wave-private LDS tile.  No K split, K % 256 == 0, ldx % 4 == 0; meant for K <= 2048 (the depth
+ * transformer and the GPT blocks, whose launches are latency chains: one launch less per linear). */
 int rst_gemm_skinny_x32_bf16_f32(const float* x, const float* alpha, float eps, int mode, int ldx, const uint16_t* wp, const float* res,
                                  const float* bias, float* y, int B, int N, int K, int ldy, uint16_t* gate_out, rst_stream_t stream);
 /* split_k = rst_skinny_bf16_split_plan(B, N, K) (> 1 only for K >= 2048): K is also split over workgroups, each taking four (two
@@ -360,10 +361,15 @@ int rst_lm_rope_append_f32(const float* qkv, float* q, float* k, float* v, const
  * layer; rows past B of the buffer are not touched (keep them zero).
  * kv_bf16 != 0 (long-ring form only): k / v are bf16 rings -- the reference's own cache precision (RingKVCache dtype,
  * modules/transformer.py:228 with the model in bf16, moshi/models/loaders.py:144): appended keys / values are rounded to
- * nearest-even, the new step attends to its own key / value at that precision, reads are widened to fp32. */
+ * nearest-even, the new step attends to its own key / value at that precision, reads are widened to fp32.
+ * rope_table (optional, long-ring form): the step's rotation as [D/2][2] (cos, sin) pairs from rst_lm_rope_table_f32 -- the same
+ * values the launch would compute itself (angle_i = exp(i * rope_coef) * pos, identity beyond rope_dims / 2), computed ONCE per
+ * frame instead of by every lane of every layer's launch (24 libm calls per lane: most of the launch at short context). */
+int rst_lm_rope_table_f32(const int64_t* pos_dev, float* table, int D, int rope_dims, float rope_coef, rst_stream_t stream);
 int rst_lm_attn_decode_f32(const float* qkv, void* k, void* v, float* ws, uint32_t* counters, float* out,
                            const int64_t* pos_dev, int B, int H, int D, int cap, int context, int splits, int ldqkv, int rope,
-                           float rope_coef, int kv_heads, int rope_dims, uint16_t* out_packed, int kv_bf16, rst_stream_t stream);
+                           float rope_coef, int kv_heads, int rope_dims, uint16_t* out_packed, int kv_bf16, const float* rope_table,
+                           rst_stream_t stream);
 
 /* The few-query form of rst_attention_f32(ring = 1) for streaming steps of the codec transformers (T <= a few new steps per
  * call): q [B][H][T][D] already rotated and k / v already appended by rst_rope_split_f32; every (b, t, h) query is split

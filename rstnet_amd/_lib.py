@@ -64,7 +64,8 @@ SIGNATURES = {
     "rst_embed_sum_bf16": [_p, C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), _i, _p, _p, _i, _i, _i, _p],
     "rst_rmsnorm_f32": [_p, _p, _p, _l, _i, _f, _p],
     "rst_lm_rope_append_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
-    "rst_lm_attn_decode_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _i, _p],
+    "rst_lm_rope_table_f32": [_p, _p, _i, _i, _f, _p],
+    "rst_lm_attn_decode_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _i, _p, _p],
     "rst_attn_decode_multi_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rst_lm_sample_workspace_bytes": [_i, _i, _i, _i],
     "rst_lm_sample_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p, _f, _p, _l, _p],

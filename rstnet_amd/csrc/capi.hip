@@ -385,9 +385,10 @@ int rst_lm_rope_append_f32(const float* qkv, float* q, float* k, float* v, const
 
 int rst_lm_attn_decode_f32(const float* qkv, void* k, void* v, float* ws, uint32_t* counters, float* out,
                            const int64_t* pos_dev, int B, int H, int D, int cap, int context, int splits, int ldqkv, int rope,
-                           float rope_coef, int kv_heads, int rope_dims, uint16_t* out_packed, int kv_bf16, rst_stream_t stream) {
+                           float rope_coef, int kv_heads, int rope_dims, uint16_t* out_packed, int kv_bf16, const float* rope_table,
+                           rst_stream_t stream) {
     LmAttnParams p;
-    p.kv_bf16 = kv_bf16;
+    p.kv_bf16 = kv_bf16; p.rope_cs = rope && !(cap <= 64 && splits == 1) ? rope_table : nullptr;
     p.q_pre = nullptr; p.T = 1; p.G = kv_heads > 0 ? kv_heads : H; p.rope_dims = rope_dims > 0 ? rope_dims : D;
     p.out_packed = out_packed; p.out_plane = (long)((B + 31) / 32 * 32) * H * D;
     p.qkv = qkv; p.k = k; p.v = v; p.ws = ws; p.counters = counters; p.out = out; p.pos_dev = (const long*)pos_dev;
@@ -396,11 +397,15 @@ int rst_lm_attn_decode_f32(const float* qkv, void* k, void* v, float* ws, uint32
     return rst_launch_lm_attn(p, (hipStream_t)stream);
 }
 
+int rst_lm_rope_table_f32(const int64_t* pos_dev, float* table, int D, int rope_dims, float rope_coef, rst_stream_t stream) {
+    return rst_launch_lm_rope_table((const long*)pos_dev, table, D, rope_dims > 0 ? rope_dims : D, rope_coef, (hipStream_t)stream);
+}
+
 int rst_attn_decode_multi_f32(const float* q, const float* k, const float* v, float* ws, uint32_t* counters, float* out,
                               const int64_t* pos_dev, int B, int T, int H, int D, int cap, int context, int splits,
                               int kv_heads, rst_stream_t stream) {
     LmAttnParams p;
-    p.kv_bf16 = 0;
+    p.kv_bf16 = 0; p.rope_cs = nullptr;
     p.G = kv_heads > 0 ? kv_heads : H; p.rope_dims = D; p.out_packed = nullptr; p.out_plane = 0;
     p.qkv = nullptr; p.q_pre = q; p.T = T; p.k = const_cast<float*>(k); p.v = const_cast<float*>(v); p.ws = ws; p.counters = counters;
     p.out = out; p.pos_dev = (const long*)pos_dev; p.B = B; p.H = H; p.D = D; p.cap = cap; p.context = context; p.splits = splits;

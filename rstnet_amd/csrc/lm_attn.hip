@@ -118,13 +118,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     const bool appender = h % qpk == 0;          // one query head per group writes the new step into the ring
 
     // rotation of this lane's 8 (real, imag) pairs at position `pos` (modules/rope.py:37-62)
+    // (with a table of the step's (cos, sin) pairs -- computed once per frame by rope_table_kernel with this very arithmetic -- the
+    // launch skips 24 libm calls per lane: at short context they were most of its duration)
     float rc[8], rs[8];
+    if (p.rope_cs) {
+        const f32x4* t4 = reinterpret_cast<const f32x4*>(p.rope_cs + sub * 16);
+        const f32x4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];
+        rc[0] = t0[0]; rs[0] = t0[1]; rc[1] = t0[2]; rs[1] = t0[3]; rc[2] = t1[0]; rs[2] = t1[1]; rc[3] = t1[2]; rs[3] = t1[3];
+        rc[4] = t2[0]; rs[4] = t2[1]; rc[5] = t2[2]; rs[5] = t2[3]; rc[6] = t3[0]; rs[6] = t3[1]; rc[7] = t3[2]; rs[7] = t3[3];
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        rc[i] = 1.f; rs[i] = 0.f;
-        if (p.rope && 2 * (sub * 8 + i) < p.rope_dims) {
-            const float ang = expf((float)(sub * 8 + i) * p.rope_coef) * (float)pos;
-            rc[i] = cosf(ang); rs[i] = sinf(ang);
+        for (int i = 0; i < 8; ++i) {
+            rc[i] = 1.f; rs[i] = 0.f;
+            if (p.rope && 2 * (sub * 8 + i) < p.rope_dims) {
+                const float ang = expf((float)(sub * 8 + i) * p.rope_coef) * (float)pos;
+                rc[i] = cosf(ang); rs[i] = sinf(ang);
+            }
         }
     }
     const float* qkv = p.q_pre ? nullptr : p.qkv + b * p.ldqkv + (long)h * D + sub * 16;
@@ -448,6 +457,26 @@ int rst_launch_lm_rope_append(const LmRopeAppendParams& p, hipStream_t stream) {
     return rst_check_launch("lm_rope_append");
 }
 
+namespace {
+__global__ __launch_bounds__(128) void rope_table_kernel(const long* pos_dev, float* out, int D, int rope_dims, float rope_coef) {
+    const int i = threadIdx.x;
+    if (i >= D / 2) return;
+    float c = 1.f, s = 0.f;
+    if (2 * i < rope_dims) {
+        const float ang = expf((float)i * rope_coef) * (float)*pos_dev;
+        c = cosf(ang); s = sinf(ang);
+    }
+    out[2 * i] = c;
+    out[2 * i + 1] = s;
+}
+}  // namespace
+
+int rst_launch_lm_rope_table(const long* pos_dev, float* out, int D, int rope_dims, float rope_coef, hipStream_t stream) {
+    RST_REQUIRE(pos_dev && out && D >= 2 && D <= 256 && D % 2 == 0 && rope_dims >= 0 && rope_dims <= D, "lm_rope_table: bad arguments (D=%d rope_dims=%d)", D, rope_dims);
+    hipLaunchKernelGGL(rope_table_kernel, dim3(1), dim3(128), 0, stream, pos_dev, out, D, rope_dims, rope_coef);
+    return rst_check_launch("lm_rope_table");
+}
+
 int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream) {
     RST_REQUIRE((p.qkv || p.q_pre) && p.k && p.v && (p.out || p.out_packed) && p.pos_dev && p.B >= 1 && p.H > 0 && p.cap > 0 && p.splits >= 1,
                 "lm_attn: bad arguments");
@@ -457,6 +486,7 @@ int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream) {
     RST_REQUIRE(p.G >= 1 && p.H % p.G == 0 && p.rope_dims >= 0 && p.rope_dims <= p.D && p.rope_dims % 2 == 0,
                 "lm_attn: bad kv head count %d for %d heads or rope_dims %d", p.G, p.H, p.rope_dims);
     RST_REQUIRE(!p.kv_bf16 || (!p.q_pre && !(p.cap <= 64 && p.splits == 1)), "lm_attn: bf16 rings are served by the long-ring single-step form only");
+    RST_REQUIRE(!p.rope_cs || (uintptr_t)p.rope_cs % 16 == 0, "lm_attn: the rope table must be 16-byte aligned");
     if (!p.q_pre && p.cap <= 64 && p.splits == 1) {
         switch (p.D) {
             case 32: hipLaunchKernelGGL(attn_small_kernel<32>, dim3(p.H, p.B), dim3(64), 0, stream, p); break;

@@ -457,7 +457,7 @@ int rst_launch_lm_sample(const LmSampleParams& p, hipStream_t stream) {
     }
     const int k = p.top_k > 0 && p.top_k < p.V ? p.top_k : p.V;
     RST_REQUIRE(!sampling || k <= 8192, "lm_sample: top-k %d exceeds the 8192 candidate stage", k);
-    const size_t lds = (size_t)((k + 7) & ~7) * 8;
+    const size_t lds = sampling ? (size_t)((k + 7) & ~7) * 8 : 0;      // greedy keeps no candidate list
     if (p.V <= 2048) hipLaunchKernelGGL((sample_kernel<256, 8>), dim3(p.B), dim3(256), lds, stream, p);
     else if (p.V <= 4096) hipLaunchKernelGGL((sample_kernel<256, 16>), dim3(p.B), dim3(256), lds, stream, p);
     else if (p.V <= 32768) hipLaunchKernelGGL((sample_kernel<1024, 32>), dim3(p.B), dim3(1024), lds, stream, p);

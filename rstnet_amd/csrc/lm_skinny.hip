@@ -94,17 +94,9 @@ constexpr int SKINNY_WAVES = 8;
 // weight byte instead of 3) and, for the longest K, only a slice of it (gridDim.y splits, so that ~256-384 workgroups exist); the partial tiles go to
 // `ws` with write-through stores, one arrival counter per column group, and the LAST workgroup to arrive sums them in split order
 // (deterministic) and runs the epilogue (the protocol of the fp32 few-row GEMM, csrc/skinny_f32.hip).
-//
-// XF (round 3): the activations arrive as fp32 rows and the launch forms its own MFMA operand -- per step a lane reads the 8 floats of
-// its (batch row, k-octet), multiplies by the RMSNorm gains, splits into bf16 hi + lo in registers (the same split as the packing
-// launch) and feeds all CT column tiles from it.  The row's 1 / rms factor commutes with the contraction, so it is applied to the
-// accumulators: the lanes sum the squares of what they load, the waves' partial sums meet in LDS next to the partial tiles.  This
-// removes the activation-packing launch in front of every normed / plain linear of the 1024-wide layers (depth transformer, GPT
-// blocks): ~150 of the ~530 launches of a batch-32 GPT frame, each a 3-4 us link of a latency-bound chain.
-template <int NB, int CT, bool XF = false>   // batch tiles of 32, weight-row tiles per workgroup
+template <int NB, int CT>   // batch tiles of 32, weight-row tiles per workgroup
 __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const SkinnyParams p) {
     __shared__ float red[SKINNY_WAVES][NB * 32][33];
-    __shared__ float ssq_red[XF ? SKINNY_WAVES : 1][NB * 32];
     __shared__ int sm_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = (p.N + 31) / 32;
@@ -144,26 +136,11 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
             }
     }
     // MFMA steps whose loads are all requested before the first is consumed.  The loop body is loads -> wait -> MFMAs, i.e. one exposed
-    // memory round trip (2-3 us for HBM weights under load) per iteration: the 1024-wide layers (8 steps per wave) run as ONE
-    // iteration where the registers allow it (one batch tile, one column tile), measured: the fp32-input form with 2 steps per
-    // iteration cost what the packing launch it removed had cost.
-    constexpr int UN = (NB == 1 && CT == 1) ? 8 : (XF ? (NB == 1 && CT == 2 ? 4 : 2) : ((NB * 2 + CT) <= 4 ? 4 : 2));
-    // XF: this lane's batch rows (lane % 32 of every batch tile) and k-octet inside a step ((lane / 32) * 8); rows past B read row
-    // B - 1 and are cleared through a mask (no load under a per-lane condition: DESIGN.md 3.12)
-    float ssq[NB];
-    const float* xrow[NB];
-    unsigned xmask[NB];
-#pragma unroll
-    for (int t = 0; t < NB; ++t) {
-        ssq[t] = 0.f;
-        const int b = t * 32 + (lane & 31);
-        xrow[t] = XF ? p.xf + (long)min(b, p.B - 1) * p.ldx + (lane >> 5) * 8 : nullptr;
-        xmask[t] = b < p.B ? 0xffffffffu : 0u;
-        asm volatile("" : "+v"(xmask[t]));
-    }
+    // memory round trip (2-3 us for HBM weights under load) per iteration: with one batch tile and one column tile the registers
+    // hold 8 steps, so the 1024-wide layers (8 steps per wave) are ONE iteration.
+    constexpr int UN = (NB == 1 && CT == 1) ? 8 : ((NB * 2 + CT) <= 4 ? 4 : 2);
     for (int s = s0; s < s1; s += UN) {
         bf16x8 a[UN][CT], bh[UN][NB], bl[UN][NB];
-        f32x4 xv[XF ? UN : 1][NB][2], gv[XF ? UN : 1][2];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const bool ok = s + u < s1;
@@ -171,43 +148,10 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
 #pragma unroll
             for (int c = 0; c < CT; ++c)
                 a[u][c] = ok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wt[c] + so)) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (XF) {
-                const int ks = min(s + u, s1 - 1) * 16;         // a step past the wave's range re-reads its last one (masked below)
 #pragma unroll
-                for (int t = 0; t < NB; ++t) {
-                    xv[u][t][0] = *reinterpret_cast<const f32x4*>(xrow[t] + ks);
-                    xv[u][t][1] = *reinterpret_cast<const f32x4*>(xrow[t] + ks + 4);
-                }
-                if (p.xmode == 1) {
-                    gv[u][0] = *reinterpret_cast<const f32x4*>(p.alpha + ks + (lane >> 5) * 8);
-                    gv[u][1] = *reinterpret_cast<const f32x4*>(p.alpha + ks + (lane >> 5) * 8 + 4);
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < NB; ++t) {
-                    bh[u][t] = ok ? *reinterpret_cast<const bf16x8*>(xh + (long)t * steps * 512 + so) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                    bl[u][t] = ok ? *reinterpret_cast<const bf16x8*>(xl + (long)t * steps * 512 + so) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                }
-            }
-        }
-        if (XF) {
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const unsigned live = s + u < s1 ? 0xffffffffu : 0u;
-#pragma unroll
-                for (int t = 0; t < NB; ++t) {
-                    float v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float xj = __uint_as_float(__float_as_uint(xv[u][t][j >> 2][j & 3]) & xmask[t] & live);
-                        ssq[t] = fmaf(xj, xj, ssq[t]);
-                        v[j] = p.xmode == 1 ? xj * gv[u][j >> 2][j & 3] : xj;
-                    }
-                    u32x4 hi, lo;
-                    split_hi_lo8(v, hi, lo);
-                    bh[u][t] = __builtin_bit_cast(bf16x8, hi);
-                    bl[u][t] = __builtin_bit_cast(bf16x8, lo);
-                }
+            for (int t = 0; t < NB; ++t) {
+                bh[u][t] = ok ? *reinterpret_cast<const bf16x8*>(xh + (long)t * steps * 512 + so) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                bl[u][t] = ok ? *reinterpret_cast<const bf16x8*>(xl + (long)t * steps * 512 + so) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
         }
 #pragma unroll
@@ -221,28 +165,14 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
                 }
     }
     const int i = lane & 31;
-    if (XF) {        // this wave's share of every row's sum of squares (both k-octet halves of the lanes), summed in wave order below
-#pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            const float sq = ssq[t] + __shfl_xor(ssq[t], 32);
-            if (lane < 32) ssq_red[wave][t * 32 + lane] = sq;
-        }
-    }
     bool single = false;            // red[slot] alone holds the tile (the summed splits) instead of one partial per wave
     int slot = 0;
-    auto rinv = [&](int b) {        // XF + RMSNorm: 1 / sqrt(eps + mean(x[b]^2)), the factor the operand left out
-        if (!XF || p.xmode != 1) return 1.0f;
-        float q = ssq_red[0][b];
-#pragma unroll
-        for (int w = 1; w < SKINNY_WAVES; ++w) q += ssq_red[XF ? w : 0][b];
-        return 1.0f / sqrtf(p.eps + q / (float)p.K);
-    };
     auto tsum = [&](int b, int col) {
         if (single) return red[slot][b][col];
         float v = red[0][b][col];
 #pragma unroll
         for (int w = 1; w < SKINNY_WAVES; ++w) v += red[w][b][col];
-        return XF ? v * rinv(b) : v;
+        return v;
     };
     auto emit = [&](int c) {        // epilogue of column tile c from the tile in `red`
         const int n0 = (tile0 + c) * 32;
@@ -371,6 +301,197 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
     }
 }
 
+// ---- fp32-input form (round 3): no activation-packing launch in front of the GEMM ---------------------------------------------------
+// x [B][ldx] fp32 goes straight into the launch; mode 1 (RMSNorm) puts x * alpha into the operand and applies 1 / rms to the
+// accumulators (the row factor commutes with the contraction; the lanes sum the squares of what they convert and the waves' partial
+// sums meet in LDS next to the partial tiles).  The MFMA wants lane l = (batch row l % 32, k-octet l / 32) -- a gather of 16-byte
+// pieces from 32 rows 4 KB apart, which the CU's address path serves one cache line at a time: a first version that loaded the
+// operand that way measured 9.6-12.9 us per launch against ~6 us for the packed GEMM (and so cost what the packing launch it
+// removed had cost).  Here a wave loads its slice COALESCED (8 lanes cover one row's 128 bytes of a 32-k round: 8 full lines per
+// instruction), all rounds of a chunk up front, and transposes through a wave-private LDS tile ([rows][32 + 4] floats: conflict-free
+// ds_read_b128 in operand order); the RMSNorm gains of the chunk ride along in LDS.  K % 256 == 0 (every wave owns whole 32-k rounds).
+template <int NB, int CT>
+__global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_x32_kernel(const SkinnyParams p) {
+    constexpr int R = NB * 32;                       // batch rows (padded)
+    constexpr int CH = NB == 1 ? 8 : 4;              // steps per chunk: the x values of a chunk sit in registers until their round
+    constexpr int QI = R / 8;                        // load instructions per round (8 rows each)
+    constexpr int ST = R * 36 + 16 * CH;             // floats of a wave's staging area: tile [R][36] | gains [16 * CH]
+    constexpr int LDS_F = SKINNY_WAVES * ST > SKINNY_WAVES * R * 33 + SKINNY_WAVES * R ? SKINNY_WAVES * ST : SKINNY_WAVES * R * 33 + SKINNY_WAVES * R;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_F];
+    float (*red)[R][33] = reinterpret_cast<float (*)[R][33]>(lds);                       // [waves][R][33] partial tiles (after the K loop)
+    float (*ssq_red)[R] = reinterpret_cast<float (*)[R]>(lds + SKINNY_WAVES * R * 33);   // [waves][R]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* stage = lds + wave * ST;
+    float* gain = stage + R * 36;
+    const int tiles = (p.N + 31) / 32;
+    const int tile0 = blockIdx.x * CT;
+    const int steps = p.K / 16;
+    const int per = steps / SKINNY_WAVES;            // K % 256 == 0: whole, even
+    const int s0 = wave * per, s1 = s0 + per;
+    const unsigned short* wt[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) wt[c] = p.w + ((long)min(tile0 + c, tiles - 1) * steps * 64 + lane) * 8;
+    f32x16 acc[NB][CT];
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
+    constexpr int EP = R * 32 / (64 * SKINNY_WAVES);
+    float rpre[CT][EP], bpre[CT][EP];
+    if (!p.gate_out) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int q = 0; q < EP; ++q) {
+                const int idx = tid + q * 64 * SKINNY_WAVES;
+                const int b = min(idx >> 5, p.B - 1), n = min((tile0 + c) * 32 + (idx & 31), p.N - 1);
+                rpre[c][q] = p.res ? p.res[(long)b * p.ldy + n] : 0.f;
+                bpre[c][q] = p.bias ? p.bias[n] : 0.f;
+            }
+    }
+    // coalesced source of this lane: row q * 8 + lane / 8 of a round, floats (lane % 8) * 4 .. +3 of its 32
+    const float* xsrc[QI];
+#pragma unroll
+    for (int q = 0; q < QI; ++q) xsrc[q] = p.xf + (long)min(q * 8 + (lane >> 3), p.B - 1) * p.ldx + (lane & 7) * 4;
+    // operand side: batch row lane % 32 of every tile; rows past B are cleared through a mask
+    unsigned xmask[NB];
+    float ssq[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+        xmask[t] = t * 32 + (lane & 31) < p.B ? 0xffffffffu : 0u;
+        asm volatile("" : "+v"(xmask[t]));
+        ssq[t] = 0.f;
+    }
+    constexpr bool WAHEAD = CT <= 2;                 // weights of the whole chunk up front (else per round: the 4-tile head is HBM-bound anyway)
+    for (int s = s0; s < s1; s += CH) {
+        const int nst = min(CH, s1 - s);             // even
+        f32x4 xr[CH / 2][QI];
+#pragma unroll
+        for (int r = 0; r < CH / 2; ++r) {
+            const int rr = min(r, nst / 2 - 1);      // a round past the chunk's end re-reads its last one (never used)
+#pragma unroll
+            for (int q = 0; q < QI; ++q) xr[r][q] = *reinterpret_cast<const f32x4*>(xsrc[q] + (s + 2 * rr) * 16);
+        }
+        f32x4 ga = {1.f, 1.f, 1.f, 1.f};
+        if (p.xmode == 1 && lane < 4 * CH) ga = *reinterpret_cast<const f32x4*>(p.alpha + s * 16 + min(lane * 4, nst * 16 - 4));
+        bf16x8 a[WAHEAD ? CH : 2][CT];
+        if (WAHEAD) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    a[u][c] = u < nst ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wt[c] + (long)(s + u) * 512)) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 4 * CH) *reinterpret_cast<f32x4*>(gain + lane * 4) = ga;
+#pragma unroll
+        for (int r = 0; r < CH / 2; ++r) {
+            if (2 * r < nst) {                       // wave-uniform
+                if (!WAHEAD) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c)
+                            a[u][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wt[c] + (long)(s + 2 * r + u) * 512));
+                }
+                // transpose of the round through the wave's tile: written row-major as loaded, read in operand order
+#pragma unroll
+                for (int q = 0; q < QI; ++q) *reinterpret_cast<f32x4*>(stage + (q * 8 + (lane >> 3)) * 36 + (lane & 7) * 4) = xr[r][q];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gain + (2 * r + u) * 16 + (lane >> 5) * 8);
+                    const f32x4 g1 = *reinterpret_cast<const f32x4*>(gain + (2 * r + u) * 16 + (lane >> 5) * 8 + 4);
+#pragma unroll
+                    for (int t = 0; t < NB; ++t) {
+                        const float* src = stage + (t * 32 + (lane & 31)) * 36 + u * 16 + (lane >> 5) * 8;
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float xj = __uint_as_float(__float_as_uint(j < 4 ? v0[j & 3] : v1[j & 3]) & xmask[t]);
+                            ssq[t] = fmaf(xj, xj, ssq[t]);
+                            v[j] = xj * (j < 4 ? g0[j & 3] : g1[j & 3]);
+                        }
+                        u32x4 hi, lo;
+                        split_hi_lo8(v, hi, lo);
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, hi), bl = __builtin_bit_cast(bf16x8, lo);
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) {
+                            const bf16x8 aw = a[WAHEAD ? 2 * r + u : u][c];
+                            acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, aw, acc[t][c], 0, 0, 0);
+                            acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, aw, acc[t][c], 0, 0, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();     // the tile is rewritten by the next round
+            }
+        }
+    }
+    __syncthreads();                                 // every wave is done with its staging area: `red` / `ssq_red` take the space
+    const int i = lane & 31;
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+        const float sq = ssq[t] + __shfl_xor(ssq[t], 32);
+        if (lane < 32) ssq_red[wave][t * 32 + lane] = sq;
+    }
+    auto rinv = [&](int b) {        // RMSNorm: 1 / sqrt(eps + mean(x[b]^2)), the factor the operand left out
+        if (p.xmode != 1) return 1.0f;
+        float q = ssq_red[0][b];
+#pragma unroll
+        for (int w = 1; w < SKINNY_WAVES; ++w) q += ssq_red[w][b];
+        return 1.0f / sqrtf(p.eps + q / (float)p.K);
+    };
+    auto tsum = [&](int b, int col) {
+        float v = red[0][b][col];
+#pragma unroll
+        for (int w = 1; w < SKINNY_WAVES; ++w) v += red[w][b][col];
+        return v * rinv(b);
+    };
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (c) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wave][t * 32 + rst_mfma32_row(e, lane)][i] = acc[t][c][e];
+        __syncthreads();
+        const int n0 = (tile0 + c) * 32;
+        if (p.gate_out) {            // interleaved gated layer: silu(u) * v as the packed operand of the next GEMM (see gemm_skinny_kernel)
+            const int half = p.N / 2;
+            for (int idx = tid; idx < R * 2; idx += 64 * SKINNY_WAVES) {
+                const int b = idx >> 1, j8 = (idx & 1) * 8;
+                const int kout = (tile0 + c) * 16 + j8;
+                if (kout < half) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float u = tsum(b, j8 + j), g = tsum(b, 16 + j8 + j);
+                        if (p.bias) { u += p.bias[kout + j]; g += p.bias[half + kout + j]; }
+                        v[j] = b < p.B ? silu(u) * g : 0.f;
+                    }
+                    store_packed8(p.gate_out, p.gate_plane, b, kout, half, v);
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int q = 0; q < EP; ++q) {
+            const int idx = tid + q * 64 * SKINNY_WAVES;
+            const int b = idx >> 5, nl = idx & 31;
+            const int n = n0 + nl;
+            if (b < p.B && n < p.N) {
+                float sv = tsum(b, nl);
+                const long o = (long)b * p.ldy + n;
+                if (p.bias) sv += bpre[c][q];
+                p.y[o] = p.res ? rpre[c][q] + sv : sv;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int rst_launch_skinny_pack_weight(const unsigned short* w, unsigned short* wp, int N, int K, int interleave, hipStream_t stream) {
@@ -418,8 +539,8 @@ int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B >= 1 && p.B <= 64 && p.N > 0 && p.K > 0 && p.K % 16 == 0, "gemm_skinny: need 1 <= B <= 64 and K %% 16 == 0 (B=%d K=%d)", p.B, p.K);
     RST_REQUIRE((p.xp || p.xf) && p.w && (p.y || p.gate_out), "gemm_skinny: null pointer");
     const bool xf = p.xp == nullptr;
-    RST_REQUIRE(!xf || (p.ldx % 4 == 0 && p.ldx >= p.K && (uintptr_t)p.xf % 16 == 0 && (p.xmode == 0 || (p.xmode == 1 && p.alpha)) && p.split_k <= 1),
-                "gemm_skinny: the fp32-input form needs 16-byte aligned rows (ldx %% 4 == 0), mode 0 / 1 (with alpha) and no K split");
+    RST_REQUIRE(!xf || (p.K % 256 == 0 && p.ldx % 4 == 0 && p.ldx >= p.K && (uintptr_t)p.xf % 16 == 0 && (p.xmode == 0 || (p.xmode == 1 && p.alpha)) && p.split_k <= 1),
+                "gemm_skinny: the fp32-input form needs K %% 256 == 0, 16-byte aligned rows (ldx %% 4 == 0), mode 0 / 1 (with alpha) and no K split");
     RST_REQUIRE(!p.gate_out || (p.N % 32 == 0 && !p.res), "gemm_skinny: the gated epilogue needs N %% 32 == 0 and takes no residual");
     const int tiles = (p.N + 31) / 32;
     const int threads = 64 * SKINNY_WAVES;
@@ -429,12 +550,12 @@ int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream) {
     const dim3 grid((tiles + ct - 1) / ct, split);
     if (xf) {
         if (p.B <= 32) {
-            if (ct == 4) hipLaunchKernelGGL((gemm_skinny_kernel<1, 4, true>), grid, dim3(threads), 0, stream, p);
-            else if (ct == 2) hipLaunchKernelGGL((gemm_skinny_kernel<1, 2, true>), grid, dim3(threads), 0, stream, p);
-            else hipLaunchKernelGGL((gemm_skinny_kernel<1, 1, true>), grid, dim3(threads), 0, stream, p);
+            if (ct == 4) hipLaunchKernelGGL((gemm_skinny_x32_kernel<1, 4>), grid, dim3(threads), 0, stream, p);
+            else if (ct == 2) hipLaunchKernelGGL((gemm_skinny_x32_kernel<1, 2>), grid, dim3(threads), 0, stream, p);
+            else hipLaunchKernelGGL((gemm_skinny_x32_kernel<1, 1>), grid, dim3(threads), 0, stream, p);
         } else {
-            if (ct == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, 2, true>), grid, dim3(threads), 0, stream, p);
-            else hipLaunchKernelGGL((gemm_skinny_kernel<2, 1, true>), grid, dim3(threads), 0, stream, p);
+            if (ct == 2) hipLaunchKernelGGL((gemm_skinny_x32_kernel<2, 2>), grid, dim3(threads), 0, stream, p);
+            else hipLaunchKernelGGL((gemm_skinny_x32_kernel<2, 1>), grid, dim3(threads), 0, stream, p);
         }
         return rst_check_launch("gemm_skinny_x32");
     }

@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int DF_THREADS = 256, DF_WAVES = 4;
-constexpr unsigned DF_SPIN_LIMIT = 1u << 17;      // polls of >= 1 us each: a lost hand-off costs ~0.2 s, once per workgroup
+constexpr long long DF_TIMEOUT_TICKS = 10000000;   // of the 100 MHz wall clock (s_memrealtime): a lost hand-off costs 0.1 s, once per workgroup
 constexpr int DF_HDR_FLOATS = 512;     // DfShared in the first KB of the header, the sampler's scratch in the second
 typedef unsigned long long u64;
 #define DF_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -45,7 +45,7 @@ __device__ __forceinline__ void df_gather(const u64* g, int n, unsigned epoch, f
     __syncthreads();        // dst may still be read by the rows of the previous op (another wave of this workgroup)
     for (int base = 0; base < n; base += GP * DF_THREADS) {
         u64 v[GP];
-        unsigned spins = 0;
+        long long t0 = 0;
         while (true) {
             bool all = true;
 #pragma unroll
@@ -56,7 +56,9 @@ __device__ __forceinline__ void df_gather(const u64* g, int n, unsigned epoch, f
 #pragma unroll
             for (int j = 0; j < GP; ++j) all = all && (unsigned)(v[j] >> 32) == epoch;
             if (all) break;
-            if (*(volatile int*)&sh.dead || ++spins > DF_SPIN_LIMIT) {
+            // time-based bound: how long a poll takes depends on what else the chip is doing (a count of polls measured 10x apart)
+            if (t0 == 0) t0 = wall_clock64();
+            if (*(volatile int*)&sh.dead || wall_clock64() - t0 > DF_TIMEOUT_TICKS) {
                 sh.dead = 1;
                 atomicOr(status, code);
                 break;

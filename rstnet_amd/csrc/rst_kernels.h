@@ -226,8 +226,12 @@ struct LmAttnParams {
     float rope_coef;
     int G;                // key/value heads (grouped-query attention: query head h reads kv head h / (H/G)); G == H for MHA
     int rope_dims;        // leading head dims that rotate (pairs (2i, 2i+1), i < rope_dims/2); D = all
+    const float* rope_cs; // optional [D/2][2] (cos, sin) of this step's rotation (rst_launch_lm_rope_table): replaces the in-kernel trig
 };
 int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream);
+// (cos, sin) of angle_i = exp(i * rope_coef) * pos for i < D/2 (identity beyond rope_dims/2): the rotation of ONE step, computed once
+// per frame with the arithmetic of the attention kernels and read by every layer's launch
+int rst_launch_lm_rope_table(const long* pos_dev, float* out, int D, int rope_dims, float rope_coef, hipStream_t stream);
 
 struct LmSampleParams {
     const float* logits;  // [B][ld]

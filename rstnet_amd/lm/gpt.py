@@ -378,13 +378,16 @@ class LLAMAStreamingTransformer(StreamingModule[_StepState]):
         c = self.config
         H, G, hs, n = c.n_head, c.n_query_groups, c.head_size, c.rope_n_elem
         f8 = self.fp8
+        rope_table = None
+        if T == 1 and st.k[0].shape[2] > 64:      # the step's rotation once for all blocks (long rings)
+            rope_table = ops.lm_rope_table(st.pos, hs, max_period=float(c.rope_base), rope_dims=n)
         for l, blk in enumerate(self.h):
             wqkv, bqkv = blk.attn.packed_qkv()
             qkv = ops.lm_linear(x, wqkv, prologue=ops.PROLOGUE_RMSNORM, alpha=blk.norm_1.gain_f32(), eps=blk.norm_1.eps, bias=bqkv,
                                 fp8=f8)
             if T == 1:
                 a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], st.pos, rope=True, context=c.context, max_period=float(c.rope_base),
-                                       scratch=st.scratch, heads=H, rope_dims=n, packed=B > 2 and not f8)
+                                       scratch=st.scratch, heads=H, rope_dims=n, packed=B > 2 and not f8, rope_table=rope_table)
             else:
                 q = ops.lm_rope_append(qkv.view(B, T, -1), st.k[l], st.v[l], st.pos, heads=H, rope=True,
                                        max_period=float(c.rope_base), rope_dims=n)

@@ -172,6 +172,8 @@ class StreamingTransformer(StreamingModule[_StepState]):
         if self.weights_per_step:
             k_idx = st.offset_cpu if step_index is None else step_index
         pos_t = st.pos if pos is None else pos
+        # the step's rotation once for all layers (long rings: the attention launches read it instead of evaluating 24 libm calls per lane)
+        rope_table = ops.lm_rope_table(pos_t, E // H, max_period=self.max_period) if self.rope and cap > 64 else None
         for l, layer in enumerate(self.layers):
             att = layer.self_attn
             if self.weights_per_step:
@@ -192,7 +194,7 @@ class StreamingTransformer(StreamingModule[_StepState]):
                 x = ops.gemv_attn(qkv, st.k[l], st.v[l], pos_t, w_out, context=self.context, res=x)
             else:
                 a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], pos_t, rope=self.rope, context=self.context,
-                                       max_period=self.max_period, scratch=st.scratch, packed=B > 2)
+                                       max_period=self.max_period, scratch=st.scratch, packed=B > 2, rope_table=rope_table)
                 x = ops.lm_linear(a, w_out, res=x)
             x = ops.lm_gated_pair(x, gate.linear_in.weight, gate.linear_out.weight, alpha=layer.norm2.alpha_f32(), eps=layer.norm2.eps,
                                   res=x)

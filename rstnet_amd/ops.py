@@ -674,7 +674,7 @@ def gemm_skinny(x, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE, alpha: Opt
     N, K = w.shape
     gate_out = gate_out and N % 32 == 0 and res is None
     wp = skinny_pack_weight(w, interleave_halves=gate_out)
-    if not isinstance(x, PackedAct) and prologue in (PROLOGUE_NONE, PROLOGUE_RMSNORM) and K <= SKINNY_X32_MAX_K and x.dim() == 2 and \
+    if not isinstance(x, PackedAct) and prologue in (PROLOGUE_NONE, PROLOGUE_RMSNORM) and K <= SKINNY_X32_MAX_K and K % 256 == 0 and x.dim() == 2 and \
             x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:      # (K this short is never split: split plan >= 4096)
         # fp32 rows straight into the GEMM (one launch instead of two)
         _chk(alpha, "alpha")
@@ -843,10 +843,19 @@ def lm_rope_append(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     return q
 
 
+def lm_rope_table(pos_dev: torch.Tensor, D: int, *, max_period: float = 10000.0, rope_dims: int = 0) -> torch.Tensor:
+    """The rotation of ONE decode step as ``[D/2, 2]`` (cos, sin) pairs (rst_lm_rope_table_f32; identity beyond ``rope_dims / 2``): computed
+    once per frame and handed to every layer's ``lm_attn_decode(rope_table=...)`` -- the values the attention launch would compute itself."""
+    _chk(pos_dev, "pos_dev", torch.int64)
+    out = torch.empty(D // 2, 2, device=pos_dev.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_lm_rope_table_f32(_ptr(pos_dev), _ptr(out), D, rope_dims, rope_coef(max_period, rope_dims or D), _stream()))
+    return out
+
+
 def lm_attn_decode(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos_dev: torch.Tensor, *, rope: bool,
                    context: Optional[int], max_period: float = 10000.0, splits: Optional[int] = None,
                    scratch: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, heads: Optional[int] = None,
-                   rope_dims: int = 0, packed: bool = False):
+                   rope_dims: int = 0, packed: bool = False, rope_table: Optional[torch.Tensor] = None):
     """Single-query attention of the new step given its qkv row ``[B, (H+2G)*D]`` (RoPE, ring append, attention and the
     reduction over slot splits in ONE launch) -> ``[B, H*D]``; the ring is ``[B,G,cap,D]`` (``heads`` = H when G < H).
     ``scratch = (ws [B,H,splits,D+2] fp32, counters [B,H] int32 zeros)`` may be passed to reuse buffers (the counters re-arm
@@ -856,9 +865,11 @@ def lm_attn_decode(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     _chk(k_cache, "k_cache", k_cache.dtype if kv16 else torch.float32)
     _chk(v_cache, "v_cache", k_cache.dtype)
     _chk(pos_dev, "pos_dev", torch.int64)
+    _chk(rope_table, "rope_table")
     B, G, cap, D = k_cache.shape
     H = heads or G
     assert qkv.shape[1] == (H + 2 * G) * D, (tuple(qkv.shape), H, G, D)
+    assert rope_table is None or rope_table.numel() == D, "rope_table: [D/2, 2] of lm_rope_table"
     if kv16 and cap <= 64:
         raise NotImplementedError("bf16 KV rings are served by the long-ring attention (capacity > 64)")
     if splits is None:
@@ -877,7 +888,8 @@ def lm_attn_decode(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     xp = _packed_buffer(qkv.device, B, H * D) if packed else None
     _lib.check(_lib.lib().rst_lm_attn_decode_f32(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(ws), _ptr(counters), _ptr(out),
                                                 _ptr(pos_dev), B, H, D, cap, int(context) if context else 0, splits, qkv.shape[1],
-                                                int(rope), rope_coef(max_period, rope_dims or D), G, rope_dims, _ptr(xp), int(kv16), _stream()))
+                                                int(rope), rope_coef(max_period, rope_dims or D), G, rope_dims, _ptr(xp), int(kv16),
+                                                _ptr(rope_table) if rope else None, _stream()))
     return PackedAct(xp, B, H * D) if packed else out
 
 
@@ -955,7 +967,7 @@ DEPTH_FRAME_MAX_L, DEPTH_FRAME_MAX_Q = 8, 8
 _depth_ws: dict = {}
 
 # ---- health of the persistent launches (csrc/persist.h).  A launch whose workgroups are not all resident (device shared with other
-# work) times out and is repaired in-stream by its one-workgroup twin: outputs stay right, but a repaired frame costs ~0.2 s.  Every
+# work) times out and is repaired in-stream by its one-workgroup twin: outputs stay right, but a repaired frame costs >= 0.1 s.  Every
 # launcher's status words are registered here; `persistent_poll` reads their repair counters WITHOUT synchronising (async copy into
 # pinned memory, evaluated on the next poll) and retires the persistent path on a device that had to repair -- sessions then
 # re-capture their frame graphs on the launch-per-op chain (`persistent_epoch` changes).
@@ -1160,7 +1172,7 @@ def codec_transformer_frame(x: torch.Tensor, layers: Sequence[dict], pos_dev: to
 for _name in ("skinny_f32_pack_weight", "gemm_win", "linear", "seanet_resblock", "layernorm", "rope_split", "attention", "rvq_pack",
               "rvq_search", "rvq_gather", "convtr_depthwise", "activation", "transpose12", "mask_tail", "hist_update", "gemv_bf16",
               "gemv_attn", "gemv_embed", "skinny_pack_weight", "skinny_pack_act", "gemm_skinny", "skinny_pack_weight_fp8", "gemm_skinny_fp8", "lm_gated_pair",
-              "lm_linear", "embed_sum", "rmsnorm", "lm_rope_append", "lm_attn_decode", "lm_sample", "lm_ring_begin", "lm_ring_commit",
+              "lm_linear", "embed_sum", "rmsnorm", "lm_rope_append", "lm_rope_table", "lm_attn_decode", "lm_sample", "lm_ring_begin", "lm_ring_commit",
               "depth_decode_frame", "codec_transformer_frame"):
     globals()[_name] = _on_tensor_device(globals()[_name])
 del _name

@@ -189,7 +189,14 @@ def _ring_attention_case(H, D, cap, context, steps, rope, kv_dtype):
         if context is not None:
             mask = mask & (delta < context)
         ref = F.scaled_dot_product_attention(q, keys, vals, mask.view(1, -1)).permute(0, 2, 1, 3).reshape(B, H * D)
-        out = ops.lm_attn_decode(qkv.to(DEV), kc, vc, pos, rope=rope, context=context)
+        # alternate the two forms of the rotation: computed by the launch, or read from the once-per-step table (cap > 64 only)
+        table = ops.lm_rope_table(pos, D) if rope and cap > 64 and s % 2 else None
+        out = ops.lm_attn_decode(qkv.to(DEV), kc, vc, pos, rope=rope, context=context, rope_table=table)
+        if rope and cap > 64 and s % 7 == 3:        # and bit for bit the same thing (a second ring copy takes the in-launch trig)
+            k2, v2 = kc.clone(), vc.clone()
+            assert torch.equal(ops.lm_attn_decode(qkv.to(DEV), k2, v2, pos, rope=rope, context=context,
+                                                  rope_table=None if table is not None else ops.lm_rope_table(pos, D)), out)
+            assert torch.equal(k2, kc) and torch.equal(v2, vc)
         pos.add_(1)
         assert rel_err(out, ref) < (1e-4 if kv_dtype == torch.float32 else 3e-3), f"step {s}"
     if kv_dtype == torch.float32:
