@@ -46,17 +46,29 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const RopeSplitParams p
     }
 }
 
+// One workgroup = (batch, head, ATT_WAVES consecutive 32-query tiles), one wave per query tile.  The K / V tiles (32 slots x D) of the
+// workgroup's key range are staged ONCE through double-buffered LDS by all 512 threads and shared by the eight waves (one barrier per
+// tile, the next tile's global loads in flight under the MFMAs of this one); a wave only computes on the tiles its own causal /
+// context range reaches.  Round 2's form ran one single-wave workgroup per query tile: every tile of a head re-staged the head's
+// keys and values on its own (366 MB fetched per launch against 131 MB of q + k + v + out, matrix pipe busy 0.24).
+constexpr int ATT_WAVES = 8;
+
 template <int D>
-__global__ __launch_bounds__(64) void attention_kernel(const AttentionParams p) {
+__global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const AttentionParams p) {
     constexpr int DT = D / 32;
     constexpr int KS = D / 8;
     constexpr int KLD = D + 4;
-    __shared__ __attribute__((aligned(16))) float Ks[32 * KLD];  // K tile; reused to stage O
-    __shared__ __attribute__((aligned(16))) float Vs[32 * D];
+    constexpr int NT = 64 * ATT_WAVES;
+    constexpr int PIECES = 32 * D / 4;                   // 16-byte pieces of a K (or V) tile
+    constexpr int LPT = (PIECES + NT - 1) / NT;          // per thread
+    __shared__ __attribute__((aligned(16))) float Ks[2][32 * KLD];
+    __shared__ __attribute__((aligned(16))) float Vs[2][32 * D];
 
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * 32;
+    const int q_first = blockIdx.x * (32 * ATT_WAVES);   // first query of the workgroup
+    const int q0 = q_first + wave * 32;                  // first query of this wave's tile
+    const bool has_q = q0 < p.T;
     const int head = blockIdx.y;
     const long b = blockIdx.z;
     const long pos0 = p.pos_dev ? *p.pos_dev : p.pos0;
@@ -72,15 +84,18 @@ __global__ __launch_bounds__(64) void attention_kernel(const AttentionParams p) 
     for (int s = 0; s < KS; ++s)     // rows past T: a clamped (valid) row, never stored -- unconditional loads, all in flight at once
         qf[s] = *reinterpret_cast<const f32x4*>(qb + (long)min(q0 + j, p.T - 1) * D + 8 * s + 4 * h);
 
-    // slots that can be visible to this query tile
-    int lo = 0, hi = p.cap - 1;
+    // slots that can be visible: to this wave's tile [lo, hi], to any tile of the workgroup [lo_wg, hi_wg]
+    const int q_last = min(q_first + 32 * (ATT_WAVES - 1), ((p.T - 1) / 32) * 32);      // first query of the workgroup's last real tile
+    int lo = 0, hi = p.cap - 1, lo_wg = 0, hi_wg = p.cap - 1;
     if (!p.ring) {
         hi = min(p.cap - 1, q0 + 31);
-        if (p.context > 0) lo = max(0, q0 - p.context + 1);
+        hi_wg = min(p.cap - 1, q_last + 31);
+        if (p.context > 0) { lo = max(0, q0 - p.context + 1); lo_wg = max(0, q_first - p.context + 1); }
     }
-    const long end_offset = pos0 + p.T;             // RingKVCache.end_offset after the append
+    if (!has_q) hi = -1;                                 // a wave past the end of the sequence only helps staging
+    const long end_offset = pos0 + p.T;                  // RingKVCache.end_offset after the append
     const int end_index = (int)(end_offset % p.cap);
-    const long pq = pos0 + q0 + j;                  // this lane's query position
+    const long pq = pos0 + q0 + j;                       // this lane's query position
 
     f32x16 oacc[DT];
 #pragma unroll
@@ -89,34 +104,51 @@ __global__ __launch_bounds__(64) void attention_kernel(const AttentionParams p) 
         for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
     float m_run = NEG_INF, l_run = 0.f;
 
-    for (int s0 = (lo / 32) * 32; s0 <= hi; s0 += 32) {
-        __syncthreads();
-        // stage K / V tile (32 slots x D).  Slots beyond cap read the last slot again (finite data): their scores are masked to -inf
-        // below, so the duplicate takes weight 0 -- and all 2 x 8 loads of the tile are unconditional, i.e. in flight together (a load
-        // under `s0 + row < cap` is waited for inside its branch: 8 round trips per tile instead of one)
-        f32x4 kreg[(32 * D / 4) / 64], vreg[(32 * D / 4) / 64];
+    // K / V tile at slots s0 .. s0 + 31 -> registers.  Slots beyond cap read the last slot again (finite data): their scores are masked
+    // to -inf below, so the duplicate takes weight 0 -- every load is unconditional (a load under a per-lane condition is waited for
+    // inside its branch); threads beyond the tile (D = 32) re-read its last piece and do not store it.
+    f32x4 kreg[LPT], vreg[LPT];
+    auto request = [&](int s0) {
 #pragma unroll
-        for (int i = 0; i < (32 * D / 4) / 64; ++i) {
-            const int idx = lane + 64 * i;
+        for (int i = 0; i < LPT; ++i) {
+            const int idx = min(tid + NT * i, PIECES - 1);
             const int row = min(s0 + idx / (D / 4), p.cap - 1), c4 = (idx % (D / 4)) * 4;
             kreg[i] = *reinterpret_cast<const f32x4*>(kb + (long)row * D + c4);
             vreg[i] = *reinterpret_cast<const f32x4*>(vb + (long)row * D + c4);
         }
+    };
+    auto stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < (32 * D / 4) / 64; ++i) {
-            const int idx = lane + 64 * i;
-            const int row = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
-            *reinterpret_cast<f32x4*>(Ks + row * KLD + c4) = kreg[i];
-            *reinterpret_cast<f32x4*>(Vs + row * D + c4) = vreg[i];
+        for (int i = 0; i < LPT; ++i) {
+            const int idx = tid + NT * i;
+            if (idx < PIECES) {
+                const int row = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
+                *reinterpret_cast<f32x4*>(Ks[buf] + row * KLD + c4) = kreg[i];
+                *reinterpret_cast<f32x4*>(Vs[buf] + row * D + c4) = vreg[i];
+            }
         }
+    };
+
+    const int s_begin = (lo_wg / 32) * 32;
+    request(s_begin);
+    int buf = 0;
+    for (int s0 = s_begin; s0 <= hi_wg; s0 += 32) {
+        // tile s0 -> LDS[buf] (the buffer last read two iterations ago: every wave has passed the barrier that followed), then the
+        // next tile's loads go out and stay in flight under this tile's MFMAs
+        stage(buf);
         __syncthreads();
+        if (s0 + 32 <= hi_wg) request(s0 + 32);
+        const float* Kt = Ks[buf];
+        const float* Vt = Vs[buf];
+        buf ^= 1;
+        if (s0 + 31 < lo || s0 > hi) continue;           // wave-uniform: outside this tile's causal / context range
 
         f32x16 sacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + j * KLD + 8 * s + 4 * h);
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + j * KLD + 8 * s + 4 * h);
 #pragma unroll
             for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[s][e], sacc, 0, 0, 0);
         }
@@ -163,27 +195,25 @@ __global__ __launch_bounds__(64) void attention_kernel(const AttentionParams p) 
             const int key = rst_mfma32_row(r, lane);
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                const float vf = Vs[key * D + d * 32 + j];
+                const float vf = Vt[key * D + d * 32 + j];
                 oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, sacc[r], oacc[d], 0, 0, 0);
             }
         }
     }
 
+    // O^T[dim][query]: this lane holds, for its query j, dims d * 32 + 8 g + 4 h + {0..3} in accumulator elements 4 g .. 4 g + 3 ->
+    // 16-byte stores straight from the registers (both lane halves of a query are adjacent: 32-byte runs per row)
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    __syncthreads();
+    if (has_q && q0 + j < p.T) {
+        float* orow = p.out + ((b * p.T + q0 + j) * p.H + head) * (long)D + 4 * h;
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+        for (int d = 0; d < DT; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Ks[j * KLD + d * 32 + rst_mfma32_row(r, lane)] = oacc[d][r] * inv;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < (32 * D / 4) / 64; ++i) {
-        const int idx = lane + 64 * i;
-        const int row = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
-        if (q0 + row < p.T)
-            *reinterpret_cast<f32x4*>(p.out + ((b * p.T + q0 + row) * p.H + head) * (long)D + c4) =
-                *reinterpret_cast<const f32x4*>(Ks + row * KLD + c4);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(orow + d * 32 + 8 * g) = v;
+            }
     }
 }
 
@@ -208,11 +238,11 @@ int rst_launch_attention(const AttentionParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B <= 65535 && p.H <= 65535, "attention: grid too large");
     if (p.B == 0 || p.T == 0) return RST_OK;
     RST_REQUIRE(p.q && p.k && p.v && p.out, "attention: null pointer");
-    const dim3 grid((p.T + 31) / 32, p.H, p.B);
+    const dim3 grid((p.T + 32 * ATT_WAVES - 1) / (32 * ATT_WAVES), p.H, p.B);
     switch (p.D) {
-        case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64), 0, stream, p); break;
-        case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64), 0, stream, p); break;
-        case 128: hipLaunchKernelGGL(attention_kernel<128>, grid, dim3(64), 0, stream, p); break;
+        case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64 * ATT_WAVES), 0, stream, p); break;
+        case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * ATT_WAVES), 0, stream, p); break;
+        case 128: hipLaunchKernelGGL(attention_kernel<128>, grid, dim3(64 * ATT_WAVES), 0, stream, p); break;
         default:
             rst_set_error("attention: head dim %d unsupported (32, 64, 128)", p.D);
             return RST_ERR_UNSUPPORTED;
