@@ -36,6 +36,8 @@ __global__ __launch_bounds__(256) void rvq_pack_kernel(const float* __restrict__
     }
 }
 
+// KQT: D / 8 when known at compile time (the codec's 256-d codebooks: 32) -- selects the pipelined operand loop; 0: any D
+template <int KQT>
 __global__ __launch_bounds__(64 * NW) void rvq_search_kernel(const RvqSearchParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int D = p.D, LD = D + 4;
@@ -69,24 +71,65 @@ __global__ __launch_bounds__(64 * NW) void rvq_search_kernel(const RvqSearchPara
         float best = INFINITY;
         int bidx = 0x7fffffff;
         const float* rrow = r_pk + j * LD + h * 4;
-        for (int ct = wave * tpw; ct < min(tiles, (wave + 1) * tpw); ++ct) {
-            const int c0 = ct * 32;
-            f32x16 acc;
+        // Codebook operand of a code tile: D / 8 16-byte loads per lane, 64 KB apart (k-major packing).  With ~250 workgroups of 7 levels
+        // on 256 CUs a SIMD holds two waves, and a loop that requested 8 steps, waited, and ran their 32 MFMAs left the matrix pipe
+        // idle through every L2 round trip (round 2: pipe busy 0.46).  KQT form: the 8 steps AFTER the ones being consumed are always
+        // in flight, across tile boundaries (two register buffers, all indices compile-time).  Either way the MFMA chain consumes k
+        // in ascending order: scores stay bit-identical to oracle/rvq_ref.c.
+        const int ct_lo = wave * tpw, ct_hi = min(tiles, (wave + 1) * tpw);
+        if (KQT > 0) {
+            constexpr int HB = 8, NH = KQT > 0 ? KQT / HB : 1;          // steps per buffer, buffers per tile (even)
+            f32x4 ab[2][HB];
+            auto request = [&](int ct, int half, f32x4 (&dst)[HB]) {
+                const float* ap = packed + (long)(ct * 32 + j) * 8 + h * 4 + (long)half * HB * p.n_codes * 8;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-            const float* ap = packed + (long)(c0 + j) * 8 + h * 4;
-#pragma unroll 8
-            for (int kq = 0; kq < D / 8; ++kq) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(ap + (long)kq * p.n_codes * 8);
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(rrow + kq * 8);
+                for (int u = 0; u < HB; ++u) dst[u] = *reinterpret_cast<const f32x4*>(ap + (long)u * p.n_codes * 8);
+            };
+            if (ct_lo < ct_hi) request(ct_lo, 0, ab[0]);
+            for (int ct = ct_lo; ct < ct_hi; ++ct) {
+                const int c0 = ct * 32;
+                f32x16 acc;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bq[e], acc, 0, 0, 0);
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int hf = 0; hf < NH; ++hf) {
+                    if (hf + 1 < NH) request(ct, hf + 1, ab[(hf + 1) & 1]);
+                    else if (ct + 1 < ct_hi) request(ct + 1, 0, ab[0]);          // NH even: the next tile starts in buffer 0
+#pragma unroll
+                    for (int u = 0; u < HB; ++u) {
+                        const f32x4 a = ab[hf & 1][u];
+                        const f32x4 bq = *reinterpret_cast<const f32x4*>(rrow + (hf * HB + u) * 8);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bq[e], acc, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int code = c0 + rst_mfma32_row(r, lane);
+                    const float sc = fmaf(-2.0f, acc[r], e2s[code]);
+                    if (sc < best) { best = sc; bidx = code; }
+                }
             }
+        } else {
+            for (int ct = ct_lo; ct < ct_hi; ++ct) {
+                const int c0 = ct * 32;
+                f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int code = c0 + rst_mfma32_row(r, lane);
-                const float sc = fmaf(-2.0f, acc[r], e2s[code]);
-                if (sc < best) { best = sc; bidx = code; }
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                const float* ap = packed + (long)(c0 + j) * 8 + h * 4;
+#pragma unroll 8
+                for (int kq = 0; kq < D / 8; ++kq) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(ap + (long)kq * p.n_codes * 8);
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(rrow + kq * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bq[e], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int code = c0 + rst_mfma32_row(r, lane);
+                    const float sc = fmaf(-2.0f, acc[r], e2s[code]);
+                    if (sc < best) { best = sc; bidx = code; }
+                }
             }
         }
         {   // the two lane halves hold different codes of the same frame
@@ -281,10 +324,13 @@ int rst_launch_rvq_search(const RvqSearchParams& p, hipStream_t stream) {
     RST_REQUIRE(lds <= 160 * 1024, "rvq_search: D=%d n_codes=%d needs %zu bytes of LDS", p.D, p.n_codes, lds);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_search_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_search_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(rvq_search_kernel, dim3((p.M + FR - 1) / FR, p.n_groups), dim3(64 * NW), lds, stream, p);
+    const dim3 grid((p.M + FR - 1) / FR, p.n_groups);
+    if (p.D == 256) hipLaunchKernelGGL(rvq_search_kernel<32>, grid, dim3(64 * NW), lds, stream, p);     // the codec's codebooks
+    else hipLaunchKernelGGL(rvq_search_kernel<0>, grid, dim3(64 * NW), lds, stream, p);
     return rst_check_launch("rvq_search");
 }
 
