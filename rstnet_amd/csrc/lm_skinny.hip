@@ -437,18 +437,15 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_x32_kernel(cons
         const float sq = ssq[t] + __shfl_xor(ssq[t], 32);
         if (lane < 32) ssq_red[wave][t * 32 + lane] = sq;
     }
-    auto rinv = [&](int b) {        // RMSNorm: 1 / sqrt(eps + mean(x[b]^2)), the factor the operand left out
-        if (p.xmode != 1) return 1.0f;
-        float q = ssq_red[0][b];
-#pragma unroll
-        for (int w = 1; w < SKINNY_WAVES; ++w) q += ssq_red[w][b];
-        return 1.0f / sqrtf(p.eps + q / (float)p.K);
-    };
+    // epilogue scratch behind the partial tiles: 1 / rms per row (computed once, not per output element) and the gated tile
+    float* rinv_s = lds + SKINNY_WAVES * R * 33 + SKINNY_WAVES * R;      // [R]
+    float* gtile = rinv_s + R;                                          // [R][16] silu(u) * v of a column tile
+    static_assert(SKINNY_WAVES * R * 33 + SKINNY_WAVES * R + R + R * 16 <= LDS_F, "epilogue scratch does not fit behind the partial tiles");
     auto tsum = [&](int b, int col) {
         float v = red[0][b][col];
 #pragma unroll
         for (int w = 1; w < SKINNY_WAVES; ++w) v += red[w][b][col];
-        return v * rinv(b);
+        return v * rinv_s[b];
     };
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -458,20 +455,37 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_x32_kernel(cons
 #pragma unroll
             for (int e = 0; e < 16; ++e) red[wave][t * 32 + rst_mfma32_row(e, lane)][i] = acc[t][c][e];
         __syncthreads();
+        if (c == 0) {               // RMSNorm: 1 / sqrt(eps + mean(x[b]^2)), the factor the operand left out (sums in wave order)
+            if (tid < R) {
+                float q = ssq_red[0][tid];
+#pragma unroll
+                for (int w = 1; w < SKINNY_WAVES; ++w) q += ssq_red[w][tid];
+                rinv_s[tid] = p.xmode == 1 ? 1.0f / sqrtf(p.eps + q / (float)p.K) : 1.0f;
+            }
+            __syncthreads();
+        }
         const int n0 = (tile0 + c) * 32;
-        if (p.gate_out) {            // interleaved gated layer: silu(u) * v as the packed operand of the next GEMM (see gemm_skinny_kernel)
+        if (p.gate_out) {
+            // interleaved gated layer: columns 0..15 of the tile are u, 16..31 the matching v.  silu(u) * v is formed by one thread per
+            // (row, pair) -- R * 16 of them -- into LDS, then R * 2 threads pack 8 consecutive k each into the hi / lo operand of the
+            // next GEMM (K_out = N / 2; zeros for the pad rows of the batch tile).  (Round 2's form had the R * 2 packing threads sum
+            // the eight partial tiles for their 16 values themselves: 64 threads busy, 448 idle, ~3 us of a 10 us launch.)
             const int half = p.N / 2;
+            for (int idx = tid; idx < R * 16; idx += 64 * SKINNY_WAVES) {
+                const int b = idx >> 4, jj = idx & 15;
+                const int kout = (tile0 + c) * 16 + jj;
+                float u = tsum(b, jj), g = tsum(b, 16 + jj);
+                if (p.bias && kout < half) { u += p.bias[kout]; g += p.bias[half + kout]; }
+                gtile[idx] = b < p.B ? silu(u) * g : 0.f;
+            }
+            __syncthreads();
             for (int idx = tid; idx < R * 2; idx += 64 * SKINNY_WAVES) {
                 const int b = idx >> 1, j8 = (idx & 1) * 8;
                 const int kout = (tile0 + c) * 16 + j8;
                 if (kout < half) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float u = tsum(b, j8 + j), g = tsum(b, 16 + j8 + j);
-                        if (p.bias) { u += p.bias[kout + j]; g += p.bias[half + kout + j]; }
-                        v[j] = b < p.B ? silu(u) * g : 0.f;
-                    }
+                    for (int jj = 0; jj < 8; ++jj) v[jj] = gtile[b * 16 + j8 + jj];
                     store_packed8(p.gate_out, p.gate_plane, b, kout, half, v);
                 }
             }

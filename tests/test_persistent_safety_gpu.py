@@ -59,13 +59,20 @@ def clean_health():
                 t.zero_()
 
 
-def test_depth_frame_without_full_residency_is_repaired(clean_health, monkeypatch):
+@pytest.mark.parametrize("B", [1, 2])
+def test_depth_frame_repair_launch_recomputes_the_frame(B, clean_health, monkeypatch):
+    """The one-workgroup repair launch of rst_depth_decode_frame, driven deterministically: a time-out code is planted in status[0]
+    before the call, so the launch enqueued behind the persistent one must recompute the whole frame alone (8 steps x 6 layers, all
+    16 heads, their KV history in the global scratch) -- same tokens, status[1] counts the repair, status[0] is cleared, the planted
+    code lands in status[2].  Then the host-side poll retires the persistent path of the device and the launch-per-op chain gives
+    the same tokens again.  (How a REAL loss of residency is detected -- bounded spins on the hand-offs -- is exercised by the codec
+    transformer test below with CUs taken away; both kernels share that code, csrc/persist.h.)"""
     monkeypatch.setenv("RST_DEPTH_FRAME", "1")
     cfg = dict(synth.LM_MOSHI_7B, num_layers=1)
     model = LMModel.from_state_dict(synth.lm_state_dict(cfg, seed=4, device=DEV), cfg)
     gen = LMGen(model, use_sampling=True)
-    B, Q = 1, cfg["dep_q"]
-    g = torch.Generator(device=DEV).manual_seed(3)
+    Q = cfg["dep_q"]
+    g = torch.Generator(device=DEV).manual_seed(3 + B)
     h_t = torch.randn(B, cfg["dim"], device=DEV, generator=g)
     text = torch.randint(0, cfg["text_card"], (B,), device=DEV, generator=g)
     noise = torch.empty(B, Q * gen.top_k, device=DEV).exponential_(1, generator=g)
@@ -78,24 +85,21 @@ def test_depth_frame_without_full_residency_is_repaired(clean_health, monkeypatc
         return tokens.cpu()
     want = run()
     tables = model.depth_frame_tables()
-    assert tables.status.tolist()[:3] == [0, 0, 0]
-    lib, side = _occ(), torch.cuda.Stream()
-    keep = _hold_cus(lib, side, ms=1500)
+    assert tables.status.tolist() == [0, 0, 0, 0]
+    code = 1 << 20
+    tables.status[0] = code
     t0 = time.perf_counter()
-    got = run()                                     # most workgroups are not resident until the occupiers leave: hand-offs time out
+    got = run()
     took = time.perf_counter() - t0
-    side.synchronize()
-    st = tables.status.tolist()
-    assert st[1] == 1 and st[0] == 0 and st[2] != 0, f"status {st} after {took:.2f} s: the launch was expected to time out and be repaired"
-    assert torch.equal(got, want), f"repaired frame {got.tolist()} vs undisturbed {want.tolist()}"
-    # an undisturbed frame afterwards runs the persistent launch again, no further repair
+    assert tables.status.tolist() == [0, 1, code, 0], tables.status.tolist()
+    assert torch.equal(got, want), f"repaired frame {got.tolist()} vs undisturbed {want.tolist()} ({took * 1e3:.1f} ms)"
+    # an undisturbed frame afterwards: the persistent launch alone, no further repair
     assert torch.equal(run(), want) and tables.status.tolist()[1] == 1
     # the host-side poll sees the repair and retires the persistent path of the device: the launch-per-op chain takes over
     with pytest.warns(RuntimeWarning, match="persistent frame launches retired"):
         ops.persistent_poll(torch.device(DEV), synchronize=True)
     assert not ops.depth_frame_enabled(torch.device(DEV)) and ops.persistent_epoch(DEV) >= 1
     assert torch.equal(run(), want) and tables.status.tolist()[1] == 1
-    del keep
 
 
 def test_codec_transformer_frame_without_full_residency_is_repaired(clean_health, monkeypatch):
