@@ -46,12 +46,16 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const RopeSplitParams p
     }
 }
 
-// One workgroup = (batch, head, ATT_WAVES consecutive 32-query tiles), one wave per query tile.  The K / V tiles (32 slots x D) of the
-// workgroup's key range are staged ONCE through double-buffered LDS by all 512 threads and shared by the eight waves (one barrier per
-// tile, the next tile's global loads in flight under the MFMAs of this one); a wave only computes on the tiles its own causal /
-// context range reaches.  Round 2's form ran one single-wave workgroup per query tile: every tile of a head re-staged the head's
-// keys and values on its own (366 MB fetched per launch against 131 MB of q + k + v + out, matrix pipe busy 0.24).
-constexpr int ATT_WAVES = 8;
+// One workgroup = (batch, head, 4 of the 8 query tiles of a 256-query group), one wave per 32-query tile.  The K / V tiles (32 slots
+// x D) of the workgroup's key range are staged through double-buffered LDS by all 256 threads and shared by its four waves (one
+// barrier per tile, the next tile's global loads in flight under the MFMAs of this one); a wave only computes on the key tiles its
+// own causal / context range reaches.  Under a causal mask tile i of a group needs i + 1 key tiles, so the two workgroups of a
+// group take the tiles {0, 2, 5, 7} and {1, 3, 4, 6}: 18 tile products each.  (Waves that are done idle at the barriers; the CU's
+// other resident workgroup keeps the matrix pipe busy meanwhile.)  Round 2's form ran one single-wave workgroup per query tile:
+// every tile of a head re-staged the head's keys and values on its own (366 MB fetched per launch against 131 MB of q + k + v + out,
+// matrix pipe busy 0.24); eight waves on the eight tiles of a group (first version of this round) left each CU with ONE resident
+// workgroup whose early tiles finish after a fraction of the loop: 120 -> 102 us per launch only.
+constexpr int ATT_WAVES = 4, ATT_GROUP = 8;
 
 template <int D>
 __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const AttentionParams p) {
@@ -66,8 +70,10 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const Attenti
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int q_first = blockIdx.x * (32 * ATT_WAVES);   // first query of the workgroup
-    const int q0 = q_first + wave * 32;                  // first query of this wave's tile
+    const int q_first = (blockIdx.x >> 1) * (32 * ATT_GROUP);   // first query of the 8-tile group this workgroup shares with its twin
+    const int local = (blockIdx.x & 1) == 0 ? (wave == 0 ? 0 : wave == 1 ? 2 : wave == 2 ? 5 : 7)
+                                            : (wave == 0 ? 1 : wave == 1 ? 3 : wave == 2 ? 4 : 6);
+    const int q0 = q_first + local * 32;                 // first query of this wave's tile
     const bool has_q = q0 < p.T;
     const int head = blockIdx.y;
     const long b = blockIdx.z;
@@ -85,12 +91,21 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const Attenti
         qf[s] = *reinterpret_cast<const f32x4*>(qb + (long)min(q0 + j, p.T - 1) * D + 8 * s + 4 * h);
 
     // slots that can be visible: to this wave's tile [lo, hi], to any tile of the workgroup [lo_wg, hi_wg]
-    const int q_last = min(q_first + 32 * (ATT_WAVES - 1), ((p.T - 1) / 32) * 32);      // first query of the workgroup's last real tile
+    // the last real tile of this workgroup's set ({0, 2, 5, 7} or {1, 3, 4, 6}): its end bounds the keys to stage
+    const int t_last = (p.T - 1) / 32 - (blockIdx.x >> 1) * ATT_GROUP;                  // last real tile of the sequence, group-local
+    int l_last = -1;
+#pragma unroll
+    for (int w = 0; w < ATT_WAVES; ++w) {
+        const int lw = (blockIdx.x & 1) == 0 ? (w == 0 ? 0 : w == 1 ? 2 : w == 2 ? 5 : 7) : (w == 0 ? 1 : w == 1 ? 3 : w == 2 ? 4 : 6);
+        if (lw <= t_last) l_last = max(l_last, lw);
+    }
+    const int q_last = q_first + 32 * max(l_last, 0);
     int lo = 0, hi = p.cap - 1, lo_wg = 0, hi_wg = p.cap - 1;
     if (!p.ring) {
         hi = min(p.cap - 1, q0 + 31);
         hi_wg = min(p.cap - 1, q_last + 31);
-        if (p.context > 0) { lo = max(0, q0 - p.context + 1); lo_wg = max(0, q_first - p.context + 1); }
+        if (p.context > 0) { lo = max(0, q0 - p.context + 1); lo_wg = max(0, q_first + 32 * (int)(blockIdx.x & 1) - p.context + 1); }
+        if (l_last < 0) hi_wg = -1;                      // (the twin of the last group may have no tile at all)
     }
     if (!has_q) hi = -1;                                 // a wave past the end of the sequence only helps staging
     const long end_offset = pos0 + p.T;                  // RingKVCache.end_offset after the append
@@ -238,7 +253,7 @@ int rst_launch_attention(const AttentionParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B <= 65535 && p.H <= 65535, "attention: grid too large");
     if (p.B == 0 || p.T == 0) return RST_OK;
     RST_REQUIRE(p.q && p.k && p.v && p.out, "attention: null pointer");
-    const dim3 grid((p.T + 32 * ATT_WAVES - 1) / (32 * ATT_WAVES), p.H, p.B);
+    const dim3 grid(2 * ((p.T + 32 * ATT_GROUP - 1) / (32 * ATT_GROUP)), p.H, p.B);
     switch (p.D) {
         case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64 * ATT_WAVES), 0, stream, p); break;
         case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * ATT_WAVES), 0, stream, p); break;

@@ -97,6 +97,7 @@ constexpr int SKINNY_WAVES = 8;
 template <int NB, int CT>   // batch tiles of 32, weight-row tiles per workgroup
 __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const SkinnyParams p) {
     __shared__ float red[SKINNY_WAVES][NB * 32][33];
+    __shared__ float gtile[NB * 32 * 16];      // gated epilogue: silu(u) * v of a column tile
     __shared__ int sm_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = (p.N + 31) / 32;
@@ -177,20 +178,27 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
     auto emit = [&](int c) {        // epilogue of column tile c from the tile in `red`
         const int n0 = (tile0 + c) * 32;
         if (p.gate_out) {
-            // interleaved gated layer: columns 0..15 of the tile are u, 16..31 the matching v; emit silu(u) * v as the packed
-            // hi / lo operand of the next GEMM (K_out = N / 2), zeros for the pad rows of the batch tile
+            // interleaved gated layer: columns 0..15 of the tile are u, 16..31 the matching v; silu(u) * v is formed by one thread per
+            // (row, pair) into LDS, then two threads per row pack 8 consecutive k each into the hi / lo operand of the next GEMM
+            // (K_out = N / 2, zeros for the pad rows of the batch tile).  (Round 2: the packing threads summed the eight partial tiles for
+            // their 16 values themselves -- 64 busy threads, 448 idle, ~3 us per column tile.)
             const int half = p.N / 2;
+            __syncthreads();                 // the previous column tile's packing threads are done with gtile
+            for (int idx = tid; idx < NB * 32 * 16; idx += 64 * SKINNY_WAVES) {
+                const int b = idx >> 4, jj = idx & 15;
+                const int kout = (tile0 + c) * 16 + jj;
+                float u = tsum(b, jj), g = tsum(b, 16 + jj);
+                if (p.bias && kout < half) { u += p.bias[kout]; g += p.bias[half + kout]; }
+                gtile[idx] = b < p.B ? silu(u) * g : 0.f;
+            }
+            __syncthreads();
             for (int idx = tid; idx < NB * 32 * 2; idx += 64 * SKINNY_WAVES) {
                 const int b = idx >> 1, j8 = (idx & 1) * 8;
                 const int kout = (tile0 + c) * 16 + j8;
                 if (kout < half) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float u = tsum(b, j8 + j), g = tsum(b, 16 + j8 + j);
-                        if (p.bias) { u += p.bias[kout + j]; g += p.bias[half + kout + j]; }
-                        v[j] = b < p.B ? silu(u) * g : 0.f;
-                    }
+                    for (int j = 0; j < 8; ++j) v[j] = gtile[b * 16 + j8 + j];
                     store_packed8(p.gate_out, p.gate_plane, b, kout, half, v);
                 }
             }
