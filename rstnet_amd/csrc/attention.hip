@@ -168,34 +168,47 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const Attenti
             for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[s][e], sacc, 0, 0, 0);
         }
 
-        // mask + online softmax; lane owns query column j, rows (keys) rst_mfma32_row(r, lane)
+        // mask + online softmax; lane owns query column j, rows (keys) rst_mfma32_row(r, lane).  Interior tiles -- every slot of the
+        // tile visible to every query of the wave's tile: all but the diagonal (and a context edge) in the batch pass -- skip the
+        // position arithmetic (64-bit compares per score: as many VALU cycles as the tile's MFMAs took); e^x runs on v_exp_f32
+        // (exp2 of x * log2 e, ~1e-7 relative on weights in [0, 1]: the softmax costs a quarter of the libm form's instructions).
+        const bool interior = !p.ring && s0 + 31 <= q0 && s0 + 31 < p.cap && (p.context <= 0 || q0 + 31 - s0 < p.context);
         float mt = NEG_INF;
+        if (interior) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int slot = s0 + rst_mfma32_row(r, lane);
-            long pk;
-            if (!p.ring) {
-                pk = pos0 + slot;
-            } else {
-                // RingKVCache.complete (modules/transformer.py:254-278), including the `delta <= 0` quirk
-                const int delta = slot - end_index;
-                pk = delta <= 0 ? end_offset + delta : end_offset + delta - p.cap;
-                if (slot >= end_offset) pk = -1;
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] *= scale;
+                mt = fmaxf(mt, sacc[r]);
             }
-            const long dlt = pq - pk;
-            bool ok = slot < p.cap && pk >= 0 && dlt >= 0;
-            if (p.context > 0) ok = ok && dlt < p.context;
-            const float sv = ok ? sacc[r] * scale : NEG_INF;
-            sacc[r] = sv;
-            mt = fmaxf(mt, sv);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int slot = s0 + rst_mfma32_row(r, lane);
+                long pk;
+                if (!p.ring) {
+                    pk = pos0 + slot;
+                } else {
+                    // RingKVCache.complete (modules/transformer.py:254-278), including the `delta <= 0` quirk
+                    const int delta = slot - end_index;
+                    pk = delta <= 0 ? end_offset + delta : end_offset + delta - p.cap;
+                    if (slot >= end_offset) pk = -1;
+                }
+                const long dlt = pq - pk;
+                bool ok = slot < p.cap && pk >= 0 && dlt >= 0;
+                if (p.context > 0) ok = ok && dlt < p.context;
+                const float sv = ok ? sacc[r] * scale : NEG_INF;
+                sacc[r] = sv;
+                mt = fmaxf(mt, sv);
+            }
         }
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = (m_run == NEG_INF) ? 1.0f : expf(m_run - m_new);
+        constexpr float LOG2E = 1.4426950408889634f;
+        const float alpha = (m_run == NEG_INF) ? 1.0f : __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pv = (sacc[r] == NEG_INF) ? 0.0f : expf(sacc[r] - m_new);
+            const float pv = (sacc[r] == NEG_INF) ? 0.0f : __builtin_amdgcn_exp2f((sacc[r] - m_new) * LOG2E);
             sacc[r] = pv;
             psum += pv;
         }
