@@ -334,7 +334,7 @@ def run_lm(args, rank, world, dev, lm=None, steps=None, warmup=None, cpu=True):
     ms_frame = elapsed / steps * 1e3
     timing = _timing(samples)
     frame_bytes = nbytes + depth_bytes
-    kern = "gemv_" if B <= 2 else "gemm_skinny_kernel"
+    kern = "gemv_" if B <= 2 else "gemm_skinny"       # packed and fp32-input (x32) forms of the bf16 skinny GEMM
     result = {
         "metric": METRIC,
         "value": round(B * world * steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": steps,
@@ -347,7 +347,7 @@ def run_lm(args, rank, world, dev, lm=None, steps=None, warmup=None, cpu=True):
                    "parallelism": f"replica x{world}"},
         "x_realtime_per_stream": round(steps / elapsed / 12.5, 2),
         "timing": timing,
-        "roofline": {"bound": "hbm", "kernel": ("gemv_kernel / gemv_norm_kernel" if B <= 2 else "gemm_skinny_kernel") + " (bf16 weight streaming)",
+        "roofline": {"bound": "hbm", "kernel": ("gemv_kernel / gemv_norm_kernel" if B <= 2 else "gemm_skinny_kernel / gemm_skinny_x32_kernel") + " (bf16 weight streaming)",
                      "achieved": round(nbytes / ms / 1e6, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                      "traffic": pmc_traffic(kern, "lm"),
@@ -506,10 +506,11 @@ def run_gpt(args, rank, world, dev, gpt=None, fp8=None, steps=None, warmup=None,
                    "gemm_precision": "fp8 e4m3 (per-row scales) in the global blocks, bf16 hi+lo elsewhere" if fp8 else "bf16 hi+lo",
                    "parallelism": f"replica x{world}"},
         "x_realtime_per_stream": round(steps / elapsed / 12.5, 2),
-        "roofline": {"bound": "hbm", "kernel": ("gemv_kernel / gemv_norm_kernel" if B <= 2 else "gemm_skinny_kernel") + " (bf16 weight streaming)",
+        "roofline": {"bound": "hbm", "kernel": ("gemv_kernel / gemv_norm_kernel" if B <= 2 else "gemm_skinny_kernel / gemm_skinny_x32_kernel"
+                                                + (" / gemm_skinny_fp8_kernel" if fp8 else "")) + " (weight streaming)",
                      "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
-                     "traffic": pmc_traffic("gemv_" if B <= 2 else "gemm_skinny_kernel", "gpt"),
+                     "traffic": pmc_traffic("gemv_" if B <= 2 else "gemm_skinny", "gpt"),
                      "algorithmic_bytes_per_launch": round(nbytes / max(1, len(gemm))), "launches_per_step": len(gemm),
                      "avg_launch_ms": round(ms / max(1, len(gemm)), 5), "kernel_ms_per_step": round(ms, 3),
                      "algorithmic_gb_per_step": round(nbytes / 1e9, 3), "share_of_step_eager": round(ms / ms_frame, 3),
@@ -519,7 +520,7 @@ def run_gpt(args, rank, world, dev, gpt=None, fp8=None, steps=None, warmup=None,
     }
     if samples:
         result["timing"] = _timing(samples)
-    _with_rocprof(result["roofline"], "gemv_" if B <= 2 else "gemm_skinny_kernel", "gpt_fp8" if fp8 else "gpt", nbytes / max(1, len(gemm)), HBM_PEAK_GBS)
+    _with_rocprof(result["roofline"], "gemv_" if B <= 2 else "gemm_skinny", "gpt_fp8" if fp8 else "gpt", nbytes / max(1, len(gemm)), HBM_PEAK_GBS)
     if cpu and not args.no_cpu_baseline and world == 1:    # the CPU leg is timed on rank 0 of the single-GPU run only
         result["cpu_baseline"] = gpt_cpu_baseline(cfg_d)
     return result

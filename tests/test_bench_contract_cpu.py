@@ -80,6 +80,29 @@ def test_default_line_carries_the_north_star_sub_benchmarks():
     assert d["e2e_b1"]["x_realtime_per_stream"] >= 10.0            # the north-star target: >= 10x real time end to end at batch 1
 
 
+@pytest.mark.skipif(TAG < "r03", reason="sub-objects added in round 3")
+def test_default_line_carries_every_baseline_config():
+    """the driver-run line also times configs[2] at a full 3000-slot ring, configs[3] at its per-GPU size (32
+    streams: LM alone and end to end) and configs[4] (GPT Qwen-0.5B shape, 32 streams) in bf16 hi+lo and with the fp8 block GEMMs --
+    each with its own roofline block and CPU baseline leg; the codec CPU leg also carries the single-thread figure."""
+    d = _last_json(os.path.join(ROOT, "profiles", f"{TAG}_codec_bench.json"))
+    for key, what, batch in (("lm_ctx3000", "configs[2]", 1), ("lm_b32", "configs[2]", 32), ("e2e_b32", "configs[3]", 32),
+                             ("gpt_b32", "configs[4]", 32), ("gpt_b32_fp8", "configs[4]", 32)):
+        sub = d[key]
+        assert what in sub["config"]["workload"] and sub["unit"] == "frames/s" and sub["value"] > 0 and sub["ms_per_step"] > 0
+        assert sub["config"].get("batch_per_gpu", sub["config"].get("streams_per_gpu")) == batch
+        assert sub["timing"]["samples"] >= 50 and sub["steps"] >= 50
+        c = sub["cpu_baseline"]
+        assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+        r = sub.get("roofline")
+        if key != "e2e_b32":
+            assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+    assert d["lm_ctx3000"]["config"]["context_frames"] >= 3000
+    assert "fp8" in d["gpt_b32_fp8"]["config"]["gemm_precision"] and "fp8" not in d["gpt_b32"]["config"]["gemm_precision"]
+    one = d["cpu_baseline"]["single_thread"]
+    assert one["cores"] == 1 and one["value"] > 0 and one["unit"] == "frames/s" and one["sample"]
+
+
 # ---- host logic of bench.py itself (no GPU needed)
 
 def _bench_module():

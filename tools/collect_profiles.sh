@@ -3,7 +3,7 @@
 #   bench JSON lines, rocprofv3 kernel traces (--kernel-trace --stats) and the two PMC passes (FETCH_SIZE / WRITE_SIZE) per
 #   workload.  The raw rocprof outputs are reduced on the box (tools/rocpd_summary.py, tools/pmc_traffic.py) to the small
 #   files that are then copied into profiles/ and committed; only those travel back (gpurun_out/ is capped at 64 MiB).
-TAG=${1:-r02}
+TAG=${1:-r03}
 WHAT=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG
@@ -26,6 +26,29 @@ prof() { local n=$1; shift
 # the bench lines quote the trace / counter summaries of the SAME code: each workload is profiled first, its summaries are copied
 # into this box's profiles/ under the tag, and only then the bench line is taken
 publish() { for f in "$O"/$1_*; do case "$f" in *.out|*.err|*_bench.json) ;; *) cp "$f" "profiles/${TAG}_$(basename "$f")";; esac; done; }
+if [ "$WHAT" = all ] || [ "$WHAT" = lm ]; then
+  prof lm python bench.py --workload lm --steps 6 --warmup 2 --no-cpu-baseline --timing-samples 2
+  db=$(find "$RAW/lm_trace" -name "*.db" | head -1); [ -n "$db" ] && python tools/frame_timeline.py "$db" "$O/lm_timeline.csv" lm_ring_begin_kernel 2
+  publish lm
+  run lm_bench python bench.py --workload lm --steps 60 --warmup 5
+  # (ring offset 3000, batch 32 and the batch-32 end-to-end frame ride on the default line as sub-objects since round 3)
+  BENCH_DEPTH_CHAINS=1 python tools/bench_depth.py 2>&1 | grep -v amdgpu > "$O/depth_phase.txt"
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = gpt ]; then
+  prof gpt python bench.py --workload gpt --steps 6 --warmup 2 --no-cpu-baseline
+  publish gpt
+  run gpt_bench python bench.py --workload gpt --steps 40 --warmup 5
+  run gpt_fp8_bench python bench.py --workload gpt --fp8 --steps 40 --warmup 5 --no-cpu-baseline
+  run gpt1_bench python bench.py --workload gpt --lm-batch 1 --steps 60 --warmup 5 --no-cpu-baseline
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = e2e ]; then
+  run e2e1_bench python bench.py --workload e2e --lm-batch 1 --steps 60 --warmup 6
+  run e2e1_trace rocprofv3 --kernel-trace --stats -d "$RAW/e2e1_trace" -o t -- python bench.py --workload e2e --lm-batch 1 --steps 30 --warmup 4 --no-cpu-baseline --timing-samples 2
+  db=$(find "$RAW/e2e1_trace" -name "*.db" | head -1); [ -n "$db" ] && python tools/rocpd_summary.py "$db" "$O/e2e1" | tail -1
+  [ -n "$db" ] && python tools/frame_timeline.py "$db" "$O/e2e1_timeline.csv" lm_ring_begin_kernel 2
+  rm -f "$O/e2e1_trace.out"
+fi
+# the codec workload last: its default line carries the LM / GPT / end-to-end sub-objects, which quote the summaries published above
 if [ "$WHAT" = all ] || [ "$WHAT" = codec ]; then
   prof codec python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sub --no-check --timing-samples 1
 fi
@@ -39,28 +62,5 @@ fi
 if [ "$WHAT" = all ] || [ "$WHAT" = codec ]; then
   publish codec
   run codec_bench python bench.py --steps 20 --warmup 5
-fi
-if [ "$WHAT" = all ] || [ "$WHAT" = lm ]; then
-  prof lm python bench.py --workload lm --steps 6 --warmup 2 --no-cpu-baseline --timing-samples 2
-  db=$(find "$RAW/lm_trace" -name "*.db" | head -1); [ -n "$db" ] && python tools/frame_timeline.py "$db" "$O/lm_timeline.csv" lm_ring_begin_kernel 2
-  publish lm
-  run lm_bench python bench.py --workload lm --steps 60 --warmup 5
-  run lm_ctx3000_bench python bench.py --workload lm --steps 60 --warmup 5 --lm-context 3000 --no-cpu-baseline
-  run lm32_bench python bench.py --workload lm --lm-batch 32 --steps 30 --warmup 5 --no-cpu-baseline
-  BENCH_DEPTH_CHAINS=1 python tools/bench_depth.py 2>&1 | grep -v amdgpu > "$O/depth_phase.txt"
-fi
-if [ "$WHAT" = all ] || [ "$WHAT" = gpt ]; then
-  prof gpt python bench.py --workload gpt --steps 6 --warmup 2 --no-cpu-baseline
-  publish gpt
-  run gpt_bench python bench.py --workload gpt --steps 40 --warmup 5
-  run gpt1_bench python bench.py --workload gpt --lm-batch 1 --steps 60 --warmup 5 --no-cpu-baseline
-fi
-if [ "$WHAT" = all ] || [ "$WHAT" = e2e ]; then
-  run e2e1_bench python bench.py --workload e2e --lm-batch 1 --steps 60 --warmup 6
-  run e2e32_bench python bench.py --workload e2e --lm-batch 32 --steps 30 --warmup 5
-  run e2e1_trace rocprofv3 --kernel-trace --stats -d "$RAW/e2e1_trace" -o t -- python bench.py --workload e2e --lm-batch 1 --steps 30 --warmup 4 --no-cpu-baseline --timing-samples 2
-  db=$(find "$RAW/e2e1_trace" -name "*.db" | head -1); [ -n "$db" ] && python tools/rocpd_summary.py "$db" "$O/e2e1" | tail -1
-  [ -n "$db" ] && python tools/frame_timeline.py "$db" "$O/e2e1_timeline.csv" lm_ring_begin_kernel 2
-  rm -f "$O/e2e1_trace.out"
 fi
 du -sh "$O"; ls "$O"
