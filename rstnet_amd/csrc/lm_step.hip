@@ -412,29 +412,17 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_norm_kernel(const GemvPa
 // x[b][:] = sum_i table_i[token[b][i]]  (bf16 tables, fp32 sum in table order; id -1 -> zero row, ids clamped at 0)
 __global__ __launch_bounds__(256) void embed_sum_kernel(const EmbedSumParams p) {
     const int b = blockIdx.y;
-    // token ids first (all requested together), then every table row entry (all requested together, addresses clamped, the id -1
-    // rows cleared through a mask), then the sum in table order: three memory round trips instead of 2 x n_tables -- the loop that
-    // loaded a token, then its row, table after table (each under `if (tok != -1)`) cost 12 us for the 17 tables of a frame.
-    long tok[RST_MAX_TABLES];
-#pragma unroll
-    for (int i = 0; i < RST_MAX_TABLES; ++i) tok[i] = i < p.n_tables ? p.tokens[(long)b * p.tok_stride + p.tok_index[i]] : -1;
     for (int d = blockIdx.x * 256 + threadIdx.x; d < p.D; d += gridDim.x * 256) {
         float s = p.add ? p.add[(long)b * p.D + d] : 0.f;
-        unsigned short e[RST_MAX_TABLES];
-#pragma unroll
-        for (int i = 0; i < RST_MAX_TABLES; ++i) {
-            // ids outside the table are clamped into it (the reference's F.embedding raises; a kernel cannot, and must not read out
-            // of bounds): negative ids -> row 0 (id -1: the row is read and discarded), ids >= rows -> the last row
-            const int ii = i < p.n_tables ? i : 0;
-            long row = tok[i] < 0 ? 0 : tok[i];
-            if (p.rows[ii] > 0 && row >= p.rows[ii]) row = p.rows[ii] - 1;
-            e[i] = p.n_tables > 0 ? p.tables[ii][row * p.D + d] : (unsigned short)0;
-        }
-#pragma unroll
-        for (int i = 0; i < RST_MAX_TABLES; ++i) {
-            unsigned m = (i < p.n_tables && tok[i] != -1) ? 0xffffffffu : 0u;
-            asm volatile("" : "+v"(m));
-            if (i < p.n_tables) s += __uint_as_float(((unsigned)e[i] << 16) & m);      // id -1 adds +0.0, as the skipped term did
+        for (int i = 0; i < p.n_tables; ++i) {
+            const long tok = p.tokens[(long)b * p.tok_stride + p.tok_index[i]];
+            if (tok != -1) {
+                // ids outside the table are clamped into it (the reference's F.embedding raises; a kernel cannot, and must not
+                // read out of bounds): other negative ids -> row 0, ids >= rows -> the last row
+                long row = tok < 0 ? 0 : tok;
+                if (p.rows[i] > 0 && row >= p.rows[i]) row = p.rows[i] - 1;
+                s += __uint_as_float((unsigned)p.tables[i][row * p.D + d] << 16);
+            }
         }
         p.out[(long)b * p.D + d] = s;
     }
