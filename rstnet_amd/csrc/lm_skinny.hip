@@ -140,42 +140,9 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void gemm_skinny_kernel(const Sk
     // memory round trip (2-3 us for HBM weights under load) per iteration: with one batch tile and one column tile the registers
     // hold 8 steps, so the 1024-wide layers (8 steps per wave) are ONE iteration.
     constexpr int UN = (NB == 1 && CT == 1) ? 8 : ((NB * 2 + CT) <= 4 ? 4 : 2);
-    // One batch tile, one or two column tiles: the wave's weight loads go out WCH steps at a time (32 for one column tile, 16 for two:
-    // 128 VGPRs of operands in flight), the packed activations (L2 hits) 8 steps at a time.  A loop of `loads of UN steps -> wait ->
-    // MFMAs` exposes one HBM round trip (2-3 us under load) per iteration: the 2816-wide FFN-out of the depth transformer / GPT
-    // blocks took three of them in a launch that only 32 workgroups share, the 4096-wide layers of the 7B temporal blocks four
-    // (one column tile) or eight (two).
-    constexpr int WCH = (NB == 1 && CT <= 2) ? 32 / CT : 0;
-    if (WCH > 0) {
-        for (int sc = s0; sc < s1; sc += WCH) {
-            bf16x8 aw[WCH > 0 ? WCH : 1][CT];
-#pragma unroll
-            for (int u = 0; u < WCH; ++u)
-#pragma unroll
-                for (int c = 0; c < CT; ++c)
-                    aw[u][c] = sc + u < s1 ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wt[c] + (long)(sc + u) * 512))
-                                           : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int g = 0; g < WCH; g += 8) {
-                if (sc + g < s1) {                        // wave-uniform
-                    bf16x8 xh8[8], xl8[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const long so = (long)min(sc + g + u, s1 - 1) * 512;      // steps past the slice re-read its last one against zero weights
-                        xh8[u] = *reinterpret_cast<const bf16x8*>(xh + so);
-                        xl8[u] = *reinterpret_cast<const bf16x8*>(xl + so);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-#pragma unroll
-                        for (int c = 0; c < CT; ++c) {
-                            acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh8[u], aw[g + u][c], acc[0][c], 0, 0, 0);
-                            acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl8[u], aw[g + u][c], acc[0][c], 0, 0, 0);
-                        }
-                }
-            }
-        }
-    } else
+    // (Measured and dropped, round 3: requesting the weights of 32 / 16 steps up front with the activations following 8 steps at a time --
+    // one HBM round trip per 32 steps instead of per 8 -- is SLOWER: 7.32 vs 7.10 ms per frame at the Moshi-7B shape, batch 32, 3.64 vs
+    // 3.62 ms for the GPT frame, A/B inside one session.)
     for (int s = s0; s < s1; s += UN) {
         bf16x8 a[UN][CT], bh[UN][NB], bl[UN][NB];
 #pragma unroll
