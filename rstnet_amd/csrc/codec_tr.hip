@@ -10,7 +10,7 @@
 // gathers the head's q / k / v of the new steps, rotates q and k (modules/rope.py:37-62, position = *pos_dev + t), appends k / v to
 // the ring in HBM (slot (pos + t) % cap: the ring persists across frames; only this workgroup index ever touches the head's
 // ring inside a launch) and runs the T queries against the ring with the slot -> position map and mask of
-// RingKVCache.complete (transformer.py:254-278,404-414, incl. the `delta <= 0` slot), one wave per query.
+// RingKVCache.complete (transformer.py:254-278,404-414, incl. the `delta <= 0` slot), the four waves sharing each query's slots.
 #include "persist.h"
 
 namespace {
@@ -121,10 +121,11 @@ __global__ __launch_bounds__(DF_THREADS) void codec_tr_kernel(const CodecTrParam
     const int gw = wg * DF_WAVES + wave, W = G * DF_WAVES;
     const int E = p.E, F = p.F, D = p.D, H = p.H, T = p.T, cap = p.cap;
     const int XW = E > F ? E : F;
-    // LDS carve (floats): header | xs [R][max(E, F)] | xres [R][E] | qh [T][3][D]
+    // LDS carve (floats): header | xs [R][max(E, F)] | xres [R][E] | qh [T][3][D] | att_part [4][D + 2]
     float* xs = lds + DF_HDR_FLOATS;
     float* xres = xs + R * XW;
     float* qh = xres + R * E;
+    float* att_part = qh + T * 3 * D;             // [DF_WAVES][D + 2] partial (max, sum, out) of a query per wave
     u64* gX = p.gran + (SOLO ? (long)R * (5L * E + F) : 0L);
     u64* gQKV = gX + (long)R * E;
     u64* gATT = gQKV + (long)R * 3 * E;
@@ -177,72 +178,103 @@ __global__ __launch_bounds__(DF_THREADS) void codec_tr_kernel(const CodecTrParam
                 kring[(long)slot * D + d] = qh[(t * 3 + 1) * D + d];
                 vring[(long)slot * D + d] = qh[(t * 3 + 2) * D + d];
             }
-            // one wave per query: lane group `grp` (LPS = D / 16 lanes, 16 dims each) owns slot s0 + grp of a pass
-            if (wave < T) {
-                const int t = wave;
+            // The T queries one after the other, each by ALL four waves: lane group `grp` (LPS = D / 16 lanes, 16 dims each) of wave w owns
+            // slot (pass * SPW + grp) of the passes w, w + 4, ..., and the K / V rows of UB passes are requested before the first is
+            // used.  (Round 2 gave each query ONE wave that walked the ring pass by pass: with the 250-slot ring of a session past
+            // 10 s that is 16 dependent memory round trips per layer -- ~24 us of a ~35 us layer.)  The four partial (max, sum, out)
+            // triples meet in LDS and are combined in wave order.
+            {
                 const int LPS = D >> 4, SPW = 64 / LPS;
                 const int sub = lane % LPS, grp = lane / LPS;
-                const long pos_q = pos + t, end_offset = pos + T;
+                const long end_offset = pos + T;
                 const int n_used = (int)min((long)cap, end_offset);
+                const int npass = (n_used + SPW - 1) / SPW;
                 const float scale = 1.0f / sqrtf((float)D);
-                float q[16];
+                constexpr int UB = 4;
+                for (int t = 0; t < T; ++t) {
+                    const long pos_q = pos + t;
+                    float q[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) q[i] = qh[(t * 3) * D + sub * 16 + i];
-                float m_run = -INFINITY, l_run = 0.f, o[16];
+                    for (int i = 0; i < 16; ++i) q[i] = qh[(t * 3) * D + sub * 16 + i];
+                    float m_run = -INFINITY, l_run = 0.f, o[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) o[i] = 0.f;
-                for (int s0 = 0; s0 < n_used; s0 += SPW) {
-                    const int slot = s0 + grp;
-                    const bool ok = slot < n_used && ring_visible(slot, pos_q, cap, p.context, end_offset);
-                    float kv[16], vv[16];
+                    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+                    for (int p0 = wave; p0 < npass; p0 += DF_WAVES * UB) {
+                        f32x4 kq[UB][4], vq[UB][4];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) { kv[i] = 0.f; vv[i] = 0.f; }
-                    // a slot written by this very step comes from LDS (the stores above may not have landed for this wave's loads)
-                    int tn = -1;
-                    for (int t2 = 0; t2 < T; ++t2) tn = (int)((pos + t2) % cap) == slot ? t2 : tn;
-                    if (ok && tn >= 0) {
+                        for (int u = 0; u < UB; ++u) {        // unconditional loads from a clamped slot; masked below
+                            const int slot = min((p0 + u * DF_WAVES) * SPW + grp, cap - 1);
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) { kv[i] = qh[(tn * 3 + 1) * D + sub * 16 + i]; vv[i] = qh[(tn * 3 + 2) * D + sub * 16 + i]; }
-                    } else if (ok) {
+                            for (int i = 0; i < 4; ++i) {
+                                kq[u][i] = *reinterpret_cast<const f32x4*>(kring + (long)slot * D + sub * 16 + 4 * i);
+                                vq[u][i] = *reinterpret_cast<const f32x4*>(vring + (long)slot * D + sub * 16 + 4 * i);
+                            }
+                        }
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const f32x4 k4 = *reinterpret_cast<const f32x4*>(kring + (long)slot * D + sub * 16 + 4 * i);
-                            const f32x4 v4 = *reinterpret_cast<const f32x4*>(vring + (long)slot * D + sub * 16 + 4 * i);
+                        for (int u = 0; u < UB; ++u) {
+                            const int pass = p0 + u * DF_WAVES;
+                            const int slot = pass * SPW + grp;
+                            const bool ok = pass < npass && slot < n_used && ring_visible(slot, pos_q, cap, p.context, end_offset);
+                            // a slot written by this very step comes from LDS (the stores above may not have landed for these loads)
+                            int tn = -1;
+                            for (int t2 = 0; t2 < T; ++t2) tn = (int)((pos + t2) % cap) == slot ? t2 : tn;
+                            float kv[16], vv[16];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { kv[4 * i + e] = k4[e]; vv[4 * i + e] = v4[e]; }
+                            for (int i = 0; i < 16; ++i) {
+                                kv[i] = tn >= 0 ? qh[(tn * 3 + 1) * D + sub * 16 + i] : kq[u][i >> 2][i & 3];
+                                vv[i] = tn >= 0 ? qh[(tn * 3 + 2) * D + sub * 16 + i] : vq[u][i >> 2][i & 3];
+                            }
+                            float d = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) d = fmaf(kv[i], q[i], d);
+                            for (int off = LPS / 2; off > 0; off >>= 1) d += __shfl_xor(d, off);
+                            const float sc = ok ? d * scale : -INFINITY;
+                            const float m_new = fmaxf(m_run, sc);
+                            if (m_new != -INFINITY) {
+                                const float alpha = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
+                                const float pw = sc == -INFINITY ? 0.f : expf(sc - m_new);
+                                l_run = l_run * alpha + pw;
+#pragma unroll
+                                for (int i = 0; i < 16; ++i) o[i] = o[i] * alpha + pw * vv[i];
+                                m_run = m_new;
+                            }
                         }
                     }
-                    float d = 0.f;
+                    // merge the lane groups of the wave (same `sub`)
+                    float m_w = m_run;
+                    for (int off = LPS; off < 64; off <<= 1) m_w = fmaxf(m_w, __shfl_xor(m_w, off));
+                    const float f = (m_run == -INFINITY) ? 0.f : expf(m_run - m_w);
+                    float l_w = l_run * f;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) d = fmaf(kv[i], q[i], d);
-                    for (int off = LPS / 2; off > 0; off >>= 1) d += __shfl_xor(d, off);
-                    const float sc = ok ? d * scale : -INFINITY;
-                    const float m_new = fmaxf(m_run, sc);
-                    if (m_new != -INFINITY) {
-                        const float alpha = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
-                        const float pw = sc == -INFINITY ? 0.f : expf(sc - m_new);
-                        l_run = l_run * alpha + pw;
+                    for (int i = 0; i < 16; ++i) o[i] *= f;
+                    for (int off = LPS; off < 64; off <<= 1) {
+                        l_w += __shfl_xor(l_w, off);
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) o[i] = o[i] * alpha + pw * vv[i];
-                        m_run = m_new;
+                        for (int i = 0; i < 16; ++i) o[i] += __shfl_xor(o[i], off);
                     }
-                }
-                // merge the lane groups of the wave (same `sub`)
-                float m_w = m_run;
-                for (int off = LPS; off < 64; off <<= 1) m_w = fmaxf(m_w, __shfl_xor(m_w, off));
-                const float f = (m_run == -INFINITY) ? 0.f : expf(m_run - m_w);
-                float l_w = l_run * f;
+                    // the waves' partials -> LDS, combined in wave order by D threads
+                    float* part = att_part + wave * (D + 2);
+                    if (grp == 0) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) o[i] *= f;
-                for (int off = LPS; off < 64; off <<= 1) {
-                    l_w += __shfl_xor(l_w, off);
+                        for (int i = 0; i < 16; ++i) part[2 + sub * 16 + i] = o[i];
+                        if (sub == 0) { part[0] = m_w; part[1] = l_w; }
+                    }
+                    __syncthreads();
+                    if (tid < D) {
+                        float M = -INFINITY;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) o[i] += __shfl_xor(o[i], off);
-                }
-                if (grp == 0) {
+                        for (int w = 0; w < DF_WAVES; ++w) M = fmaxf(M, att_part[w * (D + 2)]);
+                        float Lq = 0.f, Oq = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        df_publish(gATT + (long)(b * T + t) * E + h * D + sub * 16 + i, eATT, l_w > 0.f ? o[i] / l_w : 0.f);
+                        for (int w = 0; w < DF_WAVES; ++w) {
+                            const float mw = att_part[w * (D + 2)];
+                            const float fw = mw == -INFINITY ? 0.f : expf(mw - M);
+                            Lq = fmaf(att_part[w * (D + 2) + 1], fw, Lq);
+                            Oq = fmaf(att_part[w * (D + 2) + 2 + tid], fw, Oq);
+                        }
+                        df_publish(gATT + (long)(b * T + t) * E + h * D + tid, eATT, Lq > 0.f ? Oq / Lq : 0.f);
+                    }
+                    __syncthreads();          // att_part is rewritten by the next query
                 }
             }
         }
@@ -305,7 +337,7 @@ int rst_codec_tr_grid(int B, int T, int E, int H, int F, int L, int cap) {
     const int D = E / H;
     if (!(D >= 16 && D % 16 == 0 && D <= 256 && (64 % (D / 16)) == 0)) return 0;
     const int XW = E > F ? E : F;
-    const size_t lds = ((size_t)DF_HDR_FLOATS + (size_t)R * XW + (size_t)R * E + (size_t)T * 3 * D) * sizeof(float);
+    const size_t lds = ((size_t)DF_HDR_FLOATS + (size_t)R * XW + (size_t)R * E + (size_t)T * 3 * D + (size_t)DF_WAVES * (D + 2)) * sizeof(float);
     if (lds > 150 * 1024) return 0;
     const int G = df_grid_for_rows(ct_cu_count(), min(3 * E, F));
     if (B * H > G) return 0;
@@ -330,7 +362,7 @@ int rst_launch_codec_tr(const CodecTrParams& p, hipStream_t stream) {
         RST_REQUIRE(p.in_proj[l] && p.out_proj[l] && p.lin1[l] && p.lin2[l] && p.n1g[l] && p.n1b[l] && p.n2g[l] && p.n2b[l] && p.kc[l] && p.vc[l],
                     "codec_tr: layer %d pointers", l);
     const int XW = p.E > p.F ? p.E : p.F;
-    const size_t lds = ((size_t)DF_HDR_FLOATS + (size_t)R * XW + (size_t)R * p.E + (size_t)p.T * 3 * p.D) * sizeof(float);
+    const size_t lds = ((size_t)DF_HDR_FLOATS + (size_t)R * XW + (size_t)R * p.E + (size_t)p.T * 3 * p.D + (size_t)DF_WAVES * (p.D + 2)) * sizeof(float);
     // both granule sets (persistent launch | repair launch) start at zero in every call
     if (hipMemsetAsync(p.gran, 0, (size_t)rst_codec_tr_workspace_granules(R, p.E, p.F) * 16, stream) != hipSuccess) {
         rst_set_error("codec_tr: workspace memset failed");
