@@ -39,8 +39,7 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
     p.x = x; p.hist = hist; p.w = w; p.bias = bias; p.res = res; p.scale = scale; p.y = y;
     p.B = B; p.T_in = T_in; p.T_out = T_out; p.C = C; p.K = K; p.N = N; p.S = S; p.P = P;
     p.pad_mode = pad_mode; p.x_bstride = x_bstride; p.ldy = ldy; p.act_in = act_in; p.act_out = act_out;
-    p.split_k = split_k < 0 ? 1 : split_k; p.ws = ws; p.counters = counters;
-    p.big_tiles = split_k >= 0;      // (split_k == -1: the 128 x 128 tile shape for every large launch -- A/B measurements, same results)
+    p.split_k = split_k; p.ws = ws; p.counters = counters;
     RST_REQUIRE(split_k <= 1 || ldy == N, "gemm_win: split-K needs ldy == N");
     return rst_launch_gemm_win(p, (hipStream_t)stream);
 }

@@ -369,13 +369,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 
 // (two / three per CU) and walks its share of the tiles as ONE stream of k-tiles: the loads of the next tile's first k-tile are
 // issued under the MFMAs of this tile's last one and land in the free LDS buffer, so the only per-tile cost left is the
 // epilogue itself.  Tiles that touch an utterance edge (padding / history / ragged rows) take the general routine.
-// BIG (round 3): 256 x 128 tiles, four waves of 64 x 128 (TM = 2, TN = 4, WM = 4, WN = 1) instead of 128 x 128 tiles of 64 x 64 waves --
-// a quarter fewer LDS operand reads and a quarter fewer staged bytes per flop, two resident workgroups per CU (61 KB of LDS each,
-// 128 accumulator registers per lane) instead of three.
-template <bool ELU, int KB, int DBG = 0, bool BIG = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BIG ? 2 : (KB == 16 ? 3 : 1), BIG ? 2 : (KB == 16 ? 3 : 2)))) void gemm_win_stream_kernel(const GemmWinParams p, const int tiles) {
-    constexpr int TM = 2, TN = BIG ? 4 : 2, WM = BIG ? 4 : 2, WN = BIG ? 1 : 2;
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+template <bool ELU, int KB, int DBG = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 3 : 1, KB == 16 ? 3 : 2))) void gemm_win_stream_kernel(const GemmWinParams p, const int tiles) {
+    constexpr int TM = 2, TN = 2, WM = 2, WN = 2;
+    constexpr int BM = 128, BN = 128;
     constexpr int LDS_LD = KB + 4;
     constexpr int RP = 1024 / KB;
     constexpr int RA = BM / RP, RB = BN / RP;
@@ -590,16 +587,16 @@ static int gw_cu_count() {
     return n;
 }
 
-// the 128 x 128 (BIG: 256 x 128) configuration on 16-byte-aligned operands: resident workgroups streaming through the tiles
-template <int KB, bool BIG = false>
+// the 128 x 128 configuration on 16-byte-aligned operands: resident workgroups streaming through the tiles
+template <int KB>
 int launch_stream(const GemmWinParams& p, long tiles, hipStream_t stream) {
     if (tiles > 0x7fffffffL) {
         rst_set_error("gemm_win: too many tiles (%ld)", tiles);
         return RST_ERR_UNSUPPORTED;
     }
-    const size_t lds = 2 * ((BIG ? 256 : 128) + 128) * (KB + 4) * sizeof(float);
+    const size_t lds = 2 * (128 + 128) * (KB + 4) * sizeof(float);
     static const int per_cu_env = rst_knob("RST_GEMM_STREAM_WGS", 0);      // tools build only
-    const int per_cu = per_cu_env > 0 ? per_cu_env : (BIG ? 2 : (KB == 16 ? 3 : 2));
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (KB == 16 ? 3 : 2);
     const long resident = (long)per_cu * gw_cu_count();
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
     auto go = [&](auto kern) {
@@ -618,11 +615,6 @@ int launch_stream(const GemmWinParams& p, long tiles, hipStream_t stream) {
     if (KB == 16 && dbg == 1) { go(gemm_win_stream_kernel<false, 16, 1>); return rst_check_launch("gemm_win"); }
     if (KB == 16 && dbg == 5) { go(gemm_win_stream_kernel<false, 16, 5>); return rst_check_launch("gemm_win"); }
 #endif
-    if (BIG) {
-        if (p.act_in == 1) go(gemm_win_stream_kernel<true, 16, 0, true>);
-        else go(gemm_win_stream_kernel<false, 16, 0, true>);
-        return rst_check_launch("gemm_win");
-    }
     if (p.act_in == 1) go(gemm_win_stream_kernel<true, KB>);
     else go(gemm_win_stream_kernel<false, KB>);
     return rst_check_launch("gemm_win");
@@ -678,9 +670,6 @@ int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
             static const bool kb32_only = rst_knob("RST_GEMM_KB32", 0) != 0;
             static const bool stream_off = rst_knob("RST_GEMM_STREAM", 1) == 0;
             if (vec && !stream_off && p.split_k <= 1) {
-                // >= 4 of the 256-row tiles per resident workgroup (512 of them): the 256 x 128 form
-                const long big_tiles = ((M + 255) / 256) * ((p.N + 127) / 128);
-                if (p.big_tiles && big_tiles >= 2048 && !kb32_only) return launch_stream<16, true>(p, big_tiles, stream);
                 if (tiles >= 768 && !kb32_only) return launch_stream<16>(p, tiles, stream);
                 return launch_stream<32>(p, tiles, stream);
             }

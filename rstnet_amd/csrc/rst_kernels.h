@@ -24,7 +24,6 @@ struct GemmWinParams {
     int split_k;         // > 1: K split over gridDim.y workgroups (M <= 4096), partials in ws, one counter per tile
     float* ws;           // [split_k][M][N]
     unsigned* counters;  // [rst_gemm_split_tiles_impl(M, N)], zero before the first launch (self re-arming)
-    int big_tiles;       // 1: launches with >= 2048 tiles of 256 x 128 take that tile shape (0: 128 x 128 only; same results either way)
 };
 int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream);
 int rst_gemm_split_plan_impl(long M, int N, int K);

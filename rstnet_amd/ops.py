@@ -24,7 +24,6 @@ from . import _lib
 ACT_NONE, ACT_ELU, ACT_GELU = 0, 1, 1   # act_in: 1 = ELU ; act_out: 1 = GELU
 ACT_ELU_OUT = 2                          # act_out: ELU applied last (after the residual)
 PAD_ZERO, PAD_REPLICATE = 0, 1
-GEMM_BIG_TILES = True        # A/B switch (tools/ab.py): False keeps the 128 x 128 tile shape for the largest codec GEMMs
 
 
 # Optional per-launch instrumentation (bench.py's roofline leg): a list that receives
@@ -206,7 +205,7 @@ def gemm_win(x: torch.Tensor, w: torch.Tensor, *, B: int, T_in: int, T_out: int,
         e0.record()
     _lib.check(_lib.lib().rst_gemm_win_f32(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out),
                                            B, T_in, T_out, C_, K, N, S, P, pad_mode, T_in * C_, N, act_in, act_out,
-                                           split_k if (GEMM_BIG_TILES or split_k > 1) else -1, _ptr(ws), _ptr(cnt), _stream()))
+                                           split_k, _ptr(ws), _ptr(cnt), _stream()))
     if prof is not None:
         e1.record()
         nbytes = 4 * (x.numel() + w.numel() + out.numel() + (res.numel() if res is not None else 0))
@@ -249,9 +248,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if split_k > 1 or not GEMM_BIG_TILES:
+    if split_k > 1:
         _lib.check(_lib.lib().rst_gemm_win_f32(_ptr(x), None, _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), 1, M, M, K, K, N,
-                                               1, 0, 0, M * K, N, 0, act_out, split_k if split_k > 1 else -1, _ptr(ws), _ptr(cnt), _stream()))
+                                               1, 0, 0, M * K, N, 0, act_out, split_k, _ptr(ws), _ptr(cnt), _stream()))
     else:
         _lib.check(_lib.lib().rst_linear_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, K, N,
                                              act_out, _stream()))

@@ -365,8 +365,6 @@ def test_gemm_win_kb16_linear_epilogues():
     (100000, 200, 64),     # >= 768 tiles of 16-wide chunks; the second column tile is ragged (N = 200): fast / general alternate
     (131073 + 5, 128, 48), # ragged last row tile at the end of a workgroup's run
     (4100, 128, 4096),     # barely past the medium-M split route: 33 tiles, fewer than the resident workgroups
-    (262144 + 70, 256, 48),  # >= 2048 tiles of 256 x 128 (round 3's tile shape for the largest launches), ragged last row tile
-    (524288 + 129, 200, 32), # the same with a ragged second column tile and two k-tiles per tile
 ])
 def test_gemm_win_stream_linear_shapes(M, N, K):
     g = torch.Generator().manual_seed(M % 1000 + N + K)
@@ -376,12 +374,6 @@ def test_gemm_win_stream_linear_shapes(M, N, K):
     assert rel_err(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV)), ref.float()) < TOL
     y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), res=res.to(DEV), scale=scale.to(DEV), act_out=ops.ACT_GELU)
     assert rel_err(y, (res.double() + scale.double() * F.gelu(ref)).float()) < TOL
-    if M >= 262144:      # both tile shapes of the largest launches give the same thing
-        ops.GEMM_BIG_TILES = False
-        try:
-            assert rel_err(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), res=res.to(DEV), scale=scale.to(DEV), act_out=ops.ACT_GELU), y) < 1e-6
-        finally:
-            ops.GEMM_BIG_TILES = True
 
 
 def test_gemm_win_stream_short_utterances():
