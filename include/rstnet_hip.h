@@ -56,6 +56,20 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
                      int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, int split_k, float* ws,
                      uint32_t* counters, rst_stream_t stream);
 
+/* The same contraction on the bf16 matrix instruction at fp32 accuracy, for the large launches (B*T_out > 4096 rows, N > 64, K % 16 == 0;
+ * other shapes run exactly as rst_gemm_win_f32): every fp32 operand is the exact sum of three bf16 numbers (hi + mid + lo, each rounded
+ * to nearest even from the exact remainder), and six of the nine cross products are accumulated in fp32 (the three dropped are below
+ * 2^-23 |x||w|, one fp32 rounding of the product) -- 192 matrix-pipe cycles per 32x32x16 block instead of the f32 instruction's 512.
+ * The caller splits the weights once: w3 = rst_gemm_win_b3_weight_elems(N, K) uint16, filled by rst_gemm_win_b3_pack_weight (K % 16
+ * == 0; layout [ceil(N/128)][K/16][3][128][16], rows past N zero); activations are split inside the launch.  w (fp32) is still read
+ * by the tiles that touch an utterance edge.  Replaces the conv / linear bodies of AudioCodec/MimiCodec/modules/conv.py:178-252 for
+ * batched (non-streaming) encode / decode. */
+int rst_gemm_win_b3_weight_elems(int N, int K);   /* -1: bad sizes */
+int rst_gemm_win_b3_pack_weight(const float* w, uint16_t* w3, int N, int K, rst_stream_t stream);
+int rst_gemm_win_b3_f32(const float* x, const float* hist, const float* w, const uint16_t* w3, const float* bias, const float* res,
+                        const float* scale, float* y, int B, int T_in, int T_out, int C, int K, int N, int S, int P,
+                        int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, rst_stream_t stream);
+
 /* The few-row form of rst_gemm_win_f32 (M = B*T_out <= 128: one streaming frame for up to 64 streams), three entry points:
  *   rst_skinny_f32_pack_weight: w [N][K] fp32 -> wp [ceil(N/32)*32][Kp], Kp = K rounded up to 8, in MFMA operand order
  *     ([tile of 32 rows][Kp/8][64 lanes = 32*(k%2) + row%32][4 floats: k = 8q + 2e + k%2]); once per weight.

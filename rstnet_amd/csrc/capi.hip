@@ -27,10 +27,10 @@ extern "C" {
 int rst_version(void) { return 100; }
 const char* rst_last_error(void) { return g_err; }
 
-int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const float* bias, const float* res,
-                     const float* scale, float* y, int B, int T_in, int T_out, int C, int K, int N, int S, int P,
-                     int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, int split_k, float* ws,
-                     uint32_t* counters, rst_stream_t stream) {
+static int gemm_win_common(const float* x, const float* hist, const float* w, const uint16_t* w3, const float* bias, const float* res,
+                           const float* scale, float* y, int B, int T_in, int T_out, int C, int K, int N, int S, int P,
+                           int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, int split_k, float* ws,
+                           uint32_t* counters, rst_stream_t stream) {
     RST_REQUIRE(ldy >= N, "gemm_win: ldy (%d) < N (%d)", ldy, N);
     RST_REQUIRE(act_in == 0 || act_in == 1, "gemm_win: unknown act_in %d", act_in);
     RST_REQUIRE(act_out >= 0 && act_out <= 2, "gemm_win: unknown act_out %d", act_out);
@@ -40,8 +40,34 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
     p.B = B; p.T_in = T_in; p.T_out = T_out; p.C = C; p.K = K; p.N = N; p.S = S; p.P = P;
     p.pad_mode = pad_mode; p.x_bstride = x_bstride; p.ldy = ldy; p.act_in = act_in; p.act_out = act_out;
     p.split_k = split_k; p.ws = ws; p.counters = counters;
+    p.w3 = reinterpret_cast<const short*>(w3);
     RST_REQUIRE(split_k <= 1 || ldy == N, "gemm_win: split-K needs ldy == N");
     return rst_launch_gemm_win(p, (hipStream_t)stream);
+}
+
+int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const float* bias, const float* res,
+                     const float* scale, float* y, int B, int T_in, int T_out, int C, int K, int N, int S, int P,
+                     int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, int split_k, float* ws,
+                     uint32_t* counters, rst_stream_t stream) {
+    return gemm_win_common(x, hist, w, nullptr, bias, res, scale, y, B, T_in, T_out, C, K, N, S, P, pad_mode, x_bstride, ldy, act_in,
+                           act_out, split_k, ws, counters, stream);
+}
+
+int rst_gemm_win_b3_f32(const float* x, const float* hist, const float* w, const uint16_t* w3, const float* bias, const float* res,
+                        const float* scale, float* y, int B, int T_in, int T_out, int C, int K, int N, int S, int P,
+                        int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, rst_stream_t stream) {
+    RST_REQUIRE(w3, "gemm_win_b3: the split weights are required (rst_gemm_win_b3_pack_weight)");
+    return gemm_win_common(x, hist, w, w3, bias, res, scale, y, B, T_in, T_out, C, K, N, S, P, pad_mode, x_bstride, ldy, act_in,
+                           act_out, 1, nullptr, nullptr, stream);
+}
+
+int rst_gemm_win_b3_weight_elems(int N, int K) {
+    const long n = (N > 0 && K > 0) ? rst_gemm_win_b3_weight_elems_impl(N, K) : -1;
+    return n > 0 && n < 0x7fffffffL ? (int)n : -1;
+}
+
+int rst_gemm_win_b3_pack_weight(const float* w, uint16_t* w3, int N, int K, rst_stream_t stream) {
+    return rst_launch_gemm_win_b3_pack(w, w3, N, K, (hipStream_t)stream);
 }
 
 int rst_gemm_win_split_plan(int64_t M, int N, int K) { return rst_gemm_split_plan_impl((long)M, N, K); }

@@ -547,6 +547,344 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 
     }
 }
 
+// ---- three-plane bf16 form of the tile-streaming kernel ("b3") ---------------------------------------------------------------
+// The f32 matrix instruction runs at the VECTOR rate (157 TFLOP/s, 64 cycles per 32x32x2); the bf16 one is sixteen times faster.
+// An fp32 number is EXACTLY the sum of three bf16 numbers (hi = rne(x), mid = rne(x - hi), lo = rne(x - hi - mid): 8 + 8 + 8
+// significand bits, the two subtractions are exact), so an fp32 product is the sum of nine bf16 products, each exact in the fp32
+// accumulator.  Six of them are kept -- hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi -- and the three dropped (mid*lo, lo*mid, lo*lo)
+// are bounded by 2^-23 |x||w| (2^-8 * 2^-16 twice), the size of ONE fp32 rounding of the product: the result carries fp32 accuracy
+// (tests: <= 2e-6 of the fp64 value's scale, the same bound the f32-instruction path meets; RVQ codes as exact as with it) at
+// 6 x 32 = 192 matrix-pipe cycles per 32x32x16 block instead of 8 x 64 = 512.
+// Weights are split once on the host side of the ABI (rst_gemm_win_b3_pack_weight) into the staging order
+// [n tile of 128][K / 16][plane][128 rows][16 k] so a k-tile of W is three contiguous 4 KB pieces; activations stay fp32 in HBM and
+// are split on their way into LDS (v_cvt_pk_bf16_f32 + packed subtractions, ~4.5 VALU per element).  LDS rows are 16 bf16 + 8 pad
+// = 48 bytes: the 16 lanes of a ds_read_b128 group hold rows that are distinct mod 16, and 3 * row mod 16 is a bijection, so every
+// group covers 16 distinct 16-byte slots.  Two buffers of (128 + 128) rows x 3 planes = 72 KB: two workgroups per CU.
+// Tiles that touch an utterance edge take the f32-instruction routine above (fp32 weights), as in the fp32 stream kernel.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int B3_SETS_A = 4;                  // k-tiles of activations / of weights held in registers ahead of the one being multiplied
+constexpr int B3_SETS_B = 2;
+constexpr int B3_KB = 16;                     // k per stage (one bf16 matrix instruction deep)
+constexpr int B3_RS = 24;                     // shorts per LDS row (16 + 8 pad)
+constexpr int B3_PLANE = 128 * B3_RS;         // shorts per plane of one operand
+constexpr int B3_BUF = 6 * B3_PLANE;          // shorts per buffer: A planes 0..2, W planes 0..2
+constexpr int B3_WTILE = 3 * 128 * B3_KB;     // shorts per packed (n tile, k tile) piece of the weights
+
+// two fp32 -> the two packed bf16 (round to nearest even) and the exact remainders
+__device__ __forceinline__ unsigned b3_peel(f32x2& v) {
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    v[0] -= __uint_as_float(h << 16);
+    v[1] -= __uint_as_float(h & 0xffff0000u);
+    return h;
+}
+
+template <int V>
+struct b3_int { static constexpr int value = V; };
+
+// LDS rows are 48 bytes apart, so the rows whose 32-byte (activations: 4 lanes x 8 bytes; weights: 2 lanes x 16) pieces tile a
+// 128-byte bank window are r, r + 2, r + 4, r + 6: a write group (16 / 8 consecutive lanes = four consecutive row slots) is given
+// exactly those.  Slot g of a pass therefore stages row b3_row(g) (and the packed weights hold row b3_row(g) at slot g): with the
+// identity map every write group ran 2-way conflicted, a third of the kernel's LDS cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+__host__ __device__ __forceinline__ constexpr int b3_row(int g) { return (g & ~7) | (2 * (g & 3) + ((g >> 2) & 1)); }
+__host__ __device__ __forceinline__ constexpr int b3_slot(int r) { return (r & ~7) | (((r & 7) >> 1) + 4 * (r & 1)); }
+
+// The stream of k-tiles (tile after tile, as in gemm_win_stream_kernel) is a software pipeline in registers.  A stage (768 matrix-pipe
+// cycles, ~0.35 us) is shorter than a loaded round trip to L2 / HBM, so the loads run several stages ahead: the fp32 activation rows
+// of k-tile g + 4 and the weight planes (L2-resident) of k-tile g + 2 are requested at the top of stage g, four / two register sets
+// rotate, and the rotation is written out (b3_int<0..3>; K is a multiple of 64, so every tile starts on set 0).  While k-tile g is multiplied out of one LDS
+// buffer, k-tile g + 1 is split and written to the other buffer BETWEEN this stage's matrix instructions -- one 4-instruction peel
+// or one LDS write behind every second one, pinned there with scheduling fences: the wave issues in order, and whatever sits in
+// front of the first matrix instruction is time the pipe idles.
+// MASK: the launch has rows whose window reaches into the zero padding in front of / behind an utterance, or ragged last tiles.
+// Since C % 16 == 0, a window leaves its utterance on a k-tile boundary: every row carries the range [klo, khi) of k-tiles it really
+// reads, a k-tile outside it is loaded from a valid address of the same row and cleared when it is consumed (a bit per row travels
+// with the register set).  Launches with a history buffer or replicate padding stay on the f32-instruction kernels.
+// DBG (tools build only, WRONG results): 1 = no split / LDS writes, 2 = no global loads, 3 = matrix instructions only, 4 = no barriers
+template <bool ELU, bool MASK, int DBG = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_win_b3_stream_kernel(const GemmWinParams p, const int tiles) {
+    constexpr int TM = 2, TN = 2, WN = 2;
+    constexpr int BM = 128, BN = 128;
+    constexpr int RA = 2;                          // 64 row slots x 4 threads (16 bytes of fp32 each) per pass
+    constexpr int NSA = B3_SETS_A, NSB = B3_SETS_B;
+    static_assert(NSA == 4 && NSB == 2, "the rotation below is written out for four activation sets and two weight sets");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    short* const lds = reinterpret_cast<short*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = b3_row(tid >> 2);             // row (of the first pass) this thread stages
+    const int lk = (tid & 3) * 4;
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 8;
+
+    const int M = p.B * p.T_out;
+    const int TC = p.T_in * p.C;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nk = p.K / B3_KB;                    // a multiple of 4 (K % 64 == 0): checked by the launcher
+
+    const int xcd = blockIdx.x & 7;
+    const int first = gw_xcd_first(tiles, xcd);
+    const int count = gw_xcd_first(tiles, xcd + 1) - first;
+    const int stride = ((int)gridDim.x + 7 - xcd) >> 3;
+    int l = blockIdx.x >> 3;
+    if (l >= count) return;
+
+    struct Ctx {
+        const float* ap[RA];
+        int klo[RA], khi[RA];        // MASK: k-tiles [klo, khi) of the row's window lie inside its utterance
+    };
+    auto setup = [&](int m0, Ctx& c) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int m = m0 + lrow + 64 * j;
+            const int mm = min(m, M - 1);
+            const int b = mm / p.T_out;
+            const int t = mm - b * p.T_out;
+            const int f0 = (t * p.S - p.P) * p.C;
+            c.ap[j] = p.x + (long)b * p.x_bstride + f0 + lk;
+            if (MASK) {
+                int klo = max(0, -f0) / B3_KB, khi = min(p.K, TC - f0) / B3_KB;
+                if (m >= M || klo >= khi) {          // no such row / a window entirely in the padding: all zeros, loads parked on x
+                    klo = khi = 0;
+                    c.ap[j] = p.x + lk;
+                }
+                c.klo[j] = klo;
+                c.khi[j] = khi;
+            }
+        }
+    };
+    auto w_tile = [&](int n0) { return p.w3 + (long)(n0 / BN) * nk * B3_WTILE + tid * 8; };
+
+    f32x4 ra[NSA][RA];
+    int rm[NSA];                     // MASK: bit j = row j of the set is real data
+    u32x4 rb[NSB][3];
+    // LDS destinations of this thread's pieces (shorts from the start of a buffer)
+    const int a_dst = lrow * B3_RS + lk;
+    const int b_dst = 3 * B3_PLANE + b3_row(tid >> 1) * B3_RS + (tid & 1) * 8;
+    const int a_frag = (wm * TM * 32 + frag_row) * B3_RS + frag_k;
+    const int b_frag = 3 * B3_PLANE + (wn * TN * 32 + frag_row) * B3_RS + frag_k;
+
+    auto load_a = [&](const Ctx& c, const int kt, f32x4 (&dst)[RA], int& mask) {
+        mask = 3;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            int ks = kt;
+            if (MASK) {
+                const bool ok = kt >= c.klo[j] && kt < c.khi[j];
+                ks = ok ? kt : c.klo[j];
+                if (!ok) mask &= ~(1 << j);
+            }
+            dst[j] = *reinterpret_cast<const f32x4*>(c.ap[j] + ks * B3_KB);
+        }
+    };
+    // the fp32 values of a staged row piece as two pairs: padding cleared (MASK), ELU applied
+    auto take_a = [&](const f32x4 src, const int mask, const int j, f32x2 (&v)[2]) {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        f32x4 x = src;
+        if (MASK) {
+            int mm = (mask >> j) & 1 ? -1 : 0;
+            asm volatile("" : "+v"(mm));          // (a select the compiler could fold back into a branch around the load)
+            x = __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, x) & mm);
+        }
+        if (ELU) {
+            x[0] = rst_elu(x[0]); x[1] = rst_elu(x[1]); x[2] = rst_elu(x[2]); x[3] = rst_elu(x[3]);
+        }
+        v[0] = f32x2{x[0], x[1]};
+        v[1] = f32x2{x[2], x[3]};
+    };
+
+    f32x16 acc[TM][TN];
+    auto clear = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    };
+
+    // one stage: the k-tile of LDS buffer `buf` into the accumulators; register sets S -- the k-tile after it -- into buffer buf ^ 1;
+    // the requests of the stream position four ahead (activations: context c, k-tile kta; weights: bp, ktb) into the sets just freed
+    auto stage = [&](auto SS, const Ctx& c, const int kta, const short* bp, const int ktb, const int buf) {
+        constexpr int S = decltype(SS)::value;
+        constexpr int F = (S + 3) % 4, SB = S % 2, FB = (S + 1) % 2;
+        if (DBG != 2 && DBG != 3) {
+            // weights first: the wait for them counts requests in order, and must leave the younger activation requests in flight
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rb[FB][q] = *reinterpret_cast<const u32x4*>(bp + (long)ktb * B3_WTILE + q * (128 * B3_KB));
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(c, kta, ra[F], rm[F]);
+        }
+        bf16x8 fa[TM][3], fb[TN][3];
+        const short* rd = lds + buf * B3_BUF;
+        short* wr = lds + (buf ^ 1) * B3_BUF;
+        // fragments in the order the products below consume them
+        constexpr int QA[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+        constexpr int QB[6] = {0, 2, 1, 0, 1, 0};
+        if (DBG != 3) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j][0] = *reinterpret_cast<const bf16x8*>(rd + b_frag + j * 32 * B3_RS);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i][2] = *reinterpret_cast<const bf16x8*>(rd + a_frag + 2 * B3_PLANE + i * 32 * B3_RS);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i][0] = *reinterpret_cast<const bf16x8*>(rd + a_frag + i * 32 * B3_RS);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j][2] = *reinterpret_cast<const bf16x8*>(rd + b_frag + 2 * B3_PLANE + j * 32 * B3_RS);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i][1] = *reinterpret_cast<const bf16x8*>(rd + a_frag + B3_PLANE + i * 32 * B3_RS);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j][1] = *reinterpret_cast<const bf16x8*>(rd + b_frag + B3_PLANE + j * 32 * B3_RS);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i][q] = __builtin_bit_cast(bf16x8, ra[S][0]);
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) fb[jj][q] = __builtin_bit_cast(bf16x8, rb[SB][q]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        f32x2 v[RA][2];
+        u32x2 h[RA];
+        constexpr bool SIDE = DBG != 1 && DBG != 3;
+#pragma unroll
+        for (int m = 0; m < 24; ++m) {
+            const int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][QA[t]], fb[j][QB[t]], acc[i][j], 0, 0, 0);
+            // the side work of this slot
+            if (SIDE && m == 0) {
+#pragma unroll
+                for (int r = 0; r < RA; ++r) take_a(ra[S][r], rm[S], r, v[r]);
+            }
+            if (SIDE && m >= 1 && m <= 3) *reinterpret_cast<u32x4*>(wr + b_dst + (m - 1) * B3_PLANE) = rb[SB][m - 1];
+            if (SIDE && m >= 4 && m < 22 && (m & 1) == 0) {
+                // slots 4, 6, .., 20: plane q = (m - 4) / 6; w = 0, 1: the two rows' peels, w = 2: the LDS writes of plane q
+                const int u = (m - 4) >> 1;
+                const int q = u / 3, w = u % 3;
+                if (w < 2) {
+                    h[w][0] = b3_peel(v[w][0]);
+                    h[w][1] = b3_peel(v[w][1]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < RA; ++r) *reinterpret_cast<u32x2*>(wr + a_dst + q * B3_PLANE + r * 64 * B3_RS) = h[r];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (DBG != 4) __syncthreads();
+    };
+
+    // start of the run: k-tile 0 of the first tile to LDS, activations of k-tiles 1 .. 3 to sets 0 .. 2, weights of k-tile 1 to set 0
+    auto prime = [&](const Ctx& c, const short* bp, int buf) {
+        short* wr = lds + buf * B3_BUF;
+        {
+            f32x4 xa[RA];
+            int xm;
+            u32x4 xb[3];
+            load_a(c, 0, xa, xm);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xb[q] = *reinterpret_cast<const u32x4*>(bp + q * (128 * B3_KB));
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                f32x2 v[2];
+                take_a(xa[j], xm, j, v);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    u32x2 hh;
+                    hh[0] = b3_peel(v[0]);
+                    hh[1] = b3_peel(v[1]);
+                    *reinterpret_cast<u32x2*>(wr + a_dst + q * B3_PLANE + j * 64 * B3_RS) = hh;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(wr + b_dst + q * B3_PLANE) = xb[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rb[0][q] = *reinterpret_cast<const u32x4*>(bp + (long)B3_WTILE + q * (128 * B3_KB));
+#pragma unroll
+        for (int g = 1; g < 4; ++g) load_a(c, g, ra[g - 1], rm[g - 1]);
+        __syncthreads();
+    };
+
+    Ctx c;
+    int tile = first + l;
+    int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    setup(m0, c);
+    const short* bp = w_tile(n0);
+    const short* bpn = bp;           // weights of the tile the activation cursor has already moved on to
+    int kb = 2;
+    prime(c, bp, 0);
+    for (;;) {
+        const bool has_next = l + stride < count;
+        const int tile_n = tile + stride;
+        const int m0n = (tile_n / tiles_n) * BM, n0n = (tile_n % tiles_n) * BN;
+        clear();
+        // request cursors: activations four k-tiles ahead, weights two; each crosses into the next tile on its own stage (at the end of
+        // the run: harmless re-loads of this tile's first k-tiles)
+        int kf = 4;
+        auto cross = [&]() {
+            kf = 0;
+            if (has_next) {
+                setup(m0n, c);
+                bpn = w_tile(n0n);
+            }
+        };
+        for (int kt = 0; kt < nk; kt += 4) {
+            if (kf == nk) cross();
+            stage(b3_int<0>{}, c, kf, bp, kb, 0);
+            stage(b3_int<1>{}, c, kf + 1, bp, kb + 1, 1);
+            kb += 2;
+            if (kb == nk) {
+                kb = 0;
+                bp = bpn;
+            }
+            stage(b3_int<2>{}, c, kf + 2, bp, kb, 0);
+            stage(b3_int<3>{}, c, kf + 3, bp, kb + 1, 1);
+            kb += 2;
+            if (kb == nk) {
+                kb = 0;
+                bp = bpn;
+            }
+            kf += 4;
+        }
+        if (!MASK || (m0 + BM <= M && n0 + BN <= p.N)) gw_epilogue<TM, TN, true>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, M, lane);
+        else gw_epilogue<TM, TN, false>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, M, lane);
+        if (!has_next) break;
+        l += stride;
+        tile = tile_n;
+        m0 = m0n;
+        n0 = n0n;
+    }
+}
+
+// w fp32 [N][K] -> the three bf16 planes in staging order (rows past N: zeros); one thread per four k of one row
+__global__ __launch_bounds__(256) void gemm_win_b3_pack_kernel(const float* __restrict__ w, short* __restrict__ w3, int N, int K, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int kq = K / 4;
+    const int n = (int)(i / kq);
+    const int k = (int)(i % kq) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) v = *reinterpret_cast<const f32x4*>(w + (long)n * K + k);
+    f32x2 v0 = {v[0], v[1]}, v1 = {v[2], v[3]};
+    short* dst = w3 + ((long)(n / 128) * (K / B3_KB) + k / B3_KB) * B3_WTILE + b3_slot(n % 128) * B3_KB + k % B3_KB;     // slot g holds row b3_row(g)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        u32x2 h;
+        h[0] = b3_peel(v0);
+        h[1] = b3_peel(v1);
+        *reinterpret_cast<u32x2*>(dst + q * (128 * B3_KB)) = h;
+    }
+}
+
 template <int TM, int TN, int WM, int WN, int KB = BK>
 int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -620,6 +958,44 @@ int launch_stream(const GemmWinParams& p, long tiles, hipStream_t stream) {
     return rst_check_launch("gemm_win");
 }
 
+int launch_stream_b3(const GemmWinParams& p, long tiles, hipStream_t stream) {
+    if (tiles > 0x7fffffffL) {
+        rst_set_error("gemm_win: too many tiles (%ld)", tiles);
+        return RST_ERR_UNSUPPORTED;
+    }
+    const size_t lds = 2 * B3_BUF * sizeof(short);       // 73 728 bytes
+    static const int per_cu = rst_knob("RST_B3_WGS", 2);      // tools build only
+    const long resident = (long)per_cu * gw_cu_count();
+    const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
+    auto go = [&](auto kern) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipGetLastError();
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p, (int)tiles);
+    };
+    // rows whose window reaches into the zero padding (or past the end), ragged last tiles: the masked form
+    const long M = (long)p.B * p.T_out;
+    const bool lean = p.P == 0 && M % 128 == 0 && p.N % 128 == 0 && (long)(p.T_out - 1) * p.S * p.C + p.K <= (long)p.T_in * p.C;
+#ifdef RST_ABLATION
+    static const int dbg = rst_knob("RST_B3_DBG", 0);
+    if (dbg == 1) { go(gemm_win_b3_stream_kernel<false, true, 1>); return rst_check_launch("gemm_win_b3"); }
+    if (dbg == 2) { go(gemm_win_b3_stream_kernel<false, true, 2>); return rst_check_launch("gemm_win_b3"); }
+    if (dbg == 3) { go(gemm_win_b3_stream_kernel<false, true, 3>); return rst_check_launch("gemm_win_b3"); }
+    if (dbg == 4) { go(gemm_win_b3_stream_kernel<false, true, 4>); return rst_check_launch("gemm_win_b3"); }
+#endif
+    if (p.act_in == 1) {
+        if (lean) go(gemm_win_b3_stream_kernel<true, false>);
+        else go(gemm_win_b3_stream_kernel<true, true>);
+    } else {
+        if (lean) go(gemm_win_b3_stream_kernel<false, false>);
+        else go(gemm_win_b3_stream_kernel<false, true>);
+    }
+    return rst_check_launch("gemm_win_b3");
+}
+
 }  // namespace
 
 // Tile shape the launcher picks for (M, N): 0 = 128 x 128, 1 = 32 x 128, 2 = 128 x 64, 3 = 256 x 32.
@@ -670,6 +1046,10 @@ int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
             static const bool kb32_only = rst_knob("RST_GEMM_KB32", 0) != 0;
             static const bool stream_off = rst_knob("RST_GEMM_STREAM", 1) == 0;
             if (vec && !stream_off && p.split_k <= 1) {
+                // the three-plane bf16 form when the caller passed the split weights (K % 64 == 0: whole rotations of the four register sets)
+                // (zero padding only: a history buffer / replicate padding keeps the launch on the f32 instruction)
+                if (p.w3 && p.K % 64 == 0 && p.C % 16 == 0 && !p.hist && p.pad_mode == 0 && (uintptr_t)p.w3 % 16 == 0)
+                    return launch_stream_b3(p, tiles, stream);
                 if (tiles >= 768 && !kb32_only) return launch_stream<16>(p, tiles, stream);
                 return launch_stream<32>(p, tiles, stream);
             }
@@ -687,4 +1067,15 @@ int rst_gemm_split_tiles_impl(long M, int N) {
     int BM, BN;
     gw_tile_dims(gw_tile_cfg(M, N), BM, BN);
     return (int)(((M + BM - 1) / BM) * ((N + BN - 1) / BN));
+}
+
+// ---- split weights of the three-plane bf16 form
+long rst_gemm_win_b3_weight_elems_impl(int N, int K) { return (long)((N + 127) / 128) * 128 * K * 3; }
+
+int rst_launch_gemm_win_b3_pack(const float* w, unsigned short* w3, int N, int K, hipStream_t stream) {
+    RST_REQUIRE(w && w3 && N > 0 && K > 0 && K % 16 == 0, "gemm_win_b3_pack_weight: bad arguments (K %% 16 == 0 required, N=%d K=%d)", N, K);
+    RST_REQUIRE((uintptr_t)w % 16 == 0 && (uintptr_t)w3 % 16 == 0, "gemm_win_b3_pack_weight: pointers must be 16-byte aligned");
+    const long total = (long)((N + 127) / 128) * 128 * (K / 4);
+    hipLaunchKernelGGL(gemm_win_b3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<short*>(w3), N, K, total);
+    return rst_check_launch("gemm_win_b3_pack_weight");
 }

@@ -24,8 +24,12 @@ struct GemmWinParams {
     int split_k;         // > 1: K split over gridDim.y workgroups (M <= 4096), partials in ws, one counter per tile
     float* ws;           // [split_k][M][N]
     unsigned* counters;  // [rst_gemm_split_tiles_impl(M, N)], zero before the first launch (self re-arming)
+    const short* w3;     // optional: w as three bf16 planes in staging order (rst_launch_gemm_win_b3_pack) -- large-M launches then run
+                         // on the bf16 matrix instruction (six products per fp32 product, fp32 accuracy); nullptr: f32 instruction
 };
 int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream);
+long rst_gemm_win_b3_weight_elems_impl(int N, int K);
+int rst_launch_gemm_win_b3_pack(const float* w, unsigned short* w3, int N, int K, hipStream_t stream);
 int rst_gemm_split_plan_impl(long M, int N, int K);
 int rst_gemm_split_tiles_impl(long M, int N);
 

@@ -11,6 +11,9 @@ legacy remaps of llama_streaming.py:762-766,1000-1009,1034-1088), method signatu
 Execution (csrc/lm_step.hip, lm_attn.hip, lm_skinny.hip): bf16 weights, fp32 activations.
   * LoRA adapters are merged into the dense weights when a state dict is loaded (what the reference's ``merge_lora_weights``
     does before inference, :1120-), including the reference's zero_pad behaviour when q, k and v are all adapted.
+    ``from_state_dict(..., merge_lora=False)`` keeps them apart instead, as ``LoRALinear.forward`` / ``LoRAQKVLinear.forward`` run
+    them (:136-143, :373-406): every adapted linear is followed by two thin GEMMs, ``y += B_full (scaling * (A x))`` (same prologue as
+    the dense product; the fused-QKV / stacked-gate B is laid out block-diagonally in the kernels' row order, rank padded to 16).
   * The fused QKV rows are re-ordered once from the GQA-interleaved ``[group: q.. k v]`` layout to ``[Q | K | V]`` and, inside
     every q / k head, from rotate-half pairing ``(i, i + n/2)`` to interleaved pairing ``(2i, 2i+1)`` -- a permutation applied to
     q and k alike leaves q.k unchanged -- so the ring-attention kernels of the Moshi path serve this model too.
@@ -242,6 +245,35 @@ def _qkv_row_order(cfg: Config) -> torch.Tensor:
     return torch.cat(order)
 
 
+def _pow2(v: float) -> bool:
+    import math
+    return v > 0 and math.frexp(v)[0] == 0.5
+
+
+def _pad_rank(A: torch.Tensor, Bm: torch.Tensor, scale: float):
+    """(A ``[r', in]``, B ``[out, r']``, post-scale): the rank padded with zeros to a multiple of 16 (the K granule of the thin
+    second product); a power-of-two ``alpha / r`` is folded into B exactly, any other value is applied to ``A x`` in fp32."""
+    r = A.shape[0]
+    rp = (r + 15) // 16 * 16
+    fold = _pow2(scale)
+    Ap = torch.zeros(rp, A.shape[1], device=A.device, dtype=torch.bfloat16)
+    Ap[:r] = A.detach().to(torch.bfloat16)
+    Bp = torch.zeros(Bm.shape[0], rp, device=Bm.device, dtype=torch.bfloat16)
+    Bp[:, :r] = (Bm.detach().float() * scale).to(torch.bfloat16) if fold else Bm.detach().to(torch.bfloat16)
+    return Ap.contiguous(), Bp.contiguous(), (1.0 if fold else float(scale))
+
+
+def _lora_add(y: torch.Tensor, x, ad, **prologue) -> torch.Tensor:
+    """``y + B (scaling * (A P(x)))`` -- the unmerged LoRA branch (llama_streaming.py:136-143) as two thin products."""
+    if ad is None:
+        return y
+    A, Bm, scale = ad
+    a = ops.lm_linear(x, A, **prologue)
+    if scale != 1.0:
+        a = a * scale
+    return ops.lm_linear(a, Bm, res=y)
+
+
 # ----------------------------------------------------------------------------------------------------------------- modules
 class _Linear(nn.Module):
     """``<name>.linear.{weight,bias}`` holder (a merged LoRALinear)."""
@@ -252,6 +284,22 @@ class _Linear(nn.Module):
         self.linear.weight = nn.Parameter(torch.empty(out_f, in_f, device=device, dtype=dtype), requires_grad=False)
         self.linear.bias = nn.Parameter(torch.zeros(out_f, device=device, dtype=dtype), requires_grad=False) if bias else None
         self._b32 = _PackedCache()
+        self.register_parameter("lora_A", None)      # unmerged adapters (GPT.from_state_dict(..., merge_lora=False))
+        self.register_parameter("lora_B", None)
+        self.lora_scale = 0.0
+        self._ad = _PackedCache()
+
+    def set_adapter(self, A: Optional[torch.Tensor], Bm: Optional[torch.Tensor], scale: float) -> None:
+        self.lora_A = None if A is None else nn.Parameter(A, requires_grad=False)
+        self.lora_B = None if Bm is None else nn.Parameter(Bm, requires_grad=False)
+        self.lora_scale = float(scale)
+        self._ad = _PackedCache()
+
+    def adapter(self):
+        """``(A, B, post_scale)`` in kernel form, or None for a linear without (unmerged) adapters."""
+        if self.lora_A is None:
+            return None
+        return self._ad.get((self.lora_A, self.lora_B), lambda: _pad_rank(self.lora_A, self.lora_B, self.lora_scale))
 
     @property
     def weight(self) -> torch.Tensor:
@@ -311,6 +359,32 @@ class CausalSelfAttention(nn.Module):
                     None if b is None else b.detach().float().index_select(0, order).contiguous())
         return self._packed.get((w,) if b is None else (w, b), build)
 
+    def packed_qkv_adapter(self):
+        """The fused-QKV adapter in kernel form: ``B_full [rows of packed_qkv, r * enabled]`` holds each adapted projection's B block
+        in its own r columns (LoRAQKVLinear.conv1d, :310-354), on the rows ``zero_pad`` sends them to (:259-308, incl. its 'as is'
+        return when q, k and v are all adapted), then in the [Q | K | V] / interleaved-rotary row order of ``packed_qkv``."""
+        lin, c = self.attn, self.config
+        if lin.lora_A is None:
+            return None
+        if not hasattr(self, "_packed_ad"):
+            self._packed_ad = _PackedCache()
+
+        def build():
+            enable = (c.lora_query, c.lora_key, c.lora_value)
+            sizes = [n for n, e in zip((c.head_size * c.n_head, c.head_size * c.n_query_groups, c.head_size * c.n_query_groups), enable) if e]
+            r = c.lora_r
+            Bm = lin.lora_B.detach()
+            rows = _qkv_lora_rows(c, enable)
+            rows = torch.arange(Bm.shape[0]) if rows is None else rows
+            full = torch.zeros(lin.linear.weight.shape[0], r * len(sizes), device=Bm.device, dtype=Bm.dtype)
+            row = 0
+            for i, n in enumerate(sizes):
+                full[rows[row:row + n].to(Bm.device), i * r:(i + 1) * r] = Bm[row:row + n]
+                row += n
+            full = full.index_select(0, _qkv_row_order(c).to(Bm.device))
+            return _pad_rank(lin.lora_A, full, lin.lora_scale)
+        return self._packed_ad.get((lin.lora_A, lin.lora_B), build)
+
 
 class LLaMAMLP(nn.Module):
     """Weights of llama_streaming.py:1046-1088 / lit_model.py:391-403; fc_1 | fc_2 are stacked for the gated GEMV."""
@@ -330,6 +404,29 @@ class LLaMAMLP(nn.Module):
             return (torch.cat([w1.detach(), w2.detach()]).contiguous(),
                     None if b1 is None else torch.cat([b1.detach().float(), b2.detach().float()]).contiguous())
         return self._packed.get((w1, w2) if b1 is None else (w1, w2, b1, b2), build)
+
+    def packed_fc_adapter(self):
+        """Adapters of fc_1 | fc_2 for the stacked product: A's stacked, B's block-diagonal (either may be absent)."""
+        l1, l2 = self.fc_1, self.fc_2
+        if l1.lora_A is None and l2.lora_A is None:
+            return None
+        if not hasattr(self, "_packed_ad"):
+            self._packed_ad = _PackedCache()
+        present = [l for l in (l1, l2) if l.lora_A is not None]
+
+        def build():
+            I = l1.linear.weight.shape[0]
+            scale = present[0].lora_scale
+            As = [l.lora_A.detach() for l in present]
+            full = torch.zeros(2 * I, sum(a.shape[0] for a in As), device=As[0].device, dtype=As[0].dtype)
+            col = 0
+            for l in present:
+                r = l.lora_A.shape[0]
+                o = 0 if l is l1 else I
+                full[o:o + I, col:col + r] = l.lora_B.detach()
+                col += r
+            return _pad_rank(torch.cat(As), full, scale)
+        return self._packed_ad.get(tuple(p for l in present for p in (l.lora_A, l.lora_B)), build)
 
 
 class Block(nn.Module):
@@ -383,8 +480,8 @@ class LLAMAStreamingTransformer(StreamingModule[_StepState]):
             rope_table = ops.lm_rope_table(st.pos, hs, max_period=float(c.rope_base), rope_dims=n)
         for l, blk in enumerate(self.h):
             wqkv, bqkv = blk.attn.packed_qkv()
-            qkv = ops.lm_linear(x, wqkv, prologue=ops.PROLOGUE_RMSNORM, alpha=blk.norm_1.gain_f32(), eps=blk.norm_1.eps, bias=bqkv,
-                                fp8=f8)
+            n1 = dict(prologue=ops.PROLOGUE_RMSNORM, alpha=blk.norm_1.gain_f32(), eps=blk.norm_1.eps)
+            qkv = _lora_add(ops.lm_linear(x, wqkv, bias=bqkv, fp8=f8, **n1), x, blk.attn.packed_qkv_adapter(), **n1)
             if T == 1:
                 a = ops.lm_attn_decode(qkv, st.k[l], st.v[l], st.pos, rope=True, context=c.context, max_period=float(c.rope_base),
                                        scratch=st.scratch, heads=H, rope_dims=n, packed=B > 2 and not f8, rope_table=rope_table)
@@ -392,10 +489,17 @@ class LLAMAStreamingTransformer(StreamingModule[_StepState]):
                 q = ops.lm_rope_append(qkv.view(B, T, -1), st.k[l], st.v[l], st.pos, heads=H, rope=True,
                                        max_period=float(c.rope_base), rope_dims=n)
                 a = ops.attention(q, st.k[l], st.v[l], pos_dev=st.pos, ring=True, context=c.context).view(B * T, H * hs)
-            x = ops.lm_linear(a, blk.attn.proj.weight, res=x, bias=blk.attn.proj.bias_f32(), fp8=f8)
+            x = _lora_add(ops.lm_linear(a, blk.attn.proj.weight, res=x, bias=blk.attn.proj.bias_f32(), fp8=f8), a, blk.attn.proj.adapter())
             wfc, bfc = blk.mlp.packed_fc()
-            x = ops.lm_gated_pair(x, wfc, blk.mlp.proj.weight, alpha=blk.norm_2.gain_f32(), eps=blk.norm_2.eps, res=x, bias_in=bfc,
-                                  bias_out=blk.mlp.proj.bias_f32(), fp8=f8)
+            ad_fc, ad_proj = blk.mlp.packed_fc_adapter(), blk.mlp.proj.adapter()
+            if ad_fc is None and ad_proj is None:
+                x = ops.lm_gated_pair(x, wfc, blk.mlp.proj.weight, alpha=blk.norm_2.gain_f32(), eps=blk.norm_2.eps, res=x, bias_in=bfc,
+                                      bias_out=blk.mlp.proj.bias_f32(), fp8=f8)
+            else:       # unmerged adapters: the gate follows fc_1 / fc_2 WITH their updates, so the pair runs as two plain products
+                n2 = dict(prologue=ops.PROLOGUE_RMSNORM, alpha=blk.norm_2.gain_f32(), eps=blk.norm_2.eps)
+                u = _lora_add(ops.lm_linear(x, wfc, bias=bfc, fp8=f8, **n2), x, ad_fc, **n2)
+                x = _lora_add(ops.lm_linear(u, blk.mlp.proj.weight, prologue=ops.PROLOGUE_SILU_GATE, res=x, bias=blk.mlp.proj.bias_f32(),
+                                            fp8=f8), u, ad_proj, prologue=ops.PROLOGUE_SILU_GATE)
         st.pos.add_(T)
         st.offset_cpu += T
         return ops.rmsnorm(x, self.ln_f.gain_f32(), self.ln_f.eps)
@@ -420,6 +524,7 @@ class GPT(StreamingModule[_GPTState]):
         fk = {"device": device, "dtype": dtype}
         self.lm_head = _Linear(config.n_embd, config.padded_vocab_size, config.lm_head_bias, **fk)
         self._lora_base: Optional[Dict[str, torch.Tensor]] = None      # from_state_dict(..., keep_lora_base=True)
+        self._unmerged = False                                         # from_state_dict(..., merge_lora=False)
         self.dep_q = config.dep_q
         self.transformer = LLAMAStreamingTransformer(config, **fk)
         self.max_seq_length = config.block_size
@@ -490,11 +595,14 @@ class GPT(StreamingModule[_GPTState]):
         tables = [e.weight for e in self.input_emb] + [self.transformer.wte.weight]
         return ops.embed_sum(toks, tables, list(range(1, K)) + [0])       # audio streams first, then text, as :680-686
 
+    def _head(self, h: torch.Tensor) -> torch.Tensor:
+        return _lora_add(ops.lm_linear(h, self.lm_head.weight, bias=self.lm_head.bias_f32()), h, self.lm_head.adapter())
+
     def _global_step(self, toks: torch.Tensor):
         """One streamed position: toks int64 ``[B, n_q+1]`` -> (hidden ``[B, n_embd]``, text logits ``[B, V]``)."""
         st = self.transformer._streaming_state
         h = self.transformer.run(self._embed(toks), toks.shape[0], 1, st)
-        return h, ops.lm_linear(h, self.lm_head.weight, bias=self.lm_head.bias_f32())
+        return h, self._head(h)
 
     @torch.no_grad()
     def forward_global(self, sequence: torch.Tensor):
@@ -514,7 +622,7 @@ class GPT(StreamingModule[_GPTState]):
             st = self.transformer._make_state(B, T + 1)      # a ring that never fills: positions 0..T-1 all addressable
         toks = sequence.permute(0, 2, 1).reshape(B * T, K).contiguous()
         h = self.transformer.run(self._embed(toks), B, T, st)
-        logits = ops.lm_linear(h, self.lm_head.weight, bias=self.lm_head.bias_f32())
+        logits = self._head(h)
         return h.view(B, T, c.n_embd), logits.view(B, T, -1)
 
     # ---- local (depth) transformer
@@ -608,17 +716,26 @@ class GPT(StreamingModule[_GPTState]):
 
     # ---- loading
     @classmethod
-    def from_state_dict(cls, sd: Dict[str, torch.Tensor], config: Config, keep_lora_base: bool = False) -> "GPT":
+    def from_state_dict(cls, sd: Dict[str, torch.Tensor], config: Config, keep_lora_base: bool = False, merge_lora: bool = True) -> "GPT":
         """Model for ``config`` with weights taken from ``sd`` (reference key names, legacy base-checkpoint names accepted,
         LoRA adapters merged) without copying the dense tensors.  ``keep_lora_base``: also keep a copy of the un-adapted weight
         of every adapted linear, so that ``load_adapters`` can swap adapter sets later (the reference keeps adapters unmerged
-        for that, llama_streaming.py:113-143; here a swap re-merges in place)."""
+        for that, llama_streaming.py:113-143; here a swap re-merges in place).  ``merge_lora=False``: the dense weights stay as
+        they are and the adapters run as their own thin products behind every adapted linear (the reference's forward before
+        ``merge_lora_weights``; ``state_dict()`` then carries ``<name>.lora_A`` / ``<name>.lora_B`` like the reference's, and
+        ``load_adapters`` swaps the tensors without touching a dense weight)."""
         sd = _remap_legacy(dict(sd))
         sd = {k: v for k, v in sd.items() if not k.endswith(("cos", "sin", "_lora_ind"))}
         bases = None
         if any(k.endswith(".lora_A") for k in sd):
             if config.lora_r <= 0:
                 raise RuntimeError("state dict carries LoRA adapters but config.lora_r == 0")
+            if not merge_lora:
+                is_ad = lambda k: k.endswith((".lora_A", ".lora_B"))
+                model = cls._from_merged({k: v for k, v in sd.items() if not is_ad(k)}, config)
+                model._unmerged = True
+                model._set_adapters({k: v for k, v in sd.items() if is_ad(k)})
+                return model
             if keep_lora_base:
                 bases = _lora_bases(sd)
             sd = merge_lora_state_dict(sd, config)
@@ -633,10 +750,14 @@ class GPT(StreamingModule[_GPTState]):
         set does not adapt -- or all of them, ``adapters=None`` -- return to their base weights.  The kernel-side packed copies
         follow the weights' ``_version``, so the next call re-packs what changed; captured decode graphs hold the OLD packed
         copies, hence swaps are only allowed between sessions (outside ``streaming()`` / ``GPTGen.begin``)."""
-        if self._lora_base is None:
-            raise RuntimeError("load_adapters needs a model built with from_state_dict(..., keep_lora_base=True) from a state dict with adapters")
+        if self._lora_base is None and not self._unmerged:
+            raise RuntimeError("load_adapters needs a model built with from_state_dict(..., keep_lora_base=True) or (..., merge_lora=False) "
+                               "from a state dict with adapters")
         if self._streaming_state is not None or self.transformer._streaming_state is not None:
             raise RuntimeError("load_adapters: swap adapters between sessions, not inside streaming()")
+        if self._unmerged:      # (captured decode graphs hold the launches of the OLD adapter set, hence the same between-sessions rule)
+            self._set_adapters({} if adapters is None else {k: v for k, v in adapters.items() if k.endswith((".lora_A", ".lora_B"))})
+            return
         adapters = {} if adapters is None else {k: v for k, v in adapters.items() if k.endswith((".lora_A", ".lora_B"))}
         unknown = [k for k in adapters if k.endswith(".lora_A") and k[: -len(".lora_A")] + ".linear.weight" not in self._lora_base]
         if unknown:
@@ -648,6 +769,53 @@ class GPT(StreamingModule[_GPTState]):
         with torch.no_grad():
             for name in self._lora_base:
                 params[name].copy_(merged[name])
+
+    def _adapted_linears(self) -> Dict[str, "_Linear"]:
+        """The linears the config adapts (llama_streaming.py:870-882 attn / proj, :1049-1072 mlp, :530-537 lm_head), by key prefix."""
+        c = self.config
+        out: Dict[str, _Linear] = {}
+        if c.lora_r <= 0:
+            return out
+        if c.lora_head:
+            out["lm_head"] = self.lm_head
+        for l, blk in enumerate(self.transformer.h):
+            p = f"transformer.h.{l}"
+            if c.lora_query or c.lora_key or c.lora_value:
+                out[f"{p}.attn.attn"] = blk.attn.attn
+            if c.lora_projection:
+                out[f"{p}.attn.proj"] = blk.attn.proj
+            if c.lora_mlp:
+                out.update({f"{p}.mlp.fc_1": blk.mlp.fc_1, f"{p}.mlp.fc_2": blk.mlp.fc_2, f"{p}.mlp.proj": blk.mlp.proj})
+        return out
+
+    def _set_adapters(self, adapters: Dict[str, torch.Tensor]) -> None:
+        """Install ``<name>.lora_A`` / ``<name>.lora_B`` on the linears the config adapts (shapes as the reference allocates them,
+        :107-110, :205-221); linears without an entry run without a LoRA branch."""
+        c = self.config
+        lin = self._adapted_linears()
+        names = {k[: -len(".lora_A")] for k in adapters if k.endswith(".lora_A")} | {k[: -len(".lora_B")] for k in adapters if k.endswith(".lora_B")}
+        unknown = sorted(n for n in names if n not in lin)
+        if unknown:
+            raise RuntimeError(f"adapters for linears the config does not adapt: {unknown[:3]}")
+        dev = self.lm_head.weight.device
+        for name, m in lin.items():
+            if name not in names:
+                m.set_adapter(None, None, 0.0)
+                continue
+            if f"{name}.lora_A" not in adapters or f"{name}.lora_B" not in adapters:
+                raise RuntimeError(f"{name}: lora_A and lora_B come as a pair")
+            A, Bm = adapters[f"{name}.lora_A"], adapters[f"{name}.lora_B"]
+            n_en = sum((c.lora_query, c.lora_key, c.lora_value)) if name.endswith(".attn.attn") else 1
+            out_f = m.linear.weight.shape[0]
+            if name.endswith(".attn.attn"):
+                out_f = sum(n for n, e in zip((c.head_size * c.n_head, c.head_size * c.n_query_groups, c.head_size * c.n_query_groups),
+                                              (c.lora_query, c.lora_key, c.lora_value)) if e)
+            if tuple(A.shape) != (c.lora_r * n_en, m.linear.weight.shape[1]) or tuple(Bm.shape) != (out_f, c.lora_r):
+                raise RuntimeError(f"{name}: adapter shapes {tuple(A.shape)} / {tuple(Bm.shape)} do not fit r={c.lora_r}")
+            m.set_adapter(A.to(dev), Bm.to(dev), c.lora_alpha / c.lora_r)
+        for blk in self.transformer.h:      # kernel-side forms are rebuilt from the new tensors
+            blk.attn._packed_ad = _PackedCache()
+            blk.mlp._packed_ad = _PackedCache()
 
     @classmethod
     def _from_merged(cls, sd: Dict[str, torch.Tensor], config: Config) -> "GPT":

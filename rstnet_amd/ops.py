@@ -136,6 +136,32 @@ def _gemm_split_scratch(device, M: int, N: int, K: int):
 _skinny_f32_weights = _PackedWeights()
 SKINNY_F32_MAX_ROWS = 128
 
+# Large launches (more than 4096 rows, N > 64, K % 64 == 0 -- the batched encode / decode of utterances) run on the bf16 matrix
+# instruction with every fp32 operand split into three bf16 planes (rst_gemm_win_b3_f32: six products per fp32 product, fp32
+# accuracy, 2.7x the f32 instruction's rate).  False: the f32 matrix instruction everywhere (the A/B switch of tools/ab.py).
+GEMM_B3 = True
+_b3_weights = _PackedWeights()
+
+
+def gemm_win_b3_pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """fp32 ``[N, K]`` -> its three bf16 planes in the staging order of the large-M kernel (rst_gemm_win_b3_pack_weight), cached per
+    storage / version like the other packed copies."""
+    _chk(w, "w")
+    N, K = w.shape
+
+    def build():
+        n = int(_lib.lib().rst_gemm_win_b3_weight_elems(N, K))
+        if n <= 0:
+            raise ValueError(f"rstnet_amd.ops: no three-plane form for a [{N}, {K}] weight")
+        w3 = torch.empty(n, device=w.device, dtype=torch.int16)
+        _lib.check(_lib.lib().rst_gemm_win_b3_pack_weight(_ptr(w), _ptr(w3), N, K, _stream()))
+        return w3
+    return _b3_weights.get(w, build)
+
+
+def _b3_shape(M: int, N: int, K: int) -> bool:
+    return GEMM_B3 and M > 4096 and N > 64 and K % 64 == 0
+
 
 def skinny_f32_pack_weight(w: torch.Tensor) -> torch.Tensor:
     """fp32 ``[N, K]`` -> MFMA-ordered copy ``[ceil(N/32)*32, ceil(K/8)*8]`` (rst_skinny_f32_pack_weight), cached per storage."""
@@ -203,13 +229,20 @@ def gemm_win(x: torch.Tensor, w: torch.Tensor, *, B: int, T_in: int, T_out: int,
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.lib().rst_gemm_win_f32(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out),
-                                           B, T_in, T_out, C_, K, N, S, P, pad_mode, T_in * C_, N, act_in, act_out,
-                                           split_k, _ptr(ws), _ptr(cnt), _stream()))
+    # (zero padding only: a history buffer / replicate padding keeps the launch on the f32 instruction, as the launcher decides too)
+    b3 = split_k <= 1 and _b3_shape(B * T_out, N, K) and hist is None and pad_mode == PAD_ZERO and C_ % 16 == 0
+    if b3:
+        _lib.check(_lib.lib().rst_gemm_win_b3_f32(_ptr(x), _ptr(hist), _ptr(w), _ptr(gemm_win_b3_pack_weight(w)), _ptr(bias), _ptr(res),
+                                                  _ptr(scale), _ptr(out), B, T_in, T_out, C_, K, N, S, P, pad_mode, T_in * C_, N, act_in,
+                                                  act_out, _stream()))
+    else:
+        _lib.check(_lib.lib().rst_gemm_win_f32(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out),
+                                               B, T_in, T_out, C_, K, N, S, P, pad_mode, T_in * C_, N, act_in, act_out,
+                                               split_k, _ptr(ws), _ptr(cnt), _stream()))
     if prof is not None:
         e1.record()
         nbytes = 4 * (x.numel() + w.numel() + out.numel() + (res.numel() if res is not None else 0))
-        prof.append(("gemm_win", e0, e1, 2.0 * B * T_out * N * K, nbytes, (B * T_out, N, K)))
+        prof.append(("gemm_win_b3" if b3 else "gemm_win", e0, e1, 2.0 * B * T_out * N * K, nbytes, (B * T_out, N, K)))
     return out
 
 
@@ -248,16 +281,20 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    b3 = split_k <= 1 and _b3_shape(M, N, K)
     if split_k > 1:
         _lib.check(_lib.lib().rst_gemm_win_f32(_ptr(x), None, _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), 1, M, M, K, K, N,
                                                1, 0, 0, M * K, N, 0, act_out, split_k, _ptr(ws), _ptr(cnt), _stream()))
+    elif b3:
+        _lib.check(_lib.lib().rst_gemm_win_b3_f32(_ptr(x), None, _ptr(w), _ptr(gemm_win_b3_pack_weight(w)), _ptr(bias), _ptr(res), _ptr(scale),
+                                                  _ptr(out), 1, M, M, K, K, N, 1, 0, 0, M * K, N, 0, act_out, _stream()))
     else:
         _lib.check(_lib.lib().rst_linear_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, K, N,
                                              act_out, _stream()))
     if prof is not None:
         e1.record()
         nbytes = 4 * (x.numel() + w.numel() + out.numel() + (res.numel() if res is not None else 0))
-        prof.append(("gemm_win", e0, e1, 2.0 * M * N * K, nbytes, (M, N, K)))
+        prof.append(("gemm_win_b3" if b3 else "gemm_win", e0, e1, 2.0 * M * N * K, nbytes, (M, N, K)))
     return out
 
 

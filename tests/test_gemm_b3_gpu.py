@@ -1,0 +1,96 @@
+"""The three-plane bf16 form of the large windowed GEMMs (rst_gemm_win_b3_f32, gemm_win.hip: every fp32 operand = hi + mid + lo in
+bf16, six of the nine cross products on the bf16 matrix instruction, fp32 accumulate) against fp64 references: the split is exact,
+and the results carry fp32 accuracy -- the same error scale as the f32 matrix instruction's, which stays the route of every other
+shape (and of `ops.GEMM_B3 = False`)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mimi_oracle as O
+from rstnet_amd import _lib, ops, synth
+from rstnet_amd.codec import functional as RF
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+U = 2.0 ** -24
+
+
+def unpack_b3(w3: torch.Tensor, N: int, K: int) -> torch.Tensor:
+    """[ceil(N/128)][K/16][3][128 slots][16] int16 -> the three planes as fp32 ``[3, ceil(N/128)*128, K]``; slot g of a tile holds
+    row (g & ~7) | (2 * (g & 3) + ((g >> 2) & 1)) (the order that keeps the kernel's LDS writes free of bank conflicts)."""
+    nt = -(-N // 128)
+    t = w3.view(nt, K // 16, 3, 128, 16).permute(2, 0, 3, 1, 4).reshape(3, nt * 128, K)
+    r = torch.arange(nt * 128, device=w3.device)
+    slot = (r & ~7) | (((r & 7) >> 1) + 4 * (r & 1))
+    return (t.index_select(1, slot).to(torch.int32) << 16).view(torch.float32)
+
+
+@pytest.mark.parametrize("N,K", [(128, 32), (200, 64), (513, 2048), (64, 16)])   # (the packing itself only needs K % 16 == 0)
+def test_split_weights_are_exact(N, K):
+    g = torch.Generator().manual_seed(N + K)
+    w = (torch.randn(N, K, generator=g) * torch.exp(4 * torch.randn(N, K, generator=g))).to(DEV)      # wide dynamic range
+    w3 = ops.gemm_win_b3_pack_weight(w)
+    assert w3.numel() == _lib.lib().rst_gemm_win_b3_weight_elems(N, K) == -(-N // 128) * 128 * K * 3
+    planes = unpack_b3(w3, N, K)
+    assert not planes[:, N:].any()                                # rows past N are zero
+    hi, mid, lo = planes[:, :N]
+    assert torch.equal((hi + mid) + lo, w)                       # three bf16 numbers, exactly the fp32 value
+    assert float((mid.abs() / hi.abs().clamp_min(1e-30)).max()) <= 2.0 ** -8 * 1.01
+    assert float((lo.abs() / hi.abs().clamp_min(1e-30)).max()) <= 2.0 ** -16 * 1.01
+
+
+def _backward_error(y, ref, bound):
+    return float(((y.double().cpu() - ref).abs() / bound).max())
+
+
+@pytest.mark.parametrize("M,N,K", [(16640, 512, 192), (100000, 200, 64), (8200, 1024, 2048), (5000, 128, 64), (4100, 128, 4096)])
+def test_b3_linear_carries_fp32_accuracy(M, N, K, monkeypatch):
+    g = torch.Generator().manual_seed(M % 1000 + N + K)
+    x = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g))
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    ref = F.linear(x.double(), w.double())
+    bound = F.linear(x.double().abs(), w.double().abs())          # sum_k |x_k| |w_k|: the scale every rounding error is relative to
+    monkeypatch.setattr(ops, "GEMM_B3", True)
+    ops.PROFILE = []
+    y3 = ops.linear(x.to(DEV), w.to(DEV))
+    names, ops.PROFILE = [r[0] for r in ops.PROFILE], None
+    assert names == ["gemm_win_b3"]
+    monkeypatch.setattr(ops, "GEMM_B3", False)
+    y1 = ops.linear(x.to(DEV), w.to(DEV))
+    e3, e1 = _backward_error(y3, ref, bound), _backward_error(y1, ref, bound)
+    print(f"M={M} N={N} K={K}: backward error / 2^-24: three-plane {e3 / U:.2f}, f32 instruction {e1 / U:.2f}")
+    # measured (tools/probes/b3_numerics.py): 4.6 - 5.0 against the f32 instruction's 5.3 - 6.1 on random-sign operands for K = 96 ..
+    # 8192 (66 against 105 on all-positive ones at K = 8192): the dropped cross terms (<= 2^-23 |x||w|) cost less than the f32
+    # chain's own K roundings
+    assert e3 < 1.25 * e1 + U
+    assert e3 < 16 * U
+
+
+def test_b3_conv_with_elu_residual_and_utterance_edges():
+    """k3 s1 64 -> 256 over 40 utterances of 700 steps with ELU on load, residual and ELU-out: interior tiles on the bf16 instruction,
+    tiles that touch an utterance edge on the f32 one, alternating inside every resident workgroup; and the strided SEANet shape."""
+    g = torch.Generator().manual_seed(35)
+    B, cin, cout, T = 40, 64, 256, 700
+    x = torch.rand(B, cin, T, generator=g) * 4 - 2
+    w = synth._xavier(g, cout, cin, 3)
+    b = 0.1 * torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, T, generator=g)
+    nlc = lambda t: t.transpose(1, 2).contiguous().to(DEV)
+    y = RF.conv1d(nlc(x), RF.pack_conv_weight(w).to(DEV), b.to(DEV), k_eff=3, act_in=ops.ACT_ELU, res=nlc(res), act_out=ops.ACT_ELU_OUT)
+    ref = F.elu(res.double() + F.conv1d(F.pad(F.elu(x.double()), (2, 0)), w.double(), b.double()))
+    err = float((y.transpose(1, 2).double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+    B, cin, cout, K, S, T = 3, 64, 128, 8, 4, 131073
+    x = torch.rand(B, cin, T, generator=g) * 2 - 1
+    w = synth._xavier(g, cout, cin, K)
+    y = RF.conv1d(nlc(x), RF.pack_conv_weight(w).to(DEV), None, k_eff=K, stride=S)
+    ref = O.causal_conv1d(x.double(), w.double(), None, stride=S)
+    err = float((y.transpose(1, 2).double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+
+
+def test_b3_pack_rejects_bad_shapes():
+    w = torch.randn(64, 24, device=DEV)
+    with pytest.raises(ValueError):
+        ops.gemm_win_b3_pack_weight(w)        # K % 16 != 0
+    assert not ops._b3_shape(5000, 128, 48) and not ops._b3_shape(4096, 128, 64) and not ops._b3_shape(5000, 64, 64)

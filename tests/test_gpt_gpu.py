@@ -316,3 +316,64 @@ def test_load_adapters_repacks_kernel_side_copies():
     with model.streaming(2):
         with pytest.raises(RuntimeError):
             model.load_adapters(ad2)
+
+
+@pytest.mark.parametrize("name,extra", [("gqa", {}), ("mha", {}), ("gqa", {"lora_alpha": 6, "lora_key": True})],
+                         ids=["gqa", "mha", "gqa_qkv_alpha6"])
+@pytest.mark.parametrize("B", [2, 5])
+def test_unmerged_lora_forward_matches_the_oracle(name, extra, B):
+    """``GPT.from_state_dict(..., merge_lora=False)``: LoRALinear.forward / LoRAQKVLinear.forward with the adapters apart
+    (llama_streaming.py:136-143, 373-406) -- the full-sequence forward and graph-captured T = 1 steps across the ring wrap against the
+    oracle's UNMERGED path (the one gpt_tiny.npz pins to the reference's unmerged forward), at batch 2 (weight-streaming products)
+    and batch 5 (matrix-core products, packed attention output); the second case has q, k and v adapted under grouped queries (the
+    zero_pad 'as is' return) and an alpha / r that is not a power of two (applied to A x in fp32)."""
+    cfg_d = {**CFGS[name], **extra}
+    sd = {k: v.to(DEV) for k, v in synth.gpt_state_dict(cfg_d, cases.GPT_SEED).items()}
+    model = GPT.from_state_dict(sd, Config.from_dict(cfg_d), merge_lora=False)
+    assert any(k.endswith(".lora_A") for k in model.state_dict())
+    keep = set(Gp.GPTConfig.__dataclass_fields__)
+    ocfg = Gp.GPTConfig(**{k: v for k, v in cfg_d.items() if k in keep})
+    osd = {k: v.detach().float().cpu() for k, v in sd.items()}
+    T = cases.GPT_T_FULL
+    toks = cases.gpt_tokens(cfg_d, steps=cases.GPT_STEPS, batch=B)
+    h, lg = model.forward_global(toks[:, :, :T].to(DEV))
+    with torch.no_grad():
+        h_o, lg_o = Gp.forward_global(osd, ocfg, toks[:, :, :T])
+    assert rel_err(h, h_o) < TOL and rel_err(lg, lg_o) < TOL
+    if not extra and B == cases.GPT_BATCH:
+        g = np.load(os.path.join(GOLD, "gpt_tiny.npz"))
+        assert rel_err(lg, torch.from_numpy(g[f"{name}.full.logits"])) < TOL      # same bf16 weights on both sides: no merge rounding
+    merged = GPT.from_state_dict({k: v.clone() for k, v in sd.items()}, Config.from_dict(cfg_d))
+    assert rel_err(merged.forward_global(toks[:, :, :T].to(DEV))[1], lg) < 3e-2   # vs the merged build: bf16 rounding of W + BA
+    st = Gp.new_global_state(ocfg, B)
+    with model.streaming(B), torch.no_grad():
+        for t in range(cases.GPT_STEPS):
+            h, lg = model.forward_global(toks[:, :, t:t + 1].to(DEV))
+            h_o, lg_o = Gp.forward_global(osd, ocfg, toks[:, :, t:t + 1], st)
+            assert rel_err(h, h_o) < TOL and rel_err(lg, lg_o) < TOL, t
+
+
+def test_unmerged_lora_adapter_swap():
+    """``load_adapters`` on an unmerged model replaces the adapter tensors only: logits == a model built from [base ; new set]."""
+    cfg_d = dict(CFGS["gqa"])
+    cfg = Config.from_dict(cfg_d)
+    is_lora = lambda k: k.endswith((".lora_A", ".lora_B"))
+    sd1 = {k: v.to(DEV) for k, v in synth.gpt_state_dict(cfg_d, 21).items()}
+    ad2 = {k: v.to(DEV) for k, v in synth.gpt_state_dict(cfg_d, 22).items() if is_lora(k)}
+    toks = cases.gpt_tokens(cfg_d, steps=4, batch=3).to(DEV)
+
+    def logits_of(m):
+        with m.streaming(3):
+            return torch.cat([m.forward_global(toks[:, :, t:t + 1])[1] for t in range(4)], 1)
+
+    model = GPT.from_state_dict({k: v.clone() for k, v in sd1.items()}, cfg, merge_lora=False)
+    w_ptr = model.transformer.h[0].attn.attn.linear.weight.data_ptr()
+    first = logits_of(model)
+    model.load_adapters(ad2)
+    assert model.transformer.h[0].attn.attn.linear.weight.data_ptr() == w_ptr
+    want = logits_of(GPT.from_state_dict({**{k: v.clone() for k, v in sd1.items() if not is_lora(k)}, **ad2}, cfg, merge_lora=False))
+    got = logits_of(model)
+    assert torch.equal(got, want) and not torch.equal(got, first)
+    model.load_adapters(None)
+    base = logits_of(GPT.from_state_dict({k: v.clone() for k, v in sd1.items() if not is_lora(k)}, Config.from_dict({**cfg_d, "lora_r": 0})))
+    assert torch.equal(logits_of(model), base)

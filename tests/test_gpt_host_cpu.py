@@ -119,3 +119,56 @@ def test_load_adapters_swaps_in_place(cfg_d):
         plain.load_adapters(ad2)                              # built without keep_lora_base
     with pytest.raises(RuntimeError):
         model.load_adapters({"transformer.h.0.nope.lora_A": torch.zeros(1, 1), "transformer.h.0.nope.lora_B": torch.zeros(1, 1)})
+
+
+@pytest.mark.parametrize("cfg_d", [synth.GPT_TINY_GQA, synth.GPT_TINY_MHA, {**synth.GPT_TINY_GQA, "lora_alpha": 6, "lora_key": True}],
+                         ids=["gqa", "mha", "gqa_qkv_alpha6"])
+def test_unmerged_adapter_forms_equal_the_merged_update(cfg_d):
+    """``from_state_dict(..., merge_lora=False)``: the kernel-side adapter forms (rank padded to 16, fused-QKV / stacked-gate B laid out
+    block-diagonally in the kernels' row order, alpha / r folded into B when a power of two) multiply out to exactly the update
+    ``merge_lora_state_dict`` adds -- incl. the zero_pad scatter (q, v only) and its 'as is' return (q, k, v with grouped queries);
+    the state dict keeps the reference's ``lora_A`` / ``lora_B`` keys; adapters for un-adapted linears / wrong shapes are refused."""
+    cfg, _ = _cfgs(cfg_d)
+    sd = synth.gpt_state_dict(cfg_d, cases.GPT_SEED)                       # bf16: adapters are exact in the kernel forms
+    model = G.GPT.from_state_dict({k: v.clone() for k, v in sd.items()}, cfg, merge_lora=False)
+    assert set(model.state_dict()) == set(sd)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    f32 = {k: v.float() for k, v in sd.items()}
+    merged = G.merge_lora_state_dict(f32, cfg)
+    order = G._qkv_row_order(cfg)
+
+    def delta(ad):
+        A, Bm, post = ad
+        assert A.shape[0] % 16 == 0 and Bm.shape[1] == A.shape[0] and A.dtype == Bm.dtype == torch.bfloat16
+        return (Bm.float() @ A.float()) * post
+
+    for l, blk in enumerate(model.transformer.h):
+        p = f"transformer.h.{l}"
+        want = (merged[f"{p}.attn.attn.linear.weight"] - f32[f"{p}.attn.attn.linear.weight"])[order]
+        assert torch.allclose(delta(blk.attn.packed_qkv_adapter()), want, rtol=0, atol=2e-6)
+        if cfg.lora_mlp:
+            want = torch.cat([merged[f"{p}.mlp.{n}.linear.weight"] - f32[f"{p}.mlp.{n}.linear.weight"] for n in ("fc_1", "fc_2")])
+            assert torch.allclose(delta(blk.mlp.packed_fc_adapter()), want, rtol=0, atol=2e-6)
+            assert torch.allclose(delta(blk.mlp.proj.adapter()), merged[f"{p}.mlp.proj.linear.weight"] - f32[f"{p}.mlp.proj.linear.weight"],
+                                  rtol=0, atol=2e-6)
+        else:
+            assert blk.mlp.packed_fc_adapter() is None and blk.mlp.proj.adapter() is None
+        if not cfg.lora_projection:
+            assert blk.attn.proj.adapter() is None
+    if cfg.lora_head:
+        assert torch.allclose(delta(model.lm_head.adapter()), merged["lm_head.linear.weight"] - f32["lm_head.linear.weight"], rtol=0, atol=2e-6)
+    post = model.transformer.h[0].attn.packed_qkv_adapter()[2]
+    assert post == (1.0 if cfg.lora_alpha == 8 else cfg.lora_alpha / cfg.lora_r)
+    # swapping: a set without the head adapter drops that branch; bad names / shapes are refused
+    ad2 = {k: v for k, v in synth.gpt_state_dict(cfg_d, 5).items() if k.endswith((".lora_A", ".lora_B")) and not k.startswith("lm_head")}
+    model.load_adapters(ad2)
+    assert model.lm_head.adapter() is None
+    assert torch.equal(model.transformer.h[1].attn.attn.lora_A, ad2["transformer.h.1.attn.attn.lora_A"])
+    with pytest.raises(RuntimeError):
+        model.load_adapters({"transformer.wte.lora_A": torch.zeros(4, 4), "transformer.wte.lora_B": torch.zeros(4, 4)})
+    with pytest.raises(RuntimeError):
+        model.load_adapters({"transformer.h.0.attn.attn.lora_A": torch.zeros(3, cfg.n_embd),
+                             "transformer.h.0.attn.attn.lora_B": ad2["transformer.h.0.attn.attn.lora_B"]})
+    model.load_adapters(None)
+    assert all(blk.attn.packed_qkv_adapter() is None for blk in model.transformer.h)

@@ -2,7 +2,9 @@
 
     python tools/ab.py SKINNY_X32_MAX_K=0 -- --workload gpt --steps 40 --warmup 5 --no-cpu-baseline
 
-Every NAME=VALUE before `--` is set on rstnet_amd.ops (int / float / bool literals), the rest is bench.py's command line."""
+Every NAME=VALUE before `--` is set on rstnet_amd.ops (int / float / bool literals), the rest is bench.py's command line.
+`LIB=<path>` loads another build of the library instead (the tools build `make -C rstnet_amd/csrc ablation`, whose measurement
+knobs read RST_* environment variables; the shipped library reads none)."""
 import ast
 import os
 import runpy
@@ -15,9 +17,12 @@ sys.path.insert(0, ROOT)
 def main():
     args = sys.argv[1:]
     cut = args.index("--") if "--" in args else len(args)
-    from rstnet_amd import ops
+    from rstnet_amd import _lib, ops
     for item in args[:cut]:
         name, value = item.split("=", 1)
+        if name == "LIB":
+            _lib.LIB_PATH = os.path.abspath(value)
+            continue
         assert hasattr(ops, name), f"rstnet_amd.ops has no switch {name}"
         setattr(ops, name, ast.literal_eval(value))
     sys.argv = [os.path.join(ROOT, "bench.py")] + args[cut + 1:]
