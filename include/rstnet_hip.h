@@ -61,7 +61,8 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
  * to nearest even from the exact remainder), and six of the nine cross products are accumulated in fp32 (the three dropped are below
  * 2^-23 |x||w|, one fp32 rounding of the product) -- 192 matrix-pipe cycles per 32x32x16 block instead of the f32 instruction's 512.
  * The caller splits the weights once: w3 = rst_gemm_win_b3_weight_elems(N, K) uint16, filled by rst_gemm_win_b3_pack_weight (K % 16
- * == 0; layout [ceil(N/128)][K/16][3][128][16], rows past N zero); activations are split inside the launch.  w (fp32) is still read
+ * == 0; layout [2*ceil(N/256)][K/16][3][128][16] -- 128-row tiles, row b3_row(g) of a tile in slot g, rows past N zero); activations
+ * are split inside the launch.  w (fp32) is still read
  * by the tiles that touch an utterance edge.  Replaces the conv / linear bodies of AudioCodec/MimiCodec/modules/conv.py:178-252 for
  * batched (non-streaming) encode / decode. */
 int rst_gemm_win_b3_weight_elems(int N, int K);   /* -1: bad sizes */

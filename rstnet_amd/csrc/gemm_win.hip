@@ -15,6 +15,7 @@
 // slots -> conflict free).
 // K order inside a BK chunk is permuted (lane half h owns k = 8s + 4h .. +3) so that fragments are read with
 // one ds_read_b128 per four MFMAs; both operands use the same permutation so the product is unchanged.
+#include <algorithm>
 #include "rst_common.h"
 #include "rst_kernels.h"
 
@@ -604,21 +605,28 @@ __host__ __device__ __forceinline__ constexpr int b3_slot(int r) { return (r & ~
 // Since C % 16 == 0, a window leaves its utterance on a k-tile boundary: every row carries the range [klo, khi) of k-tiles it really
 // reads, a k-tile outside it is loaded from a valid address of the same row and cleared when it is consumed (a bit per row travels
 // with the register set).  Launches with a history buffer or replicate padding stay on the f32-instruction kernels.
+// NWN: waves along N.  2: 128 x 128 tile, 256 threads, two workgroups per CU.  4: 128 x 256 tile, 512 threads, one workgroup per CU --
+// the same eight waves per CU, but every activation element is split for 256 columns instead of 128, which halves the split work
+// (VALU + LDS writes) per matrix instruction: measured (tools build, RST_B3_DBG) that work is what the 128-wide form spends most on.
 // DBG (tools build only, WRONG results): 1 = no split / LDS writes, 2 = no global loads, 3 = matrix instructions only, 4 = no barriers
-template <bool ELU, bool MASK, int DBG = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_win_b3_stream_kernel(const GemmWinParams p, const int tiles) {
-    constexpr int TM = 2, TN = 2, WN = 2;
-    constexpr int BM = 128, BN = 128;
-    constexpr int RA = 2;                          // 64 row slots x 4 threads (16 bytes of fp32 each) per pass
+template <bool ELU, bool MASK, int NWN, int DBG = 0, bool BUFL = true>
+__global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_win_b3_stream_kernel(const GemmWinParams p, const int tiles) {
+    constexpr int TM = 2, TN = 2;
+    constexpr int NT = 128 * NWN;                  // threads
+    constexpr int BM = 128, BN = 64 * NWN;
+    constexpr int RA = 512 / NT;                   // activation row passes: NT / 4 row slots x 4 threads (16 bytes of fp32 each) per pass
+    constexpr int A_PLANE = BM * B3_RS, W_PLANE = BN * B3_RS;          // shorts per plane in LDS
+    constexpr int BUF = 3 * (A_PLANE + W_PLANE);                       // shorts per buffer: activation planes 0..2, weight planes 0..2
     constexpr int NSA = B3_SETS_A, NSB = B3_SETS_B;
     static_assert(NSA == 4 && NSB == 2, "the rotation below is written out for four activation sets and two weight sets");
+    static_assert(NWN == 2 || NWN == 4, "two or four waves along N");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     short* const lds = reinterpret_cast<short*>(smem);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int lrow = b3_row(tid >> 2);             // row (of the first pass) this thread stages
     const int lk = (tid & 3) * 4;
     const int frag_row = lane & 31;
@@ -637,62 +645,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (l >= count) return;
 
     struct Ctx {
-        const float* ap[RA];
-        int klo[RA], khi[RA];        // MASK: k-tiles [klo, khi) of the row's window lie inside its utterance
+        unsigned ao[RA];             // byte offset of the row's window (+ this thread's 16 bytes) from p.x: the loads take the uniform
+                                     // base + k-tile in scalar registers and this as the 32-bit vector offset
+        int klo[RA], kn[RA];         // MASK: k-tiles klo .. klo + kn - 1 of the row's window lie inside its utterance
     };
     auto setup = [&](int m0, Ctx& c) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            const int m = m0 + lrow + 64 * j;
+            const int m = m0 + lrow + (NT / 4) * j;
             const int mm = min(m, M - 1);
             const int b = mm / p.T_out;
             const int t = mm - b * p.T_out;
             const int f0 = (t * p.S - p.P) * p.C;
-            c.ap[j] = p.x + (long)b * p.x_bstride + f0 + lk;
+            long off = (long)b * p.x_bstride + f0 + lk;
             if (MASK) {
                 int klo = max(0, -f0) / B3_KB, khi = min(p.K, TC - f0) / B3_KB;
                 if (m >= M || klo >= khi) {          // no such row / a window entirely in the padding: all zeros, loads parked on x
                     klo = khi = 0;
-                    c.ap[j] = p.x + lk;
+                    off = lk;
                 }
                 c.klo[j] = klo;
-                c.khi[j] = khi;
+                c.kn[j] = khi - klo;
+                // (rows that start in the padding: the offset is taken at k-tile klo, which is where their loads start)
+                off += (long)klo * B3_KB;
             }
+            c.ao[j] = (unsigned)(off * 4);
         }
     };
-    auto w_tile = [&](int n0) { return p.w3 + (long)(n0 / BN) * nk * B3_WTILE + tid * 8; };
+    // this thread's 16 bytes of plane 0 of the tile's first k-tile: the packed weights come in 128-row tiles of [k-tile][plane][128][16]
+    auto w_tile = [&](int n0) { return (unsigned)(n0 / 128) * (unsigned)nk * (unsigned)(B3_WTILE * 2); };      // (bytes, uniform; the thread's part is wo)
+    const unsigned wo = (unsigned)(((long)(tid >> 8) * nk * B3_WTILE + (tid & 255) * 8) * 2);      // bytes
 
     f32x4 ra[NSA][RA];
-    int rm[NSA];                     // MASK: bit j = row j of the set is real data
+    int rm[NSA][RA];                 // MASK: all ones where row j of the set is real data, zero where it is padding
     u32x4 rb[NSB][3];
     // LDS destinations of this thread's pieces (shorts from the start of a buffer)
     const int a_dst = lrow * B3_RS + lk;
-    const int b_dst = 3 * B3_PLANE + b3_row(tid >> 1) * B3_RS + (tid & 1) * 8;
+    const int b_dst = 3 * A_PLANE + ((tid >> 8) * 128 + b3_row((tid & 255) >> 1)) * B3_RS + (tid & 1) * 8;
     const int a_frag = (wm * TM * 32 + frag_row) * B3_RS + frag_k;
-    const int b_frag = 3 * B3_PLANE + (wn * TN * 32 + frag_row) * B3_RS + frag_k;
+    const int b_frag = 3 * A_PLANE + (wn * TN * 32 + frag_row) * B3_RS + frag_k;
 
-    auto load_a = [&](const Ctx& c, const int kt, f32x4 (&dst)[RA], int& mask) {
-        mask = 3;
+    // Requests go out as buffer loads: resource (base pointer) and the k-tile's byte offset in scalar registers, the thread's own
+    // offset a 32-bit vector register set up once per tile -- no address arithmetic on the vector unit in the K loop (the launcher
+    // checks that the activations span less than 4 GB).  MM: with the masks; without, every row's whole window is real data.
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<short*>(p.w3), 0, 0xffffffff, 0x00020000);
+    auto load_a = [&](auto MM, const Ctx& c, const int kt, f32x4 (&dst)[RA], int (&mask)[RA]) {
+        constexpr bool MK = decltype(MM)::value != 0;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            int ks = kt;
-            if (MASK) {
-                const bool ok = kt >= c.klo[j] && kt < c.khi[j];
-                ks = ok ? kt : c.klo[j];
-                if (!ok) mask &= ~(1 << j);
+            if (MK) {
+                const unsigned d = (unsigned)(kt - c.klo[j]);          // (ao is taken at k-tile klo)
+                const bool ok = d < (unsigned)c.kn[j];
+                mask[j] = ok ? -1 : 0;
+                const unsigned vo = c.ao[j] + (ok ? d : 0u) * (B3_KB * 4);
+                if (BUFL) dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, 0, 0));
+                else dst[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.x) + vo);
+            } else {
+                if (BUFL) dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, c.ao[j], kt * (B3_KB * 4), 0));
+                else dst[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.x) + (long)kt * (B3_KB * 4) + c.ao[j]);
             }
-            dst[j] = *reinterpret_cast<const f32x4*>(c.ap[j] + ks * B3_KB);
+        }
+    };
+    // wb: byte offset of the tile's first k-tile inside the packed weights (uniform)
+    auto load_w = [&](const unsigned wb, const int kt, u32x4 (&dst)[3]) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const unsigned so = wb + (unsigned)kt * (B3_WTILE * 2) + q * (128 * B3_KB * 2);
+            if (BUFL) dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wo, so, 0);
+            else dst[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.w3) + so + wo);
         }
     };
     // the fp32 values of a staged row piece as two pairs: padding cleared (MASK), ELU applied
-    auto take_a = [&](const f32x4 src, const int mask, const int j, f32x2 (&v)[2]) {
+    auto take_a = [&](auto MM, const f32x4 src, const int mask, f32x2 (&v)[2]) {
         typedef int i32x4 __attribute__((ext_vector_type(4)));
         f32x4 x = src;
-        if (MASK) {
-            int mm = (mask >> j) & 1 ? -1 : 0;
-            asm volatile("" : "+v"(mm));          // (a select the compiler could fold back into a branch around the load)
-            x = __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, x) & mm);
-        }
+        if (decltype(MM)::value != 0) x = __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, x) & mask);
         if (ELU) {
             x[0] = rst_elu(x[0]); x[1] = rst_elu(x[1]); x[2] = rst_elu(x[2]); x[3] = rst_elu(x[3]);
         }
@@ -711,20 +739,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
 
     // one stage: the k-tile of LDS buffer `buf` into the accumulators; register sets S -- the k-tile after it -- into buffer buf ^ 1;
-    // the requests of the stream position four ahead (activations: context c, k-tile kta; weights: bp, ktb) into the sets just freed
-    auto stage = [&](auto SS, const Ctx& c, const int kta, const short* bp, const int ktb, const int buf) {
+    // the requests of the stream positions ahead (activations: context c, k-tile kta; weights: bp, ktb) into the sets just freed
+    auto stage = [&](auto SS, auto MM, const Ctx& c, const int kta, const unsigned bp, const int ktb, const int buf) {
         constexpr int S = decltype(SS)::value;
         constexpr int F = (S + 3) % 4, SB = S % 2, FB = (S + 1) % 2;
         if (DBG != 2 && DBG != 3) {
             // weights first: the wait for them counts requests in order, and must leave the younger activation requests in flight
-#pragma unroll
-            for (int q = 0; q < 3; ++q) rb[FB][q] = *reinterpret_cast<const u32x4*>(bp + (long)ktb * B3_WTILE + q * (128 * B3_KB));
+            load_w(bp, ktb, rb[FB]);
             __builtin_amdgcn_sched_barrier(0);
-            load_a(c, kta, ra[F], rm[F]);
+            load_a(MM, c, kta, ra[F], rm[F]);
         }
         bf16x8 fa[TM][3], fb[TN][3];
-        const short* rd = lds + buf * B3_BUF;
-        short* wr = lds + (buf ^ 1) * B3_BUF;
+        const short* rd = lds + buf * BUF;
+        short* wr = lds + (buf ^ 1) * BUF;
         // fragments in the order the products below consume them
         constexpr int QA[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
         constexpr int QB[6] = {0, 2, 1, 0, 1, 0};
@@ -732,15 +759,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j][0] = *reinterpret_cast<const bf16x8*>(rd + b_frag + j * 32 * B3_RS);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i][2] = *reinterpret_cast<const bf16x8*>(rd + a_frag + 2 * B3_PLANE + i * 32 * B3_RS);
+            for (int i = 0; i < TM; ++i) fa[i][2] = *reinterpret_cast<const bf16x8*>(rd + a_frag + 2 * A_PLANE + i * 32 * B3_RS);
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i][0] = *reinterpret_cast<const bf16x8*>(rd + a_frag + i * 32 * B3_RS);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j][2] = *reinterpret_cast<const bf16x8*>(rd + b_frag + 2 * B3_PLANE + j * 32 * B3_RS);
+            for (int j = 0; j < TN; ++j) fb[j][2] = *reinterpret_cast<const bf16x8*>(rd + b_frag + 2 * W_PLANE + j * 32 * B3_RS);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i][1] = *reinterpret_cast<const bf16x8*>(rd + a_frag + B3_PLANE + i * 32 * B3_RS);
+            for (int i = 0; i < TM; ++i) fa[i][1] = *reinterpret_cast<const bf16x8*>(rd + a_frag + A_PLANE + i * 32 * B3_RS);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j][1] = *reinterpret_cast<const bf16x8*>(rd + b_frag + B3_PLANE + j * 32 * B3_RS);
+            for (int j = 0; j < TN; ++j) fb[j][1] = *reinterpret_cast<const bf16x8*>(rd + b_frag + W_PLANE + j * 32 * B3_RS);
         } else {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -755,26 +782,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         f32x2 v[RA][2];
         u32x2 h[RA];
         constexpr bool SIDE = DBG != 1 && DBG != 3;
+        // side work, one small piece per slot: 0..2 the weight planes' LDS writes; then per plane q: 2 * RA half-row peels (4 VALU
+        // each) and the plane's LDS write
+        constexpr int PB = 2 * RA + 1, NOPS = 3 + 3 * PB;       // 18 (RA = 2: slots 1 .. 18) or 12 (RA = 1: the odd slots)
 #pragma unroll
         for (int m = 0; m < 24; ++m) {
             const int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][QA[t]], fb[j][QB[t]], acc[i][j], 0, 0, 0);
-            // the side work of this slot
             if (SIDE && m == 0) {
 #pragma unroll
-                for (int r = 0; r < RA; ++r) take_a(ra[S][r], rm[S], r, v[r]);
+                for (int r = 0; r < RA; ++r) take_a(MM, ra[S][r], rm[S][r], v[r]);
             }
-            if (SIDE && m >= 1 && m <= 3) *reinterpret_cast<u32x4*>(wr + b_dst + (m - 1) * B3_PLANE) = rb[SB][m - 1];
-            if (SIDE && m >= 4 && m < 22 && (m & 1) == 0) {
-                // slots 4, 6, .., 20: plane q = (m - 4) / 6; w = 0, 1: the two rows' peels, w = 2: the LDS writes of plane q
-                const int u = (m - 4) >> 1;
-                const int q = u / 3, w = u % 3;
-                if (w < 2) {
-                    h[w][0] = b3_peel(v[w][0]);
-                    h[w][1] = b3_peel(v[w][1]);
+            const int op = RA == 2 ? m - 1 : ((m & 1) ? (m - 1) >> 1 : -1);
+            if (SIDE && op >= 0 && op < NOPS) {
+                if (op < 3) {
+                    *reinterpret_cast<u32x4*>(wr + b_dst + op * W_PLANE) = rb[SB][op];
                 } else {
+                    const int u = op - 3;
+                    const int q = u / PB, w = u % PB;
+                    if (w < 2 * RA) {
+                        h[w >> 1][w & 1] = b3_peel(v[w >> 1][w & 1]);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < RA; ++r) *reinterpret_cast<u32x2*>(wr + a_dst + q * B3_PLANE + r * 64 * B3_RS) = h[r];
+                        for (int r = 0; r < RA; ++r) *reinterpret_cast<u32x2*>(wr + a_dst + q * A_PLANE + r * (NT / 4) * B3_RS) = h[r];
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -783,34 +814,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
 
     // start of the run: k-tile 0 of the first tile to LDS, activations of k-tiles 1 .. 3 to sets 0 .. 2, weights of k-tile 1 to set 0
-    auto prime = [&](const Ctx& c, const short* bp, int buf) {
-        short* wr = lds + buf * B3_BUF;
+    auto prime = [&](const Ctx& c, const unsigned bp, int buf) {
+        short* wr = lds + buf * BUF;
         {
             f32x4 xa[RA];
-            int xm;
+            int xm[RA];
             u32x4 xb[3];
-            load_a(c, 0, xa, xm);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) xb[q] = *reinterpret_cast<const u32x4*>(bp + q * (128 * B3_KB));
+            load_a(b3_int<MASK>{}, c, 0, xa, xm);
+            load_w(bp, 0, xb);
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
                 f32x2 v[2];
-                take_a(xa[j], xm, j, v);
+                take_a(b3_int<MASK>{}, xa[j], xm[j], v);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     u32x2 hh;
                     hh[0] = b3_peel(v[0]);
                     hh[1] = b3_peel(v[1]);
-                    *reinterpret_cast<u32x2*>(wr + a_dst + q * B3_PLANE + j * 64 * B3_RS) = hh;
+                    *reinterpret_cast<u32x2*>(wr + a_dst + q * A_PLANE + j * (NT / 4) * B3_RS) = hh;
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(wr + b_dst + q * B3_PLANE) = xb[q];
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(wr + b_dst + q * W_PLANE) = xb[q];
         }
+        load_w(bp, 1, rb[0]);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) rb[0][q] = *reinterpret_cast<const u32x4*>(bp + (long)B3_WTILE + q * (128 * B3_KB));
-#pragma unroll
-        for (int g = 1; g < 4; ++g) load_a(c, g, ra[g - 1], rm[g - 1]);
+        for (int g = 1; g < 4; ++g) load_a(b3_int<MASK>{}, c, g, ra[g - 1], rm[g - 1]);
         __syncthreads();
     };
 
@@ -818,13 +847,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int tile = first + l;
     int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     setup(m0, c);
-    const short* bp = w_tile(n0);
-    const short* bpn = bp;           // weights of the tile the activation cursor has already moved on to
+    unsigned bp = w_tile(n0);
+    unsigned bpn = bp;               // weights of the tile the activation cursor has already moved on to
     int kb = 2;
     prime(c, bp, 0);
     for (;;) {
-        const bool has_next = l + stride < count;
-        const int tile_n = tile + stride;
+        const int ln = l + stride;
+        const bool has_next = ln < count;
+        const int tile_n = first + ln;
         const int m0n = (tile_n / tiles_n) * BM, n0n = (tile_n % tiles_n) * BN;
         clear();
         // request cursors: activations four k-tiles ahead, weights two; each crosses into the next tile on its own stage (at the end of
@@ -837,17 +867,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 bpn = w_tile(n0n);
             }
         };
+        constexpr b3_int<MASK> MM{};
         for (int kt = 0; kt < nk; kt += 4) {
             if (kf == nk) cross();
-            stage(b3_int<0>{}, c, kf, bp, kb, 0);
-            stage(b3_int<1>{}, c, kf + 1, bp, kb + 1, 1);
+            stage(b3_int<0>{}, MM, c, kf, bp, kb, 0);
+            stage(b3_int<1>{}, MM, c, kf + 1, bp, kb + 1, 1);
             kb += 2;
             if (kb == nk) {
                 kb = 0;
                 bp = bpn;
             }
-            stage(b3_int<2>{}, c, kf + 2, bp, kb, 0);
-            stage(b3_int<3>{}, c, kf + 3, bp, kb + 1, 1);
+            stage(b3_int<2>{}, MM, c, kf + 2, bp, kb, 0);
+            stage(b3_int<3>{}, MM, c, kf + 3, bp, kb + 1, 1);
             kb += 2;
             if (kb == nk) {
                 kb = 0;
@@ -858,7 +889,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (!MASK || (m0 + BM <= M && n0 + BN <= p.N)) gw_epilogue<TM, TN, true>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, M, lane);
         else gw_epilogue<TM, TN, false>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, M, lane);
         if (!has_next) break;
-        l += stride;
+        l = ln;
         tile = tile_n;
         m0 = m0n;
         n0 = n0n;
@@ -958,13 +989,17 @@ int launch_stream(const GemmWinParams& p, long tiles, hipStream_t stream) {
     return rst_check_launch("gemm_win");
 }
 
-int launch_stream_b3(const GemmWinParams& p, long tiles, hipStream_t stream) {
+template <int NWN>
+int launch_stream_b3_cfg(const GemmWinParams& p, hipStream_t stream) {
+    constexpr int BN = 64 * NWN;
+    const long M = (long)p.B * p.T_out;
+    const long tiles = ((M + 127) / 128) * ((p.N + BN - 1) / BN);
     if (tiles > 0x7fffffffL) {
         rst_set_error("gemm_win: too many tiles (%ld)", tiles);
         return RST_ERR_UNSUPPORTED;
     }
-    const size_t lds = 2 * B3_BUF * sizeof(short);       // 73 728 bytes
-    static const int per_cu = rst_knob("RST_B3_WGS", 2);      // tools build only
+    const size_t lds = 2 * 3 * (128 + BN) * B3_RS * sizeof(short);       // 73 728 / 110 592 bytes
+    static const int per_cu = rst_knob("RST_B3_WGS", NWN == 2 ? 2 : 1);      // tools build only
     const long resident = (long)per_cu * gw_cu_count();
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
     auto go = [&](auto kern) {
@@ -974,26 +1009,44 @@ int launch_stream_b3(const GemmWinParams& p, long tiles, hipStream_t stream) {
             (void)hipGetLastError();
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p, (int)tiles);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NWN), lds, stream, p, (int)tiles);
     };
-    // rows whose window reaches into the zero padding (or past the end), ragged last tiles: the masked form
-    const long M = (long)p.B * p.T_out;
-    const bool lean = p.P == 0 && M % 128 == 0 && p.N % 128 == 0 && (long)(p.T_out - 1) * p.S * p.C + p.K <= (long)p.T_in * p.C;
+    // rows whose window reaches into the zero padding (or past the end), ragged last tiles: the masked form for the whole launch.
+    // (Measured: walking the interior tiles with the lean kernel and the others with the masked one as two launches gains 2 - 9 % on
+    // the 24 kHz / 4.8 kHz layers, whose edge tiles are few, and loses 20 - 40 % on the layers below, where the two half-filled
+    // launches run one after the other.)
+    const bool lean = p.P == 0 && M % 128 == 0 && p.N % BN == 0 && (long)(p.T_out - 1) * p.S * p.C + p.K <= (long)p.T_in * p.C;
 #ifdef RST_ABLATION
     static const int dbg = rst_knob("RST_B3_DBG", 0);
-    if (dbg == 1) { go(gemm_win_b3_stream_kernel<false, true, 1>); return rst_check_launch("gemm_win_b3"); }
-    if (dbg == 2) { go(gemm_win_b3_stream_kernel<false, true, 2>); return rst_check_launch("gemm_win_b3"); }
-    if (dbg == 3) { go(gemm_win_b3_stream_kernel<false, true, 3>); return rst_check_launch("gemm_win_b3"); }
-    if (dbg == 4) { go(gemm_win_b3_stream_kernel<false, true, 4>); return rst_check_launch("gemm_win_b3"); }
+    if (dbg == 1) { go(gemm_win_b3_stream_kernel<false, true, NWN, 1>); return rst_check_launch("gemm_win_b3"); }
+    if (dbg == 2) { go(gemm_win_b3_stream_kernel<false, true, NWN, 2>); return rst_check_launch("gemm_win_b3"); }
+    if (dbg == 3) { go(gemm_win_b3_stream_kernel<false, true, NWN, 3>); return rst_check_launch("gemm_win_b3"); }
+    if (dbg == 4) { go(gemm_win_b3_stream_kernel<false, true, NWN, 4>); return rst_check_launch("gemm_win_b3"); }
+    static const int bufl = rst_knob("RST_B3_BUF", 1);        // 0: plain global loads (64-bit addresses on the vector unit)
+    if (!bufl && p.act_in != 1) {
+        if (lean) go(gemm_win_b3_stream_kernel<false, false, NWN, 0, false>);
+        else go(gemm_win_b3_stream_kernel<false, true, NWN, 0, false>);
+        return rst_check_launch("gemm_win_b3");
+    }
 #endif
     if (p.act_in == 1) {
-        if (lean) go(gemm_win_b3_stream_kernel<true, false>);
-        else go(gemm_win_b3_stream_kernel<true, true>);
+        if (lean) go(gemm_win_b3_stream_kernel<true, false, NWN>);
+        else go(gemm_win_b3_stream_kernel<true, true, NWN>);
     } else {
-        if (lean) go(gemm_win_b3_stream_kernel<false, false>);
-        else go(gemm_win_b3_stream_kernel<false, true>);
+        if (lean) go(gemm_win_b3_stream_kernel<false, false, NWN>);
+        else go(gemm_win_b3_stream_kernel<false, true, NWN>);
     }
     return rst_check_launch("gemm_win_b3");
+}
+
+int launch_stream_b3(const GemmWinParams& p, hipStream_t stream) {
+    // 256 columns per tile when the output is at least that wide, a ragged last tile wastes at most an eighth of the columns and the
+    // tiles still outnumber the CUs two to one (measured per layer: N = 640 and 8000-row launches lose with the wide tile)
+    static const int wide_knob = rst_knob("RST_B3_WIDE", 1);      // tools build only
+    const int waste = ((p.N + 255) / 256) * 256 - p.N;
+    const long wide_tiles = (((long)p.B * p.T_out + 127) / 128) * ((p.N + 255) / 256);
+    if (wide_knob && p.N >= 256 && waste * 8 <= p.N && wide_tiles >= 2L * gw_cu_count()) return launch_stream_b3_cfg<4>(p, stream);
+    return launch_stream_b3_cfg<2>(p, stream);
 }
 
 }  // namespace
@@ -1048,8 +1101,12 @@ int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
             if (vec && !stream_off && p.split_k <= 1) {
                 // the three-plane bf16 form when the caller passed the split weights (K % 64 == 0: whole rotations of the four register sets)
                 // (zero padding only: a history buffer / replicate padding keeps the launch on the f32 instruction)
-                if (p.w3 && p.K % 64 == 0 && p.C % 16 == 0 && !p.hist && p.pad_mode == 0 && (uintptr_t)p.w3 % 16 == 0)
-                    return launch_stream_b3(p, tiles, stream);
+                // (and operands its 32-bit buffer offsets can reach)
+                const long x_bytes = ((long)(p.B - 1) * p.x_bstride + (long)p.T_in * p.C) * 4;
+                const long w_bytes = rst_gemm_win_b3_weight_elems_impl(p.N, p.K) * 2;
+                if (p.w3 && p.K % 64 == 0 && p.C % 16 == 0 && !p.hist && p.pad_mode == 0 && (uintptr_t)p.w3 % 16 == 0 &&
+                    x_bytes < 0xfffff000L && w_bytes < 0xfffff000L)
+                    return launch_stream_b3(p, stream);
                 if (tiles >= 768 && !kb32_only) return launch_stream<16>(p, tiles, stream);
                 return launch_stream<32>(p, tiles, stream);
             }
@@ -1070,12 +1127,12 @@ int rst_gemm_split_tiles_impl(long M, int N) {
 }
 
 // ---- split weights of the three-plane bf16 form
-long rst_gemm_win_b3_weight_elems_impl(int N, int K) { return (long)((N + 127) / 128) * 128 * K * 3; }
+long rst_gemm_win_b3_weight_elems_impl(int N, int K) { return (long)((N + 255) / 256) * 256 * K * 3; }      // whole 256-row tiles (zero rows)
 
 int rst_launch_gemm_win_b3_pack(const float* w, unsigned short* w3, int N, int K, hipStream_t stream) {
     RST_REQUIRE(w && w3 && N > 0 && K > 0 && K % 16 == 0, "gemm_win_b3_pack_weight: bad arguments (K %% 16 == 0 required, N=%d K=%d)", N, K);
     RST_REQUIRE((uintptr_t)w % 16 == 0 && (uintptr_t)w3 % 16 == 0, "gemm_win_b3_pack_weight: pointers must be 16-byte aligned");
-    const long total = (long)((N + 127) / 128) * 128 * (K / 4);
+    const long total = (long)((N + 255) / 256) * 256 * (K / 4);
     hipLaunchKernelGGL(gemm_win_b3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<short*>(w3), N, K, total);
     return rst_check_launch("gemm_win_b3_pack_weight");
 }

@@ -16,9 +16,9 @@ U = 2.0 ** -24
 
 
 def unpack_b3(w3: torch.Tensor, N: int, K: int) -> torch.Tensor:
-    """[ceil(N/128)][K/16][3][128 slots][16] int16 -> the three planes as fp32 ``[3, ceil(N/128)*128, K]``; slot g of a tile holds
+    """[ceil(N/256)*2][K/16][3][128 slots][16] int16 -> the three planes as fp32 ``[3, ceil(N/256)*256, K]``; slot g of a tile holds
     row (g & ~7) | (2 * (g & 3) + ((g >> 2) & 1)) (the order that keeps the kernel's LDS writes free of bank conflicts)."""
-    nt = -(-N // 128)
+    nt = w3.numel() // (3 * 128 * K)                 # 128-row tiles, an even number of them (the wide kernel reads them in pairs)
     t = w3.view(nt, K // 16, 3, 128, 16).permute(2, 0, 3, 1, 4).reshape(3, nt * 128, K)
     r = torch.arange(nt * 128, device=w3.device)
     slot = (r & ~7) | (((r & 7) >> 1) + 4 * (r & 1))
@@ -30,7 +30,7 @@ def test_split_weights_are_exact(N, K):
     g = torch.Generator().manual_seed(N + K)
     w = (torch.randn(N, K, generator=g) * torch.exp(4 * torch.randn(N, K, generator=g))).to(DEV)      # wide dynamic range
     w3 = ops.gemm_win_b3_pack_weight(w)
-    assert w3.numel() == _lib.lib().rst_gemm_win_b3_weight_elems(N, K) == -(-N // 128) * 128 * K * 3
+    assert w3.numel() == _lib.lib().rst_gemm_win_b3_weight_elems(N, K) == -(-N // 256) * 256 * K * 3
     planes = unpack_b3(w3, N, K)
     assert not planes[:, N:].any()                                # rows past N are zero
     hi, mid, lo = planes[:, :N]
