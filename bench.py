@@ -685,6 +685,7 @@ def main():
         tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
         all_flops = sum(v["flops"] for v in per_kernel.values())
         b3 = dom == "gemm_win_b3"
+        prefix = f"{dom}_stream" if b3 else f"{dom}_"       # (not the one-off weight-packing launches of the same family)
         peak = B3_EQUIV_PEAK_TFLOPS if b3 else FP32_MFMA_PEAK_TFLOPS
         label = (f"{dom}_stream_kernel (v_mfma_f32_32x32x16_bf16: operands split into three bf16 planes, six products per fp32 product, f32 accumulate)"
                  if b3 else f"{dom}_*kernel (fp32 v_mfma_f32_32x32x2_f32)")
@@ -693,7 +694,7 @@ def main():
             return B3_EQUIV_PEAK_TFLOPS if name == "gemm_win_b3" else FP32_MFMA_PEAK_TFLOPS
         roofline = {"bound": "mfma", "kernel": label, "achieved": round(tf, 3),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                    "traffic": pmc_traffic(f"{dom}_", "codec"), "mfma_pipe": mfma_counters(f"{dom}_", peak), "launches_per_step": d["launches"],
+                    "traffic": pmc_traffic(prefix, "codec"), "mfma_pipe": mfma_counters(prefix, peak), "launches_per_step": d["launches"],
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "kernel_ms_per_step": round(d["ms"], 3), "share_of_step": round(d["ms"] / t_step_ms, 3),
                     "algorithmic_gflop_per_step": round(d["flops"] / 1e9, 1),
@@ -709,7 +710,7 @@ def main():
             roofline["peak_note"] = (f"algorithmic (fp32) flops against the bf16 dense peak {BF16_MFMA_PEAK_TFLOPS} / 6 products; "
                                      f"the f32 matrix instruction's peak is {FP32_MFMA_PEAK_TFLOPS}")
             roofline["x_f32_mfma_peak"] = round(tf / FP32_MFMA_PEAK_TFLOPS, 3)
-        _with_rocprof(roofline, f"{dom}_", "codec", d["flops"] / d["launches"], peak)
+        _with_rocprof(roofline, prefix, "codec", d["flops"] / d["launches"], peak)
 
     result = None
     if rank == 0:

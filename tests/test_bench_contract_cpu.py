@@ -52,7 +52,9 @@ def test_bench_line_contract(path):
 
 def test_default_workload_line_has_roofline_and_cpu_baseline():
     d = _last_json(os.path.join(ROOT, "profiles", f"{TAG}_codec_bench.json"))
-    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["peak"] == 157.3 and d["dtype"] == "f32"
+    # the dominant kernel is the three-plane bf16 GEMM: fp32 results, priced in algorithmic (fp32) flops against the bf16 dense peak / 6
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["peak"] == 419.4 and d["dtype"].startswith("f32")
+    assert "gemm_win_b3" in d["roofline"]["kernel"] and d["roofline"]["x_f32_mfma_peak"] > 1.0
     assert d["cpu_baseline"]["kind"] == "port" and "configs[1]" in d["config"]["workload"]
     assert d["code_exact_match_vs_cpu_oracle"] == 1.0 and d["wav_rel_err_vs_cpu_oracle"] < 1e-3      # the parity sample rides on the default line
     assert d["timing"]["samples"] >= 50 and d["timing"]["median_ms"] <= d["timing"]["p95_ms"]
@@ -62,7 +64,7 @@ def test_default_workload_line_has_roofline_and_cpu_baseline():
     assert r["rocprof"]["source"].startswith(f"profiles/{TAG}_") and abs(r["rocprof"]["frac"] - r["frac"]) < 0.05
     assert r["traffic"]["source"].startswith(f"profiles/{TAG}_") and r["traffic"]["bytes_per_launch"] > 0
     m = r["mfma_pipe"]
-    assert 0.3 < m["busy_frac"] <= 1.0 and 1.5 < m["shader_clock_ghz"] < 2.6 and m["peak_at_that_clock_tflops"] <= 160
+    assert 0.3 < m["busy_frac"] <= 1.0 and 1.5 < m["shader_clock_ghz"] < 2.6 and m["peak_at_that_clock_tflops"] <= 425
 
 
 def test_default_line_carries_the_north_star_sub_benchmarks():

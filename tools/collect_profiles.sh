@@ -59,8 +59,27 @@ if [ "$WHAT" = all ] || [ "$WHAT" = codec ] || [ "$WHAT" = mfma ]; then
   [ -n "$mc" ] && python tools/pmc_mfma.py "$mc" "$O/codec_mfma.json" | head -8
   rm -f "$O/codec_mfma.out"
 fi
+if [ "$WHAT" = all ] || [ "$WHAT" = codec ] || [ "$WHAT" = b3 ]; then
+  # the three-plane GEMM: wave-stall / LDS-conflict counters (tools/pmc_stalls.py) and the ablation table of DESIGN.md 3.1b (tools
+  # build of the library, RST_B3_DBG: WRONG results by construction, timings only)
+  NO_CUDA_GRAPH=1 run b3_stalls_raw rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$RAW/b3_stalls" -o m -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-sub --no-check --timing-samples 1
+  python tools/pmc_stalls.py "$RAW/b3_stalls" > "$O/b3_stalls.txt"; head -4 "$O/b3_stalls.txt"
+  rm -f "$O/b3_stalls_raw.out"
+  if [ -f rstnet_amd/librstnet_hip_ablation.so ]; then
+    : > "$O/b3_ablation.txt"
+    for v in "RST_B3_DBG=0 full" "RST_B3_WGS=1 one_workgroup_per_cu_(128-wide_form)" "RST_B3_WIDE=0 128-wide_tiles_only" "RST_B3_DBG=1 no_split_no_lds_writes" "RST_B3_DBG=2 no_global_loads" "RST_B3_DBG=3 matrix_instructions_only" "RST_B3_DBG=4 no_barriers" "RST_B3_BUF=0 plain_global_loads"; do
+      set -- $v
+      env "$1" python tools/ab.py LIB=rstnet_amd/librstnet_hip_ablation.so -- --steps 6 --warmup 2 --no-sub --no-cpu-baseline --no-check --timing-samples 1 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r=d['roofline']
+print('%-44s %-14s step %7.3f ms  three-plane GEMMs %7.3f ms  %7.1f TFLOP/s (fp32-equivalent)' % ('$2', '$1', d['ms_per_step'], r['kernel_ms_per_step'], r['achieved']))" >> "$O/b3_ablation.txt"
+    done
+    cat "$O/b3_ablation.txt"
+  fi
+fi
 if [ "$WHAT" = all ] || [ "$WHAT" = codec ]; then
   publish codec
+  publish b3
   run codec_bench python bench.py --steps 20 --warmup 5
 fi
 du -sh "$O"; ls "$O"
