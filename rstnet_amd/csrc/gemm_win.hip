@@ -557,11 +557,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 
 // (tests: <= 2e-6 of the fp64 value's scale, the same bound the f32-instruction path meets; RVQ codes as exact as with it) at
 // 6 x 32 = 192 matrix-pipe cycles per 32x32x16 block instead of 8 x 64 = 512.
 // Weights are split once on the host side of the ABI (rst_gemm_win_b3_pack_weight) into the staging order
-// [n tile of 128][K / 16][plane][128 rows][16 k] so a k-tile of W is three contiguous 4 KB pieces; activations stay fp32 in HBM and
-// are split on their way into LDS (v_cvt_pk_bf16_f32 + packed subtractions, ~4.5 VALU per element).  LDS rows are 16 bf16 + 8 pad
+// [n tile of 128][K / 16][plane][128 row slots][16 k] so a k-tile of W is three contiguous 4 KB pieces; activations stay fp32 in HBM
+// and are split on their way into LDS (v_cvt_pk_bf16_f32 + subtractions, ~4.5 VALU per element).  LDS rows are 16 bf16 + 8 pad
 // = 48 bytes: the 16 lanes of a ds_read_b128 group hold rows that are distinct mod 16, and 3 * row mod 16 is a bijection, so every
-// group covers 16 distinct 16-byte slots.  Two buffers of (128 + 128) rows x 3 planes = 72 KB: two workgroups per CU.
-// Tiles that touch an utterance edge take the f32-instruction routine above (fp32 weights), as in the fp32 stream kernel.
+// group covers 16 distinct 16-byte slots.  Two buffers of (128 + BN) rows x 3 planes: 72 KB (BN = 128, two workgroups per CU) or
+// 108 KB (BN = 256, one workgroup of eight waves).  Rows whose window leaves the utterance are masked inside the kernel (below); only
+// launches with a history buffer / replicate padding / K % 64 != 0 run on the f32-instruction kernels above.
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -572,8 +573,6 @@ constexpr int B3_SETS_A = 4;                  // k-tiles of activations / of wei
 constexpr int B3_SETS_B = 2;
 constexpr int B3_KB = 16;                     // k per stage (one bf16 matrix instruction deep)
 constexpr int B3_RS = 24;                     // shorts per LDS row (16 + 8 pad)
-constexpr int B3_PLANE = 128 * B3_RS;         // shorts per plane of one operand
-constexpr int B3_BUF = 6 * B3_PLANE;          // shorts per buffer: A planes 0..2, W planes 0..2
 constexpr int B3_WTILE = 3 * 128 * B3_KB;     // shorts per packed (n tile, k tile) piece of the weights
 
 // two fp32 -> the two packed bf16 (round to nearest even) and the exact remainders
@@ -597,8 +596,8 @@ __host__ __device__ __forceinline__ constexpr int b3_slot(int r) { return (r & ~
 // The stream of k-tiles (tile after tile, as in gemm_win_stream_kernel) is a software pipeline in registers.  A stage (768 matrix-pipe
 // cycles, ~0.35 us) is shorter than a loaded round trip to L2 / HBM, so the loads run several stages ahead: the fp32 activation rows
 // of k-tile g + 4 and the weight planes (L2-resident) of k-tile g + 2 are requested at the top of stage g, four / two register sets
-// rotate, and the rotation is written out (b3_int<0..3>; K is a multiple of 64, so every tile starts on set 0).  While k-tile g is multiplied out of one LDS
-// buffer, k-tile g + 1 is split and written to the other buffer BETWEEN this stage's matrix instructions -- one 4-instruction peel
+// rotate, and the rotation is written out (b3_int<0..3>; K is a multiple of 64, so every tile starts on set 0).  While k-tile g is
+// multiplied out of one LDS buffer, k-tile g + 1 is split and written to the other buffer BETWEEN this stage's matrix instructions -- one 4-instruction peel
 // or one LDS write behind every second one, pinned there with scheduling fences: the wave issues in order, and whatever sits in
 // front of the first matrix instruction is time the pipe idles.
 // MASK: the launch has rows whose window reaches into the zero padding in front of / behind an utterance, or ragged last tiles.

@@ -89,6 +89,59 @@ def test_b3_conv_with_elu_residual_and_utterance_edges():
     assert err < 2e-6, err
 
 
+def _names_of(fn):
+    ops.PROFILE = []
+    out = fn()
+    names, ops.PROFILE = [r[0] for r in ops.PROFILE], None
+    return out, names
+
+
+def test_b3_wide_tiles_lean_and_masked():
+    """The 128 x 256 tile form (512 threads; chosen when N >= 256 and the wide tiles outnumber the CUs two to one): a linear whose tiles
+    are all full (lean body), the same with ragged rows and columns (masked body, partial epilogue), and a k3 convolution over three
+    utterances with ELU on load + residual + ELU out (masked rows at every utterance start, M not a multiple of 128)."""
+    g = torch.Generator().manual_seed(41)
+    for M, N, K in ((516 * 128, 256, 128), (66100, 520, 64), (40000, 1024, 320)):
+        x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+        b, res, scale = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.rand(N, generator=g)
+        ref = F.linear(x.double(), w.double(), b.double())
+        y, names = _names_of(lambda: ops.linear(x.to(DEV), w.to(DEV), b.to(DEV)))
+        assert names == ["gemm_win_b3"]
+        assert float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-6, (M, N, K)
+        y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), res=res.to(DEV), scale=scale.to(DEV), act_out=ops.ACT_GELU)
+        want = res.double() + scale.double() * F.gelu(ref)
+        assert float((y.double().cpu() - want).abs().max() / want.abs().max()) < 2e-6, (M, N, K)
+    B, cin, cout, T = 3, 64, 512, 22100
+    x = torch.rand(B, cin, T, generator=g) * 4 - 2
+    w = synth._xavier(g, cout, cin, 3)
+    b = 0.1 * torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, T, generator=g)
+    nlc = lambda t: t.transpose(1, 2).contiguous().to(DEV)
+    y, names = _names_of(lambda: RF.conv1d(nlc(x), RF.pack_conv_weight(w).to(DEV), b.to(DEV), k_eff=3, act_in=ops.ACT_ELU, res=nlc(res),
+                                           act_out=ops.ACT_ELU_OUT))
+    assert names == ["gemm_win_b3"]
+    ref = F.elu(res.double() + F.conv1d(F.pad(F.elu(x.double()), (2, 0)), w.double(), b.double()))
+    assert float((y.transpose(1, 2).double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+def test_b3_shapes_that_stay_on_the_f32_instruction():
+    """A history buffer (streaming chunk of > 4096 rows), replicate padding and K % 64 != 0 keep the f32 kernels -- same results as ever."""
+    g = torch.Generator().manual_seed(42)
+    B, cin, cout, K, S, T = 2, 64, 128, 4, 2, 12000
+    full = torch.rand(B, cin, T + K - S, generator=g) * 2 - 1
+    w = synth._xavier(g, cout, cin, K)
+    nlc = lambda t: t.transpose(1, 2).contiguous().to(DEV)
+    hist, x = full[:, :, :K - S], full[:, :, K - S:]
+    y, names = _names_of(lambda: RF.conv1d(nlc(x), RF.pack_conv_weight(w).to(DEV), None, k_eff=K, stride=S, hist=nlc(hist)))
+    assert names == ["gemm_win"]
+    ref = F.conv1d(full.double(), w.double(), None, stride=S)
+    assert float((y.transpose(1, 2).double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-6
+    y, names = _names_of(lambda: RF.conv1d(nlc(x), RF.pack_conv_weight(w).to(DEV), None, k_eff=K, stride=S, pad_mode=ops.PAD_REPLICATE))
+    assert names == ["gemm_win"]
+    ref = O.causal_conv1d(x.double(), w.double(), None, stride=S, pad_mode="replicate")
+    assert float((y.transpose(1, 2).double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
 def test_b3_pack_rejects_bad_shapes():
     w = torch.randn(64, 24, device=DEV)
     with pytest.raises(ValueError):
