@@ -607,7 +607,8 @@ __host__ __device__ __forceinline__ constexpr int b3_slot(int r) { return (r & ~
 // NWN: waves along N.  2: 128 x 128 tile, 256 threads, two workgroups per CU.  4: 128 x 256 tile, 512 threads, one workgroup per CU --
 // the same eight waves per CU, but every activation element is split for 256 columns instead of 128, which halves the split work
 // (VALU + LDS writes) per matrix instruction: measured (tools build, RST_B3_DBG) that work is what the 128-wide form spends most on.
-// DBG (tools build only, WRONG results): 1 = no split / LDS writes, 2 = no global loads, 3 = matrix instructions only, 4 = no barriers
+// DBG (tools build only, WRONG results): 1 = no split / LDS writes, 2 = no global loads, 3 = matrix instructions only, 4 = no barriers,
+// 5 = LDS writes of unsplit bits (what activations handed over already split would cost)
 template <bool ELU, bool MASK, int NWN, int DBG = 0, bool BUFL = true>
 __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_win_b3_stream_kernel(const GemmWinParams p, const int tiles) {
     constexpr int TM = 2, TN = 2;
@@ -800,7 +801,8 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2, 2)
                     const int u = op - 3;
                     const int q = u / PB, w = u % PB;
                     if (w < 2 * RA) {
-                        h[w >> 1][w & 1] = b3_peel(v[w >> 1][w & 1]);
+                        if (DBG == 5) h[w >> 1][w & 1] = __builtin_bit_cast(unsigned, v[w >> 1][w & 1][0]) + q;
+                        else h[w >> 1][w & 1] = b3_peel(v[w >> 1][w & 1]);
                     } else {
 #pragma unroll
                         for (int r = 0; r < RA; ++r) *reinterpret_cast<u32x2*>(wr + a_dst + q * A_PLANE + r * (NT / 4) * B3_RS) = h[r];
@@ -1021,6 +1023,7 @@ int launch_stream_b3_cfg(const GemmWinParams& p, hipStream_t stream) {
     if (dbg == 2) { go(gemm_win_b3_stream_kernel<false, true, NWN, 2>); return rst_check_launch("gemm_win_b3"); }
     if (dbg == 3) { go(gemm_win_b3_stream_kernel<false, true, NWN, 3>); return rst_check_launch("gemm_win_b3"); }
     if (dbg == 4) { go(gemm_win_b3_stream_kernel<false, true, NWN, 4>); return rst_check_launch("gemm_win_b3"); }
+    if (dbg == 5) { go(gemm_win_b3_stream_kernel<false, true, NWN, 5>); return rst_check_launch("gemm_win_b3"); }
     static const int bufl = rst_knob("RST_B3_BUF", 1);        // 0: plain global loads (64-bit addresses on the vector unit)
     if (!bufl && p.act_in != 1) {
         if (lean) go(gemm_win_b3_stream_kernel<false, false, NWN, 0, false>);
