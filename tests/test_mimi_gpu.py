@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import mimi_oracle as O
-from rstnet_amd import synth
+from rstnet_amd import ops, synth
 from rstnet_amd.codec.conv import StreamingConv1d, StreamingConvTranspose1d
 from rstnet_amd.codec.mimi import MimiCodec
 from rstnet_amd.codec.seanet import SEANetDecoder, SEANetEncoder, SEANetResnetBlock
@@ -324,11 +324,14 @@ def test_offline_tokenization_cli(tmp_path):
         assert data[f"utt{i}"].dtype == torch.int16 and torch.equal(data[f"utt{i}"], want), i
 
 
-def test_encode_decode_8x10s_full_size_kernels_vs_oracle(mimi):
+@pytest.mark.parametrize("b3", [True, False], ids=["three_plane_bf16", "f32_instruction"])
+def test_encode_decode_8x10s_full_size_kernels_vs_oracle(mimi, b3, monkeypatch):
     """Eight 10 s clips through encode + decode against the CPU oracle: at this size every GEMM of the SEANet stacks runs the
-    kernel instances of the headline benchmark (>= 768 tiles: 16-wide k-chunks, fused res-blocks at 240 000 steps), which the
-    one-second fixtures never reach.  Codes must equal the oracle's wherever the oracle's own top-2 gap is not a near tie."""
+    kernel instances of the headline benchmark (the three-plane bf16 GEMM for every unfused conv / linear, fused res-blocks at
+    240 000 steps), which the one-second fixtures never reach -- and once more with the large GEMMs kept on the f32 matrix
+    instruction (`ops.GEMM_B3 = False`).  Codes must equal the oracle's wherever the oracle's own top-2 gap is not a near tie."""
     from tests.parity import codes_match_up_to_near_ties
+    monkeypatch.setattr(ops, "GEMM_B3", b3)
     sd, model = mimi
     cfg = O.MimiConfig()
     B, T = 8, 240000
@@ -350,7 +353,7 @@ def test_encode_decode_8x10s_full_size_kernels_vs_oracle(mimi):
     assert codes.shape == ref_codes.shape == (B, 8, 125)
     excused = codes_match_up_to_near_ties(codes.cpu(), ref_codes, gaps)
     match = float((codes.cpu() == ref_codes).float().mean())
-    print(f"8 x 10 s: code exact-match {match:.6f}; {excused} frames differ, all at decisions with a top-2 gap < 2e-5 "
+    print(f"8 x 10 s (GEMM_B3={b3}): code exact-match {match:.6f}; {excused} frames differ, all at decisions with a top-2 gap < 2e-5 "
           f"(min gap {float(gaps.min()):.2e})")
     assert match > 0.999
     wav = model.decode(ref_codes.to(DEV))
