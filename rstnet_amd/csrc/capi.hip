@@ -24,7 +24,7 @@ int rst_check_launch(const char* what) {
 
 extern "C" {
 
-int rst_version(void) { return 100; }
+int rst_version(void) { return 103; }      // round 3: + three-plane GEMM, fp32-input skinny GEMM, top-p sampler, status[4] protocol
 const char* rst_last_error(void) { return g_err; }
 
 static int gemm_win_common(const float* x, const float* hist, const float* w, const uint16_t* w3, const float* bias, const float* res,
