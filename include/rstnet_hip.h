@@ -56,15 +56,24 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
                      int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, int split_k, float* ws,
                      uint32_t* counters, rst_stream_t stream);
 
-/* The same contraction on the bf16 matrix instruction at fp32 accuracy, for the large launches (B*T_out > 4096 rows, N > 64, K % 16 == 0;
- * other shapes run exactly as rst_gemm_win_f32): every fp32 operand is the exact sum of three bf16 numbers (hi + mid + lo, each rounded
- * to nearest even from the exact remainder), and six of the nine cross products are accumulated in fp32 (the three dropped are below
- * 2^-23 |x||w|, one fp32 rounding of the product) -- 192 matrix-pipe cycles per 32x32x16 block instead of the f32 instruction's 512.
+/* The same contraction on the bf16 matrix instruction at fp32 accuracy, for the large launches: every fp32 operand is the exact sum of
+ * three bf16 numbers (hi + mid + lo, each rounded to nearest even from the exact remainder), and six of the nine cross products are
+ * accumulated in fp32 (the three dropped are below 2^-23 |x||w|, one fp32 rounding of the product) -- 192 matrix-pipe cycles per
+ * 32x32x16 block instead of the f32 instruction's 512.
+ * Shapes served -- rst_gemm_win_b3_supported(...) != 0: B*T_out > 4096 rows, N > 64, K % 64 == 0, C % 16 == 0, zero padding
+ * (pad_mode RST_PAD_ZERO), no history buffer, x_bstride % 4 == 0, activations and split weights each below 4 GB; all pointers 16-byte
+ * aligned.  rst_gemm_win_b3_f32 FAILS (RST_ERR_INVALID_ARG, rst_last_error) on any other call -- it never falls back to the f32
+ * instruction silently; callers route those launches to rst_gemm_win_f32 themselves.  Rows whose window reaches into the zero
+ * padding or past the utterance, and ragged last tiles, are masked inside the kernel; w (fp32) is not read.
  * The caller splits the weights once: w3 = rst_gemm_win_b3_weight_elems(N, K) uint16, filled by rst_gemm_win_b3_pack_weight (K % 16
- * == 0; layout [2*ceil(N/256)][K/16][3][128][16] -- 128-row tiles, row b3_row(g) of a tile in slot g, rows past N zero); activations
- * are split inside the launch.  w (fp32) is still read
- * by the tiles that touch an utterance edge.  Replaces the conv / linear bodies of AudioCodec/MimiCodec/modules/conv.py:178-252 for
- * batched (non-streaming) encode / decode. */
+ * == 0 suffices for the packing; layout [2*ceil(N/256)][K/16][3][128][16] -- 128-row tiles, row b3_row(g) of a tile in slot g, rows past
+ * N zero); activations are split inside the launch.
+ * Domain of the fp32-accuracy claim: finite operands with |x|, |w| in {0} u [2^-110, 3.38e38].  Below 2^-110 the lo (then mid) plane
+ * leaves bf16's normal range: the result stays within 2^-126 sum_k |w_k| (resp. |x_k|) absolute of the exact one -- flush-to-zero
+ * class.  +-Inf / NaN operands (and finite ones beyond the largest bf16, 3.3895e38, whose hi plane rounds to Inf) make every output
+ * they touch NaN, where the f32 instruction gives +-Inf or NaN: non-finite either way, not the same non-finite value.
+ * Replaces the conv / linear bodies of AudioCodec/MimiCodec/modules/conv.py:178-252 for batched (non-streaming) encode / decode. */
+int rst_gemm_win_b3_supported(int B, int T_in, int T_out, int C, int K, int N, int S, int P, int pad_mode, int64_t x_bstride, int has_hist);
 int rst_gemm_win_b3_weight_elems(int N, int K);   /* -1: bad sizes */
 int rst_gemm_win_b3_pack_weight(const float* w, uint16_t* w3, int N, int K, rst_stream_t stream);
 int rst_gemm_win_b3_f32(const float* x, const float* hist, const float* w, const uint16_t* w3, const float* bias, const float* res,

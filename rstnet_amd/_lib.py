@@ -22,6 +22,7 @@ SIGNATURES = {
     "rst_gemm_win_split_plan": [_l, _i, _i],
     "rst_gemm_win_split_tiles": [_l, _i],
     "rst_gemm_win_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _i, _i, _i, _p, _p, _p],
+    "rst_gemm_win_b3_supported": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i],
     "rst_gemm_win_b3_weight_elems": [_i, _i],
     "rst_gemm_win_b3_pack_weight": [_p, _p, _i, _i, _p],
     "rst_gemm_win_b3_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _i, _i, _p],

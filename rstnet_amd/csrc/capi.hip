@@ -61,6 +61,11 @@ int rst_gemm_win_b3_f32(const float* x, const float* hist, const float* w, const
                            act_out, 1, nullptr, nullptr, stream);
 }
 
+int rst_gemm_win_b3_supported(int B, int T_in, int T_out, int C, int K, int N, int S, int P, int pad_mode, int64_t x_bstride, int has_hist) {
+    if (S <= 0 || P < 0) return 0;
+    return rst_gemm_win_b3_shape_ok(B, T_in, T_out, C, K, N, pad_mode, (long)x_bstride, has_hist != 0) ? 1 : 0;
+}
+
 int rst_gemm_win_b3_weight_elems(int N, int K) {
     const long n = (N > 0 && K > 0) ? rst_gemm_win_b3_weight_elems_impl(N, K) : -1;
     return n > 0 && n < 0x7fffffffL ? (int)n : -1;

@@ -219,10 +219,16 @@ __global__ __launch_bounds__(DF_THREADS) void codec_tr_kernel(const CodecTrParam
                             int tn = -1;
                             for (int t2 = 0; t2 < T; ++t2) tn = (int)((pos + t2) % cap) == slot ? t2 : tn;
                             float kv[16], vv[16];
+                            // values of a slot that is masked / not yet written are CLEARED, not multiplied by a zero weight: a ring the
+                            // caller did not zero may hold Inf / NaN there (0 * NaN would poison the row; the reference masks such slots).
+                            // The mask goes through an opaque register so that the loads above stay unconditional.
+                            int vmask = ok ? -1 : 0;
+                            asm volatile("" : "+v"(vmask));
 #pragma unroll
                             for (int i = 0; i < 16; ++i) {
                                 kv[i] = tn >= 0 ? qh[(tn * 3 + 1) * D + sub * 16 + i] : kq[u][i >> 2][i & 3];
-                                vv[i] = tn >= 0 ? qh[(tn * 3 + 2) * D + sub * 16 + i] : vq[u][i >> 2][i & 3];
+                                const float vraw = tn >= 0 ? qh[(tn * 3 + 2) * D + sub * 16 + i] : vq[u][i >> 2][i & 3];
+                                vv[i] = __int_as_float(__float_as_int(vraw) & vmask);
                             }
                             float d = 0.f;
 #pragma unroll
@@ -312,14 +318,7 @@ __global__ __launch_bounds__(DF_THREADS) void codec_tr_kernel(const CodecTrParam
 }
 
 int ct_cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
+    return rst_cu_count();       // per device (rst_common.h)
 }
 
 }  // namespace
@@ -341,15 +340,16 @@ int rst_codec_tr_grid(int B, int T, int E, int H, int F, int L, int cap) {
     if (lds > 150 * 1024) return 0;
     const int G = df_grid_for_rows(ct_cu_count(), min(3 * E, F));
     if (B * H > G) return 0;
-    static int fits = -1;
-    if (fits < 0) {
+    static signed char fits_dev[RST_MAX_DEVICES];        // per device: 0 = not asked yet, 1 = fits, -1 = does not
+    signed char& fits = fits_dev[rst_current_device()];
+    if (fits == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(codec_tr_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         int nb = 0;
         const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, codec_tr_kernel<4, false>, DF_THREADS, 150 * 1024);
         (void)hipGetLastError();
-        fits = (e == hipSuccess && nb >= 1) ? 1 : 0;
+        fits = (e == hipSuccess && nb >= 1) ? 1 : -1;
     }
-    return fits ? G : 0;
+    return fits > 0 ? G : 0;
 }
 
 int rst_launch_codec_tr(const CodecTrParams& p, hipStream_t stream) {
@@ -369,11 +369,10 @@ int rst_launch_codec_tr(const CodecTrParams& p, hipStream_t stream) {
         return RST_ERR_LAUNCH;
     }
     auto go = [&](auto kern, int grid) {
-        static bool attr_set = false;       // one flag per kernel instance
-        if (!attr_set) {
+        static RstOncePerDevice attr_once;       // one flag per kernel instance
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             (void)hipGetLastError();
-            attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DF_THREADS), lds, stream, p);
     };

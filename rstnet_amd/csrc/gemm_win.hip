@@ -929,12 +929,11 @@ int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
     }
     const size_t lds = 2 * (BM + BN) * (KB + 4) * sizeof(float);
     auto go = [&](auto kern) {
-        static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel instantiation
-        if (!attr_set) {
+        static RstOncePerDevice attr_once;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel instantiation
+        if (attr_once.first()) {
             // the kernel also has a few bytes of static LDS: stay below the 160 KiB total (the largest tile needs 83 KiB)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipGetLastError();
-            attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)(p.split_k > 1 ? p.split_k : 1)), dim3(256), lds, stream, p);
     };
@@ -947,14 +946,7 @@ int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
 }
 
 static int gw_cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
+    return rst_cu_count();       // per device (rst_common.h)
 }
 
 // the 128 x 128 configuration on 16-byte-aligned operands: resident workgroups streaming through the tiles
@@ -970,11 +962,10 @@ int launch_stream(const GemmWinParams& p, long tiles, hipStream_t stream) {
     const long resident = (long)per_cu * gw_cu_count();
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
     auto go = [&](auto kern) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static RstOncePerDevice attr_once;
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipGetLastError();
-            attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p, (int)tiles);
     };
@@ -1004,11 +995,10 @@ int launch_stream_b3_cfg(const GemmWinParams& p, hipStream_t stream) {
     const long resident = (long)per_cu * gw_cu_count();
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
     auto go = [&](auto kern) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static RstOncePerDevice attr_once;
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipGetLastError();
-            attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NWN), lds, stream, p, (int)tiles);
     };
@@ -1079,6 +1069,19 @@ int rst_gemm_split_plan_impl(long M, int N, int K) {
     return s;
 }
 
+// Shapes the three-plane bf16 kernel serves (pointer alignment apart): the 128 x 128 tile class (more than 4096 rows, N > 64), whole
+// rotations of the four register sets (K % 64 == 0), windows that leave their utterance on a k-tile boundary (C % 16 == 0), zero padding,
+// no history buffer, 16-byte-aligned rows, and operands its 32-bit buffer offsets can reach.
+bool rst_gemm_win_b3_shape_ok(int B, int T_in, int T_out, int C, int K, int N, int pad_mode, long x_bstride, bool has_hist) {
+    if (B <= 0 || T_in <= 0 || T_out <= 0 || C <= 0 || K <= 0 || N <= 0) return false;
+    const long M = (long)B * T_out;
+    if (gw_tile_cfg(M, N) != 0) return false;
+    if (K % 64 != 0 || C % 16 != 0 || x_bstride % 4 != 0 || has_hist || pad_mode != 0) return false;
+    const long x_bytes = ((long)(B - 1) * x_bstride + (long)T_in * C) * 4;
+    const long w_bytes = rst_gemm_win_b3_weight_elems_impl(N, K) * 2;
+    return x_bytes < 0xfffff000L && w_bytes < 0xfffff000L;
+}
+
 int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B >= 0 && p.T_in >= 0 && p.T_out >= 0 && p.C > 0 && p.K > 0 && p.N > 0 && p.S > 0 && p.P >= 0,
                 "gemm_win: bad sizes B=%d T_in=%d T_out=%d C=%d K=%d N=%d S=%d P=%d", p.B, p.T_in, p.T_out, p.C,
@@ -1092,6 +1095,7 @@ int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
                      (!p.hist || (uintptr_t)p.hist % 16 == 0);
     const long M = (long)p.B * p.T_out;
     RST_REQUIRE(p.split_k <= 1 || (p.ws && p.counters && M <= 4096), "gemm_win: split-K needs M <= 4096 and the scratch buffers");
+    RST_REQUIRE(!p.w3 || gw_tile_cfg(M, p.N) == 0, "gemm_win_b3: %ld x %d is not a large-launch shape (more than 4096 rows, N > 64)", M, p.N);
     switch (gw_tile_cfg(M, p.N)) {
         case 0: {                                                            // 128 x 128
             // >= 3 tiles per CU: k-chunks of 16 (40 KB of LDS, accumulators in VGPRs) put three workgroups on a CU instead of two
@@ -1100,15 +1104,16 @@ int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
             // 3.1), RST_GEMM_STREAM=0 one workgroup per tile (the pre-streaming form, for A/B measurements)
             static const bool kb32_only = rst_knob("RST_GEMM_KB32", 0) != 0;
             static const bool stream_off = rst_knob("RST_GEMM_STREAM", 1) == 0;
+            // the three-plane bf16 form when the caller passed the split weights: either it runs, or the call fails -- never a silent
+            // change of instruction (callers ask rst_gemm_win_b3_supported first)
+            if (p.w3) {
+                RST_REQUIRE(vec && p.split_k <= 1 && (uintptr_t)p.w3 % 16 == 0 &&
+                            rst_gemm_win_b3_shape_ok(p.B, p.T_in, p.T_out, p.C, p.K, p.N, p.pad_mode, p.x_bstride, p.hist != nullptr),
+                            "gemm_win_b3: shape / alignment not served by the three-plane kernel (B=%d T_in=%d T_out=%d C=%d K=%d N=%d pad=%d "
+                            "hist=%d); ask rst_gemm_win_b3_supported", p.B, p.T_in, p.T_out, p.C, p.K, p.N, p.pad_mode, p.hist != nullptr);
+                return launch_stream_b3(p, stream);
+            }
             if (vec && !stream_off && p.split_k <= 1) {
-                // the three-plane bf16 form when the caller passed the split weights (K % 64 == 0: whole rotations of the four register sets)
-                // (zero padding only: a history buffer / replicate padding keeps the launch on the f32 instruction)
-                // (and operands its 32-bit buffer offsets can reach)
-                const long x_bytes = ((long)(p.B - 1) * p.x_bstride + (long)p.T_in * p.C) * 4;
-                const long w_bytes = rst_gemm_win_b3_weight_elems_impl(p.N, p.K) * 2;
-                if (p.w3 && p.K % 64 == 0 && p.C % 16 == 0 && !p.hist && p.pad_mode == 0 && (uintptr_t)p.w3 % 16 == 0 &&
-                    x_bytes < 0xfffff000L && w_bytes < 0xfffff000L)
-                    return launch_stream_b3(p, stream);
                 if (tiles >= 768 && !kb32_only) return launch_stream<16>(p, tiles, stream);
                 return launch_stream<32>(p, tiles, stream);
             }

@@ -297,14 +297,7 @@ __global__ __launch_bounds__(DF_THREADS) void depth_frame_kernel(const DepthFram
 }
 
 int df_cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
+    return rst_cu_count();       // per device (rst_common.h)
 }
 
 size_t df_lds_bytes(const DepthFrameParams& p) {
@@ -338,9 +331,10 @@ int rst_depth_frame_grid(const DepthFrameParams& p) {
     const int G = df_grid_for_rows(df_cu_count(), rows);
     if (p.H > G) return 0;
     // residency: all G workgroups must run at once, one per CU -- ask the runtime whether a CU takes a workgroup of this footprint
-    static int fits[2][2] = {{-1, -1}, {-1, -1}};        // [B - 1][lds > 64 KB]: the answer does not change within a footprint class
-    int& f = fits[p.B - 1][lds > 64 * 1024];
-    if (f < 0) {
+    static signed char fits[RST_MAX_DEVICES][2][2];      // [device][B - 1][lds > 64 KB]: 0 = not asked yet, 1 = fits, -1 = does not; the
+                                                         // answer does not change within a footprint class
+    signed char& f = fits[rst_current_device()][p.B - 1][lds > 64 * 1024];
+    if (f == 0) {
         const void* kern = p.B == 1 ? reinterpret_cast<const void*>(depth_frame_kernel<1, false>) : reinterpret_cast<const void*>(depth_frame_kernel<2, false>);
         (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         int nb = 0;
@@ -348,9 +342,9 @@ int rst_depth_frame_grid(const DepthFrameParams& p) {
         const hipError_t e = p.B == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, depth_frame_kernel<1, false>, DF_THREADS, probe)
                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, depth_frame_kernel<2, false>, DF_THREADS, probe);
         (void)hipGetLastError();
-        f = (e == hipSuccess && nb >= 1) ? 1 : 0;
+        f = (e == hipSuccess && nb >= 1) ? 1 : -1;
     }
-    return f ? G : 0;
+    return f > 0 ? G : 0;
 }
 
 int rst_launch_depth_frame(const DepthFrameParams& p, hipStream_t stream) {
@@ -372,11 +366,10 @@ int rst_launch_depth_frame(const DepthFrameParams& p, hipStream_t stream) {
         return RST_ERR_LAUNCH;
     }
     auto go = [&](auto kern, int grid) {
-        static bool attr_set = false;       // one flag per kernel instance (the lambda is instantiated per `kern` type)
-        if (!attr_set) {
+        static RstOncePerDevice attr_once;       // one flag per kernel instance (the lambda is instantiated per `kern` type)
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             (void)hipGetLastError();
-            attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DF_THREADS), lds, stream, p);
     };

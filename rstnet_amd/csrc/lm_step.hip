@@ -473,12 +473,11 @@ int rst_launch_gemv(const GemvParams& p, hipStream_t stream) {
     const long groups = p.gate_out ? ((long)p.N / 2 + GEMV_WAVES - 1) / GEMV_WAVES : ((long)p.N + rows_per_group - 1) / rows_per_group;
     const unsigned grid = cap_grid(groups, norm_stream ? 1024 : (lds > 48 * 1024 ? 512 : 768));
     auto go = [&](auto kern) {
-        static bool attr_set = false;     // one flag per kernel instantiation (generic lambda)
-        if (!attr_set) {
+        static RstOncePerDevice attr_once;     // one flag per kernel instantiation (generic lambda)
+        if (attr_once.first()) {
             // static LDS (the 16-byte reduction scratch) counts against the 160 KiB budget: ask for what the check above allows
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipGetLastError();
-            attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GEMV_WAVES), lds, stream, p);
     };

@@ -345,11 +345,10 @@ int launch(const ResblockParams& p, hipStream_t stream) {
     const int halo = POST ? p.Kf - 1 : 0;
     const long tiles = (long)p.B * ((p.T + (BM - halo) - 1) / (BM - halo));
     if (tiles > 0x7fffffffL) { rst_set_error("resblock: grid too large"); return RST_ERR_UNSUPPORTED; }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static RstOncePerDevice attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<C, BM, WM, WN, PRE, POST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL((resblock_kernel<C, BM, WM, WN, PRE, POST>), dim3((unsigned)tiles), dim3(256), lds, stream, p);
     return rst_check_launch("resblock");
@@ -643,18 +642,11 @@ int launch64_stream(const ResblockParams& p, hipStream_t stream) {
     const long tiles_u = (p.T + (RS_BM - halo) - 1) / (RS_BM - halo);
     const long total = (long)p.B * tiles_u;
     if (total > 0x7fffffffL) { rst_set_error("resblock: grid too large"); return RST_ERR_UNSUPPORTED; }
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
+    const int cus = rst_cu_count();
+    static RstOncePerDevice attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resblock64_stream_kernel<PRE, POST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     const long resident = 2L * cus;
     const unsigned grid = (unsigned)(total < resident ? total : resident);

@@ -33,6 +33,37 @@ static inline int rst_knob(const char* name, int dflt) {
 static inline constexpr int rst_knob(const char*, int dflt) { return dflt; }
 #endif
 
+// ---- per-device host-side state ------------------------------------------------------------------------------------------------
+// A process may drive several GPUs (one rank per GPU is the deployment, but the library does not assume it): kernel attributes
+// (hipFuncSetAttribute applies to the current device's copy of a kernel), CU counts and residency answers are cached PER DEVICE.
+#define RST_MAX_DEVICES 64
+static inline int rst_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return dev >= 0 && dev < RST_MAX_DEVICES ? dev : 0;
+}
+// `static RstOncePerDevice once; if (once.first()) { ...opt-in... }`: true the first time it is asked on each device
+struct RstOncePerDevice {
+    unsigned long long mask = 0;
+    bool first() {
+        const unsigned long long bit = 1ull << rst_current_device();
+        if (mask & bit) return false;
+        mask |= bit;
+        return true;
+    }
+};
+// CUs of the current device
+static inline int rst_cu_count() {
+    static int n[RST_MAX_DEVICES] = {0};
+    const int dev = rst_current_device();
+    if (n[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
+        if (n[dev] <= 0) n[dev] = 256;
+    }
+    return n[dev];
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

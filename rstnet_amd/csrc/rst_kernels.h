@@ -28,6 +28,7 @@ struct GemmWinParams {
                          // on the bf16 matrix instruction (six products per fp32 product, fp32 accuracy); nullptr: f32 instruction
 };
 int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream);
+bool rst_gemm_win_b3_shape_ok(int B, int T_in, int T_out, int C, int K, int N, int pad_mode, long x_bstride, bool has_hist);
 long rst_gemm_win_b3_weight_elems_impl(int N, int K);
 int rst_launch_gemm_win_b3_pack(const float* w, unsigned short* w3, int N, int K, hipStream_t stream);
 int rst_gemm_split_plan_impl(long M, int N, int K);

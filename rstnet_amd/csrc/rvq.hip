@@ -322,11 +322,10 @@ int rst_launch_rvq_search(const RvqSearchParams& p, hipStream_t stream) {
     if (p.M == 0) return RST_OK;
     const size_t lds = ((size_t)FR * (p.D + 4) + p.n_codes + 2 * NW * FR + FR) * sizeof(float);
     RST_REQUIRE(lds <= 160 * 1024, "rvq_search: D=%d n_codes=%d needs %zu bytes of LDS", p.D, p.n_codes, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static RstOncePerDevice attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_search_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_search_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     const dim3 grid((p.M + FR - 1) / FR, p.n_groups);
     if (p.D == 256) hipLaunchKernelGGL(rvq_search_kernel<32>, grid, dim3(64 * NW), lds, stream, p);     // the codec's codebooks

@@ -101,7 +101,7 @@ class GPTGen:
         h_all = ops.lm_linear(h, m.codecformer_in_all())      # codecformer_in[k](h) of all dep_q steps in one launch
         E, H = dep.d_model, dep.num_heads
         Hd = dep.layers[0].gating[0].linear_out.weight.shape[1]
-        if ops.depth_frame_enabled(text_token.device) and ops.depth_frame_supported(B, E, H, Hd, cfg.audio_card, cfg.dep_q, len(dep.layers), k_eff):
+        if ops.depth_frame_enabled(text_token.device) and ops.depth_frame_supported(B, E, H, Hd, cfg.audio_card, cfg.dep_q, len(dep.layers), k_eff, device=text_token.device):
             # batch 1 / 2: the dep_q steps with their samplers are one persistent launch (csrc/lm_depth.hip)
             tokens = torch.empty(B, cfg.dep_q + 1, device=text_token.device, dtype=torch.long)
             tokens[:, 0] = text_token

@@ -455,7 +455,7 @@ class LMGen(StreamingModule[_LMGenState]):
         h_all = ops.lm_linear(h_t, lm.depformer_in_all())
         E, H = dep.d_model, dep.num_heads
         Hd = dep.layers[0].gating[0].linear_out.weight.shape[1]
-        if ops.depth_frame_enabled(h_t.device) and h_t.is_cuda and ops.depth_frame_supported(B, E, H, Hd, lm.card, lm.dep_q, len(dep.layers), self.top_k):
+        if ops.depth_frame_enabled(h_t.device) and h_t.is_cuda and ops.depth_frame_supported(B, E, H, Hd, lm.card, lm.dep_q, len(dep.layers), self.top_k, device=h_t.device):
             # batch 1 / 2: the whole phase (dep_q x (L layers + head + sampler)) is ONE persistent launch whose ops hand their
             # vectors over in-kernel; the depth KV ring lives in its LDS
             tables = lm.depth_frame_tables()

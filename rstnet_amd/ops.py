@@ -163,6 +163,22 @@ def _b3_shape(M: int, N: int, K: int) -> bool:
     return GEMM_B3 and M > 4096 and N > 64 and K % 64 == 0
 
 
+@functools.lru_cache(maxsize=1024)
+def _b3_supported(B: int, T_in: int, T_out: int, C_: int, K: int, N: int, S: int, P: int, pad_mode: int, x_bstride: int, has_hist: bool) -> bool:
+    return bool(_lib.lib().rst_gemm_win_b3_supported(B, T_in, T_out, C_, K, N, S, P, pad_mode, x_bstride, int(has_hist)))
+
+
+def _b3_route(x, hist, w, B: int, T_in: int, T_out: int, C_: int, K: int, N: int, S: int, P: int, pad_mode: int) -> bool:
+    """True when this launch runs on the three-plane bf16 kernel: the LIBRARY's predicate (rst_gemm_win_b3_supported: shape, padding,
+    4 GB buffer-offset reach) plus 16-byte-aligned operands -- rst_gemm_win_b3_f32 refuses everything else, so a profile row labelled
+    `gemm_win_b3` names the kernel that ran."""
+    if not GEMM_B3 or not _b3_shape(B * T_out, N, K):
+        return False
+    if x.data_ptr() % 16 or w.data_ptr() % 16:
+        return False
+    return _b3_supported(B, T_in, T_out, C_, K, N, S, P, pad_mode, T_in * C_, hist is not None)
+
+
 def skinny_f32_pack_weight(w: torch.Tensor) -> torch.Tensor:
     """fp32 ``[N, K]`` -> MFMA-ordered copy ``[ceil(N/32)*32, ceil(K/8)*8]`` (rst_skinny_f32_pack_weight), cached per storage."""
     _chk(w, "w")
@@ -229,8 +245,8 @@ def gemm_win(x: torch.Tensor, w: torch.Tensor, *, B: int, T_in: int, T_out: int,
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    # (zero padding only: a history buffer / replicate padding keeps the launch on the f32 instruction, as the launcher decides too)
-    b3 = split_k <= 1 and _b3_shape(B * T_out, N, K) and hist is None and pad_mode == PAD_ZERO and C_ % 16 == 0
+    # (zero padding only: a history buffer / replicate padding keeps the launch on the f32 instruction)
+    b3 = split_k <= 1 and _b3_route(x, hist, w, B, T_in, T_out, C_, K, N, S, P, pad_mode)
     if b3:
         _lib.check(_lib.lib().rst_gemm_win_b3_f32(_ptr(x), _ptr(hist), _ptr(w), _ptr(gemm_win_b3_pack_weight(w)), _ptr(bias), _ptr(res),
                                                   _ptr(scale), _ptr(out), B, T_in, T_out, C_, K, N, S, P, pad_mode, T_in * C_, N, act_in,
@@ -281,7 +297,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    b3 = split_k <= 1 and _b3_shape(M, N, K)
+    b3 = split_k <= 1 and _b3_route(x, None, w, 1, M, M, K, K, N, 1, 0, PAD_ZERO)
     if split_k > 1:
         _lib.check(_lib.lib().rst_gemm_win_f32(_ptr(x), None, _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), 1, M, M, K, K, N,
                                                1, 0, 0, M * K, N, 0, act_out, split_k, _ptr(ws), _ptr(cnt), _stream()))
@@ -1013,6 +1029,7 @@ _persist_status: dict = {}          # device -> list of weakrefs of status tenso
 _persist_off: dict = {}             # device -> reason string
 _persist_epoch: dict = {}           # device -> int, bumped when the device's persistent path is retired
 _persist_pending: dict = {}         # device -> (event, [pinned int32 [4] copies])
+_persist_seen: dict = {}            # device -> repairs counted by the last completed poll
 
 
 def new_persistent_status(device) -> torch.Tensor:
@@ -1030,10 +1047,34 @@ def persistent_epoch(device) -> int:
 
 
 def persistent_repairs(device, synchronize: bool = True) -> int:
-    """Frames / codec steps of `device` that the repair launches had to recompute so far (reads the device words: synchronises)."""
+    """Frames / codec steps of `device` that the repair launches had to recompute so far.  ``synchronize=True`` reads the device words
+    now (a device-to-host copy: waits for the stream); ``False`` returns the count seen by the last completed `persistent_poll` copy
+    without touching the device (0 before the first one)."""
     device = torch.device(device)
+    if not synchronize:
+        pend = _persist_pending.get(device)
+        if pend is not None and pend[0].query():
+            _persist_seen[device] = int(sum(int(c[1]) for c in pend[1]))
+        return _persist_seen.get(device, 0)
     alive = [r() for r in _persist_status.get(device, [])]
-    return int(sum(int(t[1].item()) for t in alive if t is not None))
+    n = int(sum(int(t[1].item()) for t in alive if t is not None))
+    _persist_seen[device] = n
+    return n
+
+
+def persistent_rearm(device) -> None:
+    """Gives `device` its persistent frame launches back after `persistent_poll` retired them (e.g. the process that shared the GPU
+    has gone): clears the repair counters, bumps the epoch so that sessions re-capture their graphs.  The in-stream repair launch
+    keeps every frame correct either way; this is about speed only."""
+    device = torch.device(device)
+    for r in _persist_status.get(device, []):
+        t = r()
+        if t is not None:
+            t.zero_()
+    _persist_pending.pop(device, None)
+    _persist_seen.pop(device, None)
+    if _persist_off.pop(device, None) is not None:
+        _persist_epoch[device] = _persist_epoch.get(device, 0) + 1
 
 
 def _retire_persistent(device, reason: str) -> None:
@@ -1063,6 +1104,7 @@ def persistent_poll(device, synchronize: bool = False) -> None:
         if not ev.query():
             return
         n = int(sum(int(c[1]) for c in copies))
+        _persist_seen[device] = n
         _persist_pending.pop(device, None)
         if n > PERSISTENT_MAX_REPAIRS:
             _retire_persistent(device, f"{n} frame(s) needed the one-workgroup repair launch (hand-offs timed out: not all workgroups were resident)")
@@ -1091,18 +1133,28 @@ def depth_frame_enabled(device=None) -> bool:
 
 
 @functools.lru_cache(maxsize=256)
-def _depth_frame_grid(B: int, E: int, H: int, Hd: int, card: int, dep_q: int, L: int, top_k: int) -> int:
-    return int(_lib.lib().rst_depth_frame_supported(B, E, H, Hd, card, dep_q, L, top_k))
+def _depth_frame_grid(dev: int, B: int, E: int, H: int, Hd: int, card: int, dep_q: int, L: int, top_k: int) -> int:
+    # keyed by the device ordinal: the answer embeds that device's CU count and its occupancy query
+    with torch.cuda.device(dev):
+        return int(_lib.lib().rst_depth_frame_supported(B, E, H, Hd, card, dep_q, L, top_k))
 
 
-def depth_frame_supported(B: int, E: int, H: int, Hd: int, card: int, dep_q: int, L: int, top_k: int) -> bool:
+def _device_index(device=None) -> int:
+    """Ordinal of ``device`` (a torch device / int / None = the current device): the key of every per-device cache."""
+    if device is None:
+        return torch.cuda.current_device()
+    d = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+def depth_frame_supported(B: int, E: int, H: int, Hd: int, card: int, dep_q: int, L: int, top_k: int, device=None) -> bool:
     """Shapes ``rst_depth_decode_frame`` serves -- the library's own answer (rst_depth_frame_supported: batch 1 / 2, E and Hd multiples
     of 8, card <= 4096, at most 8 layers and 8 steps, the LDS footprint, a grid in which every workgroup owns rows of every
     all-to-all op and that still has a workgroup per head, and the occupancy query), so that callers can pick the per-op path
     instead of catching an error."""
     if not (1 <= B <= 2 and 1 <= dep_q <= DEPTH_FRAME_MAX_Q and 1 <= L <= DEPTH_FRAME_MAX_L and H >= 1 and E % max(H, 1) == 0):
         return False
-    return _depth_frame_grid(B, E, H, Hd, card, dep_q, L, top_k if 0 < top_k < card else card) > 0
+    return _depth_frame_grid(_device_index(device), B, E, H, Hd, card, dep_q, L, top_k if 0 < top_k < card else card) > 0
 
 
 def depth_decode_frame(tables, h_all: torch.Tensor, tokens: torch.Tensor, noise: Optional[torch.Tensor], *, use_sampling: bool,
@@ -1151,8 +1203,9 @@ _ctr_status: dict = {}
 
 
 @functools.lru_cache(maxsize=256)
-def _codec_tr_grid(B: int, T: int, E: int, H: int, F: int, L: int, cap: int) -> int:
-    return int(_lib.lib().rst_codec_transformer_supported(B, T, E, H, F, L, cap))
+def _codec_tr_grid(dev: int, B: int, T: int, E: int, H: int, F: int, L: int, cap: int) -> int:
+    with torch.cuda.device(dev):
+        return int(_lib.lib().rst_codec_transformer_supported(B, T, E, H, F, L, cap))
 
 
 def codec_transformer_frame_supported(B: int, T: int, E: int, H: int, F: int, L: int, cap: int, device=None) -> bool:
@@ -1161,7 +1214,7 @@ def codec_transformer_frame_supported(B: int, T: int, E: int, H: int, F: int, L:
     grid with rows for every workgroup and a workgroup per (stream, head), the occupancy query)."""
     if not (depth_frame_enabled(device) and B >= 1 and 1 <= T <= 4 and B * T <= 4 and H >= 1 and E % max(H, 1) == 0):
         return False
-    return _codec_tr_grid(B, T, E, H, F, L, cap) > 0
+    return _codec_tr_grid(_device_index(device), B, T, E, H, F, L, cap) > 0
 
 
 def codec_transformer_status(device) -> torch.Tensor:

@@ -141,3 +141,27 @@ def test_timing_summary_is_median_and_p95():
     b = _bench_module()
     t = b._timing([float(i) for i in range(1, 101)])
     assert t["samples"] == 100 and t["median_ms"] == 50.5 and t["p95_ms"] == 95.0 and t["min_ms"] == 1.0
+
+
+def test_summary_object_is_compact_and_complete():
+    """the driver keeps a 2 000-character tail and scalar keys only -- the line ends with one flat `summary` object that
+    carries every configuration's time, x-real-time and roofline fraction."""
+    b = _bench_module()
+    d = _last_json(os.path.join(ROOT, "profiles", f"{TAG}_codec_bench.json"))
+    names = ("lm_b1", "e2e_b1", "lm_ctx3000", "lm_b32", "e2e_b32", "gpt_b32", "gpt_b32_fp8")
+    s = b.make_summary(d, {n: d[n] for n in names})
+    assert all(isinstance(v, (int, float, type(None))) for v in s.values())
+    for n in names:
+        assert s[f"{n}_ms"] == d[n]["ms_per_step"] and s[f"{n}_xrt"] == d[n]["x_realtime_per_stream"]
+    assert s["codec_b64_ms"] == d["ms_per_step"] and s["codec_b64_frac"] == d["roofline"]["frac"]
+    assert len(json.dumps(s)) < 1400
+
+
+@pytest.mark.skipif(TAG < "r04", reason="summary added in round 4")
+def test_default_line_ends_with_the_summary():
+    with open(os.path.join(ROOT, "profiles", f"{TAG}_codec_bench.json")) as f:
+        line = [ln for ln in f.read().splitlines() if ln.startswith("{")][0]
+    d = json.loads(line)
+    assert list(d)[-1] == "summary" and line.rstrip().endswith("}}")
+    assert '"summary"' in line[-2000:]
+    assert d["summary"]["e2e_b1_xrt"] >= 10.0 and d["summary"]["codec_b64_code_match"] is not None

@@ -147,3 +147,97 @@ def test_b3_pack_rejects_bad_shapes():
     with pytest.raises(ValueError):
         ops.gemm_win_b3_pack_weight(w)        # K % 16 != 0
     assert not ops._b3_shape(5000, 128, 48) and not ops._b3_shape(4096, 128, 64) and not ops._b3_shape(5000, 64, 64)
+
+
+def test_b3_refuses_what_it_does_not_run():
+    """rst_gemm_win_b3_f32 never changes instruction silently: a call outside rst_gemm_win_b3_supported fails, and the Python layer
+    routes by that predicate (so `gemm_win_b3` in a profile names the kernel that ran)."""
+    L = _lib.lib()
+    assert L.rst_gemm_win_b3_supported(1, 5000, 5000, 128, 128, 128, 1, 0, 0, 5000 * 128, 0) == 1
+    assert L.rst_gemm_win_b3_supported(1, 5000, 5000, 128, 128, 128, 1, 0, 1, 5000 * 128, 0) == 0      # replicate padding
+    assert L.rst_gemm_win_b3_supported(1, 5000, 5000, 128, 128, 128, 1, 0, 0, 5000 * 128, 1) == 0      # history buffer
+    assert L.rst_gemm_win_b3_supported(1, 5000, 5000, 96, 96, 128, 1, 0, 0, 5000 * 96, 0) == 0         # K % 64
+    assert L.rst_gemm_win_b3_supported(1, 4096, 4096, 128, 128, 128, 1, 0, 0, 4096 * 128, 0) == 0      # not a large launch
+    assert L.rst_gemm_win_b3_supported(1, 5000, 5000, 128, 128, 64, 1, 0, 0, 5000 * 128, 0) == 0       # N <= 64
+    assert L.rst_gemm_win_b3_supported(70, 240000, 240000, 64, 64, 128, 1, 0, 0, 240000 * 64, 0) == 0  # activations beyond 4 GB
+    M, N, K = 5000, 128, 128
+    x, w = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV)
+    w3 = ops.gemm_win_b3_pack_weight(w)
+    y = torch.empty(M, N, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    args = lambda xx, pad: (xx.data_ptr(), None, w.data_ptr(), w3.data_ptr(), None, None, None, y.data_ptr(), 1, M, M, K, K, N, 1, 0, pad, M * K, N, 0, 0, st)
+    assert L.rst_gemm_win_b3_f32(*args(x, 0)) == 0
+    assert L.rst_gemm_win_b3_f32(*args(x, 1)) < 0 and b"gemm_win_b3" in L.rst_last_error()
+    x_off = torch.randn(M * K + 4, device=DEV)[1:1 + M * K].view(M, K)          # 4-byte aligned only
+    assert x_off.data_ptr() % 16 != 0
+    assert L.rst_gemm_win_b3_f32(*args(x_off, 0)) < 0
+    out, names = _names_of(lambda: ops.linear(x_off, w))
+    assert names == ["gemm_win"]                                                 # routed to the f32 instruction by the caller
+    assert float((out - x_off @ w.t()).abs().max()) < 1e-3
+
+
+def test_b3_tiny_magnitudes_degrade_like_flush_to_zero():
+    """Operands whose lo (then mid) plane leaves bf16's normal range: |x| ~ 2^-100 .. 2^-124.  fp32 still carries 24 bits there; the
+    three-plane form keeps fp32 accuracy down to |x| ~ 2^-110 and below that stays within 2 * 2^-126 * sum_k |w_k| absolute of the exact
+    result (the planes that fall out of range are at most that large) -- the statement of include/rstnet_hip.h."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 4224, 128, 256
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    for e in (-100, -112, -118, -124):
+        x = torch.randn(M, K, generator=g) * 2.0 ** e
+        ref = F.linear(x.double(), w.double())
+        bound = F.linear(x.double().abs(), w.double().abs())
+        y3, names = _names_of(lambda: ops.linear(x.to(DEV), w.to(DEV)))
+        assert names == ["gemm_win_b3"]
+        err = (y3.double().cpu() - ref).abs()
+        floor = 2 * 2.0 ** -126 * w.double().abs().sum(1)                        # per output column
+        excess = float(((err - floor[None, :]).clamp_min(0) / bound).max())
+        print(f"|x| ~ 2^{e}: max backward error {float((err / bound).max()) / U:.2f} x 2^-24, beyond the 2^-126 floor {excess / U:.2f} x 2^-24")
+        assert excess < 16 * U
+        if e >= -108:
+            assert float((err / bound).max()) < 16 * U
+    # and tiny WEIGHTS against normal activations (the split is symmetric)
+    x = torch.randn(M, K, generator=g)
+    w_t = w * 2.0 ** -118
+    ref = F.linear(x.double(), w_t.double())
+    bound = F.linear(x.double().abs(), w_t.double().abs())
+    y3 = ops.linear(x.to(DEV), w_t.to(DEV))
+    err = (y3.double().cpu() - ref).abs()
+    floor = 2 * 2.0 ** -126 * x.double().abs().sum(1)
+    assert float(((err - floor[:, None]).clamp_min(0) / bound).max()) < 16 * U
+
+
+def test_b3_non_finite_operands_stay_non_finite():
+    """+-Inf / NaN activations (and finite ones beyond the largest bf16, whose hi plane rounds to Inf): every output of the rows they
+    sit in is non-finite on both routes -- the f32 instruction gives +-Inf or NaN, the three-plane form NaN (x - hi = Inf - Inf) -- and
+    every other row is untouched, bit for bit.  Same for a non-finite weight and its output column."""
+    g = torch.Generator().manual_seed(6)
+    M, N, K = 4224, 192, 128
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    clean3 = ops.linear(x.to(DEV), w.to(DEV)).cpu()
+    bad = {7: float("inf"), 1000: float("-inf"), 2049: float("nan"), 4223: 3.4e38}
+    xb = x.clone()
+    for r, v in bad.items():
+        xb[r, (r * 7) % K] = v
+    y3, names = _names_of(lambda: ops.linear(xb.to(DEV), w.to(DEV)))
+    assert names == ["gemm_win_b3"]
+    y3 = y3.cpu()
+    ops.GEMM_B3 = False
+    try:
+        y1 = ops.linear(xb.to(DEV), w.to(DEV)).cpu()
+    finally:
+        ops.GEMM_B3 = True
+    rows = torch.tensor(sorted(bad))
+    assert not torch.isfinite(y3[rows[:3]]).any() and not torch.isfinite(y1[rows[:3]]).any()       # Inf, -Inf, NaN rows: both non-finite
+    assert not torch.isfinite(y3[4223]).any() and torch.isfinite(y1[4223]).all()                   # 3.4e38: finite fp32, beyond bf16 (documented)
+    keep = torch.ones(M, dtype=torch.bool)
+    keep[rows] = False
+    assert torch.equal(y3[keep], clean3[keep])                                                     # nothing leaks across rows
+    wb = w.clone()
+    wb[5, 3] = float("inf")
+    y3 = ops.linear(x.to(DEV), wb.to(DEV)).cpu()
+    assert not torch.isfinite(y3[:, 5]).any()
+    colkeep = torch.ones(N, dtype=torch.bool)
+    colkeep[5] = False
+    assert torch.equal(y3[:, colkeep], clean3[:, colkeep])

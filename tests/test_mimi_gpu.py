@@ -363,6 +363,70 @@ def test_encode_decode_8x10s_full_size_kernels_vs_oracle(mimi, b3, monkeypatch):
     assert rel_err(wav, ref_wav) < 1e-3
 
 
+def _oracle_gaps(sd, z, B):
+    """Top-2 relative gap of every RVQ decision of the oracle for latent `z` (as make_golden.py records it for the fixtures)."""
+    gaps = []
+    for p, n_q in (("quantizer.rvq_first", 1), ("quantizer.rvq_rest", 7)):
+        r = torch.nn.functional.conv1d(z, sd[f"{p}.input_proj.weight"]).transpose(1, 2).reshape(-1, 256)
+        for j in range(n_q):
+            emb = O.codebook(sd, f"{p}.vq.layers.{j}")
+            t2 = torch.cdist(r[None], emb[None])[0].topk(2, largest=False)
+            gaps.append(((t2.values[:, 1] - t2.values[:, 0]) / t2.values[:, 0]).view(B, -1))
+            r = r - emb[t2.indices[:, 0]]
+    return torch.stack(gaps, 1)
+
+
+def test_encode_decode_64x10s_headline_batch_vs_oracle(mimi):
+    """BASELINE configs[1] at its real size: the 64 x 10 s batch of the headline benchmark through encode + decode on the GPU, clips
+    0 / 31 / 63 against the CPU oracle.  At this batch the 25 / 12.5 Hz layers (M = 16 000 / 8 000 rows: both transformers' linears, the
+    512 -> 1024 k16 convolution, the 1024 -> 512 transposed convolution, the k3 / k7 convolutions around them) run the three-plane bf16
+    kernel -- at 8 clips (the test above) they have fewer than 4096 rows and stay on the f32 instruction.  The profile rows are labelled
+    from the library's own route predicate (`ops._b3_route`; rst_gemm_win_b3_f32 refuses anything it would not run), so the assertion
+    names the kernel that ran."""
+    from tests.parity import codes_match_up_to_near_ties
+    sd, model = mimi
+    cfg = O.MimiConfig()
+    B, T = 64, 240000
+    audio = synth.synth_audio(B, T, seed=100)
+    audio_dev = audio.to(DEV)
+    ops.PROFILE = []
+    codes = model.encode(audio_dev)
+    enc_rows, ops.PROFILE = ops.PROFILE, []
+    wav = model.decode(codes)
+    torch.cuda.synchronize()
+    dec_rows, ops.PROFILE = ops.PROFILE, None
+    assert codes.shape == (B, 8, 125) and wav.shape == (B, 1, T)
+    for what, rows in (("encode", enc_rows), ("decode", dec_rows)):
+        low = [(r[0], r[5]) for r in rows if r[0].startswith("gemm_win") and r[5][0] in (16000, 8000)]
+        assert len(low) >= 33, (what, len(low))          # 8 layers x 4 linears + the convolutions next to the transformer
+        f32 = [(n, s) for n, s in low if n != "gemm_win_b3"]
+        # the only 25 / 12.5 Hz GEMM left on the f32 instruction: the 512-channel downsample convolution (replicate padding; encode)
+        assert all(s == (8000, 512, 2048) for _, s in f32) and len(f32) <= 1, (what, f32)
+        assert not [r for r in rows if r[0] == "gemm_win_b3" and r[5][0] <= 4096]
+    sel = [0, 31, 63]
+    with torch.no_grad():
+        z = O.encode_latent(sd, cfg, audio[sel])
+        ref_codes = O.rvq_encode(sd, cfg, z)
+        gaps = _oracle_gaps(sd, z, len(sel))
+        ref_wav = O.decode(sd, cfg, ref_codes)
+    got = codes[sel].cpu()
+    excused = codes_match_up_to_near_ties(got, ref_codes, gaps)
+    match = float((got == ref_codes).float().mean())
+    print(f"64 x 10 s, clips {sel}: code exact-match {match:.6f}; {excused} frames differ at oracle top-2 gaps < 2e-5 (min gap {float(gaps.min()):.2e})")
+    assert match > 0.999
+    # decode at B = 64 of the GPU's own codes: comparable with the oracle's waveform for every clip whose codes are the oracle's
+    same = [i for i, b in enumerate(sel) if torch.equal(got[i], ref_codes[i])]
+    assert same, "no selected clip reproduced the oracle's codes exactly"
+    err = rel_err(wav[sel].cpu()[same], ref_wav[same])
+    print(f"64 x 10 s decode (B = 64 plan), clips {[sel[i] for i in same]}: wav rel err {err:.2e}")
+    assert err < 1e-3
+    # and the decode of the oracle's codes inside a 64-clip batch (rows 0 / 31 / 63 replaced): every selected clip
+    codes2 = codes.clone()
+    codes2[sel] = ref_codes.to(DEV)
+    wav2 = model.decode(codes2)
+    assert rel_err(wav2[sel].cpu(), ref_wav) < 1e-3
+
+
 def test_audiocodec_twin_code_layout(mimi):
     """The AudioCodec/MimiCodec twin (AudioCodec/MimiCodec/models/MimiCodec.py:94-111) moves codes as [B, T, K] (vq_dc.py:148-162
     concatenates the per-level indices on the last axis): `code_layout="btk"` gives exactly the transposed tensors, both ways,

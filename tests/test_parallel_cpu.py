@@ -52,3 +52,53 @@ def test_shard_utterances_partitions():
     items = list("abcdefg")
     parts = [parallel.shard_utterances(items, r, 3) for r in range(3)]
     assert sorted(sum(parts, [])) == sorted(items) and parts[0] == ["a", "d", "g"]
+
+
+def test_plan_affinity_slices_are_disjoint_and_numa_local():
+    allowed = list(range(128))
+    flat = [parallel.plan_affinity(allowed, r, 8) for r in range(8)]
+    assert all(len(s) == 16 for s in flat) and sorted(sum(flat, [])) == allowed
+    # two NUMA nodes of 64 CPUs, four GPUs each: a rank's CPUs come from its GPU's node, four disjoint slices per node
+    near = [parallel.plan_affinity(allowed, r % 4, 4, range(64 * (r // 4), 64 * (r // 4) + 64)) for r in range(8)]
+    assert all(len(s) == 16 and s[0] // 64 == r // 4 for r, s in enumerate(near)) and sorted(sum(near, [])) == allowed
+    # a cgroup that allows 8 CPUs, pool outside it: falls back to the allowed set; fewer CPUs than ranks: one each, wrapping
+    assert parallel.plan_affinity(range(8), 1, 4, [100, 101]) == [2, 3]
+    assert parallel.plan_affinity(range(3), 5, 8) == [2] and parallel.plan_affinity([], 0, 4) == []
+
+
+def _worker_big(rank, world, port, nbytes, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # three entries whose byte offsets inside the blob straddle 2^31: a small head, a body of `nbytes`, a tail after it
+        def pattern(n, mul):       # byte i = i * mul % 251 (period 251: built by tiling, not from a 17 GB index vector)
+            return (torch.arange(251) * mul % 251).to(torch.uint8).repeat(n // 251 + 1)[:n]
+        sd = None
+        if rank == 0:
+            sd = {"head": torch.arange(37, dtype=torch.float32), "body": pattern(nbytes, 7), "tail.bf16": torch.arange(1000).bfloat16(),
+                  "tail.i64": torch.arange(5) + (1 << 40)}
+        stats = {}
+        got = parallel.broadcast_state_dict(sd, torch.device("cpu"), src=0, stats=stats)
+        ok = stats["bytes"] > nbytes and stats["seconds"] > 0
+        ok = ok and torch.equal(got["head"], torch.arange(37, dtype=torch.float32)) and got["body"].numel() == nbytes
+        # the tail entries live past the 2^31 boundary: offsets must not have wrapped
+        ok = ok and torch.equal(got["tail.bf16"], torch.arange(1000).bfloat16()) and torch.equal(got["tail.i64"], torch.arange(5) + (1 << 40))
+        probe = torch.tensor([0, 1, nbytes // 2, (1 << 31) - 1, 1 << 31, (1 << 31) + 12345, nbytes - 1])
+        probe = probe[probe < nbytes]
+        ok = ok and torch.equal(got["body"][probe], (probe * 7 % 251).to(torch.uint8))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_world4_blob_past_2_gib():
+    """VERDICT r3 #7: world 4, a 2 GB-class blob -- entry offsets beyond 2^31 bytes (the 15 GB LM blob is far beyond)."""
+    import psutil
+    nbytes = (1 << 31) + (1 << 20)
+    if psutil.virtual_memory().available < 6 * nbytes:
+        pytest.skip("needs ~14 GB of host memory for four ranks")
+    world, port = 4, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_big, args=(world, port, nbytes, ret), nprocs=world, join=True)
+        assert dict(ret) == {r: True for r in range(world)}

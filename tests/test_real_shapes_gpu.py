@@ -149,6 +149,113 @@ def test_depth_phase_at_the_moshi_shape_matches_the_oracle(B, sampling, monkeypa
     assert worst["persistent_last_logits"] > 0.0, "the persistent launch's logits were never compared"
 
 
+# ------------------------------------------------------------------------------------------- configs[2]: the temporal layers as a model
+_TEMPORAL = {}
+
+
+def _temporal_models():
+    """Moshi-7B with the temporal stack cut to TWO layers (dim 4096, 32 heads of 128, gating hidden 11264, text head 32000 x 4096, 17
+    embedding tables) and the full depth transformer; bf16 temporal rings of 3000 slots as in the benchmark; oracle weights = the
+    same bf16 values widened to fp32."""
+    if not _TEMPORAL:
+        cfg = dict(synth.LM_MOSHI_7B, num_layers=2)
+        sd = synth.lm_state_dict(cfg, seed=6)
+        model = LMModel.from_state_dict({k: v.to(DEV) for k, v in sd.items()}, cfg)          # kv_dtype bf16: the default
+        osd = {k: v.float() for k, v in sd.items()}
+        _TEMPORAL.update(cfg=cfg, model=model, osd=osd)
+    return _TEMPORAL["cfg"], _TEMPORAL["model"], _TEMPORAL["osd"]
+
+
+def _seed_rings(model, oracle_state, B, start, seed):
+    """Both sides as if `start` steps had already been appended: the same random bf16-representable keys / values in every slot of the
+    temporal rings, position counters at `start` (the product's device scalar and host mirror; the oracle's offset / end_offset)."""
+    g = torch.Generator().manual_seed(seed)
+    st = model.transformer._streaming_state
+    assert st is not None and st.k[0].dtype == torch.bfloat16 and st.k[0].shape[2] == 3000
+    for l, kv in enumerate(oracle_state.kv):
+        kv.dtype = torch.bfloat16
+        for name, ring in (("k", st.k[l]), ("v", st.v[l])):
+            t = (0.5 * torch.randn(ring.shape, generator=g)).to(torch.bfloat16)
+            ring.copy_(t.to(DEV))
+            setattr(kv, name, t.float())
+        kv.end_offset = start
+    oracle_state.offset = start
+    st.pos.fill_(start)
+    st.offset_cpu = start
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_temporal_layers_at_the_moshi_shape_across_the_ring_wrap(B):
+    """`LMModel.forward_text` (models/model.py:364-389) at the 7B layer shape -- GEMVs 12288 x 4096, 4096 x 4096, 22528 x 4096 (gated),
+    4096 x 11264, the 32000-way text head, attention with 32 heads of 128 over a bf16 ring of 3000 slots (modules/transformer.py:211-278) --
+    against `lm_oracle.forward_text`, started at ring offset 2990 so that the 14 steps walk positions 2990 .. 3003: the ring is full,
+    wraps at 3000, and the `context` window starts to hide the oldest slots."""
+    cfg, model, osd = _temporal_models()
+    ocfg = L.LMConfig(**cfg)
+    start, steps = 2990, 14
+    g = torch.Generator().manual_seed(60 + B)
+    worst = {"transformer_out": 0.0, "text_logits": 0.0, "argmax_agree": 0}
+    with model.streaming(B), torch.no_grad():
+        st_o = L.new_transformer_state(B, cfg["num_layers"], cfg["num_heads"], cfg["dim"] // cfg["num_heads"], cfg["context"])
+        _seed_rings(model, st_o, B, start, seed=7 + B)
+        for s in range(steps):
+            toks = torch.randint(0, cfg["card"], (B, cfg["n_q"] + 1, 1), generator=g)
+            toks[:, 0] = torch.randint(0, cfg["text_card"], (B, 1), generator=g)
+            out, logits = model.forward_text(toks.to(DEV))
+            out_o, logits_o = L.forward_text(osd, ocfg, toks, st_o)
+            worst["transformer_out"] = max(worst["transformer_out"], rel_err(out, out_o))
+            worst["text_logits"] = max(worst["text_logits"], rel_err(logits, logits_o))
+            worst["argmax_agree"] += int((logits.view(B, -1).argmax(-1).cpu() == logits_o.view(B, -1).argmax(-1)).sum())
+        assert int(model.transformer._streaming_state.pos) == start + steps == st_o.offset
+    _record(f"temporal_moshi_B{B}_ring_wrap", worst)
+    assert worst["transformer_out"] < 1e-3 and worst["text_logits"] < 1e-3, worst
+    assert worst["argmax_agree"] == B * steps, worst
+
+
+def test_lmgen_greedy_frames_at_the_moshi_shape_across_the_ring_wrap(monkeypatch):
+    """16 greedy `LMGen.step` frames (models/model.py:490-597: token ring, temporal step, text sample, 8 depth steps, delayed output) of
+    the two-temporal-layer Moshi-7B-shaped model, one captured graph per frame, with the temporal rings seeded at offset 2990 (they wrap
+    during the run): the delayed token streams equal `LMGenOracle`'s.  A differing token is excused only at an oracle decision margin
+    below 1e-4 of the logit scale, and the comparison stops there (later frames are conditioned on it)."""
+    cfg, model, osd = _temporal_models()
+    ocfg = L.LMConfig(**cfg)
+    B, start, frames = 1, 2990, 16
+    gen = LMGen(model, use_sampling=False)
+    ora = L.LMGenOracle(osd, ocfg, B, use_sampling=False)
+    seen = []                  # the oracle's logits, one entry per sampled token (1 text + dep_q audio per frame)
+    real_sample = L.sample_token
+
+    def recording_sample(logits, *a, **kw):
+        seen.append(logits.reshape(B, -1).clone())
+        return real_sample(logits, *a, **kw)
+    monkeypatch.setattr(L, "sample_token", recording_sample)
+    g = torch.Generator().manual_seed(91)
+    user = torch.randint(0, cfg["card"], (frames, B, cfg["n_q"] - cfg["dep_q"], 1), generator=g)
+    compared = 0
+    with gen.streaming(B), torch.no_grad():
+        _seed_rings(model, ora.main, B, start, seed=12)
+        for f in range(frames):
+            del seen[:-(cfg["dep_q"] + 1)]          # keep the previous frame's decisions: a delayed stream shows them one frame later
+            got, want = gen.step(user[f].to(DEV)), ora.step(user[f])
+            assert (got is None) == (want is None), f
+            if got is None:
+                continue
+            got = got.cpu()
+            if not torch.equal(got, want):
+                # the output of frame f is the delay-aligned view of tokens sampled at frames f - 1 and f: one of those oracle decisions
+                # must be a near tie, else fail
+                margins = []
+                for lg in seen:
+                    top2 = lg.topk(2, -1).values
+                    margins.append(float(((top2[:, 0] - top2[:, 1]) / lg.abs().max()).min()))
+                assert min(margins) < 1e-4, f"frame {f}: tokens {got.flatten().tolist()} vs oracle {want.flatten().tolist()}; smallest oracle margin {min(margins):.2e}"
+                break
+            compared += 1
+        assert int(model.transformer._streaming_state.pos) > 3000
+    _record("lmgen_moshi_ring_wrap", {"frames_compared": compared})
+    assert compared >= frames - gen.max_delay - 2, compared
+
+
 # ---------------------------------------------------------------------------------------------------------------- configs[4]
 _GPT = {}
 
