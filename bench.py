@@ -745,7 +745,7 @@ def main():
                  if b3 else f"{dom}_*kernel (fp32 v_mfma_f32_32x32x2_f32)")
 
         def peak_of(name):
-            return B3_EQUIV_PEAK_TFLOPS if name == "gemm_win_b3" else FP32_MFMA_PEAK_TFLOPS
+            return B3_EQUIV_PEAK_TFLOPS if name in ("gemm_win_b3", "resblock_b3") else FP32_MFMA_PEAK_TFLOPS
         roofline = {"bound": "mfma", "kernel": label, "achieved": round(tf, 3),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                     "traffic": pmc_traffic(prefix, "codec"), "mfma_pipe": mfma_counters(prefix, peak), "launches_per_step": d["launches"],

@@ -133,6 +133,24 @@ int rst_seanet_resblock_f32(const float* x, const float* hist, const float* w0, 
                             float* y, int B, int T, int C, int H, int Kw, int K0, int Kf, int elu_out,
                             rst_stream_t stream);
 
+/* The same block on the bf16 matrix instruction at fp32 accuracy (three-plane operands, as rst_gemm_win_b3_f32) for the batched
+ * (whole-utterance) encode / decode: C = 64 (plain, "pre" or "post") and C = 128 (plain), H = C / 2, Kw = 3, no streaming history.
+ * Every activation is split into its planes once (input tile at staging, hidden activation in the first GEMM's epilogue); the first
+ * convolution of "pre" runs on the matrix pipe as well.  rst_seanet_resblock_b3_supported(...) != 0 tells whether a call is served
+ * (an utterance must span less than 4 GB); rst_seanet_resblock_b3_f32 fails on any other call -- no silent change of kernel.
+ * The caller packs the weights once: wp = rst_seanet_resblock_b3_weight_elems(C) uint16, filled by rst_seanet_resblock_b3_pack from
+ * w0 [C][K0] (or NULL), w1 [H][Kw*C] (tap-major, as rst_conv1d_causal_f32) and w2 [C][H]: the planes of every matrix in matrix-instruction
+ * operand order (W2's hidden index permuted to the first GEMM's accumulator order for C = 64).  "pre" is selected by b0 != NULL (x is
+ * then the mono audio and wp must have been packed with w0), "post" by wf != NULL (wf [Kf][C] and bf [1] stay fp32; y is the waveform).
+ * Same numerics contract as rst_gemm_win_b3_f32.  Replaces modules/seanet.py:21-94 (+ :184-193 / :368-379 for pre / post). */
+int rst_seanet_resblock_b3_supported(int B, int T, int C, int H, int Kw, int pre, int post, int K0, int Kf);
+int rst_seanet_resblock_b3_weight_elems(int C);   /* -1: C not served */
+int rst_seanet_resblock_b3_pack(const float* w0, const float* w1, const float* w2, uint16_t* wp, int C, int H, int Kw, int K0,
+                                rst_stream_t stream);
+int rst_seanet_resblock_b3_f32(const float* x, const uint16_t* wp, const float* b0, const float* b1, const float* b2, const float* wf,
+                               const float* bf, float* y, int B, int T, int C, int H, int Kw, int K0, int Kf, int elu_out,
+                               rst_stream_t stream);
+
 /* y[M][N] = epi(x[M][K] * w[N][K]^T + bias): F.linear call sites of modules/transformer.py:395,421,562 and the 1x1
  * Conv1d projections of quantization/vq.py:88-96. */
 int rst_linear_f32(const float* x, const float* w, const float* bias, const float* res, const float* scale, float* y,

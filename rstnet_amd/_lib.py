@@ -30,6 +30,10 @@ SIGNATURES = {
     "rst_convtr1d_causal_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rst_seanet_resblock_supported": [_i, _i, _i, _i, _i, _i, _i],
     "rst_seanet_resblock_f32": [_p] * 11 + [_i] * 8 + [_p],
+    "rst_seanet_resblock_b3_supported": [_i] * 9,
+    "rst_seanet_resblock_b3_weight_elems": [_i],
+    "rst_seanet_resblock_b3_pack": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "rst_seanet_resblock_b3_f32": [_p] * 8 + [_i] * 8 + [_p],
     "rst_linear_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p],
     "rst_layernorm_f32": [_p, _p, _p, _p, _l, _i, _f, _p],
     "rst_rope_split_f32": [_p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _f, _p],

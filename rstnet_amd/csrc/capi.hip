@@ -24,7 +24,7 @@ int rst_check_launch(const char* what) {
 
 extern "C" {
 
-int rst_version(void) { return 103; }      // round 3: + three-plane GEMM, fp32-input skinny GEMM, top-p sampler, status[4] protocol
+int rst_version(void) { return 104; }      // round 4: + three-plane residual blocks, rst_gemm_win_b3_supported (strict b3 route)
 const char* rst_last_error(void) { return g_err; }
 
 static int gemm_win_common(const float* x, const float* hist, const float* w, const uint16_t* w3, const float* bias, const float* res,
@@ -117,6 +117,32 @@ int rst_seanet_resblock_f32(const float* x, const float* hist, const float* w0, 
     p.pre = w0 != nullptr; p.post = wf != nullptr; p.elu_out = elu_out;
     RST_REQUIRE(!(p.post && elu_out), "resblock: elu_out has no meaning with the fused last conv");
     return rst_launch_resblock(p, (hipStream_t)stream);
+}
+
+int rst_seanet_resblock_b3_supported(int B, int T, int C, int H, int Kw, int pre, int post, int K0, int Kf) {
+    if (B <= 0 || T <= 0 || (long)T * C * 4 >= 0xfffff000L) return 0;       // (32-bit buffer offsets inside an utterance)
+    return rst_resblock_b3_supported(C, H, Kw, pre, post, K0, Kf) ? 1 : 0;
+}
+
+int rst_seanet_resblock_b3_weight_elems(int C) { return (int)rst_resblock_b3_weight_elems(C); }
+
+int rst_seanet_resblock_b3_pack(const float* w0, const float* w1, const float* w2, uint16_t* wp, int C, int H, int Kw, int K0,
+                                rst_stream_t stream) {
+    return rst_launch_resblock_b3_pack(w0, w1, w2, wp, C, H, Kw, K0, (hipStream_t)stream);
+}
+
+int rst_seanet_resblock_b3_f32(const float* x, const uint16_t* wp, const float* b0, const float* b1, const float* b2, const float* wf,
+                               const float* bf, float* y, int B, int T, int C, int H, int Kw, int K0, int Kf, int elu_out,
+                               rst_stream_t stream) {
+    ResblockB3Params p;
+    p.x = x; p.wp = wp; p.b0 = b0; p.b1 = b1; p.b2 = b2; p.wf = wf; p.bf = bf; p.y = y;
+    p.B = B; p.T = T; p.C = C; p.H = H; p.Kw = Kw; p.K0 = K0; p.Kf = Kf;
+    p.pre = b0 != nullptr; p.post = wf != nullptr; p.elu_out = elu_out;
+    RST_REQUIRE(!(p.post && elu_out), "resblock_b3: elu_out has no meaning with the fused last conv");
+    RST_REQUIRE(B <= 0 || T <= 0 || rst_seanet_resblock_b3_supported(B, T, C, H, Kw, p.pre, p.post, K0, Kf),
+                "resblock_b3: unsupported shape (B=%d T=%d C=%d H=%d Kw=%d pre=%d post=%d K0=%d Kf=%d); ask rst_seanet_resblock_b3_supported", B, T, C, H,
+                Kw, p.pre, p.post, K0, Kf);
+    return rst_launch_resblock_b3(p, (hipStream_t)stream);
 }
 
 int rst_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int D, float eps,

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include "rst_common.h"
 #include "rst_kernels.h"
+#include "b3_common.h"
 
 namespace {
 
@@ -563,25 +564,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 
 // group covers 16 distinct 16-byte slots.  Two buffers of (128 + BN) rows x 3 planes: 72 KB (BN = 128, two workgroups per CU) or
 // 108 KB (BN = 256, one workgroup of eight waves).  Rows whose window leaves the utterance are masked inside the kernel (below); only
 // launches with a history buffer / replicate padding / K % 64 != 0 run on the f32-instruction kernels above.
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int B3_SETS_A = 4;                  // k-tiles of activations / of weights held in registers ahead of the one being multiplied
 constexpr int B3_SETS_B = 2;
 constexpr int B3_KB = 16;                     // k per stage (one bf16 matrix instruction deep)
 constexpr int B3_RS = 24;                     // shorts per LDS row (16 + 8 pad)
 constexpr int B3_WTILE = 3 * 128 * B3_KB;     // shorts per packed (n tile, k tile) piece of the weights
-
-// two fp32 -> the two packed bf16 (round to nearest even) and the exact remainders
-__device__ __forceinline__ unsigned b3_peel(f32x2& v) {
-    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-    v[0] -= __uint_as_float(h << 16);
-    v[1] -= __uint_as_float(h & 0xffff0000u);
-    return h;
-}
 
 template <int V>
 struct b3_int { static constexpr int value = V; };

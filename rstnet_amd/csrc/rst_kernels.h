@@ -79,6 +79,25 @@ struct ResblockParams {
 bool rst_resblock_supported(int C, int H, int Kw, int pre, int post, int K0, int Kf);
 int rst_launch_resblock(const ResblockParams& p, hipStream_t stream);
 
+// ---- resblock_b3.hip: the same block on the bf16 matrix instruction (three-plane operands), batched encode / decode only
+struct ResblockB3Params {
+    const float* x;             // [B][T][C] block input, or (pre) the mono audio [B][T]
+    const unsigned short* wp;   // packed weight planes (rst_launch_resblock_b3_pack)
+    const float* b0;            // pre: bias of the first convolution [C]
+    const float* b1;            // [H]
+    const float* b2;            // [C]
+    const float* wf;            // post: last conv weight [Kf][C] (fp32), bias bf [1]
+    const float* bf;
+    float* y;                   // [B][T][C], or (post) the mono waveform [B][T]
+    int B, T, C, H, Kw, K0, Kf;
+    int pre, post, elu_out;
+};
+bool rst_resblock_b3_supported(int C, int H, int Kw, int pre, int post, int K0, int Kf);
+long rst_resblock_b3_weight_elems(int C);
+int rst_launch_resblock_b3_pack(const float* w0, const float* w1, const float* w2, unsigned short* out, int C, int H, int Kw, int K0,
+                                hipStream_t stream);
+int rst_launch_resblock_b3(const ResblockB3Params& p, hipStream_t stream);
+
 // ---- norm_elt.hip -----------------------------------------------------------------------------
 int rst_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D,
                          float eps, hipStream_t stream);

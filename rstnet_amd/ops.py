@@ -346,14 +346,50 @@ def seanet_resblock(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: tor
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.lib().rst_seanet_resblock_f32(_ptr(x), _ptr(hist), _ptr(w0), _ptr(b0), _ptr(w1), _ptr(b1), _ptr(w2),
-                                                  _ptr(b2), _ptr(wf), _ptr(bf), _ptr(out), B, T, C, H, Kw, K0, Kf, int(elu_out),
-                                                  _stream()))
+    # whole-utterance launches (more than 4096 rows, no streaming history): the three-plane bf16 form, as the large GEMMs
+    b3 = (GEMM_B3 and hist is None and B * T > 4096 and x.data_ptr() % 16 == 0
+          and _resblock_b3_supported(B, T, C, H, Kw, pre is not None, post is not None, K0, Kf))
+    if b3:
+        wp = resblock_b3_pack_weights(w0, w1, w2, Kw)
+        _lib.check(_lib.lib().rst_seanet_resblock_b3_f32(_ptr(x), _ptr(wp), _ptr(b0), _ptr(b1), _ptr(b2), _ptr(wf), _ptr(bf), _ptr(out),
+                                                         B, T, C, H, Kw, K0, Kf, int(elu_out), _stream()))
+    else:
+        _lib.check(_lib.lib().rst_seanet_resblock_f32(_ptr(x), _ptr(hist), _ptr(w0), _ptr(b0), _ptr(w1), _ptr(b1), _ptr(w2),
+                                                      _ptr(b2), _ptr(wf), _ptr(bf), _ptr(out), B, T, C, H, Kw, K0, Kf, int(elu_out),
+                                                      _stream()))
     if prof is not None:
         e1.record()
         flops = 2.0 * B * T * (Kw * C * H + H * C) + (2.0 * B * T * C * K0) + (2.0 * B * T * C * Kf)
-        prof.append(("resblock", e0, e1, flops, 4 * (x.numel() + out.numel()), (B * T, C, Kw * C)))
+        prof.append(("resblock_b3" if b3 else "resblock", e0, e1, flops, 4 * (x.numel() + out.numel()), (B * T, C, Kw * C)))
     return out
+
+
+@functools.lru_cache(maxsize=256)
+def _resblock_b3_supported(B: int, T: int, C: int, H: int, Kw: int, pre: bool, post: bool, K0: int, Kf: int) -> bool:
+    return bool(_lib.lib().rst_seanet_resblock_b3_supported(B, T, C, H, Kw, int(pre), int(post), K0, Kf))
+
+
+_rb3_weights = _PackedWeights()
+
+
+def resblock_b3_pack_weights(w0: Optional[torch.Tensor], w1: torch.Tensor, w2: torch.Tensor, Kw: int) -> torch.Tensor:
+    """The block's matrices as three bf16 planes in matrix-instruction operand order (rst_seanet_resblock_b3_pack), cached per
+    storage / version of ``w1`` (a block's three weights change together: they are re-packed from one state dict)."""
+    C, H = w2.shape
+
+    def build():
+        n = int(_lib.lib().rst_seanet_resblock_b3_weight_elems(C))
+        if n <= 0:
+            raise ValueError(f"rstnet_amd.ops: no three-plane residual block for C = {C}")
+        wp = torch.empty(n, device=w1.device, dtype=torch.int16)
+        _lib.check(_lib.lib().rst_seanet_resblock_b3_pack(_ptr(w0), _ptr(w1), _ptr(w2), _ptr(wp), C, H, Kw, w0.shape[1] if w0 is not None else 0,
+                                                          _stream()))
+        return (wp, w2._version, None if w0 is None else w0._version)
+    hit = _rb3_weights.get(w1, build)
+    if hit[1] != w2._version or hit[2] != (None if w0 is None else w0._version):       # the companions changed in place: re-pack
+        _rb3_weights._d.pop((w1.device, w1.data_ptr(), tuple(w1.shape), w1.dtype), None)
+        hit = _rb3_weights.get(w1, build)
+    return hit[0]
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
