@@ -34,6 +34,15 @@ namespace {
 
 __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
+// A per-lane value the optimizer cannot see through.  Used INSIDE a tile body on the lane's coordinates: everything derived from it (LDS
+// offsets of 9 staging pieces, 12 k-tiles, ...) is recomputed per tile in a couple of VALU instructions instead of being hoisted out of
+// the tile loop into ~40 long-lived registers, which spilled -- and a spill RELOAD is a memory operation: waiting for it (in order) drains
+// the next tile's requests that are meant to stay in flight.
+__device__ __forceinline__ int opq(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // 8 fp32 values (consecutive k of one operand row) -> the three bf16x8 planes
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&out)[3]) {
     f32x2 pr[4] = {{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}};
@@ -68,12 +77,13 @@ __device__ __forceinline__ int r6_xoff(int rx, int chunk) { return rx * 128 + ((
 
 template <bool PRE, bool POST>
 __global__ __launch_bounds__(64 * R6_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const long total) {
+void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const int total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* const W1F = smem_raw;
     unsigned char* const W2F = W1F + R6_W1F;
     float* const CST = reinterpret_cast<float*>(W2F + R6_W2F);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // (scalar: the tile bookkeeping below stays on the scalar unit)
     const int m = lane & 31, h = lane >> 5;
     unsigned char* const XW = reinterpret_cast<unsigned char*>(CST + R6_CST) + wave * r6_per_wave<PRE, POST>();
     float* const AUD = reinterpret_cast<float*>(XW + 3 * R6_XPLANE);
@@ -104,29 +114,37 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const lon
     }
     __syncthreads();
 
-    const long stride = (long)gridDim.x * R6_WAVES;
-    long idx = (long)blockIdx.x * R6_WAVES + wave;
+    const int stride = (int)gridDim.x * R6_WAVES;
+    int idx = (int)blockIdx.x * R6_WAVES + wave;
     if (idx >= total) return;
+
+    // Global traffic goes through buffer instructions: the utterance's base in scalar registers, a 32-bit byte offset per lane (the
+    // launcher checks that an utterance spans less than 4 GB).  Per-lane parts of the offsets, once:
+    constexpr int XCB = PRE ? 4 : R6_C * 4;                      // bytes per time step of x
+    const unsigned ld_lane = PRE ? 0u : (unsigned)((lane & 15) * 16);
+    const unsigned io_lane = (unsigned)(4 * h) * 4u;             // skip loads / stores: 16 bytes at channel 32 cb + 8 g + 4 h
+    auto rsrc_of = [](const float* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0xffffffff, 0x00020000); };
 
     // ---- input requests of a tile: rows t0 - 2 .. t0 + 31 (lane -> row 4 i + lane / 16, 4 channels), or the audio window of PRE;
     // always from addresses clamped into the utterance (zeroed at staging where the row does not exist)
     f32x4 xv[PRE ? 1 : 9];
     float av[2];
-    auto request = [&](long id) {
-        const long b = id / tiles_u;
-        const int t0 = (int)(id - b * tiles_u) * RO - halo;
+    auto request = [&](const int b, const int tu) {
+        const int t0 = tu * RO - halo;
+        const __amdgpu_buffer_rsrc_t rs = rsrc_of(p.x + (long)b * T * (PRE ? 1 : R6_C));
         if (PRE) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int t = t0 - 9 + lane + 64 * j;        // j = 1: lanes 0 .. 15 matter
-                av[j] = p.x[b * T + min(max(t, 0), T - 1)];
+                const int t = min(max(t0 - 9 + lane + 64 * j, 0), T - 1);        // j = 1: lanes 0 .. 15 matter
+                av[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)t * 4u, 0, 0));
             }
         } else {
+            const int r0 = opq(lane >> 4);
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
-                const int rx = min(4 * i + (lane >> 4), R6_XR - 1);
-                const int t = t0 - (R6_KW - 1) + rx;
-                xv[i] = *reinterpret_cast<const f32x4*>(p.x + ((b * T + min(max(t, 0), T - 1)) * R6_C + (lane & 15) * 4));
+                const int rx = min(4 * i + r0, R6_XR - 1);
+                const int t = min(max(t0 - (R6_KW - 1) + rx, 0), T - 1);
+                xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)t * XCB + ld_lane, 0, 0));
             }
         }
     };
@@ -134,7 +152,9 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const lon
     // conv0 of 32 rows on the matrix pipe: D[c][row] = acc + sum_s W0F[c][s] AUD[first + row + s], s < 16, where slot s = k + 8 - K0
     // holds tap k of w0 (the other slots are zero): x0[t][c] = b0[c] + sum_k w0[c][k] a[t - (K0 - 1) + k] with AUD[i] = a[t0 - 9 + i] and
     // first = (row 0's time) - t0 + 2.  A = the W0 planes (registers), B = the audio windows, split here.
-    auto conv0 = [&](const int first, f32x16 (&acc)[2]) {
+    // (a matrix instruction waits for the previous one into the SAME accumulator: four independent chains -- even / odd products of the
+    // two channel blocks -- keep three instructions between dependent ones; with two the pipe idled half the time)
+    auto conv0 = [&](const int first, f32x16 (&acc)[2], f32x16 (&accx)[2]) {
         constexpr int QA_[6] = B3_QA, QB_[6] = B3_QB;      // weight-side / activation-side plane of product t
         float a8[8];
 #pragma unroll
@@ -144,7 +164,10 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const lon
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0f[cb][QA_[t]], af[QB_[t]], acc[cb], 0, 0, 0);
+            for (int cb = 0; cb < 2; ++cb) {
+                if (t & 1) accx[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0f[cb][QA_[t]], af[QB_[t]], accx[cb], 0, 0, 0);
+                else acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0f[cb][QA_[t]], af[QB_[t]], acc[cb], 0, 0, 0);
+            }
     };
     // four consecutive channels of a lane's accumulator group -> three 8-byte plane pieces of input-tile row rx
     auto put_x = [&](const int rx, const int c0, f32x4 v) {
@@ -158,14 +181,33 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const lon
             *reinterpret_cast<u32x2*>(XW + q * R6_XPLANE + off) = w;
         }
     };
+    // operand fragments of GEMM1's k-tile kt (tap kt / 4, channels 16 (kt % 4) ..): W1 planes from the workgroup's copy, X planes from
+    // the wave's tile
+    auto frags1 = [&](const int m, const int h, const int kt, bf16x8 (&xb)[3], bf16x8 (&wa)[3]) {
+        const int xo = r6_xoff(m + (kt >> 2), 2 * (kt & 3) + h);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            xb[q] = lds_frag(XW + q * R6_XPLANE + xo);
+            wa[q] = lds_frag(W1F + ((kt * 3 + q) * 64 + lane) * 16);
+        }
+    };
+    auto frags2 = [&](const int kt2, bf16x8 (&w2)[2][3]) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) w2[cb][q] = lds_frag(W2F + (((cb * 2 + kt2) * 3 + q) * 64 + lane) * 16);
+    };
 
-    auto tile_body = [&](auto full_tag, const long id, const long id_next) {
+    auto tile_body = [&](auto full_tag, const int b, const int tu, const int b_next, const int tu_next) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr int QA_[6] = B3_QA, QB_[6] = B3_QB;
-        const long b = id / tiles_u;
-        const int t0 = (int)(id - b * tiles_u) * RO - halo;       // time of output row 0 of the tile
+        const int m = opq(lane & 31), h = opq(lane >> 5);    // (opaque copies: see opq)
+        const int t0 = tu * RO - halo;                       // time of output row 0 of the tile
+        const int t_out = t0 + m;
+        const bool valid = FULL || (t_out >= 0 && t_out < T);
+        const unsigned io_off = (unsigned)(FULL ? t_out : min(max(t_out, 0), T - 1)) * (R6_C * 4) + io_lane;
 
-        // ---- stage the ELU'd input tile as planes (rows rx = 0 .. 33 <-> t = t0 - 2 + rx), then request the next tile's input
+        // ---- stage the ELU'd input tile as planes (rows rx = 0 .. 33 <-> t = t0 - 2 + rx)
         if (PRE) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -173,19 +215,20 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const lon
                 const int t = t0 - 9 + i;
                 if (i < R6_AUD) AUD[i] = (FULL || t >= 0) ? av[j] : 0.f;       // the first convolution's own zero padding
             }
-            request(id_next);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {         // rows 0 .. 31, then 32 .. 63 of which only 32 and 33 exist in the tile
-                f32x16 acc[2];
+                f32x16 acc[2], accx[2];
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 bv = *reinterpret_cast<const f32x4*>(CST + 96 + 32 * cb + 8 * g + 4 * h);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[cb][4 * g + j] = bv[j];
+                        for (int j = 0; j < 4; ++j) { acc[cb][4 * g + j] = bv[j]; accx[cb][4 * g + j] = 0.f; }
                     }
-                conv0(32 * rb, acc);
+                conv0(32 * rb, acc, accx);
+                // (rows past 33 of the second block: lanes m >= 2 rewrite row 33 with the values lane m = 1 ... no: every lane of
+                // the second block writes the row min(32 + m, 33) it did NOT compute, so those lanes are masked instead)
                 const int rx = 32 * rb + m;
                 const int t = t0 - (R6_KW - 1) + rx;
                 if (rb == 0 || m < R6_XR - 32) {
@@ -195,7 +238,7 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const lon
                         for (int g = 0; g < 4; ++g) {
                             f32x4 v;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = (FULL || t >= 0) ? rst_elu(acc[cb][4 * g + j]) : 0.f;
+                            for (int j = 0; j < 4; ++j) v[j] = (FULL || t >= 0) ? rst_elu(acc[cb][4 * g + j] + accx[cb][4 * g + j]) : 0.f;
                             put_x(rx, 32 * cb + 8 * g + 4 * h, v);
                         }
                 }
@@ -203,47 +246,54 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const lon
         } else {
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
-                const int rx = 4 * i + (lane >> 4);
+                // (i = 8: the lane groups past row 33 loaded row 33 again and store it again -- same values, no branch: a divergent
+                // branch here makes the compiler wait for EVERY outstanding load at its join, the next tile's included)
+                const int rx = min(4 * i + opq(lane >> 4), R6_XR - 1);
                 const int t = t0 - (R6_KW - 1) + rx;
                 f32x4 v = xv[i];
                 v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]);
                 if (!FULL && t < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (i < 8 || (lane >> 4) < R6_XR - 32) put_x(rx, (lane & 15) * 4, v);
+                put_x(rx, (lane & 15) * 4, v);
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);    // (two row pieces in flight at a time: all nine interleaved spill)
             }
-            request(id_next);
         }
 
-        // ---- GEMM1 (transposed): acc1[n][row] = sum_k W1[n][k] X[row + tap][c], k = tap * 64 + c; two accumulator chains
-        f32x16 accA, accB;
+        // ---- the next tile's input: in flight under this tile's matrix instructions
+        request(b_next, tu_next);
+
+        // ---- GEMM1 (transposed): acc1[n][row] = sum_k W1[n][k] X[row + tap][c], k = tap * 64 + c; two accumulator chains.  The
+        // fragments of k-tile kt + 1 are requested before the matrix instructions of k-tile kt (two register sets, pinned: left alone the
+        // scheduler serialises read -> wait -> multiply through one set)
+        f32x16 acc1[4];                                          // four independent chains (see conv0), summed in the hidden epilogue
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { accA[e] = 0.f; accB[e] = 0.f; }
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc1[c][e] = 0.f;
+        bf16x8 xb[2][3], wa[2][3], w2a[2][3], w2b[2][3];
+        frags1(m, h, 0, xb[0], wa[0]);
 #pragma unroll
         for (int kt = 0; kt < 12; ++kt) {
-            const int tap = kt >> 2, cq = kt & 3;
-            const int xo = r6_xoff(m + tap, 2 * cq + h);
-            bf16x8 xb[3], wa[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                xb[q] = lds_frag(XW + q * R6_XPLANE + xo);
-                wa[q] = lds_frag(W1F + ((kt * 3 + q) * 64 + lane) * 16);
-            }
+            if (kt + 1 < 12) frags1(m, h, kt + 1, xb[(kt + 1) & 1], wa[(kt + 1) & 1]);
+            else frags2(0, w2a);                                 // (under the last k-tile: GEMM2's first weight fragments)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
-                if (t & 1) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[QA_[t]], xb[QB_[t]], accB, 0, 0, 0);
-                else accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[QA_[t]], xb[QB_[t]], accA, 0, 0, 0);
+                const int c = (kt * 6 + t) & 3;
+                acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kt & 1][QA_[t]], xb[kt & 1][QB_[t]], acc1[c], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-
         // ---- skip operand: x rows of the output tile as the 16-byte pieces of the accumulator layout (lane = row, 4 x 4 channels per
-        // 32-channel block); requested now, consumed after GEMM2.  PRE: recomputed below on the matrix pipe.
+        // 32-channel block; L2 hits), landing under the hidden epilogue and GEMM2.  (Memory operations retire in order, so the wait for
+        // these also waits for the next tile's rows requested above -- a whole GEMM1 ago.)  PRE: the skip is recomputed on the matrix pipe.
         f32x4 skip[PRE ? 1 : 8];
-        const int t_out = t0 + m;
         if (!PRE) {
-            const float* xr = p.x + (b * T + (FULL ? t_out : min(max(t_out, 0), T - 1))) * R6_C + 4 * h;
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(p.x + (long)b * T * R6_C);
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) skip[cb * 4 + g] = *reinterpret_cast<const f32x4*>(xr + 32 * cb + 8 * g);
+                for (int g = 0; g < 4; ++g)
+                    skip[cb * 4 + g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, io_off, (32 * cb + 8 * g) * 4, 0));
         }
 
         // ---- hidden activation: bias + ELU + split, accumulator -> GEMM2's B operand in registers.  Lane (row, h) holds hidden
@@ -255,7 +305,8 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const lon
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(CST + 8 * g + 4 * h);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) hv[4 * g + j] = rst_elu((accA[4 * g + j] + accB[4 * g + j]) + bv[j]);
+                for (int j = 0; j < 4; ++j)
+                    hv[4 * g + j] = rst_elu(((acc1[0][4 * g + j] + acc1[1][4 * g + j]) + (acc1[2][4 * g + j] + acc1[3][4 * g + j])) + bv[j]);
             }
 #pragma unroll
             for (int kt2 = 0; kt2 < 2; ++kt2) {
@@ -267,7 +318,7 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const lon
         }
 
         // ---- GEMM2 (transposed): acc2[c][row] = sum_n W2[c][n] H[row][n]  (+ PRE: conv0 of the output rows, the skip)
-        f32x16 acc2[2];
+        f32x16 acc2[2], acc2x[2];                                // even / odd products: four chains
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -278,37 +329,40 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const lon
                     bv[0] += b0v[0]; bv[1] += b0v[1]; bv[2] += b0v[2]; bv[3] += b0v[3];
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc2[cb][4 * g + j] = bv[j];
+                for (int j = 0; j < 4; ++j) { acc2[cb][4 * g + j] = bv[j]; acc2x[cb][4 * g + j] = 0.f; }
             }
-        if (PRE) conv0(R6_KW - 1, acc2);             // rows t0 .. t0 + 31: windows start two samples later than the input tile's
+        frags2(1, w2b);
+        if (PRE) conv0(R6_KW - 1, acc2, acc2x);      // rows t0 .. t0 + 31: windows start two samples later than the input tile's
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2) {
-            bf16x8 w2[2][3];
+        for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+            for (int cb = 0; cb < 2; ++cb) {
+                if (t & 1) acc2x[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2a[cb][QA_[t]], hop[0][QB_[t]], acc2x[cb], 0, 0, 0);
+                else acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2a[cb][QA_[t]], hop[0][QB_[t]], acc2[cb], 0, 0, 0);
+            }
 #pragma unroll
-                for (int q = 0; q < 3; ++q) w2[cb][q] = lds_frag(W2F + (((cb * 2 + kt2) * 3 + q) * 64 + lane) * 16);
+        for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-                    acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[cb][QA_[t]], hop[kt2][QB_[t]], acc2[cb], 0, 0, 0);
-        }
+            for (int cb = 0; cb < 2; ++cb) {
+                if (t & 1) acc2x[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2b[cb][QA_[t]], hop[1][QB_[t]], acc2x[cb], 0, 0, 0);
+                else acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2b[cb][QA_[t]], hop[1][QB_[t]], acc2[cb], 0, 0, 0);
+            }
 
         // ---- epilogue: y = x + acc2 (biases are in the accumulators)
-        const bool valid = FULL || (t_out >= 0 && t_out < T);
         float dk[R6_MAXKF];
         if (POST) {
 #pragma unroll
             for (int k = 0; k < R6_MAXKF; ++k) dk[k] = 0.f;
         }
+        const __amdgpu_buffer_rsrc_t rs_y = rsrc_of(p.y + (long)b * T * (POST ? 1 : R6_C));
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc2[cb][4 * g + j];
+                for (int j = 0; j < 4; ++j) v[j] = acc2[cb][4 * g + j] + acc2x[cb][4 * g + j];
                 if (!PRE) { v[0] += skip[cb * 4 + g][0]; v[1] += skip[cb * 4 + g][1]; v[2] += skip[cb * 4 + g][2]; v[3] += skip[cb * 4 + g][3]; }
                 if (POST || p.elu_out) { v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]); }
                 if (POST) {
@@ -320,7 +374,7 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const lon
                         dk[k] = fmaf(wv[2], v[2], dk[k]); dk[k] = fmaf(wv[3], v[3], dk[k]);
                     }
                 } else if (valid) {
-                    *reinterpret_cast<f32x4*>(p.y + (b * T + t_out) * R6_C + 32 * cb + 8 * g + 4 * h) = v;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, io_off, (32 * cb + 8 * g) * 4, 0);
                 }
             }
         if (POST) {
@@ -335,22 +389,27 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const lon
                 float s = p.bf[0];
                 for (int k = 0; k < p.Kf; ++k) s += DS[k * R6_M + lane - halo + k];
                 const int t = t0 + lane;
-                if (FULL || (t >= 0 && t < T)) p.y[b * T + t] = s;
+                if (FULL || (t >= 0 && t < T)) p.y[(long)b * T + t] = s;
             }
         }
     };
 
-    request(idx);
+    // (utterance, tile inside it) of the wave's current tile, advanced by `stride` tiles per step without a division in the loop
+    const int dq = stride / tiles_u, dr = stride - dq * tiles_u;
+    int b = idx / tiles_u, tu = idx - b * tiles_u;
+    request(b, tu);
     for (; idx < total; idx += stride) {
-        const long b = idx / tiles_u;
-        const int t0 = (int)(idx - b * tiles_u) * RO - halo;
-        const long nxt = idx + stride < total ? idx + stride : idx;       // (at the end of the run: a harmless re-load of this tile)
+        int b_next = b + dq, tu_next = tu + dr;
+        if (tu_next >= tiles_u) { tu_next -= tiles_u; ++b_next; }
+        if (idx + stride >= total) { b_next = b; tu_next = tu; }          // (at the end of the run: a harmless re-load of this tile)
+        const int t0 = tu * RO - halo;
         const bool full = t0 - (R6_KW - 1) - (PRE ? R6_MAXK0 : 0) >= 0 && t0 + R6_M <= T;
-        if (full) tile_body(std::true_type{}, idx, nxt);
-        else tile_body(std::false_type{}, idx, nxt);
+        if (full) tile_body(std::true_type{}, b, tu, b_next, tu_next);
+        else tile_body(std::false_type{}, b, tu, b_next, tu_next);
+        b = b_next;
+        tu = tu_next;
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------- C = 128
 constexpr int R8_C = 128, R8_H = 64, R8_KW = 3, R8_BM = 128, R8_XR = R8_BM + R8_KW - 1;     // 130 input rows per workgroup tile
@@ -426,15 +485,15 @@ void resblock128_b3_kernel(const ResblockB3Params p, const int tiles_u, const in
     // ---- input rows of a tile: thread -> row 16 i + tid / 32, 4 channels.  Buffer loads: the utterance's base in scalar registers, a
     // 32-bit byte offset per lane (the launcher checks that an utterance spans less than 4 GB)
     f32x4 xv[9];
-    auto request = [&](const int id) {
-        const int b = id / tiles_u;
-        const int t0 = (id - b * tiles_u) * R8_BM;
+    auto request = [&](const int b, const int tu) {
+        const int t0 = tu * R8_BM;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (long)b * T * R8_C), 0, 0xffffffff, 0x00020000);
+        const int r0 = opq(tid >> 5), c0 = opq((tid & 31) * 16);        // (opaque: recomputed per tile, not hoisted into 18 registers)
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-            const int rx = min(16 * i + (tid >> 5), R8_XR - 1);
+            const int rx = min(16 * i + r0, R8_XR - 1);
             const int t = min(max(t0 - (R8_KW - 1) + rx, 0), T - 1);
-            xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(t * R8_C + (tid & 31) * 4) * 4u, 0, 0));
+            xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)t * (R8_C * 4) + c0, 0, 0));
         }
     };
     // one stage of the weight stream behind the matrix instructions of stage s: the set that holds stage s + 1 goes to the other ring
@@ -444,20 +503,20 @@ void resblock128_b3_kernel(const ResblockB3Params p, const int tiles_u, const in
         w_load(gbase + s + 3, wr[s & 1]);
     };
 
-    auto tile_body = [&](auto full_tag, const int id, const int id_next, const int gbase) {
+    auto tile_body = [&](auto full_tag, const int b, const int tu, const int b_next, const int tu_next, const int gbase) {
         constexpr bool FULL = decltype(full_tag)::value;
-        const long b = id / tiles_u;
-        const int t0 = (id - (int)b * tiles_u) * R8_BM;
+        const int t0 = tu * R8_BM;
 
         // ---- stage the ELU'd input tile as planes (every wave is past the previous tile's last read of the hidden planes: barrier below)
+        const int r0s = opq(tid >> 5);
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-            const int rx = 16 * i + (tid >> 5);
+            const int rx = 16 * i + r0s;
             const int t = t0 - (R8_KW - 1) + rx;
             f32x4 v = xv[i];
             v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]);
             if (!FULL && t < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i < 8 || (tid >> 5) < R8_XR - 128) {
+            if (i < 8 || r0s < R8_XR - 128) {
                 f32x2 p0 = {v[0], v[1]}, p1 = {v[2], v[3]};
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -468,42 +527,51 @@ void resblock128_b3_kernel(const ResblockB3Params p, const int tiles_u, const in
                 }
             }
         }
-        request(id_next);
+        request(b_next, tu_next);
         __syncthreads();                                         // input planes (and stage 0 of the weights) visible
 
         // ---- GEMM1 (transposed): acc1[n][row] = sum_k W1[n][k] X[row + tap][c], k = tap * 128 + c; six stages of four k-tiles
-        f32x16 accA, accB;
+        f32x16 acc1[4];                                          // four independent accumulator chains (a matrix instruction waits for the
+                                                                 // previous one into the same accumulator), summed in the hidden epilogue
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { accA[e] = 0.f; accB[e] = 0.f; }
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc1[c][e] = 0.f;
+        // (fragments of k-tile kl + 1 are requested before the matrix instructions of k-tile kl: two register sets, pinned)
+        bf16x8 xb[2][3], wa[2][3];
+        auto frags1 = [&](const int s, const int kl, bf16x8 (&x)[3], bf16x8 (&w)[3]) {
+            const int kt = 4 * s + kl;
+            const int tap = kt >> 3, cq = kt & 7;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                x[q] = lds_frag(x_rd[q] + tap * R8_XLD + cq * 32);
+                w[q] = lds_frag(ring_rd + (s & 1) * R8_STAGE + ((kl * 3 + q) * 2) * 1024);
+            }
+        };
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
-            const unsigned char* rd = ring_rd + (s & 1) * R8_STAGE;
+            frags1(s, 0, xb[0], wa[0]);
 #pragma unroll
             for (int kl = 0; kl < 4; ++kl) {
-                const int kt = 4 * s + kl;
-                const int tap = kt >> 3, cq = kt & 7;
-                bf16x8 xb[3], wa[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    xb[q] = lds_frag(x_rd[q] + tap * R8_XLD + cq * 32);
-                    wa[q] = lds_frag(rd + ((kl * 3 + q) * 2) * 1024);
-                }
+                if (kl + 1 < 4) frags1(s, kl + 1, xb[(kl + 1) & 1], wa[(kl + 1) & 1]);
+                if (kl == 1) advance(gbase, s);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
-                    if (t & 1) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[QA_[t]], xb[QB_[t]], accB, 0, 0, 0);
-                    else accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[QA_[t]], xb[QB_[t]], accA, 0, 0, 0);
+                    const int c = ((4 * s + kl) * 6 + t) & 3;
+                    acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kl & 1][QA_[t]], xb[kl & 1][QB_[t]], acc1[c], 0, 0, 0);
                 }
-                if (kl == 1) advance(gbase, s);
-                __builtin_amdgcn_sched_barrier(0);               // (left alone, the scheduler hoists the fragment reads of many k-tiles: spills)
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
         }
 
-        // ---- skip operand of the output rows (accumulator layout of GEMM2: lane = row, 4 x 4 channels per 32-channel block)
+        // ---- skip operand of the output rows (accumulator layout of GEMM2: lane = row, 4 x 4 channels per 32-channel block; L2 hits).
+        // (The next tile's input was requested six stages ago and has landed: the in-order wait for these costs nothing extra.)
         const int t_out = t0 + row;
         f32x4 skip[8];
         {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + b * T * R8_C), 0, 0xffffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (long)b * T * R8_C), 0, 0xffffffff, 0x00020000);
             const unsigned vo = (unsigned)((FULL ? t_out : min(max(t_out, 0), T - 1)) * R8_C + 64 * wn + 4 * h) * 4u;
 #pragma unroll
             for (int ci = 0; ci < 2; ++ci)
@@ -517,8 +585,9 @@ void resblock128_b3_kernel(const ResblockB3Params p, const int tiles_u, const in
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(cst + 8 * g);
-            f32x2 p0 = {rst_elu((accA[4 * g] + accB[4 * g]) + bv[0]), rst_elu((accA[4 * g + 1] + accB[4 * g + 1]) + bv[1])};
-            f32x2 p1 = {rst_elu((accA[4 * g + 2] + accB[4 * g + 2]) + bv[2]), rst_elu((accA[4 * g + 3] + accB[4 * g + 3]) + bv[3])};
+            auto hsum = [&](const int e) { return (acc1[0][e] + acc1[1][e]) + (acc1[2][e] + acc1[3][e]); };
+            f32x2 p0 = {rst_elu(hsum(4 * g) + bv[0]), rst_elu(hsum(4 * g + 1) + bv[1])};
+            f32x2 p1 = {rst_elu(hsum(4 * g + 2) + bv[2]), rst_elu(hsum(4 * g + 3) + bv[3])};
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 u32x2 w;
@@ -530,34 +599,40 @@ void resblock128_b3_kernel(const ResblockB3Params p, const int tiles_u, const in
         __syncthreads();                                         // hidden planes visible
 
         // ---- GEMM2 (transposed): acc2[c][row] = sum_n W2[c][n] H[row][n]; wave (wm, wn) owns channel blocks 2 wn, 2 wn + 1
-        f32x16 acc2[2];
+        f32x16 acc2[2], acc2x[2];                                // even / odd products: four chains
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(cst + 64 + 32 * wn + 32 * ci + 8 * g);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc2[ci][4 * g + j] = bv[j];
+                for (int j = 0; j < 4; ++j) { acc2[ci][4 * g + j] = bv[j]; acc2x[ci][4 * g + j] = 0.f; }
             }
-#pragma unroll
-        for (int s = 6; s < 8; ++s) {
+        bf16x8 hb[3], w2[2][3];                                  // (one register set: a second one spills, and GEMM2 is four k-tiles)
+        auto frags2 = [&](const int s, const int kl, bf16x8 (&hx)[3], bf16x8 (&w)[2][3]) {
+            const int kt2 = 2 * (s - 6) + kl;
             const unsigned char* rd = ring_rd + wn * 1024 + (s & 1) * R8_STAGE;      // (channel blocks 2 wn, 2 wn + 1)
 #pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                hx[q] = lds_frag(h_rd + q * R8_HPLANE + kt2 * 32);
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) w[ci][q] = lds_frag(rd + ((kl * 3 + q) * 4 + ci) * 1024);
+            }
+        };
+#pragma unroll
+        for (int s = 6; s < 8; ++s) {
+#pragma unroll
             for (int kl = 0; kl < 2; ++kl) {
-                const int kt2 = 2 * (s - 6) + kl;
-                bf16x8 hb[3], w2[2][3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    hb[q] = lds_frag(h_rd + q * R8_HPLANE + kt2 * 32);
-#pragma unroll
-                    for (int ci = 0; ci < 2; ++ci) w2[ci][q] = lds_frag(rd + ((kl * 3 + q) * 4 + ci) * 1024);
-                }
+                frags2(s, kl, hb, w2);
+                if (kl == 0) advance(gbase, s);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
 #pragma unroll
-                    for (int ci = 0; ci < 2; ++ci)
-                        acc2[ci] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[ci][QA_[t]], hb[QB_[t]], acc2[ci], 0, 0, 0);
-                if (kl == 0) advance(gbase, s);
+                    for (int ci = 0; ci < 2; ++ci) {
+                        if (t & 1) acc2x[ci] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[ci][QA_[t]], hb[QB_[t]], acc2x[ci], 0, 0, 0);
+                        else acc2[ci] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[ci][QA_[t]], hb[QB_[t]], acc2[ci], 0, 0, 0);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();                                     // (s = 7: every wave is done with the hidden planes -> the next tile may stage)
@@ -571,21 +646,27 @@ void resblock128_b3_kernel(const ResblockB3Params p, const int tiles_u, const in
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc2[ci][4 * g + j] + skip[ci * 4 + g][j];
+                for (int j = 0; j < 4; ++j) v[j] = (acc2[ci][4 * g + j] + acc2x[ci][4 * g + j]) + skip[ci * 4 + g][j];
                 if (p.elu_out) { v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]); }
-                if (valid) *reinterpret_cast<f32x4*>(p.y + (b * T + t_out) * R8_C + 64 * wn + 32 * ci + 8 * g + 4 * h) = v;
+                if (valid) *reinterpret_cast<f32x4*>(p.y + ((long)b * T + t_out) * R8_C + 64 * wn + 32 * ci + 8 * g + 4 * h) = v;
             }
     };
 
+    const int stride = gridDim.x;
+    const int dq = stride / tiles_u, dr = stride - dq * tiles_u;
     int idx = blockIdx.x;
-    request(idx);
-    for (int it = 0; idx < total; idx += gridDim.x, ++it) {
-        const long b = idx / tiles_u;
-        const int t0 = (idx - (int)b * tiles_u) * R8_BM;
-        const int nxt = idx + (int)gridDim.x < total ? idx + (int)gridDim.x : idx;
+    int b = idx / tiles_u, tu = idx - b * tiles_u;
+    request(b, tu);
+    for (int it = 0; idx < total; idx += stride, ++it) {
+        int b_next = b + dq, tu_next = tu + dr;
+        if (tu_next >= tiles_u) { tu_next -= tiles_u; ++b_next; }
+        if (idx + stride >= total) { b_next = b; tu_next = tu; }
+        const int t0 = tu * R8_BM;
         const bool full = t0 - (R8_KW - 1) >= 0 && t0 + R8_BM <= T;
-        if (full) tile_body(std::true_type{}, idx, nxt, it * R8_NSTAGE);
-        else tile_body(std::false_type{}, idx, nxt, it * R8_NSTAGE);
+        if (full) tile_body(std::true_type{}, b, tu, b_next, tu_next, it * R8_NSTAGE);
+        else tile_body(std::false_type{}, b, tu, b_next, tu_next, it * R8_NSTAGE);
+        b = b_next;
+        tu = tu_next;
     }
 }
 
@@ -652,7 +733,7 @@ int launch64(const ResblockB3Params& p, hipStream_t stream) {
     const int halo = POST ? p.Kf - 1 : 0;
     const long tiles_u = (p.T + (R6_M - halo) - 1) / (R6_M - halo);
     const long total = (long)p.B * tiles_u;
-    if (tiles_u > 0x7fffffffL) { rst_set_error("resblock_b3: utterance too long"); return RST_ERR_UNSUPPORTED; }
+    if (total > 0x7ffffff0L - 8L * rst_cu_count()) { rst_set_error("resblock_b3: too many tiles (%ld)", total); return RST_ERR_UNSUPPORTED; }
     static RstOncePerDevice attr_once;
     if (attr_once.first())
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resblock64_b3_kernel<PRE, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -660,7 +741,7 @@ int launch64(const ResblockB3Params& p, hipStream_t stream) {
     const long resident = rst_cu_count();
     const unsigned grid = (unsigned)(wgs < resident ? wgs : resident);
     constexpr int lds = r6_lds_bytes<PRE, POST>();
-    hipLaunchKernelGGL((resblock64_b3_kernel<PRE, POST>), dim3(grid), dim3(64 * R6_WAVES), lds, stream, p, (int)tiles_u, total);
+    hipLaunchKernelGGL((resblock64_b3_kernel<PRE, POST>), dim3(grid), dim3(64 * R6_WAVES), lds, stream, p, (int)tiles_u, (int)total);
     return rst_check_launch("resblock_b3");
 }
 
