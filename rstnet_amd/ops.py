@@ -1302,3 +1302,4 @@ for _name in ("skinny_f32_pack_weight", "gemm_win", "linear", "seanet_resblock",
               "depth_decode_frame", "codec_transformer_frame"):
     globals()[_name] = _on_tensor_device(globals()[_name])
 del _name
+
