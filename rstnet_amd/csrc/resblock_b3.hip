@@ -63,8 +63,13 @@ constexpr int R6_W2F = 2 * 2 * 3 * 1024;         // [c-block 2][k-tile 2][plane 
 constexpr int R6_W0F = 2 * 3 * 1024;             // [c-block 2][plane 3][lane][8] (PRE; lives in registers)
 constexpr int R6_CST = 32 + 64 + 64 + 4 * 64;    // floats: b1 | b2 | b0 | wf [4][64]
 constexpr int R6_XPLANE = R6_XR * 128;           // bytes per plane of a wave's input tile (64 bf16 per row)
-constexpr int R6_AUD = 80;                       // PRE: audio samples of a wave tile, AUD[i] = a[t0 - 9 + i]
+constexpr int R6_AUD = 64;                       // PRE: audio samples of a wave tile, AUD[i] = a[t0 - 9 + i]
+constexpr int R6_PRE_RO = R6_M - (R6_KW - 1);    // PRE: a tile stages 32 input rows (ONE block of the first convolution on the matrix pipe)
+                                                 // and yields 30 output rows; staging the two halo rows as a second, 94 % empty block cost
+                                                 // 12 matrix instructions and ~300 VALU per tile
 constexpr int R6_MAXKF = 4, R6_MAXK0 = 8;
+constexpr int R6_YLD = R6_C * 4 + 16;            // bytes per row of the output tile while it is transposed through LDS (32 rows: 8.5 KB of
+                                                 // the wave's 13 KB input tile, dead by then)
 
 template <bool PRE, bool POST>
 constexpr int r6_per_wave() { return 3 * R6_XPLANE + (PRE ? R6_AUD * 4 : 0) + (POST ? R6_MAXKF * R6_M * 4 : 0); }
@@ -90,7 +95,7 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const int
     float* const DS = reinterpret_cast<float*>(XW + 3 * R6_XPLANE + (PRE ? R6_AUD * 4 : 0));
     const int T = p.T;
     const int halo = POST ? p.Kf - 1 : 0;
-    const int RO = R6_M - halo;                      // output rows a tile contributes
+    const int RO = PRE ? R6_PRE_RO : R6_M - halo;    // output rows a tile contributes
 
     // ---- constants of the workgroup: W1 / W2 planes and the small vectors into LDS, once
     {
@@ -128,16 +133,13 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const int
     // ---- input requests of a tile: rows t0 - 2 .. t0 + 31 (lane -> row 4 i + lane / 16, 4 channels), or the audio window of PRE;
     // always from addresses clamped into the utterance (zeroed at staging where the row does not exist)
     f32x4 xv[PRE ? 1 : 9];
-    float av[2];
+    float av[1];
     auto request = [&](const int b, const int tu) {
         const int t0 = tu * RO - halo;
         const __amdgpu_buffer_rsrc_t rs = rsrc_of(p.x + (long)b * T * (PRE ? 1 : R6_C));
         if (PRE) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int t = min(max(t0 - 9 + lane + 64 * j, 0), T - 1);        // j = 1: lanes 0 .. 15 matter
-                av[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)t * 4u, 0, 0));
-            }
+            const int t = min(max(t0 - 9 + lane, 0), T - 1);
+            av[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)t * 4u, 0, 0));
         } else {
             const int r0 = opq(lane >> 4);
 #pragma unroll
@@ -204,19 +206,15 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const int
         const int m = opq(lane & 31), h = opq(lane >> 5);    // (opaque copies: see opq)
         const int t0 = tu * RO - halo;                       // time of output row 0 of the tile
         const int t_out = t0 + m;
-        const bool valid = FULL || (t_out >= 0 && t_out < T);
+        const bool valid = (!PRE || m < R6_PRE_RO) && (FULL || (t_out >= 0 && t_out < T));      // (PRE: rows 30, 31 belong to the next tile)
         const unsigned io_off = (unsigned)(FULL ? t_out : min(max(t_out, 0), T - 1)) * (R6_C * 4) + io_lane;
 
         // ---- stage the ELU'd input tile as planes (rows rx = 0 .. 33 <-> t = t0 - 2 + rx)
         if (PRE) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int i = lane + 64 * j;
-                const int t = t0 - 9 + i;
-                if (i < R6_AUD) AUD[i] = (FULL || t >= 0) ? av[j] : 0.f;       // the first convolution's own zero padding
-            }
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {         // rows 0 .. 31, then 32 .. 63 of which only 32 and 33 exist in the tile
+            AUD[lane] = (FULL || t0 - 9 + lane >= 0) ? av[0] : 0.f;            // the first convolution's own zero padding
+            {                                        // input rows 0 .. 31 (rows 32, 33 of the LDS tile are never written: they only reach
+                                                     // the discarded output rows 30, 31 -- a lane's column of the product sees its own rows)
+                constexpr int rb = 0;
                 f32x16 acc[2], accx[2];
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
@@ -227,11 +225,9 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const int
                         for (int j = 0; j < 4; ++j) { acc[cb][4 * g + j] = bv[j]; accx[cb][4 * g + j] = 0.f; }
                     }
                 conv0(32 * rb, acc, accx);
-                // (rows past 33 of the second block: lanes m >= 2 rewrite row 33 with the values lane m = 1 ... no: every lane of
-                // the second block writes the row min(32 + m, 33) it did NOT compute, so those lanes are masked instead)
                 const int rx = 32 * rb + m;
                 const int t = t0 - (R6_KW - 1) + rx;
-                if (rb == 0 || m < R6_XR - 32) {
+                {
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -286,14 +282,27 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const int
         // ---- skip operand: x rows of the output tile as the 16-byte pieces of the accumulator layout (lane = row, 4 x 4 channels per
         // 32-channel block; L2 hits), landing under the hidden epilogue and GEMM2.  (Memory operations retire in order, so the wait for
         // these also waits for the next tile's rows requested above -- a whole GEMM1 ago.)  PRE: the skip is recomputed on the matrix pipe.
+        // Not POST: the skip rows are fetched ROW-MAJOR (16 lanes = one row's 256 bytes, as the staging loads) and meet the output after
+        // its transposition through LDS (below): in the accumulator layout a load / store instruction touches 32 rows x 32 bytes, and
+        // with the output written that way the PRE form ran at 1.5 TB/s of stores, whatever its instruction count.
         f32x4 skip[PRE ? 1 : 8];
+        const int rm_r = opq(lane >> 4), rm_c = opq((lane & 15) * 16);     // row-major coordinates: row 4 i + rm_r, byte rm_c of the row
         if (!PRE) {
             const __amdgpu_buffer_rsrc_t rs = rsrc_of(p.x + (long)b * T * R6_C);
+            if (POST) {
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    skip[cb * 4 + g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, io_off, (32 * cb + 8 * g) * 4, 0));
+                    for (int g = 0; g < 4; ++g)
+                        skip[cb * 4 + g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, io_off, (32 * cb + 8 * g) * 4, 0));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int t = t0 + 4 * i + rm_r;
+                    skip[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        rs, (unsigned)(FULL ? t : min(max(t, 0), T - 1)) * (R6_C * 4) + rm_c, 0, 0));
+                }
+            }
         }
 
         // ---- hidden activation: bias + ELU + split, accumulator -> GEMM2's B operand in registers.  Lane (row, h) holds hidden
@@ -363,20 +372,37 @@ void resblock64_b3_kernel(const ResblockB3Params p, const int tiles_u, const int
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc2[cb][4 * g + j] + acc2x[cb][4 * g + j];
-                if (!PRE) { v[0] += skip[cb * 4 + g][0]; v[1] += skip[cb * 4 + g][1]; v[2] += skip[cb * 4 + g][2]; v[3] += skip[cb * 4 + g][3]; }
-                if (POST || p.elu_out) { v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]); }
+                if (!POST) {
+                    // accumulator layout -> the wave's (dead) input-tile bytes as fp32 rows of 256 + 16 bytes (conflict-free both ways)
+                    *reinterpret_cast<f32x4*>(XW + m * R6_YLD + (32 * cb + 8 * g + 4 * h) * 4) = v;
+                    continue;
+                }
+                v[0] += skip[cb * 4 + g][0]; v[1] += skip[cb * 4 + g][1]; v[2] += skip[cb * 4 + g][2]; v[3] += skip[cb * 4 + g][3];
+                v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]);
                 if (POST) {
                     if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int k = 0; k < R6_MAXKF; ++k) {
+                        if (k >= p.Kf) break;                    // (uniform)
                         const f32x4 wv = *reinterpret_cast<const f32x4*>(CST + 160 + k * 64 + 32 * cb + 8 * g + 4 * h);
                         dk[k] = fmaf(wv[0], v[0], dk[k]); dk[k] = fmaf(wv[1], v[1], dk[k]);
                         dk[k] = fmaf(wv[2], v[2], dk[k]); dk[k] = fmaf(wv[3], v[3], dk[k]);
                     }
-                } else if (valid) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, io_off, (32 * cb + 8 * g) * 4, 0);
                 }
             }
+        if (!POST) {
+            // row-major: + skip, ELU?, whole 256-byte rows per 16 lanes
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = 4 * i + rm_r;
+                const int t = t0 + r;
+                f32x4 v = *reinterpret_cast<const f32x4*>(XW + r * R6_YLD + rm_c);
+                if (!PRE) { v[0] += skip[i][0]; v[1] += skip[i][1]; v[2] += skip[i][2]; v[3] += skip[i][3]; }
+                if (p.elu_out) { v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]); }
+                if ((!PRE || r < R6_PRE_RO) && (FULL || (t >= 0 && t < T)))
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, (unsigned)t * (R6_C * 4) + rm_c, 0, 0);
+            }
+        }
         if (POST) {
             // last convolution 64 -> 1: out[t] = bf + sum_k d_k[t - Kf + 1 + k], d_k[row] = sum_c wf[k][c] ELU(y[row][c]); the two
             // lanes of a row meet, the taps meet across rows through the wave's own LDS strip
@@ -432,7 +458,7 @@ void resblock128_b3_kernel(const ResblockB3Params p, const int tiles_u, const in
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* const RING = smem_raw;                        // two stages of weights
     float* const CST = reinterpret_cast<float*>(RING + 2 * R8_STAGE);
-    unsigned char* const XP = RING + 2 * R8_STAGE + R8_CST * 4;  // input planes; later the hidden planes
+    // (the input planes, later the hidden planes, follow at byte XP0 = 2 * R8_STAGE + R8_CST * 4)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;                     // GEMM1: row block, hidden block; GEMM2: row block, pair of channel blocks
@@ -731,7 +757,8 @@ __global__ __launch_bounds__(64) void resblock128_b3_pack_kernel(const float* w1
 template <bool PRE, bool POST>
 int launch64(const ResblockB3Params& p, hipStream_t stream) {
     const int halo = POST ? p.Kf - 1 : 0;
-    const long tiles_u = (p.T + (R6_M - halo) - 1) / (R6_M - halo);
+    const int RO = PRE ? R6_PRE_RO : R6_M - halo;
+    const long tiles_u = (p.T + RO - 1) / RO;
     const long total = (long)p.B * tiles_u;
     if (total > 0x7ffffff0L - 8L * rst_cu_count()) { rst_set_error("resblock_b3: too many tiles (%ld)", total); return RST_ERR_UNSUPPORTED; }
     static RstOncePerDevice attr_once;
