@@ -3,50 +3,91 @@
 from __future__ import annotations
 
 import os
-from typing import List, Optional
+from contextlib import contextmanager
+from typing import Any, List, Optional
 
 import torch
 
+_in_graph = False      # a Graphed call is on the stack: nothing below it captures a graph of its own (compile.py:145-165)
+
+
+def in_cuda_graph() -> bool:
+    return _in_graph
+
+
+@contextmanager
+def _set_in_graph():
+    global _in_graph
+    old, _in_graph = _in_graph, True
+    try:
+        yield
+    finally:
+        _in_graph = old
+
 
 class Graphed:
-    """Capture-after-warm-up / replay wrapper over a function of static-shaped device tensors (the role of the
-    reference's CUDAGraphed, utils/compile.py:189-277).  Disabled on request or by NO_CUDA_GRAPH=1."""
+    """Capture-after-warm-up / replay wrapper over a function whose TENSOR arguments are top-level positional arguments of static
+    shape (the role of the reference's CUDAGraphed, utils/compile.py:189-277).  As there: keyword arguments are refused; a
+    non-tensor argument is baked into the capture, so a later call must pass an equal value (and a tensor must stay a tensor of the
+    same shape); a Graphed function called from inside another Graphed call runs plainly (one capture, the outer one).  Disabled
+    on request or by NO_CUDA_GRAPH=1."""
 
     def __init__(self, fn, warmup: int = 1, disable: bool = False):
         self.fn, self.warmup, self.calls = fn, warmup, 0
         self.disable = disable or os.environ.get("NO_CUDA_GRAPH", "") not in ("", "0")
         self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.static_in: List[torch.Tensor] = []
+        self.static_in: List[Any] = []
         self.static_out = None
 
-    def reset(self) -> None:
-        self.graph, self.calls = None, 0
+    def reset(self, warmup_steps: int = 0) -> None:
+        """The next call (after ``warmup_steps`` plain ones) captures again: shapes or external state (KV rings) changed."""
+        self.graph, self.calls, self.warmup = None, 0, warmup_steps
+        self.static_in, self.static_out = [], None
 
-    def __call__(self, *args: torch.Tensor):
-        if self.disable:
+    def __call__(self, *args, **kwargs):
+        if kwargs:
+            raise RuntimeError("Named arguments not supported for now.")
+        if self.disable or in_cuda_graph():
             return self.fn(*args)
         dev = next((a.device for a in args if isinstance(a, torch.Tensor) and a.is_cuda), None)
-        if dev is not None and dev.index != torch.cuda.current_device():
-            with torch.cuda.device(dev):        # capture / replay on the device the arguments live on
-                return self._call(*args)
-        return self._call(*args)
+        with _set_in_graph():
+            if dev is not None and dev.index != torch.cuda.current_device():
+                with torch.cuda.device(dev):        # capture / replay on the device the arguments live on
+                    return self._call(*args)
+            return self._call(*args)
 
-    def _call(self, *args: torch.Tensor):
+    def _match_values_copy_tensors(self, args) -> None:
+        if len(args) != len(self.static_in):
+            raise ValueError(f"Expected {len(self.static_in)} arguments, but got {len(args)} for a graphed function.")
+        for idx, (source, target) in enumerate(zip(args, self.static_in)):
+            if isinstance(target, torch.Tensor):
+                if not isinstance(source, torch.Tensor):
+                    raise ValueError(f"Argument #{idx} was a tensor, and is no longer (now {source}).")
+                if source.shape != target.shape:
+                    raise ValueError(f"Argument #{idx} had shape {tuple(target.shape)}, but got shape {tuple(source.shape)}")
+                target.copy_(source)
+            else:
+                if isinstance(source, torch.Tensor):
+                    raise ValueError(f"Argument #{idx} was not a tensor {target}, but is now one.")
+                if source is not target and source != target:
+                    raise ValueError(f"Argument #{idx} changed value from {target} to {source}.")
+
+    def _call(self, *args):
         if self.graph is None:
             self.calls += 1
             if self.calls <= self.warmup:
                 return self.fn(*args)
-            self.static_in = [a.clone() for a in args]
+            self.static_in = [a.clone() if isinstance(a, torch.Tensor) else a for a in args]
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.static_out = self.fn(*self.static_in)
-            # the capture itself does not execute: replay below produces this call's result
-        for s, a in zip(self.static_in, args):
-            if s.shape != a.shape:
-                raise RuntimeError(f"graphed call with a different shape: {tuple(a.shape)} vs {tuple(s.shape)}")
-            s.copy_(a)
+            # the capture itself does not execute: the replay below produces this call's result
+            self.graph.replay()
+            return self.static_out
+        self._match_values_copy_tensors(args)
         self.graph.replay()
         return self.static_out
 
 
+CUDAGraphed = Graphed       # the reference's name

@@ -9,7 +9,8 @@ What differs, and why: the reference moves audio as Opus pages through ``sphn`` 
 ``sphn`` / libopus are not part of this image, so the transport here is RAW PCM -- the payload of a kind-1 message is
 little-endian mono samples at the codec rate, ``f32`` (default) or ``s16`` (``/api/chat?pcm=s16``), in both directions.  The
 message kinds, the handshake, the framing and the locking are the reference's; a client only swaps its Opus codec for a
-memcpy.  (An Opus front end would sit exactly where ``PcmFramer`` sits.)
+memcpy.  ``/api/chat?pcm=opus`` selects ``OpusFramer`` -- the reference's ``sphn`` reader / writer at the same seam -- which needs the
+``sphn`` package and says so when it is missing.
 """
 from __future__ import annotations
 
@@ -58,6 +59,44 @@ class PcmFramer:
         if self.fmt == "f32":
             return pcm.astype("<f4").tobytes()
         return (np.clip(pcm, -1.0, 1.0) * 32767.0).astype("<i2").tobytes()
+
+
+class OpusFramer:
+    """The reference's own transport at the same seam (server.py:105-153): kind-1 payloads are Opus pages, decoded by
+    ``sphn.OpusStreamReader`` and re-encoded by ``sphn.OpusStreamWriter``.  ``sphn`` (Rust + libopus) is not part of this image, so
+    the class imports it on construction and raises a clear error when it is absent; with it installed, ``/api/chat?pcm=opus``
+    speaks the reference client's wire format."""
+
+    def __init__(self, frame_size: int, sample_rate: int):
+        try:
+            import sphn
+        except ImportError as e:
+            raise RuntimeError("the Opus transport needs the `sphn` package (absent from this image); use pcm=f32 or pcm=s16") from e
+        self.frame_size = frame_size
+        self._reader = sphn.OpusStreamReader(sample_rate)
+        self._writer = sphn.OpusStreamWriter(sample_rate)
+        self._pcm = np.zeros(0, dtype=np.float32)
+
+    def append_bytes(self, payload: bytes) -> None:
+        self._reader.append_bytes(payload)
+
+    def frames(self) -> List[np.ndarray]:
+        pcm = self._reader.read_pcm()                       # server.py:113-121
+        if pcm.shape[-1]:
+            self._pcm = np.concatenate((self._pcm, np.asarray(pcm, dtype=np.float32).reshape(-1)))
+        n = self._pcm.shape[0] // self.frame_size
+        out = [self._pcm[i * self.frame_size:(i + 1) * self.frame_size].copy() for i in range(n)]
+        self._pcm = self._pcm[n * self.frame_size:]
+        return out
+
+    def encode(self, pcm: np.ndarray) -> bytes:
+        """float32 samples -> the Opus bytes that are ready (possibly empty: the writer emits whole pages), server.py:133,146-150."""
+        self._writer.append_pcm(np.asarray(pcm, dtype=np.float32).reshape(-1))
+        return bytes(self._writer.read_bytes())
+
+
+def make_framer(frame_size: int, fmt: str, sample_rate: int):
+    return OpusFramer(frame_size, sample_rate) if fmt == "opus" else PcmFramer(frame_size, fmt)
 
 
 class ServerState:
@@ -114,7 +153,7 @@ class ServerState:
         from aiohttp import WSMsgType, web
         ws = web.WebSocketResponse()
         await ws.prepare(request)
-        framer = PcmFramer(self.frame_size, request.query.get("pcm", "f32"))
+        framer = make_framer(self.frame_size, request.query.get("pcm", "f32"), int(getattr(self.mimi, "sample_rate", 24000)))
         close = False
         outbox: asyncio.Queue = asyncio.Queue()
 
@@ -149,7 +188,9 @@ class ServerState:
                     be = time.time()
                     chunk = torch.from_numpy(pcm).to(self.device)[None, None]
                     for out_pcm, text_token in self.frame(chunk):
-                        await outbox.put(bytes([KIND_AUDIO]) + framer.encode(out_pcm))
+                        payload = framer.encode(out_pcm)
+                        if len(payload) > 0:            # (an Opus writer hands out whole pages: nothing yet is not a message)
+                            await outbox.put(bytes([KIND_AUDIO]) + payload)
                         piece = self.text_piece(text_token)
                         if piece is not None:
                             await outbox.put(bytes([KIND_TEXT]) + piece.encode("utf8"))

@@ -172,3 +172,29 @@ def test_unmerged_adapter_forms_equal_the_merged_update(cfg_d):
                              "transformer.h.0.attn.attn.lora_B": ad2["transformer.h.0.attn.attn.lora_B"]})
     model.load_adapters(None)
     assert all(blk.attn.packed_qkv_adapter() is None for blk in model.transformer.h)
+
+
+def test_graphed_argument_contract_matches_cudagraphed():
+    """`Graphed` keeps the argument contract of the reference's CUDAGraphed (utils/compile.py:216-256) -- checked here on the host-side
+    paths that need no device: keyword arguments refused, a disabled / nested wrapper calls straight through, `reset(warmup_steps)`."""
+    from rstnet_amd import graphs
+    calls = []
+    g = graphs.Graphed(lambda a, k: calls.append((a, k)) or a, disable=True)
+    assert g(3, 4) == 3 and calls == [(3, 4)]
+    with pytest.raises(RuntimeError):
+        g(3, k=4)
+    inner = graphs.Graphed(lambda a: a + 1)              # enabled, but called from inside another graphed call: runs plainly
+    with graphs._set_in_graph():
+        assert graphs.in_cuda_graph() and inner(1) == 2 and inner.graph is None and inner.calls == 0
+    assert not graphs.in_cuda_graph()
+    inner.reset(warmup_steps=3)
+    assert inner.warmup == 3 and inner.graph is None
+    # the value / type checks of a captured call (no capture needed to exercise them)
+    g2 = graphs.Graphed(lambda a, n: a)
+    g2.static_in = [torch.zeros(2, 3), 7]
+    g2._match_values_copy_tensors((torch.ones(2, 3), 7))
+    assert float(g2.static_in[0].sum()) == 6.0
+    for bad in ((torch.ones(2, 4), 7), (torch.ones(2, 3), 8), (5, 7), (torch.ones(2, 3), torch.ones(1)), (torch.ones(2, 3),)):
+        with pytest.raises(ValueError):
+            g2._match_values_copy_tensors(bad)
+    assert graphs.CUDAGraphed is graphs.Graphed

@@ -156,3 +156,61 @@ def test_websocket_session_frames_text_and_lock():
             await client.close()
 
     _run(scenario())
+
+
+def test_opus_framer_seam_with_a_stand_in_sphn(monkeypatch):
+    """`?pcm=opus`: the reference's transport (server.py:105-153) at the PcmFramer seam.  `sphn` is absent from the image, so the
+    plumbing is exercised with a stand-in module that keeps sphn's call surface (OpusStreamReader.append_bytes / read_pcm,
+    OpusStreamWriter.append_pcm / read_bytes) and moves float32 samples unchanged; without any `sphn` the framer refuses loudly."""
+    import sys
+    import types
+    from rstnet_amd import server as S
+    monkeypatch.setitem(sys.modules, "sphn", None)          # import sphn -> ImportError
+    with pytest.raises(RuntimeError, match="sphn"):
+        S.make_framer(4, "opus", 24000)
+
+    class Reader:
+        def __init__(self, sr):
+            self.sr, self.buf = sr, bytearray()
+
+        def append_bytes(self, b):
+            self.buf += b
+
+        def read_pcm(self):
+            n = len(self.buf) // 4
+            out = np.frombuffer(bytes(self.buf[:4 * n]), dtype="<f4").copy()
+            del self.buf[:4 * n]
+            return out
+
+    class Writer:
+        def __init__(self, sr):
+            self.sr, self.out = sr, bytearray()
+
+        def append_pcm(self, pcm):
+            self.out += np.asarray(pcm, dtype="<f4").tobytes()
+
+        def read_bytes(self):
+            b, self.out = bytes(self.out), bytearray()
+            return b
+    fake = types.ModuleType("sphn")
+    fake.OpusStreamReader, fake.OpusStreamWriter = Reader, Writer
+    monkeypatch.setitem(sys.modules, "sphn", fake)
+    f = S.make_framer(4, "opus", 24000)
+    assert isinstance(f, S.OpusFramer) and isinstance(S.make_framer(4, "s16", 24000), S.PcmFramer)
+    x = np.arange(10, dtype=np.float32)
+    f.append_bytes(x[:3].tobytes())
+    assert f.frames() == []
+    f.append_bytes(x[3:].tobytes())
+    got = f.frames()
+    assert len(got) == 2 and np.array_equal(got[0], x[:4]) and np.array_equal(got[1], x[4:8]) and f.frames() == []
+    assert f.encode(x[:4]) == x[:4].tobytes()
+
+
+def test_opus_framer_with_the_real_sphn():
+    sphn = pytest.importorskip("sphn")           # not in this image: skipped here, runs where a deployment installs it
+    from rstnet_amd import server as S
+    f = S.make_framer(1920, "opus", 24000)
+    w = sphn.OpusStreamWriter(24000)
+    w.append_pcm(np.zeros(1920 * 4, dtype=np.float32))
+    f.append_bytes(w.read_bytes())
+    assert all(fr.shape == (1920,) for fr in f.frames())
