@@ -3,7 +3,7 @@
 #   bench JSON lines, rocprofv3 kernel traces (--kernel-trace --stats) and the two PMC passes (FETCH_SIZE / WRITE_SIZE) per
 #   workload.  The raw rocprof outputs are reduced on the box (tools/rocpd_summary.py, tools/pmc_traffic.py) to the small
 #   files that are then copied into profiles/ and committed; only those travel back (gpurun_out/ is capped at 64 MiB).
-TAG=${1:-r03}
+TAG=${1:-r04}
 WHAT=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG
@@ -77,9 +77,19 @@ print('%-44s %-14s step %7.3f ms  three-plane GEMMs %7.3f ms  %7.1f TFLOP/s (fp3
     cat "$O/b3_ablation.txt"
   fi
 fi
+if [ "$WHAT" = all ] || [ "$WHAT" = codec ] || [ "$WHAT" = rb ]; then
+  # the fused residual blocks alone (tools/bench_resblock.py): times, wave-stall split, instruction counts per launch
+  python tools/bench_resblock.py --iters 10 2>&1 | grep -v amdgpu.ids > "$O/rb_times.txt"
+  python tools/bench_resblock.py --iters 10 --f32 2>&1 | grep -v amdgpu.ids >> "$O/rb_times.txt"
+  cat "$O/rb_times.txt"
+  NO_CUDA_GRAPH=1 run rb_stalls_raw rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$RAW/rb_stalls" -o m -- python tools/bench_resblock.py --iters 2
+  python tools/pmc_stalls.py "$RAW/rb_stalls" | grep resblock > "$O/rb_stalls.txt"; cat "$O/rb_stalls.txt"
+  rm -f "$O/rb_stalls_raw.out"
+fi
 if [ "$WHAT" = all ] || [ "$WHAT" = codec ]; then
   publish codec
   publish b3
+  publish rb
   run codec_bench python bench.py --steps 20 --warmup 5
 fi
 du -sh "$O"; ls "$O"
