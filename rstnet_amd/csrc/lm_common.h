@@ -20,14 +20,57 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
+// DPP forms (no LDS crossbar round trip per step: a __shfl_xor butterfly is 6 dependent ds_bpermute, ~0.3 us for a lone wave).
+// row16_*: over the 16 lanes of a DPP row, result in every lane of the row; wave_*_fast: over the wave, result uniform.  Call with
+// all 64 lanes active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+#define DPP_QUAD_XOR1 0xB1        /* quad_perm [1, 0, 3, 2] */
+#define DPP_QUAD_XOR2 0x4E        /* quad_perm [2, 3, 0, 1] */
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<DPP_QUAD_XOR1>(v);
+    v += dpp_f<DPP_QUAD_XOR2>(v);
+    v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f<DPP_ROW_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ float lane_value(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float wave_sum_fast(float v) {
+    v = row16_sum(v);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ __forceinline__ float wave_max_fast(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
+}
+// sum over aligned groups of GS lanes (4 <= GS <= 64, a power of two), result in every lane of the group
+__device__ __forceinline__ float group_sum(float v, int GS) {
+    v += dpp_f<DPP_QUAD_XOR1>(v);
+    v += dpp_f<DPP_QUAD_XOR2>(v);
+    if (GS >= 8) v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+    if (GS >= 16) v += dpp_f<DPP_ROW_MIRROR>(v);
+    if (GS >= 32) v += __shfl_xor(v, 16);
+    if (GS >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
 
 // Ring slot -> position map of RingKVCache.complete (modules/transformer.py:254-278) incl. the `delta <= 0` quirk (Q1);
 // returns whether `slot` is visible to the query at position `pos` (= the step just appended).
-__device__ __forceinline__ bool ring_visible(int slot, long pos, int cap, int context, long end_offset) {
-    const int end_index = (int)(end_offset % cap);
+__device__ __forceinline__ bool ring_visible_at(int slot, long pos, int cap, int context, long end_offset, int end_index) {
     const int delta = slot - end_index;
     long pk = delta <= 0 ? end_offset + delta : end_offset + delta - cap;
     if (slot >= end_offset) pk = -1;
@@ -35,6 +78,9 @@ __device__ __forceinline__ bool ring_visible(int slot, long pos, int cap, int co
     bool ok = slot < cap && pk >= 0 && dl >= 0;
     if (context > 0) ok = ok && dl < context;
     return ok;
+}
+__device__ __forceinline__ bool ring_visible(int slot, long pos, int cap, int context, long end_offset) {
+    return ring_visible_at(slot, pos, cap, context, end_offset, (int)(end_offset % cap));
 }
 
 // ---- MFMA-ordered operand layout of the skinny GEMM (lm_skinny.hip) -- shared with the producers that emit it directly

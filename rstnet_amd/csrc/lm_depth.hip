@@ -18,27 +18,61 @@
 // that head's keys / values of the frame's earlier steps in its LDS (the depth transformer's KV ring never touches HBM here)
 // and reproduces RingKVCache.complete's slot -> position map for a ring of dep_q slots (modules/transformer.py:254-278, incl. the
 // `delta <= 0` slot that hides step 0 at the last step).  The sampler (lm_sample_impl.h) runs in workgroup 0.
-// Arithmetic (per-lane k order, wave reduction, norm, gate, softmax) is that of the launch-per-op path (lm_step.hip, lm_attn.hip).
+// Arithmetic (per-lane k order, norm partials, gate, softmax) is that of the launch-per-op path (lm_step.hip, lm_attn.hip) up to the
+// order of the additions inside a wave reduction (DPP steps here, a shuffle butterfly there).
 #include "lm_common.h"
 #include "lm_sample_impl.h"
 #include "persist.h"
 
 namespace {
 
+// tools build only: wall-clock stamps (100 MHz) of workgroup 0 at the op boundaries of every (step, layer), kept in LDS while the
+// launch runs (tools/probes/depth_frame_phases.py prints them; a stamp costs ~0.2 us itself)
+#ifdef RST_ABLATION
+#define DF_ST_LAYER 13
+#define DF_ST_STEP (DF_ST_LAYER * RST_DEPTH_MAX_L + 4 + 8)
+#define DF_ST_TOTAL (DF_ST_STEP * RST_DEPTH_MAX_Q + 2)
+__device__ unsigned long long df_stamps[DF_ST_TOTAL];
+#define DF_STAMP(i) do { if (!SOLO && tid == 0) df_lds_stamps[(i)] = wall_clock64(); } while (0)
+#else
+#define DF_STAMP(i) do {} while (0)
+#endif
+
 // xs[b][i] = x[b][i] * alpha[i] / sqrt(eps + mean(x[b]^2))   (modules/transformer.py:34-46; the summation order of gemv_kernel)
+// Every wave computes the statistic of every row for itself (no exchange through LDS, one barrier at the end): the four partial
+// sums are those of the four waves of gemv_kernel's prologue (element i belongs to partial (i / 64) % 4), added in the same order.
+// Round 3's version exchanged the partials through LDS (3 barriers per row, shuffle butterflies): ~1 us per norm.
+// alpha of the first DF_NORM_J * 256 columns rides in registers across the hand-off in front of the norm (df_norm_issue): read
+// where it is used it cost a global round trip (~0.8 us) in every norm.
+constexpr int DF_NORM_J = 8;
+struct DfNorm { float a[DF_NORM_J]; };
+__device__ __forceinline__ void df_norm_issue(DfNorm& c, const float* alpha, int E) {
+#pragma unroll
+    for (int j = 0; j < DF_NORM_J; ++j) c.a[j] = alpha[min((int)threadIdx.x + DF_THREADS * j, E - 1)];      // clamped: unconditional loads
+}
+
 template <int B>
-__device__ __forceinline__ void df_rmsnorm(const float* x, const float* alpha, float eps, int E, float* xs, DfShared& sh) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void df_rmsnorm(const float* x, const DfNorm& c, const float* alpha, float eps, int E, float* xs) {
+    const int tid = threadIdx.x, lane = tid & 63;
     for (int b = 0; b < B; ++b) {
-        float s = 0.f;
-        for (int i = tid; i < E; i += DF_THREADS) s = fmaf(x[b * E + i], x[b * E + i], s);
-        s = wave_sum(s);
-        __syncthreads();
-        if (lane == 0) sh.red[wave] = s;
-        __syncthreads();
-        const float tot = sh.red[0] + sh.red[1] + sh.red[2] + sh.red[3];
+        float s[DF_WAVES] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = lane; i < E; i += DF_THREADS) {
+#pragma unroll
+            for (int w = 0; w < DF_WAVES; ++w) {
+                const float v = i + 64 * w < E ? x[b * E + i + 64 * w] : 0.f;
+                s[w] = fmaf(v, v, s[w]);
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < DF_WAVES; ++w) s[w] = wave_sum_fast(s[w]);
+        const float tot = s[0] + s[1] + s[2] + s[3];
         const float r = 1.0f / sqrtf(eps + tot / (float)E);
-        for (int i = tid; i < E; i += DF_THREADS) xs[b * E + i] = x[b * E + i] * (alpha[i] * r);
+#pragma unroll
+        for (int j = 0; j < DF_NORM_J; ++j) {
+            const int i = tid + DF_THREADS * j;
+            if (i < E) xs[b * E + i] = x[b * E + i] * (c.a[j] * r);
+        }
+        for (int i = tid + DF_THREADS * DF_NORM_J; i < E; i += DF_THREADS) xs[b * E + i] = x[b * E + i] * (alpha[i] * r);
     }
     __syncthreads();
 }
@@ -117,7 +151,7 @@ __device__ __forceinline__ void df_rows(DfPre<RU, CU, PAIR>& pre, const unsigned
 #pragma unroll
             for (int h = 0; h < HV; ++h)
 #pragma unroll
-                for (int b = 0; b < B; ++b) s[h][b] = wave_sum(acc[j][h][b]);
+                for (int b = 0; b < B; ++b) s[h][b] = wave_sum_fast(acc[j][h][b]);
             if (lane == 0 && r < rows) epi(r, s);
         }
     }
@@ -162,7 +196,12 @@ __global__ __launch_bounds__(DF_THREADS) void depth_frame_kernel(const DepthFram
     u64* gLOG = gH + (long)B * Hd;
     u64* gTOK = gLOG + (long)B * card;
     if (tid == 0) sh.dead = 0;
+#ifdef RST_ABLATION
+    __shared__ __attribute__((aligned(16))) unsigned long long df_lds_stamps[DF_ST_TOTAL];
+    for (int i = tid; i < DF_ST_TOTAL; i += DF_THREADS) df_lds_stamps[i] = 0;
+#endif
     __syncthreads();
+    DF_STAMP(0);
     unsigned eX = 0, eQKV = 0, eATT = 0, eH = 0, eLOG = 0, eTOK = 0;      // epochs (number of completed writes) per buffer
     const float att_div = sqrtf((float)D);
 
@@ -171,8 +210,10 @@ __global__ __launch_bounds__(DF_THREADS) void depth_frame_kernel(const DepthFram
     DfPre<3, 2, true> pi;       // gated FFN in (u, v row pairs)
     DfPre<1, 6, false> pf;      // gated FFN out
     DfPre<2, 2, false> ph;      // head
+    DfNorm n1, n2;              // alpha of the two norms of a layer
     df_rows_issue<3, 2, false>(pq, p.in_proj[0], 3 * E, E, gw, W, lane);
     for (int k = 0; k < dep_q; ++k) {
+        df_norm_issue(n1, p.norm1[0], E);
         // ---- input of the step: x = depformer_in[k](h) + emb_k[previous token]   (models/model.py:411-417)
         if (k == 0) {
             if (tid < B) sh.tok[tid] = p.tokens[(long)tid * p.tok_stride];
@@ -194,15 +235,25 @@ __global__ __launch_bounds__(DF_THREADS) void depth_frame_kernel(const DepthFram
             }
         }
         __syncthreads();
+#ifdef RST_ABLATION
+        const int sk = 1 + k * DF_ST_STEP;
+#endif
+        DF_STAMP(sk);
 
         for (int l = 0; l < p.L; ++l) {
+#ifdef RST_ABLATION
+            const int sl = sk + 1 + l * DF_ST_LAYER;
+#endif
             // ---- in-projection: qkv = W_in[k] rmsnorm(x)   (its weights were requested before the hand-off that produced x)
-            df_rmsnorm<B>(xres, p.norm1[l], p.eps, E, xs, sh);
+            df_rmsnorm<B>(xres, n1, p.norm1[l], p.eps, E, xs);
+            df_norm_issue(n2, p.norm2[l], E);
+            DF_STAMP(sl + 0);
             ++eQKV;
             df_rows<B, 3, 2, false>(pq, p.in_proj[l] + (long)k * 3 * E * E, 3 * E, E, xs, gw, W, lane, [&](int r, float (&s)[1][B]) {
 #pragma unroll
                 for (int b = 0; b < B; ++b) df_publish(gQKV + (long)b * 3 * E + r, eQKV, s[0][b]);
             });
+            DF_STAMP(sl + 1);
             df_rows_issue<1, 2, false>(po, p.out_proj[l] + (long)k * E * E, E, E, gw, W, lane);
             // ---- attention of head `wg` (modules/transformer.py:376-416 on a ring of ring_cap slots, no rope)
             ++eATT;
@@ -210,6 +261,7 @@ __global__ __launch_bounds__(DF_THREADS) void depth_frame_kernel(const DepthFram
                 const long hb = SOLO ? h * hist_head : 0;
                 df_gather<2>(gQKV, B * 3 * D, eQKV, qh, [&](int i) { const int b = i / (3 * D), j = i - b * 3 * D, part = j / D;
                                                                   return b * 3 * E + part * E + h * D + (j - part * D); }, sh, p.status, 2u);
+                DF_STAMP(sl + 2);
                 const long hk = hb + (((long)l * dep_q + k) * B) * 2 * D;       // [B][2][D] of this (layer, step)
                 for (int i = tid; i < B * 2 * D; i += DF_THREADS) {
                     const int b = i / (2 * D), j = i - b * 2 * D;
@@ -217,54 +269,74 @@ __global__ __launch_bounds__(DF_THREADS) void depth_frame_kernel(const DepthFram
                 }
                 if (SOLO) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the write-through stores have landed before the reads below
                 __syncthreads();
+                DF_STAMP(sl + 3);
                 if (wave == 0) {
+                    // steps unrolled to the table size (scores stay in registers; the dot products of the steps are independent)
+                    const int end_index = (k + 1) % p.ring_cap;
                     for (int b = 0; b < B; ++b) {
                         float sc[RST_DEPTH_MAX_Q], m = -INFINITY;
-                        for (int s = 0; s <= k; ++s) {
-                            const long ks = hb + ((((long)l * dep_q + s) * B + b) * 2) * D;
-                            float d = 0.f;
-                            for (int dd = lane; dd < D; dd += 64) d = fmaf(hist.rd(ks + dd), qh[b * 3 * D + dd], d);
-                            d = wave_sum(d);
-                            sc[s] = ring_visible(s, k, p.ring_cap, p.context, (long)k + 1) ? d / att_div : -INFINITY;
-                            m = fmaxf(m, sc[s]);
+#pragma unroll
+                        for (int s = 0; s < RST_DEPTH_MAX_Q; ++s) {
+                            sc[s] = -INFINITY;
+                            if (s <= k) {
+                                const long ks = hb + ((((long)l * dep_q + s) * B + b) * 2) * D;
+                                float d = 0.f;
+                                for (int dd = lane; dd < D; dd += 64) d = fmaf(hist.rd(ks + dd), qh[b * 3 * D + dd], d);
+                                d = wave_sum_fast(d);
+                                sc[s] = ring_visible_at(s, k, p.ring_cap, p.context, (long)k + 1, end_index) ? d / att_div : -INFINITY;
+                                m = fmaxf(m, sc[s]);
+                            }
                         }
                         float lsum = 0.f;
-                        for (int s = 0; s <= k; ++s) { sc[s] = sc[s] == -INFINITY ? 0.f : expf(sc[s] - m); lsum += sc[s]; }
+#pragma unroll
+                        for (int s = 0; s < RST_DEPTH_MAX_Q; ++s) { sc[s] = sc[s] == -INFINITY ? 0.f : expf(sc[s] - m); lsum += sc[s]; }
                         for (int dd = lane; dd < D; dd += 64) {
                             float o = 0.f;
-                            for (int s = 0; s <= k; ++s) o = fmaf(sc[s], hist.rd(hb + ((((long)l * dep_q + s) * B + b) * 2 + 1) * D + dd), o);
+#pragma unroll
+                            for (int s = 0; s < RST_DEPTH_MAX_Q; ++s)
+                                if (s <= k) o = fmaf(sc[s], hist.rd(hb + ((((long)l * dep_q + s) * B + b) * 2 + 1) * D + dd), o);
                             df_publish(gATT + (long)b * E + h * D + dd, eATT, o / lsum);
                         }
                     }
                 }
+                DF_STAMP(sl + 4);
             }
             // ---- out-projection + residual
             df_gather<4>(gATT, B * E, eATT, xs, [](int i) { return i; }, sh, p.status, 4u);
+            DF_STAMP(sl + 5);
             ++eX;
             df_rows<B, 1, 2, false>(po, p.out_proj[l] + (long)k * E * E, E, E, xs, gw, W, lane, [&](int r, float (&s)[1][B]) {
 #pragma unroll
                 for (int b = 0; b < B; ++b) df_publish(gX + (long)b * E + r, eX, xres[b * E + r] + s[0][b]);
             });
+            DF_STAMP(sl + 6);
             df_rows_issue<3, 2, true>(pi, p.gate_in[l][k], 2 * Hd, E, gw, W, lane);
             df_gather<4>(gX, B * E, eX, xres, [](int i) { return i; }, sh, p.status, 8u);
+            DF_STAMP(sl + 7);
             // ---- gated FFN: x + W_out (silu(u) * v), [u ; v] = W_in rmsnorm(x)   (modules/gating.py:12-51)
-            df_rmsnorm<B>(xres, p.norm2[l], p.eps, E, xs, sh);
+            df_rmsnorm<B>(xres, n2, p.norm2[l], p.eps, E, xs);
+            if (l + 1 < p.L) df_norm_issue(n1, p.norm1[l + 1], E);
+            DF_STAMP(sl + 8);
             ++eH;
             df_rows<B, 3, 2, true>(pi, p.gate_in[l][k], 2 * Hd, E, xs, gw, W, lane, [&](int q, float (&s)[2][B]) {
 #pragma unroll
                 for (int b = 0; b < B; ++b) df_publish(gH + (long)b * Hd + q, eH, silu(s[0][b]) * s[1][b]);
             });
+            DF_STAMP(sl + 9);
             df_rows_issue<1, 6, false>(pf, p.gate_out[l][k], E, Hd, gw, W, lane);
             df_gather<6>(gH, B * Hd, eH, xs, [](int i) { return i; }, sh, p.status, 16u);
+            DF_STAMP(sl + 10);
             ++eX;
             df_rows<B, 1, 6, false>(pf, p.gate_out[l][k], E, Hd, xs, gw, W, lane, [&](int r, float (&s)[1][B]) {
 #pragma unroll
                 for (int b = 0; b < B; ++b) df_publish(gX + (long)b * E + r, eX, xres[b * E + r] + s[0][b]);
             });
+            DF_STAMP(sl + 11);
             // the next consumer of x: the next layer's in-projection, or the head of this step
             if (l + 1 < p.L) df_rows_issue<3, 2, false>(pq, p.in_proj[l + 1] + (long)k * 3 * E * E, 3 * E, E, gw, W, lane);
             else df_rows_issue<2, 2, false>(ph, p.heads[k], card, E, gw, W, lane);
             df_gather<4>(gX, B * E, eX, xres, [](int i) { return i; }, sh, p.status, 32u);
+            DF_STAMP(sl + 12);
         }
 
         // ---- head: logits = linears[k](x)   (models/model.py:425-427; no norm in front)
@@ -274,27 +346,54 @@ __global__ __launch_bounds__(DF_THREADS) void depth_frame_kernel(const DepthFram
 #pragma unroll
             for (int b = 0; b < B; ++b) df_publish(gLOG + (long)b * card + r, eLOG, s[0][b] + bias);
         });
+        DF_STAMP(sk + 1 + DF_ST_LAYER * RST_DEPTH_MAX_L);
         if (k + 1 < dep_q) df_rows_issue<3, 2, false>(pq, p.in_proj[0] + (long)(k + 1) * 3 * E * E, 3 * E, E, gw, W, lane);
         // ---- sampler (workgroup 0): utils/sampling.py:85-105
         ++eTOK;
         if (wg == 0) {
             df_gather<8>(gLOG, B * card, eLOG, lg, [](int i) { return i; }, sh, p.status, 64u);
+            DF_STAMP(sk + 2 + DF_ST_LAYER * RST_DEPTH_MAX_L);
             for (int b = 0; b < B; ++b) {
                 const float* nz = p.noise ? p.noise + (long)b * p.noise_stride + (long)k * p.top_k : nullptr;
                 const int limit = p.v_limit ? p.v_limit[k] : 0;
+#ifdef RST_ABLATION
+                unsigned long long* sdbg = SOLO || b ? nullptr : df_lds_stamps + sk + 4 + DF_ST_LAYER * RST_DEPTH_MAX_L;
+#else
+                unsigned long long* sdbg = nullptr;
+#endif
                 const int tok = card <= 8 * DF_THREADS
-                    ? sample_row<DF_THREADS, 8>(lg + b * card, nz, card, p.top_k, p.use_sampling && p.temp > 0.f, p.temp, limit, comp, ssh)
-                    : sample_row<DF_THREADS, 16>(lg + b * card, nz, card, p.top_k, p.use_sampling && p.temp > 0.f, p.temp, limit, comp, ssh);
+                    ? sample_row<DF_THREADS, 8>(lg + b * card, nz, card, p.top_k, p.use_sampling && p.temp > 0.f, p.temp, limit, comp, ssh, 0, nullptr, sdbg)
+                    : sample_row<DF_THREADS, 16>(lg + b * card, nz, card, p.top_k, p.use_sampling && p.temp > 0.f, p.temp, limit, comp, ssh, 0, nullptr, sdbg);
                 if (tid == 0) {
                     p.tokens[(long)b * p.tok_stride + k + 1] = tok;
                     df_publish(gTOK + b, eTOK, __int_as_float(tok));
                 }
                 __syncthreads();
             }
+            DF_STAMP(sk + 3 + DF_ST_LAYER * RST_DEPTH_MAX_L);
         }
     }
+#ifdef RST_ABLATION
+    if (!SOLO && wg == 0) {
+        __syncthreads();
+        for (int i = tid; i < DF_ST_TOTAL; i += DF_THREADS) df_stamps[i] = df_lds_stamps[i];
+    }
+#endif
     if (SOLO) df_solo_done(p.status);
 }
+
+}  // namespace
+
+#ifdef RST_ABLATION
+// tools build only: the stamps of workgroup 0 of the last persistent launch, 100 MHz ticks; layout: [0] start, then per step
+// [embed | 13 per layer x RST_DEPTH_MAX_L | head rows | sampler gather | sampler done]
+extern "C" int rst_debug_depth_frame_stamps(unsigned long long* out, int n) {
+    if (n > DF_ST_TOTAL) n = DF_ST_TOTAL;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(df_stamps), sizeof(unsigned long long) * n) == hipSuccess ? n : -1;
+}
+#endif
+
+namespace {
 
 int df_cu_count() {
     return rst_cu_count();       // per device (rst_common.h)
@@ -328,7 +427,9 @@ int rst_depth_frame_grid(const DepthFrameParams& p) {
     const size_t lds = df_lds_bytes(p);
     if (lds > 150 * 1024) return 0;
     const int rows = min(min(3 * p.E, p.Hd), p.card);
-    const int G = df_grid_for_rows(df_cu_count(), rows);
+    int G = df_grid_for_rows(df_cu_count(), rows);
+    static const int cap = rst_knob("RST_DF_GRID", 0);      // tools build only (see codec_tr.hip)
+    if (cap > 0 && G > cap) G = cap;
     if (p.H > G) return 0;
     // residency: all G workgroups must run at once, one per CU -- ask the runtime whether a CU takes a workgroup of this footprint
     static signed char fits[RST_MAX_DEVICES][2][2];      // [device][B - 1][lds > 64 KB]: 0 = not asked yet, 1 = fits, -1 = does not; the

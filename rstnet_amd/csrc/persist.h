@@ -38,7 +38,11 @@ struct DfShared {
 };
 
 // Sweep `n` granules (source index of item i = map(i)) until every tag == epoch; values -> dst[i] (LDS).  All threads of the
-// workgroup take part (up to GP granules per thread and pass, all requested before any is examined).
+// workgroup take part (up to GP granules per thread and pass, all requested before any is examined).  ONE sweep in flight per
+// workgroup, re-issued when it returns: both variations measured in round 4 were slower (profiles/r04_handoff_polling.txt) -- a
+// second sweep in flight (half the detection delay on paper) doubles 2-6 TB/s of fabric traffic that the publishing stores and the
+// next op's weight prefetch queue behind (+1 to +4 us per hand-off); watching one sentinel granule per thread first and sweeping
+// when it turns adds a round trip (+0.3 to +0.7 us per hand-off).
 template <int GP, typename Map>
 __device__ __forceinline__ void df_gather(const u64* g, int n, unsigned epoch, float* dst, Map map, DfShared& sh, unsigned* status, unsigned code) {
     const int tid = threadIdx.x;
