@@ -409,6 +409,73 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_norm_kernel(const GemvPa
     }
 }
 
+// Batch-1 GEMV on a plain activation vector (out-proj 4096 x 4096, ffn-out 4096 x 11264 of the temporal transformer: 33 / 92 MB of
+// weights per launch) with K split over the four waves of a workgroup: wave w takes the 512-k chunks c = w, w + 4, ... of RW = 8
+// rows, and the eight k of a chunk that a lane multiplies come straight from global memory (L2) into registers -- no activation
+// stage in LDS, no barrier in front of the weight stream.  gemv_kernel<1, 2> stages the whole vector first (45 KB per workgroup
+// at K = 11264, ~3 us during which only the first chunk of each row is in flight): ffn-out measured 21.4 us = 4.3 TB/s there.
+// The four partial sums of a row meet in LDS and are added in wave order (so the rounding differs from gemv_kernel's single
+// chain per lane in the last bits; same for every call).
+template <int RW>
+__global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_ksplit_kernel(const GemvParams p) {
+    __shared__ float part[GEMV_WAVES][RW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K, nchunks = (K + 511) >> 9;
+    const int kl = lane * 8;
+    const int groups = (p.N + RW - 1) / RW;
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int n0 = grp * RW;
+        long wrow[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) wrow[r] = (long)min(n0 + r, p.N - 1) * K;
+        float acc[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[r] = 0.f;
+        // two chunks in flight: the weights of both are requested before the first is multiplied
+        WChunk<false> wa[RW], wb[RW];
+        f32x4 xa0, xa1, xb0, xb1;
+        auto issue = [&](WChunk<false> (&w)[RW], f32x4& x0, f32x4& x1, int c) {
+            const int kk = (c << 9) + kl;
+            const bool ok = c < nchunks && kk < K;
+            x0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            x1 = x0;
+            if (ok) {
+                x0 = *reinterpret_cast<const f32x4*>(p.x + kk);
+                x1 = *reinterpret_cast<const f32x4*>(p.x + kk + 4);
+            }
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                if (ok) w[r].load(p.w, wrow[r] + kk);
+                else w[r].zero();
+            }
+        };
+        issue(wa, xa0, xa1, wave);
+        for (int c = wave; c < nchunks; c += 2 * GEMV_WAVES) {
+            issue(wb, xb0, xb1, c + GEMV_WAVES);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) acc[r] = wa[r].dot(xa0, xa1, acc[r]);
+            issue(wa, xa0, xa1, c + 2 * GEMV_WAVES);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) acc[r] = wb[r].dot(xb0, xb1, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[r] = wave_sum(acc[r]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < RW; ++r) part[wave][r] = acc[r];
+        }
+        __syncthreads();
+        if (tid < RW && n0 + tid < p.N) {
+            const int n = n0 + tid;
+            const float s = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+            float sb = p.bias ? s + p.bias[n] : s;
+            if (p.scale) sb *= p.scale[n];
+            p.y[n] = p.res ? p.res[n] + sb : sb;
+        }
+        __syncthreads();          // part is rewritten by the next group
+    }
+}
+
 // x[b][:] = sum_i table_i[token[b][i]]  (bf16 tables, fp32 sum in table order; id -1 -> zero row, ids clamped at 0)
 __global__ __launch_bounds__(256) void embed_sum_kernel(const EmbedSumParams p) {
     const int b = blockIdx.y;
@@ -497,6 +564,12 @@ int rst_launch_gemv(const GemvParams& p, hipStream_t stream) {
     }
     if (norm_stream) {
         if (p.gate_out) go(gemv_norm_kernel<true>); else go(gemv_norm_kernel<false>);
+        return rst_check_launch("gemv_bf16");
+    }
+    // the large batch-1 layers on a plain vector: K split over the waves, activations straight into registers (gemv_ksplit_kernel)
+    if (!p.w_f32 && p.B == 1 && p.prologue == 0 && !p.act_out && !p.gate_out && (long)p.N * p.K >= (1L << 24) && p.K >= 2048) {
+        const long g8 = ((long)p.N + 7) / 8;
+        hipLaunchKernelGGL(gemv_ksplit_kernel<8>, dim3(cap_grid(g8, 1024)), dim3(64 * GEMV_WAVES), 0, stream, p);
         return rst_check_launch("gemv_bf16");
     }
     switch (p.B * 2 + (rpw4 ? 1 : 0)) {
