@@ -370,7 +370,7 @@ def run_lm(args, rank, world, dev, lm=None, steps=None, warmup=None, cpu=True):
                    "parallelism": f"replica x{world}"},
         "x_realtime_per_stream": round(steps / elapsed / 12.5, 2),
         "timing": timing,
-        "roofline": {"bound": "hbm", "kernel": ("gemv_kernel / gemv_norm_kernel" if B <= 2 else "gemm_skinny_kernel / gemm_skinny_x32_kernel") + " (bf16 weight streaming)",
+        "roofline": {"bound": "hbm", "kernel": ("gemv_kernel / gemv_norm_kernel / gemv_ksplit_kernel" if B <= 2 else "gemm_skinny_kernel / gemm_skinny_x32_kernel") + " (bf16 weight streaming)",
                      "achieved": round(nbytes / ms / 1e6, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                      "traffic": pmc_traffic(kern, "lm"),
@@ -531,7 +531,7 @@ def run_gpt(args, rank, world, dev, gpt=None, fp8=None, steps=None, warmup=None,
                    "gemm_precision": "fp8 e4m3 (per-row scales) in the global blocks, bf16 hi+lo elsewhere" if fp8 else "bf16 hi+lo",
                    "parallelism": f"replica x{world}"},
         "x_realtime_per_stream": round(steps / elapsed / 12.5, 2),
-        "roofline": {"bound": "hbm", "kernel": ("gemv_kernel / gemv_norm_kernel" if B <= 2 else "gemm_skinny_kernel / gemm_skinny_x32_kernel"
+        "roofline": {"bound": "hbm", "kernel": ("gemv_kernel / gemv_norm_kernel / gemv_ksplit_kernel" if B <= 2 else "gemm_skinny_kernel / gemm_skinny_x32_kernel"
                                                 + (" / gemm_skinny_fp8_kernel" if fp8 else "")) + " (weight streaming)",
                      "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),

@@ -48,6 +48,12 @@ if [ "$WHAT" = all ] || [ "$WHAT" = e2e ]; then
   [ -n "$db" ] && python tools/frame_timeline.py "$db" "$O/e2e1_timeline.csv" lm_ring_begin_kernel 2
   rm -f "$O/e2e1_trace.out"
 fi
+if [ "$WHAT" = all ] || [ "$WHAT" = phases ]; then
+  # op-boundary stamps of the two persistent kernels (tools build: librstnet_hip_ablation.so)
+  (python tools/probes/codec_tr_phases.py 1 2; python tools/probes/codec_tr_phases.py 1 1; python tools/probes/codec_tr_phases.py 2 2) 2>&1 | grep -v amdgpu.ids > "$O/codec_tr_phases.txt"
+  (python tools/probes/depth_frame_phases.py 1; python tools/probes/depth_frame_phases.py 2) 2>&1 | grep -v amdgpu.ids > "$O/depth_frame_phases.txt"
+  cp "$O/codec_tr_phases.txt" "$O/depth_frame_phases.txt" profiles/ 2>/dev/null; for f in codec_tr_phases depth_frame_phases; do mv "profiles/$f.txt" "profiles/${TAG}_$f.txt"; done
+fi
 # the codec workload last: its default line carries the LM / GPT / end-to-end sub-objects, which quote the summaries published above
 if [ "$WHAT" = all ] || [ "$WHAT" = codec ]; then
   prof codec python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sub --no-check --timing-samples 1
