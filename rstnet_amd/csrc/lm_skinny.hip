@@ -535,13 +535,32 @@ int rst_launch_skinny_pack_act(const float* x, const float* alpha, unsigned shor
     return rst_check_launch("skinny_pack_act");
 }
 
-// Column tiles per workgroup.  Long K (>= 2048) with the split scratch available: as many as the kernel has (the activations of a
-// step are then shared by 4 / 2 weight tiles); otherwise by tile count alone, as before the split form existed.
-static int skinny_ct(int B, int tiles, int K, int split) {
+// Column tiles per workgroup.  A workgroup's bytes go through ONE CU's L1 (~60 GB/s sustained): the activations of a step (2 KB)
+// are shared by CT weight tiles (CT KB), and two workgroups on a CU share that path.  Without a K split: the fewest tiles that
+// leave at most one workgroup per CU, ceil(tiles / CUs) -- round 3's thresholds (one tile below 512, two below 2048) put 1.5
+// workgroups per CU on the 12288-row qkv and 1.4 on the 22528-row gated layer of the Moshi-7B shape, and the CUs that held two took
+// twice as long (31 / 47 us; `profiles/r04_skinny_ct.txt`: the batch-32 LM frame 7.02 -> 6.44 ms with this rule).  With a K split
+// (long K, few tiles): as many as the kernel has, as before.
+static int skinny_ct_round3(int B, int tiles, int K, int split) {
     const int max_ct = B <= 32 ? 4 : 2;
     if (K >= 2048 && (split > 1 || tiles >= 192 * max_ct)) return tiles >= max_ct ? max_ct : (tiles >= 2 ? 2 : 1);
     if (B <= 32) return tiles >= 2048 ? 4 : (tiles >= 512 ? 2 : 1);
     return tiles >= 512 ? 2 : 1;
+}
+static int skinny_ct(int B, int tiles, int K, int split) {
+    const int max_ct = B <= 32 ? 4 : 2;
+    int ct;
+    if (split > 1) ct = tiles >= max_ct ? max_ct : (tiles >= 2 ? 2 : 1);
+    else {
+        const int cus = rst_cu_count();
+        ct = (tiles + cus - 1) / cus;
+        ct = ct < 1 ? 1 : (ct > max_ct ? max_ct : ct);
+    }
+    // tools build only -- RST_SKINNY_CT: 1..4 forces the column tiles per workgroup, 8 = round 3's thresholds
+    static const int kct = rst_knob("RST_SKINNY_CT", 0);
+    if (kct >= 1 && kct <= 4) ct = kct < max_ct ? kct : max_ct;
+    if (kct == 8) ct = skinny_ct_round3(B, tiles, K, split);
+    return ct > tiles ? tiles : ct;
 }
 
 // K splits of a launch (1: none).  The in-launch hand-off costs ~8 us (drained write-through stores, the counter round trip, the
@@ -576,6 +595,7 @@ int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream) {
     if (xf) {
         if (p.B <= 32) {
             if (ct == 4) hipLaunchKernelGGL((gemm_skinny_x32_kernel<1, 4>), grid, dim3(threads), 0, stream, p);
+            else if (ct == 3) hipLaunchKernelGGL((gemm_skinny_x32_kernel<1, 3>), grid, dim3(threads), 0, stream, p);
             else if (ct == 2) hipLaunchKernelGGL((gemm_skinny_x32_kernel<1, 2>), grid, dim3(threads), 0, stream, p);
             else hipLaunchKernelGGL((gemm_skinny_x32_kernel<1, 1>), grid, dim3(threads), 0, stream, p);
         } else {
@@ -586,6 +606,7 @@ int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream) {
     }
     if (p.B <= 32) {
         if (ct == 4) hipLaunchKernelGGL((gemm_skinny_kernel<1, 4>), grid, dim3(threads), 0, stream, p);
+        else if (ct == 3) hipLaunchKernelGGL((gemm_skinny_kernel<1, 3>), grid, dim3(threads), 0, stream, p);
         else if (ct == 2) hipLaunchKernelGGL((gemm_skinny_kernel<1, 2>), grid, dim3(threads), 0, stream, p);
         else hipLaunchKernelGGL((gemm_skinny_kernel<1, 1>), grid, dim3(threads), 0, stream, p);
     } else {
