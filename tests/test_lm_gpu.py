@@ -53,7 +53,9 @@ def test_gemv_bf16_prologues(B, N, K):
 # K >= 8192 (>= 4096 above 32 rows): K is also split across workgroups (rst_skinny_bf16_split_plan > 1), four / two column tiles per
 # workgroup; N = 1001: ragged last tile and the 4-byte partial stores (N % 4 != 0)
 @pytest.mark.parametrize("B,N,K", [(32, 4096, 4096), (5, 1000, 1024), (17, 37, 2816), (64, 2048, 1024), (33, 12288, 4096), (8, 96, 64),
-                                   (32, 1000, 8192), (7, 1001, 8192), (3, 4096, 11264), (48, 200, 4096)])
+                                   (32, 1000, 8192), (7, 1001, 8192), (3, 4096, 11264), (48, 200, 4096),
+                                   # column tiles per workgroup = ceil(tiles / CUs) without a K split (round 4): 2, 3 (ragged last tile) and 4
+                                   (32, 12288, 1024), (32, 22500, 1024), (16, 32000, 256)])
 def test_gemm_skinny_bf16(B, N, K):
     """bf16-MFMA skinny GEMM with hi/lo-split activations: fp32-class accuracy against the fp32 oracle product."""
     g = torch.Generator().manual_seed(B + N + K)
