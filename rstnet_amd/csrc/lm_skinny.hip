@@ -548,7 +548,9 @@ static int skinny_ct_round3(int B, int tiles, int K, int split) {
     return tiles >= 512 ? 2 : 1;
 }
 static int skinny_ct(int B, int tiles, int K, int split) {
-    const int max_ct = B <= 32 ? 4 : 2;
+    // (two batch tiles: up to 3 column tiles without a K split -- 4 spill; RST_SKINNY_CT2MAX = 2, tools build, restores round 3's limit)
+    static const int ct2max = rst_knob("RST_SKINNY_CT2MAX", 3) > 3 ? 3 : rst_knob("RST_SKINNY_CT2MAX", 3);
+    const int max_ct = B <= 32 ? 4 : (split > 1 ? 2 : ct2max);
     int ct;
     if (split > 1) ct = tiles >= max_ct ? max_ct : (tiles >= 2 ? 2 : 1);
     else {
@@ -599,7 +601,8 @@ int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream) {
             else if (ct == 2) hipLaunchKernelGGL((gemm_skinny_x32_kernel<1, 2>), grid, dim3(threads), 0, stream, p);
             else hipLaunchKernelGGL((gemm_skinny_x32_kernel<1, 1>), grid, dim3(threads), 0, stream, p);
         } else {
-            if (ct == 2) hipLaunchKernelGGL((gemm_skinny_x32_kernel<2, 2>), grid, dim3(threads), 0, stream, p);
+            if (ct == 3) hipLaunchKernelGGL((gemm_skinny_x32_kernel<2, 3>), grid, dim3(threads), 0, stream, p);
+            else if (ct == 2) hipLaunchKernelGGL((gemm_skinny_x32_kernel<2, 2>), grid, dim3(threads), 0, stream, p);
             else hipLaunchKernelGGL((gemm_skinny_x32_kernel<2, 1>), grid, dim3(threads), 0, stream, p);
         }
         return rst_check_launch("gemm_skinny_x32");
@@ -610,7 +613,8 @@ int rst_launch_gemm_skinny(const SkinnyParams& p, hipStream_t stream) {
         else if (ct == 2) hipLaunchKernelGGL((gemm_skinny_kernel<1, 2>), grid, dim3(threads), 0, stream, p);
         else hipLaunchKernelGGL((gemm_skinny_kernel<1, 1>), grid, dim3(threads), 0, stream, p);
     } else {
-        if (ct == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, 2>), grid, dim3(threads), 0, stream, p);
+        if (ct == 3) hipLaunchKernelGGL((gemm_skinny_kernel<2, 3>), grid, dim3(threads), 0, stream, p);
+        else if (ct == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, 2>), grid, dim3(threads), 0, stream, p);
         else hipLaunchKernelGGL((gemm_skinny_kernel<2, 1>), grid, dim3(threads), 0, stream, p);
     }
     return rst_check_launch("gemm_skinny");
