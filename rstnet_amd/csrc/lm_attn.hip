@@ -97,8 +97,8 @@ template <> struct KvRow<true> {        // bf16 ring: the same 16 elements in 32
     static __device__ __forceinline__ float round(float f) { return df_bf16_round(f); }
 };
 
-template <int D, bool KV16 = false>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) {
+template <int D, bool KV16, int UNR>
+__device__ __forceinline__ void attn_decode_body(const LmAttnParams& p) {
     constexpr int LPS = D / 16;            // lanes per slot
     constexpr int SPW = 64 / LPS;          // slots per wave iteration
     __shared__ float sm_m[4], sm_l[4];
@@ -167,7 +167,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
     // UNR slots per lane group and iteration: the K / V rows of all of them are requested before the first score is formed (a
     // wave that waits out one memory latency per slot streams the ring at a fraction of the bandwidth).  The scores are folded
     // into the running softmax one slot at a time, in slot order, as before.
-    constexpr int UNR = 2;
     for (int s0 = s_lo + wave * SPW; s0 < s_hi; s0 += 4 * SPW * UNR) {
         float kv[UNR][16], vv[UNR][16];
         bool ok[UNR];
@@ -325,6 +324,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) 
         else p.out[((b * T + tq) * p.H + h) * (long)D + tid] = r;
     }
     if (p.out_packed) emit_packed();
+}
+
+template <int D, bool KV16 = false>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const LmAttnParams p) {
+    attn_decode_body<D, KV16, 2>(p);
+}
+// The same for launches of more workgroups than three per CU hold (batch x heads x splits > 3 x CUs): one slot per lane group
+// in flight instead of two keeps the kernel under 128 VGPRs, i.e. FOUR workgroups per CU -- at 32 streams x 32 heads the 1024
+// workgroups ran as two rounds (768 + 256) of a launch that is one dependent chain (18 us; `profiles/r04_kernel_resources.txt`:
+// 161 VGPRs, occupancy 3).
+template <int D, bool KV16 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_decode_dense_kernel(const LmAttnParams p) {
+    attn_decode_body<D, KV16, 1>(p);
 }
 
 // Short ring (capacity <= 64, e.g. the depth transformer's 8 steps): one wave per (b, h), no split and no workspace.
@@ -500,6 +512,17 @@ int rst_launch_lm_attn(const LmAttnParams& p, hipStream_t stream) {
     }
     RST_REQUIRE(p.splits == 1 || (p.ws && p.counters), "lm_attn: splits > 1 need the workspace and the (zeroed) counters");
     const dim3 grid(p.splits, p.H, p.B * T);
+    const bool dense = (long)p.splits * p.H * p.B * T > 3L * rst_cu_count();
+    if (dense && (p.D == 64 || p.D == 128)) {
+        if (p.kv_bf16) {
+            if (p.D == 64) hipLaunchKernelGGL((attn_decode_dense_kernel<64, true>), grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((attn_decode_dense_kernel<128, true>), grid, dim3(256), 0, stream, p);
+            return rst_check_launch("lm_attn_kv16");
+        }
+        if (p.D == 64) hipLaunchKernelGGL(attn_decode_dense_kernel<64>, grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(attn_decode_dense_kernel<128>, grid, dim3(256), 0, stream, p);
+        return rst_check_launch("lm_attn");
+    }
     if (p.kv_bf16) {
         switch (p.D) {
             case 64: hipLaunchKernelGGL((attn_decode_kernel<64, true>), grid, dim3(256), 0, stream, p); break;

@@ -172,10 +172,17 @@ def test_ring_attention_bf16_kv(H, D, cap, context, steps):
     _ring_attention_case(H, D, cap, context, steps, True, torch.bfloat16)
 
 
-def _ring_attention_case(H, D, cap, context, steps, rope, kv_dtype):
+@pytest.mark.parametrize("H,D,cap,context,steps,kv_dtype", [(32, 128, 300, 300, 30, torch.bfloat16), (32, 64, 70, 70, 90, torch.float32),
+                                                            (32, 128, 70, 60, 80, torch.bfloat16)])
+def test_ring_attention_many_streams(H, D, cap, context, steps, kv_dtype):
+    """26 streams x 32 heads = 832 workgroups: more than three per CU, i.e. the launch takes `attn_decode_dense_kernel` (one slot per
+    lane group in flight, four workgroups per CU) -- same slot order per lane group, so the same results as the two-slot form."""
+    _ring_attention_case(H, D, cap, context, steps, True, kv_dtype, B=26)
+
+
+def _ring_attention_case(H, D, cap, context, steps, rope, kv_dtype, B=2):
     """Step-by-step against the oracle's RingKV (slot->position map of RingKVCache.complete incl. SURVEY Q1)."""
     g = torch.Generator().manual_seed(H * D)
-    B = 2
     ring = L.RingKV(B, H, D, cap, dtype=kv_dtype)
     kc = torch.zeros(B, H, cap, D, device=DEV, dtype=kv_dtype)
     vc = torch.zeros(B, H, cap, D, device=DEV, dtype=kv_dtype)
