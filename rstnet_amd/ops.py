@@ -447,7 +447,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, pos0: int = 
     if ring and pos_dev is not None and (T <= 8 or G != H) and D in (64, 128):
         # streaming step with a handful of new queries: split every query over the occupied ring slots instead of walking
         # the ring tile by tile with one wave per head
-        splits = max(1, min(4, cap // 64))
+        # (at most ~1024 workgroups: four of them fit a CU -- attn_decode_dense_kernel -- and a fifth would wait for a second round)
+        splits = max(1, min(4, cap // 64, 1024 // max(1, B * T * H)))
         sc = _scratch(_attn_scratch, q.device, (B * T, H, splits, D),
                       lambda: (torch.empty(B * T, H, splits, D + 2, device=q.device, dtype=torch.float32),
                                torch.zeros(B * T, H, device=q.device, dtype=torch.int32)))
