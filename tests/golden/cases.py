@@ -85,6 +85,45 @@ def transformer_input(batch: int = 1, frames: int = 300):
     return torch.randn(batch, 512, frames, generator=g)
 
 
+# ---- the codec's streaming transformer at other head dims (tests/golden/transformer_dims.npz) -----------------------------------
+# name: (d_model E, heads H, feed-forward F, layers L, ring = context, streams B, positions per step)
+TRANSFORMER_DIMS = {
+    "d16": (64, 4, 128, 2, 12, 2, (2, 1, 2, 2, 1) * 5),            # head dim 16 (steps of <= 4 rows: the launch-per-op attention has no 16-dim form)
+    "d32": (128, 4, 256, 2, 20, 1, (3, 4, 1, 2) * 5),              # 32
+    "d128": (256, 2, 512, 2, 24, 2, (2,) * 20),                    # 128
+    "d256": (512, 2, 512, 1, 12, 1, (4, 1) * 8),                   # 256 (<= 4 rows per step as well)
+}
+TRANSFORMER_DIMS_LAYER_SCALE = 0.3
+
+
+def transformer_dims_state(name: str, prefix: str = "tr"):
+    """Seeded weights of a ProjectedTransformer whose input / output width equals d_model (no projections), keyed as the module's
+    state_dict is (`transformer.layers.N...`) under `prefix`."""
+    E, H, F, L, _, _, _ = TRANSFORMER_DIMS[name]
+    g = torch.Generator().manual_seed(1000 + E + H)
+    sd = {}
+    for l in range(L):
+        p = f"{prefix}.transformer.layers.{l}"
+        sd[f"{p}.norm1.weight"] = 1 + 0.1 * torch.randn(E, generator=g)
+        sd[f"{p}.norm1.bias"] = 0.1 * torch.randn(E, generator=g)
+        sd[f"{p}.norm2.weight"] = 1 + 0.1 * torch.randn(E, generator=g)
+        sd[f"{p}.norm2.bias"] = 0.1 * torch.randn(E, generator=g)
+        sd[f"{p}.self_attn.in_proj_weight"] = torch.randn(3 * E, E, generator=g) / E ** 0.5
+        sd[f"{p}.self_attn.out_proj.weight"] = torch.randn(E, E, generator=g) / E ** 0.5
+        sd[f"{p}.linear1.weight"] = torch.randn(F, E, generator=g) / E ** 0.5
+        sd[f"{p}.linear2.weight"] = torch.randn(E, F, generator=g) / F ** 0.5
+        sd[f"{p}.layer_scale_1.scale"] = torch.full((E,), TRANSFORMER_DIMS_LAYER_SCALE)
+        sd[f"{p}.layer_scale_2.scale"] = torch.full((E,), TRANSFORMER_DIMS_LAYER_SCALE)
+    return sd
+
+
+def transformer_dims_input(name: str):
+    """[B, E, sum(positions)] in conv layout; the steps cut it along the last axis."""
+    E, _, _, _, _, B, chunks = TRANSFORMER_DIMS[name]
+    g = torch.Generator().manual_seed(2000 + E)
+    return torch.randn(B, E, sum(chunks), generator=g)
+
+
 # ---- LM (tiny config, CPU-feasible for the imported reference) ------------------------------------------------------
 LM_SEED = 3
 LM_STEPS = 14       # > context (10) so the temporal ring wraps (SURVEY Q1), and > max_delay

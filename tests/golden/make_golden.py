@@ -88,6 +88,33 @@ def gen_transformer():
 
 
 @torch.no_grad()
+def gen_transformer_dims():
+    """The reference's ProjectedTransformer (modules/transformer.py:595-750) in STREAMING mode at head dims 16 / 32 / 128 / 256, several
+    positions per step, past the ring wrap: what the oracle's TransformerStream and the persistent HIP launch are held to at shapes
+    other than Mimi's 64-dim heads."""
+    from moshi.modules import transformer
+    out = {}
+    for name, (E, H, F, L, ctx, B, chunks) in cases.TRANSFORMER_DIMS.items():
+        m = transformer.ProjectedTransformer(input_dimension=E, output_dimensions=(E,), d_model=E, num_heads=H, num_layers=L,
+                                             dim_feedforward=F, causal=True, context=ctx, conv_layout=True, max_period=10000,
+                                             gating="none", norm="layer_norm", positional_embedding="rope",
+                                             layer_scale=cases.TRANSFORMER_DIMS_LAYER_SCALE, device="cpu").eval()
+        sd = {k[len("tr."):]: v for k, v in cases.transformer_dims_state(name).items()}
+        missing, unexpected = m.load_state_dict(sd, strict=True)
+        assert not missing and not unexpected
+        x = cases.transformer_dims_input(name)
+        ys, i = [], 0
+        with m.streaming(B):
+            for T in chunks:
+                ys.append(m(x[:, :, i:i + T])[0])
+                i += T
+        assert i == x.shape[-1] > ctx
+        out[name] = torch.cat(ys, -1).numpy()
+        print("transformer_dims", name, out[name].shape, float(np.abs(out[name]).max()))
+    np.savez_compressed(os.path.join(HERE, "transformer_dims.npz"), **out)
+
+
+@torch.no_grad()
 def gen_layers():
     """F2: the reference's own conv / conv-transpose / resnet-block test shapes
     (MLLM_v2/moshi/modules/conv_test.py:11-48, seanet_test.py) with seed-41 Xavier weights."""
@@ -446,6 +473,6 @@ def gen_gpt_generate():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["layers", "rvq", "transformer", "mimi_e2e", "lm_tiny", "gpt_tiny", "sampling", "reverse_delay",
-                             "gpt_generate", "tokenizer", "lm_tiny_sampling", "mimi_model", "mimi_stream_long"]
+                             "gpt_generate", "tokenizer", "lm_tiny_sampling", "mimi_model", "mimi_stream_long", "transformer_dims"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -77,6 +77,26 @@ def test_transformer_matches_reference():
     assert rel_err(y, ref) < 1e-5
 
 
+@pytest.mark.parametrize("name", list(cases.TRANSFORMER_DIMS))
+def test_transformer_stream_matches_reference_at_other_head_dims(name):
+    """tests/golden/transformer_dims.npz: the REFERENCE's ProjectedTransformer streamed in steps of 1-4 positions past the ring wrap at
+    head dims 16 / 32 / 128 / 256 (modules/transformer.py:376-423,595-750) vs the oracle's TransformerStream."""
+    E, H, F, L, ctx, B, chunks = cases.TRANSFORMER_DIMS[name]
+    ref = torch.from_numpy(np.load(os.path.join(G, "transformer_dims.npz"))[name])
+    cfg = O.MimiConfig(latent_dim=E, num_heads=H, num_layers=L, context=ctx, dim_feedforward=F)
+    ts = O.TransformerStream(cases.transformer_dims_state(name), "tr", cfg, B)
+    x = cases.transformer_dims_input(name)
+    ys, i = [], 0
+    with torch.no_grad():
+        for T in chunks:
+            ys.append(ts.step(x[:, :, i:i + T]))
+            i += T
+    y = torch.cat(ys, -1)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert float((y - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+
 @pytest.mark.parametrize("name", list(cases.MIMI_E2E))
 def test_mimi_encode_decode_matches_reference(mimi_sd, name):
     cfg = O.MimiConfig()
