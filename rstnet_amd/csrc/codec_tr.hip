@@ -454,7 +454,8 @@ int rst_codec_tr_grid(int B, int T, int E, int H, int F, int L, int cap) {
     if (gcap > 0 && G > gcap) G = gcap;
     if (B * H > G) return 0;
     static signed char fits_dev[RST_MAX_DEVICES];        // per device: 0 = not asked yet, 1 = fits, -1 = does not
-    signed char& fits = fits_dev[rst_current_device()];
+    signed char uncached = 0;
+    signed char& fits = rst_device_cell(fits_dev, 1, uncached);
     if (fits == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(codec_tr_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         int nb = 0;

@@ -434,7 +434,8 @@ int rst_depth_frame_grid(const DepthFrameParams& p) {
     // residency: all G workgroups must run at once, one per CU -- ask the runtime whether a CU takes a workgroup of this footprint
     static signed char fits[RST_MAX_DEVICES][2][2];      // [device][B - 1][lds > 64 KB]: 0 = not asked yet, 1 = fits, -1 = does not; the
                                                          // answer does not change within a footprint class
-    signed char& f = fits[rst_current_device()][p.B - 1][lds > 64 * 1024];
+    signed char uncached = 0;
+    signed char& f = rst_device_cell(&fits[0][p.B - 1][lds > 64 * 1024], 4, uncached);
     if (f == 0) {
         const void* kern = p.B == 1 ? reinterpret_cast<const void*>(depth_frame_kernel<1, false>) : reinterpret_cast<const void*>(depth_frame_kernel<2, false>);
         (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

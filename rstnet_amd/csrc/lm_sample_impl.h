@@ -143,9 +143,12 @@ __device__ __forceinline__ int sample_row(const float* lg, const float* noise_ro
         exact = clo == k;
 #pragma unroll 1
         for (int round = 0; !exact && hi - lo > 1ull; ++round) {
+            // value-space probes (interpolation on the counts / midpoint, alternating) for the first eight rounds only: a row with a
+            // huge dynamic range (ids masked to -3.4e38, k close to the live keys) lets them creep; from then on the middle KEY,
+            // which halves a bracket of at most 2^32 keys per round -- the loop is bounded by 8 + 32 block-wide counts
             float v = (round & 1) ? 0.5f * (vlo + vhi) : vlo + (vhi - vlo) * (((float)(clo - k) + 0.5f) / (float)(clo - chi));
             unsigned t = to_key(v);
-            if (!(t > lo && (unsigned long long)t < hi)) {       // no progress in value space (or a non-finite end): the middle key
+            if (round >= 8 || !(t > lo && (unsigned long long)t < hi)) {   // (or no progress in value space / a non-finite end)
                 t = lo + (unsigned)((hi - lo) >> 1);
                 v = from_key(t);
             }

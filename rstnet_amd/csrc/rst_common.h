@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define RST_OK 0
 #define RST_ERR_INVALID_ARG (-1)
@@ -37,31 +38,46 @@ static inline constexpr int rst_knob(const char*, int dflt) { return dflt; }
 // A process may drive several GPUs (one rank per GPU is the deployment, but the library does not assume it): kernel attributes
 // (hipFuncSetAttribute applies to the current device's copy of a kernel), CU counts and residency answers are cached PER DEVICE.
 #define RST_MAX_DEVICES 64
-static inline int rst_current_device() {
+// cache slot of the current device, or -1 for an ordinal the tables do not cover: such a device is never cached (its attributes are
+// set and its properties queried on every call) instead of sharing device 0's answers
+static inline int rst_device_slot() {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    return dev >= 0 && dev < RST_MAX_DEVICES ? dev : 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev >= 0 && dev < RST_MAX_DEVICES ? dev : -1;
 }
-// `static RstOncePerDevice once; if (once.first()) { ...opt-in... }`: true the first time it is asked on each device
+// `static RstOncePerDevice once; if (once.first()) { ...opt-in... }`: true the first time it is asked on each device.  Host threads
+// driving different GPUs may get here together: the mask is one atomic fetch_or (two threads on the SAME device can at worst both
+// see "first" -- the opt-ins are idempotent -- never neither).
 struct RstOncePerDevice {
-    unsigned long long mask = 0;
+    std::atomic<unsigned long long> mask{0};
     bool first() {
-        const unsigned long long bit = 1ull << rst_current_device();
-        if (mask & bit) return false;
-        mask |= bit;
-        return true;
+        const int slot = rst_device_slot();
+        if (slot < 0) return true;
+        const unsigned long long bit = 1ull << slot;
+        if (mask.load(std::memory_order_acquire) & bit) return false;
+        return !(mask.fetch_or(bit, std::memory_order_acq_rel) & bit);
     }
 };
 // CUs of the current device
 static inline int rst_cu_count() {
-    static int n[RST_MAX_DEVICES] = {0};
-    const int dev = rst_current_device();
-    if (n[dev] == 0) {
+    static std::atomic<int> n[RST_MAX_DEVICES];
+    const int slot = rst_device_slot();
+    int v = slot >= 0 ? n[slot].load(std::memory_order_relaxed) : 0;
+    if (v == 0) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
-        if (n[dev] <= 0) n[dev] = 256;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
+        if (v <= 0) v = 256;
+        if (slot >= 0) n[slot].store(v, std::memory_order_relaxed);
     }
-    return n[dev];
+    return v;
+}
+// per-device cache cell of a residency answer (0 = not asked yet): `scratch` serves devices the tables do not cover (asked every time)
+static inline signed char& rst_device_cell(signed char* table, int stride, signed char& scratch) {
+    const int slot = rst_device_slot();
+    if (slot < 0) { scratch = 0; return scratch; }
+    return table[slot * stride];
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

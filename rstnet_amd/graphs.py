@@ -46,7 +46,7 @@ class Graphed:
 
     def __call__(self, *args, **kwargs):
         if kwargs:
-            raise RuntimeError("Named arguments not supported for now.")
+            raise RuntimeError(f"a graphed function takes positional arguments only (got keywords {sorted(kwargs)})")
         if self.disable or in_cuda_graph():
             return self.fn(*args)
         dev = next((a.device for a in args if isinstance(a, torch.Tensor) and a.is_cuda), None)
@@ -56,21 +56,32 @@ class Graphed:
                     return self._call(*args)
             return self._call(*args)
 
-    def _match_values_copy_tensors(self, args) -> None:
+    @staticmethod
+    def _slot(a) -> tuple:
+        """What a capture bakes in about one argument: a tensor's shape, or a plain value itself."""
+        return ("tensor", tuple(a.shape)) if isinstance(a, torch.Tensor) else ("value", a)
+
+    def _refresh_inputs(self, args) -> None:
+        """Feed a replay: every argument is compared with what the capture baked in BEFORE anything is copied (a refused call
+        leaves the static inputs untouched), then the tensors are copied into the captured buffers.  ValueError on a different
+        argument count, a tensor / plain-value swap, another shape or another plain value (the exception type of
+        utils/compile.py:231-256)."""
+        problems = []
         if len(args) != len(self.static_in):
-            raise ValueError(f"Expected {len(self.static_in)} arguments, but got {len(args)} for a graphed function.")
-        for idx, (source, target) in enumerate(zip(args, self.static_in)):
-            if isinstance(target, torch.Tensor):
-                if not isinstance(source, torch.Tensor):
-                    raise ValueError(f"Argument #{idx} was a tensor, and is no longer (now {source}).")
-                if source.shape != target.shape:
-                    raise ValueError(f"Argument #{idx} had shape {tuple(target.shape)}, but got shape {tuple(source.shape)}")
-                target.copy_(source)
-            else:
-                if isinstance(source, torch.Tensor):
-                    raise ValueError(f"Argument #{idx} was not a tensor {target}, but is now one.")
-                if source is not target and source != target:
-                    raise ValueError(f"Argument #{idx} changed value from {target} to {source}.")
+            problems.append(f"captured with {len(self.static_in)} positional arguments, called with {len(args)}")
+        for i, (new, held) in enumerate(zip(args, self.static_in)):
+            (kind_n, what_n), (kind_h, what_h) = self._slot(new), self._slot(held)
+            if kind_n != kind_h:
+                problems.append(f"argument {i}: captured as a {kind_h}, called with a {kind_n}")
+            elif kind_h == "tensor" and what_n != what_h:
+                problems.append(f"argument {i}: captured with shape {what_h}, called with shape {what_n}")
+            elif kind_h == "value" and not (new is held or new == held):
+                problems.append(f"argument {i}: the capture baked in {held!r}, called with {new!r}")
+        if problems:
+            raise ValueError("graphed call does not match its capture: " + "; ".join(problems))
+        for new, held in zip(args, self.static_in):
+            if isinstance(held, torch.Tensor):
+                held.copy_(new)
 
     def _call(self, *args):
         if self.graph is None:
@@ -85,7 +96,7 @@ class Graphed:
             # the capture itself does not execute: the replay below produces this call's result
             self.graph.replay()
             return self.static_out
-        self._match_values_copy_tensors(args)
+        self._refresh_inputs(args)
         self.graph.replay()
         return self.static_out
 

@@ -1102,8 +1102,14 @@ def persistent_repairs(device, synchronize: bool = True) -> int:
 def persistent_rearm(device) -> None:
     """Gives `device` its persistent frame launches back after `persistent_poll` retired them (e.g. the process that shared the GPU
     has gone): clears the repair counters, bumps the epoch so that sessions re-capture their graphs.  The in-stream repair launch
-    keeps every frame correct either way; this is about speed only."""
+    keeps every frame correct either way; this is about speed only.
+
+    Call it with NO frame in flight on `device`: the status words are shared with captured graphs and per-session streams, and a
+    repair launch's atomics racing with the reset would lose or mis-count a repair.  The whole device is therefore drained first
+    (every stream, not only the current one), and the counters are zeroed on a quiet device."""
     device = torch.device(device)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
     for r in _persist_status.get(device, []):
         t = r()
         if t is not None:

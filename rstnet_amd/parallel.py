@@ -66,12 +66,20 @@ def pin_rank_threads(local_rank: int, local_world: int) -> Dict[str, object]:
         return info
     try:
         allowed = sorted(os.sched_getaffinity(0))
-        nears = [tuple(_gpu_numa_cpus(r) or ()) if torch.cuda.is_available() else () for r in range(local_world)]
-        near = nears[local_rank]
-        if near:        # the ranks whose GPUs share this NUMA node split its CPUs in rank order
-            mine = plan_affinity(allowed, sum(1 for r in range(local_rank) if nears[r] == near), sum(1 for n in nears if n == near), near)
+        visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if 0 < visible < local_world:
+            # every rank sees only its own GPU (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank): the other ranks' NUMA nodes
+            # cannot be asked, so the rank takes slot local_rank of local_world of ITS node's CPUs -- NUMA-near, and disjoint from
+            # every other rank whatever node that one sits on (same slot count everywhere)
+            near = tuple(_gpu_numa_cpus(torch.cuda.current_device()) or ())
+            mine = plan_affinity(allowed, local_rank, local_world, near) if near else plan_affinity(allowed, local_rank, local_world)
         else:
-            mine = plan_affinity(allowed, local_rank, local_world)
+            nears = [tuple(_gpu_numa_cpus(r) or ()) if visible else () for r in range(local_world)]
+            near = nears[local_rank]
+            if near:        # the ranks whose GPUs share this NUMA node split its CPUs in rank order
+                mine = plan_affinity(allowed, sum(1 for r in range(local_rank) if nears[r] == near), sum(1 for n in nears if n == near), near)
+            else:
+                mine = plan_affinity(allowed, local_rank, local_world)
         if mine:
             os.sched_setaffinity(0, mine)
             torch.set_num_threads(max(1, min(len(mine), 16)))

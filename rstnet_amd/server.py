@@ -151,9 +151,14 @@ class ServerState:
 
     async def handle_chat(self, request):
         from aiohttp import WSMsgType, web
+        # the transport is settled BEFORE the upgrade: an unknown ?pcm= value, or pcm=opus without `sphn`, is answered with 400 and the
+        # reason (after ws.prepare() the client would only see an abrupt 1011 close)
+        try:
+            framer = make_framer(self.frame_size, request.query.get("pcm", "f32"), int(getattr(self.mimi, "sample_rate", 24000)))
+        except (ValueError, RuntimeError) as e:
+            raise web.HTTPBadRequest(text=str(e))
         ws = web.WebSocketResponse()
         await ws.prepare(request)
-        framer = make_framer(self.frame_size, request.query.get("pcm", "f32"), int(getattr(self.mimi, "sample_rate", 24000)))
         close = False
         outbox: asyncio.Queue = asyncio.Queue()
 

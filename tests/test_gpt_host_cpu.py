@@ -192,9 +192,10 @@ def test_graphed_argument_contract_matches_cudagraphed():
     # the value / type checks of a captured call (no capture needed to exercise them)
     g2 = graphs.Graphed(lambda a, n: a)
     g2.static_in = [torch.zeros(2, 3), 7]
-    g2._match_values_copy_tensors((torch.ones(2, 3), 7))
+    g2._refresh_inputs((torch.ones(2, 3), 7))
     assert float(g2.static_in[0].sum()) == 6.0
     for bad in ((torch.ones(2, 4), 7), (torch.ones(2, 3), 8), (5, 7), (torch.ones(2, 3), torch.ones(1)), (torch.ones(2, 3),)):
         with pytest.raises(ValueError):
-            g2._match_values_copy_tensors(bad)
+            g2._refresh_inputs(bad)
+        assert float(g2.static_in[0].sum()) == 6.0        # a refused call copies nothing
     assert graphs.CUDAGraphed is graphs.Graphed

@@ -66,6 +66,37 @@ def test_plan_affinity_slices_are_disjoint_and_numa_local():
     assert parallel.plan_affinity(range(3), 5, 8) == [2] and parallel.plan_affinity([], 0, 4) == []
 
 
+def test_pin_rank_threads_when_each_rank_sees_only_its_own_gpu(monkeypatch):
+    """HIP_VISIBLE_DEVICES per rank: device 0 is every rank's own GPU and the others cannot be asked.  Eight ranks, two NUMA
+    nodes of 64 CPUs, GPUs 0-3 on node 0 and 4-7 on node 1: every rank stays on its GPU's node and no two slices overlap."""
+    applied = {}
+    monkeypatch.setattr(parallel.os, "sched_getaffinity", lambda pid: set(range(128)), raising=False)
+    monkeypatch.setattr(parallel.os, "sched_setaffinity", lambda pid, cpus: applied.__setitem__("cpus", list(cpus)), raising=False)
+    monkeypatch.setattr(torch, "set_num_threads", lambda n: None)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    slices = []
+    for r in range(8):
+        node = r // 4
+        asked = []
+        monkeypatch.setattr(parallel, "_gpu_numa_cpus", lambda i, node=node, asked=asked: asked.append(i) or list(range(64 * node, 64 * node + 64)))
+        info = parallel.pin_rank_threads(r, 8)
+        assert asked == [0] and info["numa"] is True              # only the visible device is queried
+        assert all(c // 64 == node for c in applied["cpus"]) and len(applied["cpus"]) == 8
+        slices.append(applied["cpus"])
+    flat = sum(slices, [])
+    assert len(flat) == len(set(flat))
+    # all GPUs visible to every rank (the other launch style): the four ranks of a node split its 64 CPUs
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(parallel, "_gpu_numa_cpus", lambda i: list(range(64 * (i // 4), 64 * (i // 4) + 64)))
+    slices = []
+    for r in range(8):
+        parallel.pin_rank_threads(r, 8)
+        slices.append(applied["cpus"])
+    assert all(len(c) == 16 and c[0] // 64 == r // 4 for r, c in enumerate(slices)) and sorted(sum(slices, [])) == list(range(128))
+
+
 def _worker_big(rank, world, port, nbytes, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

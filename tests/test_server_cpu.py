@@ -206,6 +206,72 @@ def test_opus_framer_seam_with_a_stand_in_sphn(monkeypatch):
     assert f.encode(x[:4]) == x[:4].tobytes()
 
 
+def test_bad_transport_is_refused_before_the_upgrade_and_opus_pages_are_paced(monkeypatch):
+    """an unknown `?pcm=` value, or `pcm=opus` without `sphn`, is a 400 with the reason -- not an upgraded socket that dies
+    with 1011.  With a (stand-in) `sphn` whose writer hands out whole pages only, a frame whose page is not complete yields NO kind-1
+    message (server.py:146-150 skips empty payloads); its text message still arrives, and the audio follows with the page."""
+    import sys
+    import types
+    from aiohttp import WSServerHandshakeError
+    from aiohttp.test_utils import TestClient, TestServer
+
+    class Reader:
+        def __init__(self, sr):
+            self.buf = bytearray()
+
+        def append_bytes(self, b):
+            self.buf += b
+
+        def read_pcm(self):
+            n = len(self.buf) // 4
+            out = np.frombuffer(bytes(self.buf[:4 * n]), dtype="<f4").copy()
+            del self.buf[:4 * n]
+            return out
+
+    class PagedWriter:                       # a page = two frames of samples
+        def __init__(self, sr):
+            self.out = bytearray()
+
+        def append_pcm(self, pcm):
+            self.out += np.asarray(pcm, dtype="<f4").tobytes()
+
+        def read_bytes(self):
+            if len(self.out) < 2 * 4 * FRAME:
+                return b""
+            b, self.out = bytes(self.out[:2 * 4 * FRAME]), self.out[2 * 4 * FRAME:]
+            return b
+
+    async def scenario():
+        st = _state()
+        client = TestClient(TestServer(S.make_app(st)))
+        await client.start_server()
+        try:
+            monkeypatch.setitem(sys.modules, "sphn", None)
+            for q, why in (("pcm=mp3", "unknown pcm format"), ("pcm=opus", "sphn")):
+                with pytest.raises(WSServerHandshakeError) as e:
+                    await client.ws_connect("/api/chat?" + q)
+                assert e.value.status == 400
+                resp = await client.get("/api/chat?" + q)
+                assert resp.status == 400 and why in await resp.text()
+            assert st.mimi.resets == 0                                   # no session was started for them
+            fake = types.ModuleType("sphn")
+            fake.OpusStreamReader, fake.OpusStreamWriter = Reader, PagedWriter
+            monkeypatch.setitem(sys.modules, "sphn", fake)
+            ws = await client.ws_connect("/api/chat?pcm=opus")
+            assert (await ws.receive_bytes()) == b"\x00"
+            await ws.send_bytes(b"\x01" + np.zeros(3 * FRAME, dtype="<f4").tobytes())
+            got = []
+            while not any(m[0] == 1 for m in got):
+                got.append(await asyncio.wait_for(ws.receive_bytes(), timeout=2.0))
+            # frame 1: LMGen returns None; frame 2: half a page -> text only; frame 3 completes the page -> one kind-1 message of 2 frames
+            assert [m[0] for m in got] == [2, 1] and len(got[1]) == 1 + 2 * 4 * FRAME
+            await ws.close()
+        finally:
+            await client.close()
+
+    _run(scenario())
+
+
 def test_opus_framer_with_the_real_sphn():
     sphn = pytest.importorskip("sphn")           # not in this image: skipped here, runs where a deployment installs it
     from rstnet_amd import server as S
