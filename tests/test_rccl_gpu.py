@@ -1,0 +1,118 @@
+"""RCCL on the hardware the tests do get: a world-size-1 `nccl` process group on cuda:0 running the SAME plumbing
+`bench.py --gpus N` runs -- `parallel.broadcast_state_dict` (the Mimi weights, and a synthetic blob past 2^31 bytes), a barrier and
+the all-gather of `_timed_loop` -- plus `bench.py --gpus 1 --force-dist` against the plain single-GPU line.  A one-rank communicator
+moves no bytes over xGMI; what it proves is that the RCCL library initialises on this device, that the calls of the multi-GPU path
+are accepted with the tensors it passes (uint8 views of one device blob, offsets past int32), and that the path costs nothing in
+the timed region.  No scaling curve is claimed from it (README)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture()
+def nccl_world1():
+    import torch.distributed as dist
+    assert not dist.is_initialized()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    try:
+        yield dev
+    finally:
+        dist.destroy_process_group()
+
+
+def _check_views(got, blob_owner_key=None):
+    """Every returned tensor is a 16-byte aligned view of ONE device allocation."""
+    bases = {t.untyped_storage().data_ptr() for t in got.values()}
+    assert len(bases) == 1, "the broadcast result must be views of one flat blob"
+    for k, t in got.items():
+        assert t.is_cuda and t.data_ptr() % 16 == 0, k
+
+
+def test_rccl_broadcast_mimi_blob_world1(nccl_world1):
+    import torch.distributed as dist
+    from rstnet_amd import parallel, synth
+    dev = nccl_world1
+    sd = synth.mimi_state_dict(0)
+    stats = {}
+    got = parallel.broadcast_state_dict(sd, dev, src=0, stats=stats)
+    assert list(got) == list(sd)
+    _check_views(got)
+    for k, v in sd.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and torch.equal(got[k].cpu(), v), k
+    assert stats["bytes"] >= sum(v.numel() * v.element_size() for v in sd.values()) and stats["seconds"] > 0
+    # the rest of what bench.py's distributed path calls: barrier + all-gather of the rank times (_timed_loop)
+    dist.barrier()
+    mine = torch.tensor([1.25], device=dev, dtype=torch.float64)
+    every = [torch.zeros_like(mine)]
+    dist.all_gather(every, mine)
+    assert float(every[0].item()) == 1.25
+    # and the model built from the broadcast views computes what the model built from the source does (same weights, device views)
+    from rstnet_amd.codec.mimi import MimiCodec
+    audio = synth.synth_audio(1, 24000, seed=5).to(dev)
+    a = MimiCodec.from_state_dict(dict(got)).to(dev).encode(audio)
+    b = MimiCodec.from_state_dict(sd).to(dev).encode(audio)
+    assert torch.equal(a, b)
+
+
+def test_rccl_broadcast_blob_past_2g_world1(nccl_world1):
+    from rstnet_amd import parallel
+    dev = nccl_world1
+    n_body = (1 << 29) + 17                     # int32 entries: 2^31 + 68 bytes -> the tail's offset does not fit int32
+    sd = {"head": torch.arange(5, device=dev, dtype=torch.float32),
+          "body": torch.arange(n_body, device=dev, dtype=torch.int32),
+          "tail.bf16": torch.arange(33, device=dev, dtype=torch.float32).bfloat16(),
+          "last": torch.tensor([7, 8, 9], device=dev, dtype=torch.int64)}
+    stats = {}
+    got = parallel.broadcast_state_dict(sd, dev, src=0, stats=stats)
+    _check_views(got)
+    assert stats["bytes"] > (1 << 31)
+    base = next(iter(got.values())).untyped_storage().data_ptr()
+    assert got["tail.bf16"].data_ptr() - base > (1 << 31)
+    for k, v in sd.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and torch.equal(got[k], v), k
+    del got, sd
+    torch.cuda.empty_cache()
+
+
+def _bench_line(extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "3", "--batch", "16", "--no-sub",
+           "--no-check", "--no-cpu-baseline", "--timing-samples", "1"] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_force_dist_takes_the_multi_gpu_path_and_agrees_with_the_plain_line():
+    """`bench.py --gpus 1 --force-dist`: process group, one-blob weight broadcast, rank pinning, barriers and the all-gather of the
+    per-rank times -- the code path of `--gpus 8` -- on one GPU; its step time must agree with the plain single-GPU line (the
+    distributed plumbing sits outside the timed steps).  Two short runs on a shared box: 5 % (the driver-sized runs agree within 2 %,
+    profiles/r05_force_dist.txt)."""
+    plain = _bench_line([])
+    forced = _bench_line(["--force-dist"])
+    assert plain.get("multi_gpu") is None
+    mg = forced["multi_gpu"]
+    assert mg["forced_at_world_1"] is True and len(mg["per_rank_ms_per_step"]) == 1
+    assert mg["weight_broadcast"]["bytes"] > 2e8 and mg["weight_broadcast"]["seconds"] > 0
+    assert forced["n_gpus"] == 1 and forced["config"]["parallelism"].startswith("replica x1")
+    ratio = forced["ms_per_step"] / plain["ms_per_step"]
+    print(f"force-dist {forced['ms_per_step']} ms vs plain {plain['ms_per_step']} ms per step: ratio {ratio:.4f}")
+    assert 0.95 < ratio < 1.05, (forced["ms_per_step"], plain["ms_per_step"])

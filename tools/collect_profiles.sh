@@ -3,7 +3,7 @@
 #   bench JSON lines, rocprofv3 kernel traces (--kernel-trace --stats) and the two PMC passes (FETCH_SIZE / WRITE_SIZE) per
 #   workload.  The raw rocprof outputs are reduced on the box (tools/rocpd_summary.py, tools/pmc_traffic.py) to the small
 #   files that are then copied into profiles/ and committed; only those travel back (gpurun_out/ is capped at 64 MiB).
-TAG=${1:-r04}
+TAG=${1:-r05}
 WHAT=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG
@@ -23,6 +23,16 @@ prof() { local n=$1; shift
   [ -n "$fc" ] && [ -n "$wc" ] && python tools/pmc_traffic.py "$fc" "$wc" "$O/${n}_pmc_traffic.json" | head -6
   rm -f "$O/${n}_trace.out" "$O/${n}_fetch.out" "$O/${n}_write.out"
 }
+# trace only (no counter passes): prof_trace <name> <cmd...>
+prof_trace() { local n=$1; shift
+  run "${n}_trace" rocprofv3 --kernel-trace --stats -d "$RAW/${n}_trace" -o t -- "$@"
+  local db; db=$(find "$RAW/${n}_trace" -name "*.db" | head -1)
+  [ -n "$db" ] && python tools/rocpd_summary.py "$db" "$O/${n}" | tail -1
+  rm -f "$O/${n}_trace.out"
+}
+# the tools build of the library (measurement knobs, op-boundary stamps) does not travel with the snapshot (.gpurunignore): the sections
+# that need it build it on the box
+need_ablation() { [ -f rstnet_amd/librstnet_hip_ablation.so ] || make -C rstnet_amd/csrc -j32 ablation > "$O/ablation_build.log" 2>&1 || tail -5 "$O/ablation_build.log"; }
 # the bench lines quote the trace / counter summaries of the SAME code: each workload is profiled first, its summaries are copied
 # into this box's profiles/ under the tag, and only then the bench line is taken
 publish() { for f in "$O"/$1_*; do case "$f" in *.out|*.err|*_bench.json) ;; *) cp "$f" "profiles/${TAG}_$(basename "$f")";; esac; done; }
@@ -30,25 +40,37 @@ if [ "$WHAT" = all ] || [ "$WHAT" = lm ]; then
   prof lm python bench.py --workload lm --steps 6 --warmup 2 --no-cpu-baseline --timing-samples 2
   db=$(find "$RAW/lm_trace" -name "*.db" | head -1); [ -n "$db" ] && python tools/frame_timeline.py "$db" "$O/lm_timeline.csv" lm_ring_begin_kernel 2
   publish lm
+  # batch 32 (configs[2] at the per-GPU stream count): its own trace + counter summaries -> profiles/TAG_lm32_*
+  prof lm32 python bench.py --workload lm --lm-batch 32 --steps 6 --warmup 2 --no-cpu-baseline --timing-samples 2
+  publish lm32
   run lm_bench python bench.py --workload lm --steps 60 --warmup 5
+  run lm32_bench python bench.py --workload lm --lm-batch 32 --steps 60 --warmup 5 --no-cpu-baseline
   # (ring offset 3000, batch 32 and the batch-32 end-to-end frame ride on the default line as sub-objects since round 3)
   BENCH_DEPTH_CHAINS=1 python tools/bench_depth.py 2>&1 | grep -v amdgpu > "$O/depth_phase.txt"
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = gpt ]; then
   prof gpt python bench.py --workload gpt --steps 6 --warmup 2 --no-cpu-baseline
   publish gpt
+  prof gpt_fp8 python bench.py --workload gpt --fp8 --steps 6 --warmup 2 --no-cpu-baseline
+  publish gpt_fp8
   run gpt_bench python bench.py --workload gpt --steps 40 --warmup 5
   run gpt_fp8_bench python bench.py --workload gpt --fp8 --steps 40 --warmup 5 --no-cpu-baseline
   run gpt1_bench python bench.py --workload gpt --lm-batch 1 --steps 60 --warmup 5 --no-cpu-baseline
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = e2e ]; then
-  run e2e1_bench python bench.py --workload e2e --lm-batch 1 --steps 60 --warmup 6
   run e2e1_trace rocprofv3 --kernel-trace --stats -d "$RAW/e2e1_trace" -o t -- python bench.py --workload e2e --lm-batch 1 --steps 30 --warmup 4 --no-cpu-baseline --timing-samples 2
   db=$(find "$RAW/e2e1_trace" -name "*.db" | head -1); [ -n "$db" ] && python tools/rocpd_summary.py "$db" "$O/e2e1" | tail -1
   [ -n "$db" ] && python tools/frame_timeline.py "$db" "$O/e2e1_timeline.csv" lm_ring_begin_kernel 2
   rm -f "$O/e2e1_trace.out"
+  # 32 streams (configs[3] at its per-GPU size): kernel trace -> profiles/TAG_e2e32_kernel_stats.csv
+  prof_trace e2e32 python bench.py --workload e2e --lm-batch 32 --steps 20 --warmup 4 --no-cpu-baseline --timing-samples 2
+  publish e2e1
+  publish e2e32
+  run e2e1_bench python bench.py --workload e2e --lm-batch 1 --steps 60 --warmup 6
+  run e2e32_bench python bench.py --workload e2e --lm-batch 32 --steps 60 --warmup 6 --no-cpu-baseline
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = phases ]; then
+  need_ablation
   # op-boundary stamps of the two persistent kernels (tools build: librstnet_hip_ablation.so)
   (python tools/probes/codec_tr_phases.py 1 2; python tools/probes/codec_tr_phases.py 1 1; python tools/probes/codec_tr_phases.py 2 2) 2>&1 | grep -v amdgpu.ids > "$O/codec_tr_phases.txt"
   (python tools/probes/depth_frame_phases.py 1; python tools/probes/depth_frame_phases.py 2) 2>&1 | grep -v amdgpu.ids > "$O/depth_frame_phases.txt"
@@ -71,6 +93,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = codec ] || [ "$WHAT" = b3 ]; then
   NO_CUDA_GRAPH=1 run b3_stalls_raw rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$RAW/b3_stalls" -o m -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-sub --no-check --timing-samples 1
   python tools/pmc_stalls.py "$RAW/b3_stalls" > "$O/b3_stalls.txt"; head -4 "$O/b3_stalls.txt"
   rm -f "$O/b3_stalls_raw.out"
+  need_ablation
   if [ -f rstnet_amd/librstnet_hip_ablation.so ]; then
     : > "$O/b3_ablation.txt"
     for v in "RST_B3_DBG=0 full" "RST_B3_WGS=1 one_workgroup_per_cu_(128-wide_form)" "RST_B3_WIDE=0 128-wide_tiles_only" "RST_B3_DBG=5 lds_writes_of_unsplit_bits_(no_split_VALU)" "RST_B3_DBG=1 no_split_no_lds_writes" "RST_B3_DBG=2 no_global_loads" "RST_B3_DBG=3 matrix_instructions_only" "RST_B3_DBG=4 no_barriers" "RST_B3_BUF=0 plain_global_loads"; do
