@@ -66,7 +66,8 @@ int rst_gemm_win_f32(const float* x, const float* hist, const float* w, const fl
  * instruction silently; callers route those launches to rst_gemm_win_f32 themselves.  Rows whose window reaches into the zero
  * padding or past the utterance, and ragged last tiles, are masked inside the kernel; w (fp32) is not read.
  * The caller splits the weights once: w3 = rst_gemm_win_b3_weight_elems(N, K) uint16, filled by rst_gemm_win_b3_pack_weight (K % 16
- * == 0 suffices for the packing; layout [2*ceil(N/256)][K/16][3][128][16] -- 128-row tiles, row b3_row(g) of a tile in slot g, rows past
+ * == 0 suffices for the packing; layout [8*ceil(N/256)][K/16][3][64][8] -- matrix-instruction operand order: blocks of 32 rows, lane
+ * (n % 32) + 32 * (k % 16 / 8) of a (block, k-tile, plane) holds k % 8 .. + 7 of row n, so a wave-level load is one contiguous KB; rows past
  * N zero); activations are split inside the launch.
  * Domain of the fp32-accuracy claim: finite operands with |x|, |w| in {0} u [2^-110, 3.38e38].  Below 2^-110 the lo (then mid) plane
  * leaves bf16's normal range: the result stays within 2^-126 sum_k |w_k| (resp. |x_k|) absolute of the exact one -- flush-to-zero
@@ -373,9 +374,10 @@ int rst_gemm_skinny_fp8_f32(const uint8_t* xp, const float* xscale, const uint8_
  * LMModel.forward_text / forward_depformer (models/model.py:67-91, 372-380, 413-419): id -1 -> zero row; tables bf16
  * [rows][D], summed in table order in fp32.  Ids outside a table are clamped into it (other negative ids -> row 0, ids >=
  * table_rows[i] -> the last row; the reference's F.embedding raises -- use LMGen(check=True) for that behaviour; table_rows
- * may be NULL: no upper check).  `tables` / `tok_index` / `table_rows` are HOST arrays (n_tables <= 24). */
+ * may be NULL: no upper check).  `tables` / `tok_index` / `table_rows` are HOST arrays (n_tables <= 24).  `add_stride`: floats between
+ * the rows of `add` (>= D: a column block of a wider matrix, e.g. step k's slice of the stacked depformer_in product, is read in place). */
 int rst_embed_sum_bf16(const int64_t* tokens, const uint16_t* const* tables, const int* tok_index, const int* table_rows, int n_tables,
-                       const float* add, float* out, int B, int D, int tok_stride, rst_stream_t stream);
+                       const float* add, float* out, int B, int D, int tok_stride, int add_stride, rst_stream_t stream);
 
 /* RMSNorm rows (rms_norm_f32, modules/transformer.py:34-46): out_norm of LMModel.forward_text. */
 int rst_rmsnorm_f32(const float* x, const float* alpha, float* y, int64_t rows, int D, float eps, rst_stream_t stream);

@@ -69,7 +69,7 @@ SIGNATURES = {
     "rst_gemm_skinny_bf16_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p],
     "rst_gemm_skinny_x32_bf16_f32": [_p, _p, _f, _i, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "rst_skinny_bf16_split_plan": [_i, _i, _i],
-    "rst_embed_sum_bf16": [_p, C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), _i, _p, _p, _i, _i, _i, _p],
+    "rst_embed_sum_bf16": [_p, C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), _i, _p, _p, _i, _i, _i, _i, _p],
     "rst_rmsnorm_f32": [_p, _p, _p, _l, _i, _f, _p],
     "rst_lm_rope_append_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "rst_lm_rope_table_f32": [_p, _p, _i, _i, _f, _p],

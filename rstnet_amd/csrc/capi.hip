@@ -418,10 +418,12 @@ int rst_gemm_skinny_fp8_f32(const uint8_t* xp, const float* xscale, const uint8_
 }
 
 int rst_embed_sum_bf16(const int64_t* tokens, const uint16_t* const* tables, const int* tok_index, const int* table_rows, int n_tables,
-                       const float* add, float* out, int B, int D, int tok_stride, rst_stream_t stream) {
+                       const float* add, float* out, int B, int D, int tok_stride, int add_stride, rst_stream_t stream) {
     RST_REQUIRE(n_tables >= 0 && n_tables <= RST_MAX_TABLES && (n_tables == 0 || (tables && tok_index)), "embed_sum: bad tables");
+    RST_REQUIRE(!add || add_stride >= D, "embed_sum: add_stride %d < D %d", add_stride, D);
     EmbedSumParams p;
     p.tokens = (const long*)tokens; p.add = add; p.out = out; p.B = B; p.D = D; p.n_tables = n_tables; p.tok_stride = tok_stride;
+    p.add_stride = add ? add_stride : D;
     for (int i = 0; i < n_tables; ++i) { p.tables[i] = tables[i]; p.tok_index[i] = tok_index[i]; p.rows[i] = table_rows ? table_rows[i] : 0; }
     return rst_launch_embed_sum(p, (hipStream_t)stream);
 }

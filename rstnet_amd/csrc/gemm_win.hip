@@ -557,12 +557,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KB == 16 ? 
 // are bounded by 2^-23 |x||w| (2^-8 * 2^-16 twice), the size of ONE fp32 rounding of the product: the result carries fp32 accuracy
 // (tests: <= 2e-6 of the fp64 value's scale, the same bound the f32-instruction path meets; RVQ codes as exact as with it) at
 // 6 x 32 = 192 matrix-pipe cycles per 32x32x16 block instead of 8 x 64 = 512.
-// Weights are split once on the host side of the ABI (rst_gemm_win_b3_pack_weight) into the staging order
-// [n tile of 128][K / 16][plane][128 row slots][16 k] so a k-tile of W is three contiguous 4 KB pieces; activations stay fp32 in HBM
+// Weights are split once on the host side of the ABI (rst_gemm_win_b3_pack_weight) into matrix-instruction operand order
+// [block of 32 rows][K / 16][plane][64 lanes][8 k] (round 5, DIRW below: every wave requests the fragments of its own columns from
+// L2 straight into registers; the tools build keeps the round-3 form, [n tile of 128][K / 16][plane][128 row slots][16 k] staged through
+// LDS, for the A/B of DESIGN.md 3.1b); activations stay fp32 in HBM
 // and are split on their way into LDS (v_cvt_pk_bf16_f32 + subtractions, ~4.5 VALU per element).  LDS rows are 16 bf16 + 8 pad
 // = 48 bytes: the 16 lanes of a ds_read_b128 group hold rows that are distinct mod 16, and 3 * row mod 16 is a bijection, so every
-// group covers 16 distinct 16-byte slots.  Two buffers of (128 + BN) rows x 3 planes: 72 KB (BN = 128, two workgroups per CU) or
-// 108 KB (BN = 256, one workgroup of eight waves).  Rows whose window leaves the utterance are masked inside the kernel (below); only
+// group covers 16 distinct 16-byte slots.  Two buffers of 128 activation rows x 3 planes: 36 KB (staged form: (128 + BN) rows, 72 /
+// 108 KB).  Rows whose window leaves the utterance are masked inside the kernel (below); only
 // launches with a history buffer / replicate padding / K % 64 != 0 run on the f32-instruction kernels above.
 
 constexpr int B3_SETS_A = 4;                  // k-tiles of activations / of weights held in registers ahead of the one being multiplied
@@ -597,13 +599,19 @@ __host__ __device__ __forceinline__ constexpr int b3_slot(int r) { return (r & ~
 // (VALU + LDS writes) per matrix instruction: measured (tools build, RST_B3_DBG) that work is what the 128-wide form spends most on.
 // DBG (tools build only, WRONG results): 1 = no split / LDS writes, 2 = no global loads, 3 = matrix instructions only, 4 = no barriers,
 // 5 = LDS writes of unsplit bits (what activations handed over already split would cost)
-template <bool ELU, bool MASK, int NWN, int DBG = 0, bool BUFL = true>
+// DIRW: the weight fragments never pass through LDS.  The packed weights are then in matrix-instruction operand order ([32-column
+// block][k-tile][plane][64 lanes][8 bf16]: a wave-level load is one contiguous KB, as in lm_skinny.hip) and every wave requests the
+// fragments of its own 64 columns straight into the registers the matrix instructions read -- two k-tiles ahead, each plane into
+// the registers its last product of the current k-tile has just released.  LDS then holds the split activations only: a third of
+// the write instructions and half of the fragment reads of a stage are gone (what the ablation table prices highest), at the cost
+// of the weights crossing the L1 once per wave row (twice per workgroup) instead of once.
+template <bool ELU, bool MASK, int NWN, int DBG = 0, bool BUFL = true, bool DIRW = false>
 __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_win_b3_stream_kernel(const GemmWinParams p, const int tiles) {
     constexpr int TM = 2, TN = 2;
     constexpr int NT = 128 * NWN;                  // threads
     constexpr int BM = 128, BN = 64 * NWN;
     constexpr int RA = 512 / NT;                   // activation row passes: NT / 4 row slots x 4 threads (16 bytes of fp32 each) per pass
-    constexpr int A_PLANE = BM * B3_RS, W_PLANE = BN * B3_RS;          // shorts per plane in LDS
+    constexpr int A_PLANE = BM * B3_RS, W_PLANE = DIRW ? 0 : BN * B3_RS;          // shorts per plane in LDS
     constexpr int BUF = 3 * (A_PLANE + W_PLANE);                       // shorts per buffer: activation planes 0..2, weight planes 0..2
     constexpr int NSA = B3_SETS_A, NSB = B3_SETS_B;
     static_assert(NSA == 4 && NSB == 2, "the rotation below is written out for four activation sets and two weight sets");
@@ -661,12 +669,18 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2, 2)
         }
     };
     // this thread's 16 bytes of plane 0 of the tile's first k-tile: the packed weights come in 128-row tiles of [k-tile][plane][128][16]
-    auto w_tile = [&](int n0) { return (unsigned)(n0 / 128) * (unsigned)nk * (unsigned)(B3_WTILE * 2); };      // (bytes, uniform; the thread's part is wo)
-    const unsigned wo = (unsigned)(((long)(tid >> 8) * nk * B3_WTILE + (tid & 255) * 8) * 2);      // bytes
+    // DIRW: [32-column block][k-tile][plane][64 lanes][8]: 3 KB per (block, k-tile); the wave's first block is part of the lane offset
+    auto w_tile = [&](int n0) {
+        return DIRW ? (unsigned)(n0 / 32) * (unsigned)nk * 3072u : (unsigned)(n0 / 128) * (unsigned)nk * (unsigned)(B3_WTILE * 2);
+    };      // (bytes, uniform; the thread's part is wo)
+    const unsigned wo = DIRW ? (unsigned)(wn * TN) * (unsigned)nk * 3072u + (unsigned)lane * 16u
+                             : (unsigned)(((long)(tid >> 8) * nk * B3_WTILE + (tid & 255) * 8) * 2);      // bytes
+    const unsigned wo_blk = (unsigned)nk * 3072u;       // DIRW: from one 32-column block to the next
 
     f32x4 ra[NSA][RA];
     int rm[NSA][RA];                 // MASK: all ones where row j of the set is real data, zero where it is padding
-    u32x4 rb[NSB][3];
+    u32x4 rb[NSB][3];                // !DIRW: the thread's staging pieces of a k-tile's three weight planes
+    u32x4 rw[NSB][TN][3];            // DIRW: the wave's weight fragments (32-column block j, plane q) of k-tiles g, g + 1 (sets g % 2)
     // LDS destinations of this thread's pieces (shorts from the start of a buffer)
     const int a_dst = lrow * B3_RS + lk;
     const int b_dst = 3 * A_PLANE + ((tid >> 8) * 128 + b3_row((tid & 255) >> 1)) * B3_RS + (tid & 1) * 8;
@@ -704,6 +718,16 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2, 2)
             else dst[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.w3) + so + wo);
         }
     };
+    // DIRW: plane q of the wave's TN blocks of k-tile kt (stream position relative to wb) into set U
+    auto load_wq = [&](auto UU, auto QQ, const unsigned wb, const int kt) {
+        constexpr int U = decltype(UU)::value, q = decltype(QQ)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const unsigned so = wb + (unsigned)kt * 3072u + q * 1024u;
+            if (BUFL) rw[U][j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wo + j * wo_blk, so, 0);
+            else rw[U][j][q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.w3) + so + wo + j * wo_blk);
+        }
+    };
     // the fp32 values of a staged row piece as two pairs: padding cleared (MASK), ELU applied
     auto take_a = [&](auto MM, const f32x4 src, const int mask, f32x2 (&v)[2]) {
         typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -733,17 +757,29 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2, 2)
         constexpr int F = (S + 3) % 4, SB = S % 2, FB = (S + 1) % 2;
         if (DBG != 2 && DBG != 3) {
             // weights first: the wait for them counts requests in order, and must leave the younger activation requests in flight
-            load_w(bp, ktb, rb[FB]);
-            __builtin_amdgcn_sched_barrier(0);
+            if (!DIRW) {
+                load_w(bp, ktb, rb[FB]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             load_a(MM, c, kta, ra[F], rm[F]);
         }
         bf16x8 fa[TM][3], fb[TN][3];
         const short* rd = lds + buf * BUF;
         short* wr = lds + (buf ^ 1) * BUF;
         // fragments in the order the products below consume them
-        constexpr int QA[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
-        constexpr int QB[6] = {0, 2, 1, 0, 1, 0};
-        if (DBG != 3) {
+        // !DIRW: smallest terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi.  DIRW: the three products of weight plane 0 first,
+        // then plane 2, then plane 1 -- a plane's registers are re-requested (k-tile g + 2) as soon as its last product has issued, which
+        // gives every request >= 1.5 stages; the order inside a k-tile moves the result by roundings of the running sum only
+        constexpr int QA[6] = {2, DIRW ? 1 : 0, DIRW ? 0 : 1, DIRW ? 0 : 1, DIRW ? 1 : 0, 0};
+        constexpr int QB[6] = {0, DIRW ? 0 : 2, DIRW ? 0 : 1, DIRW ? 2 : 0, 1, DIRW ? 1 : 0};
+        if (DIRW && DBG != 3) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i][2] = *reinterpret_cast<const bf16x8*>(rd + a_frag + 2 * A_PLANE + i * 32 * B3_RS);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i][1] = *reinterpret_cast<const bf16x8*>(rd + a_frag + A_PLANE + i * 32 * B3_RS);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i][0] = *reinterpret_cast<const bf16x8*>(rd + a_frag + i * 32 * B3_RS);
+        } else if (DBG != 3) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j][0] = *reinterpret_cast<const bf16x8*>(rd + b_frag + j * 32 * B3_RS);
 #pragma unroll
@@ -772,21 +808,28 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2, 2)
         constexpr bool SIDE = DBG != 1 && DBG != 3;
         // side work, one small piece per slot: 0..2 the weight planes' LDS writes; then per plane q: 2 * RA half-row peels (4 VALU
         // each) and the plane's LDS write
-        constexpr int PB = 2 * RA + 1, NOPS = 3 + 3 * PB;       // 18 (RA = 2: slots 1 .. 18) or 12 (RA = 1: the odd slots)
+        constexpr int PB = 2 * RA + 1, WOPS = DIRW ? 0 : 3, NOPS = WOPS + 3 * PB;       // 18 (RA = 2: slots 1 .. 18) or 12 (RA = 1: the odd slots); DIRW: 15 / 9
 #pragma unroll
         for (int m = 0; m < 24; ++m) {
             const int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][QA[t]], fb[j][QB[t]], acc[i][j], 0, 0, 0);
+            if (DIRW && DBG != 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][QA[t]], __builtin_bit_cast(bf16x8, rw[SB][j][QB[t]]), acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][QA[t]], fb[j][QB[t]], acc[i][j], 0, 0, 0);
+            if (DIRW && DBG != 2 && DBG != 3) {
+                // a weight plane's last product of this k-tile has issued: its registers take the plane of k-tile g + 2 (same set)
+                if (m == 11) load_wq(b3_int<SB>{}, b3_int<0>{}, bp, ktb);
+                if (m == 15) load_wq(b3_int<SB>{}, b3_int<2>{}, bp, ktb);
+                if (m == 23) load_wq(b3_int<SB>{}, b3_int<1>{}, bp, ktb);
+            }
             if (SIDE && m == 0) {
 #pragma unroll
                 for (int r = 0; r < RA; ++r) take_a(MM, ra[S][r], rm[S][r], v[r]);
             }
             const int op = RA == 2 ? m - 1 : ((m & 1) ? (m - 1) >> 1 : -1);
             if (SIDE && op >= 0 && op < NOPS) {
-                if (op < 3) {
+                if (op < WOPS) {
                     *reinterpret_cast<u32x4*>(wr + b_dst + op * W_PLANE) = rb[SB][op];
                 } else {
-                    const int u = op - 3;
+                    const int u = op - WOPS;
                     const int q = u / PB, w = u % PB;
                     if (w < 2 * RA) {
                         if (DBG == 5) h[w >> 1][w & 1] = __builtin_bit_cast(unsigned, v[w >> 1][w & 1][0]) + q;
@@ -810,7 +853,7 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2, 2)
             int xm[RA];
             u32x4 xb[3];
             load_a(b3_int<MASK>{}, c, 0, xa, xm);
-            load_w(bp, 0, xb);
+            if (!DIRW) load_w(bp, 0, xb);
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
                 f32x2 v[2];
@@ -823,10 +866,17 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2, 2)
                     *reinterpret_cast<u32x2*>(wr + a_dst + q * A_PLANE + j * (NT / 4) * B3_RS) = hh;
                 }
             }
+            if (!DIRW) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(wr + b_dst + q * W_PLANE) = xb[q];
+                for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(wr + b_dst + q * W_PLANE) = xb[q];
+            }
         }
-        load_w(bp, 1, rb[0]);
+        if (DIRW) {         // k-tiles 0 and 1 of the wave's fragments into sets 0 and 1
+            load_wq(b3_int<0>{}, b3_int<0>{}, bp, 0); load_wq(b3_int<0>{}, b3_int<2>{}, bp, 0); load_wq(b3_int<0>{}, b3_int<1>{}, bp, 0);
+            load_wq(b3_int<1>{}, b3_int<0>{}, bp, 1); load_wq(b3_int<1>{}, b3_int<2>{}, bp, 1); load_wq(b3_int<1>{}, b3_int<1>{}, bp, 1);
+        } else {
+            load_w(bp, 1, rb[0]);
+        }
 #pragma unroll
         for (int g = 1; g < 4; ++g) load_a(b3_int<MASK>{}, c, g, ra[g - 1], rm[g - 1]);
         __syncthreads();
@@ -886,6 +936,8 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2, 2)
 }
 
 // w fp32 [N][K] -> the three bf16 planes in staging order (rows past N: zeros); one thread per four k of one row
+// DIRW: operand order [32-row block][k-tile][plane][64 lanes][8] instead -- lane (n % 32) + 32 * (k % 16 / 8) of the block holds k % 8 ..
+template <bool DIRW>
 __global__ __launch_bounds__(256) void gemm_win_b3_pack_kernel(const float* __restrict__ w, short* __restrict__ w3, int N, int K, long total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -895,14 +947,24 @@ __global__ __launch_bounds__(256) void gemm_win_b3_pack_kernel(const float* __re
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (n < N) v = *reinterpret_cast<const f32x4*>(w + (long)n * K + k);
     f32x2 v0 = {v[0], v[1]}, v1 = {v[2], v[3]};
-    short* dst = w3 + ((long)(n / 128) * (K / B3_KB) + k / B3_KB) * B3_WTILE + b3_slot(n % 128) * B3_KB + k % B3_KB;     // slot g holds row b3_row(g)
+    short* dst = DIRW ? w3 + ((long)(n / 32) * (K / B3_KB) + k / B3_KB) * (3 * 512) + ((n % 32) + 32 * ((k % B3_KB) / 8)) * 8 + k % 8
+                      : w3 + ((long)(n / 128) * (K / B3_KB) + k / B3_KB) * B3_WTILE + b3_slot(n % 128) * B3_KB + k % B3_KB;     // slot g holds row b3_row(g)
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         u32x2 h;
         h[0] = b3_peel(v0);
         h[1] = b3_peel(v1);
-        *reinterpret_cast<u32x2*>(dst + q * (128 * B3_KB)) = h;
+        *reinterpret_cast<u32x2*>(dst + q * (DIRW ? 512 : 128 * B3_KB)) = h;
     }
+}
+
+// Which of the two weight layouts / kernel forms the library runs (one answer per process: the pack routine and the GEMM must agree).
+// The tools build reads RST_B3_DIRW for A/B measurements.
+// The shipped library runs the direct form only; the staged form (weights through LDS) is compiled into the tools build for the A/B of
+// DESIGN.md 3.1b (RST_B3_DIRW=0).
+static bool b3_dirw() {
+    static const int v = rst_knob("RST_B3_DIRW", 1);
+    return v != 0;
 }
 
 template <int TM, int TN, int WM, int WN, int KB = BK>
@@ -978,7 +1040,8 @@ int launch_stream_b3_cfg(const GemmWinParams& p, hipStream_t stream) {
         rst_set_error("gemm_win: too many tiles (%ld)", tiles);
         return RST_ERR_UNSUPPORTED;
     }
-    const size_t lds = 2 * 3 * (128 + BN) * B3_RS * sizeof(short);       // 73 728 / 110 592 bytes
+    const bool dirw = b3_dirw();
+    const size_t lds = 2 * 3 * (128 + (dirw ? 0 : BN)) * B3_RS * sizeof(short);       // 73 728 / 110 592 bytes; 36 864 without the weight planes
     static const int per_cu = rst_knob("RST_B3_WGS", NWN == 2 ? 2 : 1);      // tools build only
     const long resident = (long)per_cu * gw_cu_count();
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
@@ -1009,12 +1072,24 @@ int launch_stream_b3_cfg(const GemmWinParams& p, hipStream_t stream) {
         return rst_check_launch("gemm_win_b3");
     }
 #endif
+#ifdef RST_ABLATION
+    if (!dirw) {
+        if (p.act_in == 1) {
+            if (lean) go(gemm_win_b3_stream_kernel<true, false, NWN>);
+            else go(gemm_win_b3_stream_kernel<true, true, NWN>);
+        } else {
+            if (lean) go(gemm_win_b3_stream_kernel<false, false, NWN>);
+            else go(gemm_win_b3_stream_kernel<false, true, NWN>);
+        }
+        return rst_check_launch("gemm_win_b3");
+    }
+#endif
     if (p.act_in == 1) {
-        if (lean) go(gemm_win_b3_stream_kernel<true, false, NWN>);
-        else go(gemm_win_b3_stream_kernel<true, true, NWN>);
+        if (lean) go(gemm_win_b3_stream_kernel<true, false, NWN, 0, true, true>);
+        else go(gemm_win_b3_stream_kernel<true, true, NWN, 0, true, true>);
     } else {
-        if (lean) go(gemm_win_b3_stream_kernel<false, false, NWN>);
-        else go(gemm_win_b3_stream_kernel<false, true, NWN>);
+        if (lean) go(gemm_win_b3_stream_kernel<false, false, NWN, 0, true, true>);
+        else go(gemm_win_b3_stream_kernel<false, true, NWN, 0, true, true>);
     }
     return rst_check_launch("gemm_win_b3");
 }
@@ -1128,6 +1203,12 @@ int rst_launch_gemm_win_b3_pack(const float* w, unsigned short* w3, int N, int K
     RST_REQUIRE(w && w3 && N > 0 && K > 0 && K % 16 == 0, "gemm_win_b3_pack_weight: bad arguments (K %% 16 == 0 required, N=%d K=%d)", N, K);
     RST_REQUIRE((uintptr_t)w % 16 == 0 && (uintptr_t)w3 % 16 == 0, "gemm_win_b3_pack_weight: pointers must be 16-byte aligned");
     const long total = (long)((N + 255) / 256) * 256 * (K / 4);
-    hipLaunchKernelGGL(gemm_win_b3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<short*>(w3), N, K, total);
+#ifdef RST_ABLATION
+    if (!b3_dirw()) {
+        hipLaunchKernelGGL(gemm_win_b3_pack_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<short*>(w3), N, K, total);
+        return rst_check_launch("gemm_win_b3_pack_weight");
+    }
+#endif
+    hipLaunchKernelGGL(gemm_win_b3_pack_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<short*>(w3), N, K, total);
     return rst_check_launch("gemm_win_b3_pack_weight");
 }

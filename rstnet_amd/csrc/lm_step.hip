@@ -480,7 +480,7 @@ __global__ __launch_bounds__(64 * GEMV_WAVES) void gemv_ksplit_kernel(const Gemv
 __global__ __launch_bounds__(256) void embed_sum_kernel(const EmbedSumParams p) {
     const int b = blockIdx.y;
     for (int d = blockIdx.x * 256 + threadIdx.x; d < p.D; d += gridDim.x * 256) {
-        float s = p.add ? p.add[(long)b * p.D + d] : 0.f;
+        float s = p.add ? p.add[(long)b * p.add_stride + d] : 0.f;
         for (int i = 0; i < p.n_tables; ++i) {
             const long tok = p.tokens[(long)b * p.tok_stride + p.tok_index[i]];
             if (tok != -1) {

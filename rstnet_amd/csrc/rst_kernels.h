@@ -215,9 +215,9 @@ struct EmbedSumParams {
     const unsigned short* tables[RST_MAX_TABLES];  // bf16 [rows][D]
     int tok_index[RST_MAX_TABLES];               // token column feeding table i
     int rows[RST_MAX_TABLES];                    // rows of table i (ids are clamped into it; 0 = unknown: not checked)
-    const float* add;                            // optional fp32 [B][D] added first
+    const float* add;                            // optional fp32 [B][add_stride >= D] added first
     float* out;                                  // [B][D]
-    int B, D, n_tables, tok_stride;
+    int B, D, n_tables, tok_stride, add_stride;
 };
 int rst_launch_embed_sum(const EmbedSumParams& p, hipStream_t stream);
 int rst_launch_rmsnorm(const float* x, const float* alpha, float* y, long rows, int D, float eps, hipStream_t stream);

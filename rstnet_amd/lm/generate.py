@@ -73,6 +73,7 @@ class GPTGen:
         m._streaming_state = _GPTState(_Graphed(m._global_step, disable=eager))
         m.codecformer._streaming_state = m.codecformer._init_streaming_state(batch_size, capacity=cfg.dep_q + 1)
         self._limits = torch.full((cfg.dep_q,), self.n_audio_codes + 1, device=dev, dtype=torch.int32)
+        self._depth_pos = torch.arange(cfg.dep_q, device=dev, dtype=torch.long)
         self._depth = _Graphed(self._depth_frame, disable=eager)
         self._regime, self.B, self._eager = None, batch_size, eager
         self._frames, self._persist_epoch = 0, ops.persistent_epoch(dev)
@@ -89,38 +90,100 @@ class GPTGen:
             return self.noise(kind, g_idx, l_idx).reshape(B, k).to(self.model.device, torch.float32).contiguous()
         return torch.empty(B, k, device=self.model.device, dtype=torch.float32).exponential_(1)    # utils/sampling.py:44-46
 
-    def _depth_frame(self, text_token: torch.Tensor, h: torch.Tensor, g_idx: int = 0) -> torch.Tensor:
-        """dep_q depth-transformer steps + sampling: text_token int64 [B], h fp32 [B, n_embd] -> tokens int64 [B, dep_q]."""
+    def _frame_noise(self, g_idx: int, B: int, with_text: bool) -> Optional[torch.Tensor]:
+        """Exp(1) noise of one frame's samplers, ``[B, (k_text +) dep_q * k]``: ONE draw (utils/sampling.py:44-46 draws per call; the
+        values are i.i.d. either way), or the test hook's per-sampler draws side by side."""
+        if not self.use_sampling:
+            return None
+        cfg = self.model.config
+        k_text, k_eff = min(self.top_k_text, cfg.padded_vocab_size), min(self.top_k, cfg.audio_card)
+        if self.noise is not None:
+            parts = [self._exp_noise("text", g_idx, 0, B, k_text)] if with_text else []
+            return torch.cat(parts + [self._exp_noise("audio", g_idx, l_idx, B, k_eff) for l_idx in range(cfg.dep_q)], 1)
+        n = (k_text if with_text else 0) + cfg.dep_q * k_eff
+        return torch.empty(B, n, device=self.model.device, dtype=torch.float32).exponential_(1)
+
+    def _depth_into(self, tokens: torch.Tensor, h: torch.Tensor, noise: Optional[torch.Tensor]) -> None:
+        """dep_q depth-transformer steps + sampling IN PLACE: ``tokens`` int64 ``[B, >= dep_q + 1]`` (any row stride) holds the text
+        token in column 0; step l embeds column l and samples column l + 1 (the layout of ``LMGen._depth``).  ``noise``: Exp(1)
+        draws ``[B, dep_q * k]`` or None (greedy)."""
         m = self.model
         dep, cfg = m.codecformer, m.config
-        (B,) = text_token.shape
-        dep._streaming_state.reset()
-        out = torch.empty(B, cfg.dep_q, device=text_token.device, dtype=torch.long)
-        prev = text_token
+        B = tokens.shape[0]
         k_eff = min(self.top_k, cfg.audio_card)
         h_all = ops.lm_linear(h, m.codecformer_in_all())      # codecformer_in[k](h) of all dep_q steps in one launch
         E, H = dep.d_model, dep.num_heads
         Hd = dep.layers[0].gating[0].linear_out.weight.shape[1]
-        if ops.depth_frame_enabled(text_token.device) and ops.depth_frame_supported(B, E, H, Hd, cfg.audio_card, cfg.dep_q, len(dep.layers), k_eff, device=text_token.device):
-            # batch 1 / 2: the dep_q steps with their samplers are one persistent launch (csrc/lm_depth.hip)
-            tokens = torch.empty(B, cfg.dep_q + 1, device=text_token.device, dtype=torch.long)
-            tokens[:, 0] = text_token
-            noise = None
-            if self.use_sampling:
-                noise = torch.cat([self._exp_noise("audio", g_idx, l_idx, B, k_eff) for l_idx in range(cfg.dep_q)], 1)
+        if ops.depth_frame_enabled(tokens.device) and ops.depth_frame_supported(B, E, H, Hd, cfg.audio_card, cfg.dep_q, len(dep.layers), k_eff, device=tokens.device):
+            # batch 1 / 2: the dep_q steps with their samplers are one persistent launch (csrc/lm_depth.hip), on a dense [B, dep_q + 1] buffer
+            dense = tokens if tokens.shape[1] == cfg.dep_q + 1 and tokens.is_contiguous() else tokens[:, :cfg.dep_q + 1].contiguous()
             self._tables = m.depth_frame_tables()      # a captured frame embeds the tables' device pointers: kept alive with the graph
-            ops.depth_decode_frame(self._tables, h_all, tokens, noise, use_sampling=self.use_sampling, temp=self.temp, top_k=k_eff,
+            ops.depth_decode_frame(self._tables, h_all, dense, noise, use_sampling=self.use_sampling, temp=self.temp, top_k=k_eff,
                                    eps=dep.layers[0].norm1.eps, context=dep.context, limits=self._limits,
                                    ring_cap=dep._streaming_state.k[0].shape[2])
-            return tokens[:, 1:].contiguous()
+            if dense is not tokens:
+                tokens[:, 1:cfg.dep_q + 1] = dense[:, 1:]
+            return
         for l_idx in range(cfg.dep_q):
-            y = m._codec_step(l_idx, prev, None, h_all)
+            add = h_all[:, l_idx * E:(l_idx + 1) * E]
+            table = m.codecformer_text_emb.weight if l_idx == 0 else m.codecformer_emb[l_idx - 1].weight
+            # positions 0 .. dep_q - 1 of a ring that restarts every frame, as constant device scalars (no counter to zero and bump:
+            # nine glue launches per frame); the step's input is formed inside its first launch
+            y = dep.step(None, step_index=l_idx, pos=self._depth_pos[l_idx:l_idx + 1], embed=(add, table, tokens, l_idx))
             head = m.audio_linears[l_idx]
             logits = ops.lm_linear(y, head.weight, bias=head.bias_f32())
-            prev = ops.lm_sample(logits, use_sampling=self.use_sampling, temp=self.temp, top_k=k_eff,
-                                 noise=self._exp_noise("audio", g_idx, l_idx, B, k_eff), limit_dev=self._limits[l_idx:l_idx + 1])
-            out[:, l_idx] = prev
-        return out
+            ops.lm_sample(logits, use_sampling=self.use_sampling, temp=self.temp, top_k=k_eff,
+                          noise=None if noise is None else noise[:, l_idx * k_eff:(l_idx + 1) * k_eff],
+                          limit_dev=self._limits[l_idx:l_idx + 1], out=tokens[:, l_idx + 1])
+
+    def _depth_frame(self, text_token: torch.Tensor, h: torch.Tensor, g_idx: int = 0) -> torch.Tensor:
+        """dep_q depth-transformer steps + sampling: text_token int64 [B], h fp32 [B, n_embd] -> tokens int64 [B, dep_q]."""
+        (B,) = text_token.shape
+        tokens = torch.empty(B, self.model.config.dep_q + 1, device=text_token.device, dtype=torch.long)
+        tokens[:, 0] = text_token
+        self._depth_into(tokens, h, self._frame_noise(g_idx, B, with_text=False))
+        return tokens[:, 1:].contiguous()
+
+    # ---- the whole frame as ONE captured graph (serving / benchmark loop): global step of the previous frame's tokens, text sample,
+    # dep_q depth steps with their samples -- fed by nothing, reading and writing the session's token column on the device
+    def start(self, h: torch.Tensor, logits: torch.Tensor, g_idx: int = 0):
+        """First frame after ``prefill``: samples it (``frame``) and loads it into the session's token column, from which ``step``
+        continues.  Returns (text [B], audio [B, dep_q])."""
+        text, audio = self.frame(h.contiguous(), logits.contiguous(), g_idx)
+        cfg = self.model.config
+        self._col = torch.full((h.shape[0], cfg.n_q + 1), self.model.initial_token_id, device=h.device, dtype=torch.long)
+        self._col[:, 0] = text
+        self._col[:, 1:cfg.dep_q + 1] = audio
+        self._fused = _Graphed(self._step_fn, disable=self._eager)
+        self._g_idx = g_idx
+        return text, audio
+
+    def _step_fn(self):
+        m, cfg, col = self.model, self.model.config, self._col
+        B = col.shape[0]
+        # the completed frame through the global transformer (rows beyond dep_q carry the initial-token pad, infer_no_streaming.py:243-244);
+        # its embedding launch reads the column before the samplers below overwrite it (stream order)
+        h, logits = m._global_step(col)
+        k_text = min(self.top_k_text, cfg.padded_vocab_size)
+        noise = self._frame_noise(self._g_idx, B, with_text=True)
+        ops.lm_sample(logits, use_sampling=self.use_sampling, temp=self.temp_text, top_k=k_text,
+                      noise=None if noise is None else noise[:, :k_text], out=col[:, 0])
+        self._depth_into(col, h, None if noise is None else noise[:, k_text:])
+        return h, logits
+
+    def step(self):
+        """``advance`` of the previous frame + ``frame`` of the next one as ONE graph replay with no host-side tensor traffic: returns
+        (text [B], audio [B, dep_q]) as VIEWS of the session's token column (valid until the next ``step``; clone to keep)."""
+        col, cfg = self._col, self.model.config
+        if self._frames % 64 == 0 and col.is_cuda and not self._eager:
+            ops.persistent_poll(col.device)
+            if self._persist_epoch != ops.persistent_epoch(col.device):
+                self._persist_epoch = ops.persistent_epoch(col.device)
+                self._fused = _Graphed(self._step_fn)
+        self._frames += 1
+        self._g_idx += 1
+        self.last_h, self.last_logits = self._fused()
+        return col[:, 0], col[:, 1:cfg.dep_q + 1]
 
     def set_blanking(self, wide: list) -> None:
         """Per-codebook id limit of the next frames: n_audio_codes + 1 where ``wide`` (sample_token_audio) else n_audio_codes

@@ -187,7 +187,7 @@ class StreamingTransformer(StreamingModule[_StepState]):
                 if B <= 2 and E <= 4096 and E % 8 == 0:
                     qkv, x = ops.gemv_embed(add, table, tokens, col, w_in, alpha=layer.norm1.alpha_f32(), eps=layer.norm1.eps)
                 else:
-                    x = ops.embed_sum(tokens, [table], [col], add=add.contiguous())
+                    x = ops.embed_sum(tokens, [table], [col], add=add)        # (a column block of h_all is read in place: no copy launch)
             if l > 0 or embed is None or not (B <= 2 and E <= 4096 and E % 8 == 0):
                 qkv = ops.lm_linear(x, w_in, prologue=ops.PROLOGUE_RMSNORM, alpha=layer.norm1.alpha_f32(), eps=layer.norm1.eps)
             if fused_attn:

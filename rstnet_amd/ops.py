@@ -89,14 +89,14 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr() if t.numel() > 0 else None
 
 
-def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32) -> None:
+def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32, contiguous: bool = True) -> None:
     if t is None:
         return
     if not t.is_cuda:
         raise RuntimeError(f"rstnet_amd.ops: `{name}` is on {t.device}; the HIP path needs a CUDA/HIP tensor (no CPU fallback)")
     if t.dtype != dtype:
         raise TypeError(f"rstnet_amd.ops: `{name}` must be {dtype}, got {t.dtype}")
-    if not t.is_contiguous():
+    if contiguous and not t.is_contiguous():
         raise ValueError(f"rstnet_amd.ops: `{name}` must be contiguous")
 
 
@@ -144,7 +144,7 @@ _b3_weights = _PackedWeights()
 
 
 def gemm_win_b3_pack_weight(w: torch.Tensor) -> torch.Tensor:
-    """fp32 ``[N, K]`` -> its three bf16 planes in the staging order of the large-M kernel (rst_gemm_win_b3_pack_weight), cached per
+    """fp32 ``[N, K]`` -> its three bf16 planes in the operand order of the large-M kernel (rst_gemm_win_b3_pack_weight), cached per
     storage / version like the other packed copies."""
     _chk(w, "w")
     N, K = w.shape
@@ -896,16 +896,21 @@ def lm_linear(x: torch.Tensor, w: torch.Tensor, *, prologue: int = PROLOGUE_NONE
 
 def embed_sum(tokens: torch.Tensor, tables: Sequence[torch.Tensor], tok_index: Sequence[int],
               add: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``out[b] = (add[b] +) sum_i tables[i][tokens[b, tok_index[i]]]``; tokens int64 ``[B, n]``, tables bf16 ``[rows, D]``."""
-    _chk(tokens, "tokens", torch.int64)
-    _chk(add, "add")
+    """``out[b] = (add[b] +) sum_i tables[i][tokens[b, tok_index[i]]]``; tokens int64 ``[B, n]`` (rows contiguous, any row stride), tables
+    bf16 ``[rows, D]``; ``add`` fp32 ``[B, D]`` with unit column stride and any row stride (a column block of a wider matrix is read in place)."""
+    _chk(tokens, "tokens", torch.int64, contiguous=False)
+    if add is not None:
+        _chk(add, "add", contiguous=False)
+        assert add.dim() == 2 and add.stride(1) == 1, "embed_sum: `add` needs unit column stride"
+    assert tokens.dim() == 2 and tokens.stride(1) == 1, "embed_sum: `tokens` needs unit column stride"
     for t in tables:
         _chk(t, "table", torch.bfloat16)
     B, D = tokens.shape[0], tables[0].shape[1]
     out = torch.empty(B, D, device=tokens.device, dtype=torch.float32)
     tabs = (C.c_void_p * len(tables))(*[t.data_ptr() for t in tables])
     _lib.check(_lib.lib().rst_embed_sum_bf16(_ptr(tokens), tabs, _int_array(list(tok_index)), _int_array([t.shape[0] for t in tables]),
-                                            len(tables), _ptr(add), _ptr(out), B, D, tokens.shape[1], _stream()))
+                                            len(tables), _ptr(add), _ptr(out), B, D, tokens.stride(0), add.stride(0) if add is not None else D,
+                                            _stream()))
     return out
 
 

@@ -16,13 +16,12 @@ U = 2.0 ** -24
 
 
 def unpack_b3(w3: torch.Tensor, N: int, K: int) -> torch.Tensor:
-    """[ceil(N/256)*2][K/16][3][128 slots][16] int16 -> the three planes as fp32 ``[3, ceil(N/256)*256, K]``; slot g of a tile holds
-    row (g & ~7) | (2 * (g & 3) + ((g >> 2) & 1)) (the order that keeps the kernel's LDS writes free of bank conflicts)."""
-    nt = w3.numel() // (3 * 128 * K)                 # 128-row tiles, an even number of them (the wide kernel reads them in pairs)
-    t = w3.view(nt, K // 16, 3, 128, 16).permute(2, 0, 3, 1, 4).reshape(3, nt * 128, K)
-    r = torch.arange(nt * 128, device=w3.device)
-    slot = (r & ~7) | (((r & 7) >> 1) + 4 * (r & 1))
-    return (t.index_select(1, slot).to(torch.int32) << 16).view(torch.float32)
+    """[ceil(N/256)*8 blocks of 32 rows][K/16][3 planes][64 lanes][8] int16 (matrix-instruction operand order: lane (n % 32) + 32 *
+    (k % 16 // 8) of a block holds k % 8 .. of row n) -> the three planes as fp32 ``[3, ceil(N/256)*256, K]``."""
+    nb = w3.numel() // (3 * 32 * K)                  # 32-row blocks, a multiple of 8 (whole 256-row tiles)
+    t = w3.view(nb, K // 16, 3, 2, 32, 8)            # [block][k-tile][plane][k half][row in block][k % 8]
+    t = t.permute(2, 0, 4, 1, 3, 5).reshape(3, nb * 32, K)
+    return (t.to(torch.int32) << 16).view(torch.float32)
 
 
 @pytest.mark.parametrize("N,K", [(128, 32), (200, 64), (513, 2048), (64, 16)])   # (the packing itself only needs K % 16 == 0)
