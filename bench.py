@@ -499,9 +499,13 @@ def run_gpt(args, rank, world, dev, gpt=None, fp8=None, steps=None, warmup=None,
     gen.set_blanking([False] + [True] * (cfg_d["dep_q"] - 1))
     h, logits = gen.prefill(prompt)
 
+    # first frame after the prompt, then every step = ONE graph replay: global step of the completed frame + text sample + dep_q
+    # depth steps with their samples, on the session's device-resident token column (GPTGen.step)
+    gen.start(h, logits)
+
     def frame(h, logits):
-        text, audio = gen.frame(h.contiguous(), logits.contiguous())
-        return gen.advance(text, audio)
+        gen.step()
+        return h, logits
     for _ in range(warmup):
         h, logits = frame(h, logits)
     torch.cuda.synchronize()
@@ -536,10 +540,11 @@ def run_gpt(args, rank, world, dev, gpt=None, fp8=None, steps=None, warmup=None,
     os.environ["NO_CUDA_GRAPH"] = "1"
     gen2.begin(B)
     h, logits = gen2.prefill(prompt)
-    h, logits = gen2.advance(*gen2.frame(h, logits))
+    gen2.start(h, logits)
+    gen2.step()
     recs = []
     ops.PROFILE = recs
-    h, logits = gen2.advance(*gen2.frame(h.contiguous(), logits.contiguous()))
+    gen2.step()
     torch.cuda.synchronize()
     ops.PROFILE = None
     gen2.end()

@@ -181,6 +181,15 @@ int rst_rope_split_f32(const float* qkv, float* q, float* k, float* v, const int
 int rst_attention_f32(const float* q, const float* k, const float* v, float* out, const int64_t* pos_dev, int64_t pos0,
                       int B, int T, int H, int D, int cap, int ring, int context, rst_stream_t stream);
 
+/* The whole-utterance pass of the same attention WITHOUT the split launch: q / k / v are read in place from the in-projection's output
+ * qkv [B][T][3][H][D] ("b t (p h d)", modules/transformer.py:376-388) and rotated on their way in by `rope_table` [T][D] -- (cos, sin) of
+ * pair i of position t at [t][2i], [t][2i+1], filled once per (T, D, max_period) by rst_rope_table_f32 with the arithmetic of
+ * modules/rope.py:37-62 (angle = exp(i * rope_coef) * (pos0 + t)); NULL = no rotation.  Positions 0 .. T-1, causal + `context` mask,
+ * no ring (the streaming steps keep rst_rope_split_f32 + rst_attention_f32 / rst_attn_decode_multi_f32).  out [B][T][H*D]. */
+int rst_rope_table_f32(float* table, int T, int D, float rope_coef, int64_t pos0, rst_stream_t stream);
+int rst_attention_qkv_f32(const float* qkv, const float* rope_table, float* out, int B, int T, int H, int D, int context,
+                          rst_stream_t stream);
+
 /* Codebook preparation for rst_rvq_search_f32: packed [D/8][n_codes][2][4], e2[n_codes] = |e|^2 (k-ordered fmaf). */
 int rst_rvq_pack_f32(const float* emb, float* packed, float* e2, int n_codes, int D, rst_stream_t stream);
 

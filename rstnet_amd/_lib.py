@@ -38,6 +38,8 @@ SIGNATURES = {
     "rst_layernorm_f32": [_p, _p, _p, _p, _l, _i, _f, _p],
     "rst_rope_split_f32": [_p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "rst_attention_f32": [_p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rst_rope_table_f32": [_p, _i, _i, _f, _l, _p],
+    "rst_attention_qkv_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "rst_rvq_pack_f32": [_p, _p, _p, _i, _i, _p],
     "rst_rvq_search_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _p],
     "rst_rvq_gather_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _p],

@@ -146,7 +146,10 @@ class StreamingMultiheadAttention(StreamingModule[_MHAState]):
         qkv = self._project(self.in_proj_weight, x, offset, ln=ln)
         use_rope = self.rope is not None
         period = self.rope.max_period if use_rope else 10000.0
-        if state is None:
+        if state is None and ops.ATTENTION_FUSED_QKV and qkv.is_cuda and (qkv.shape[2] // (3 * H)) in (32, 64, 128):
+            # whole-utterance pass: q / k / v read in place from the in-projection's output, rotated on load (no split launch)
+            a = ops.attention_qkv(qkv, H, rope=use_rope, max_period=period, context=self.context)
+        elif state is None:
             q, k, v = ops.rope_split(qkv, H, pos0=0, rope=use_rope, max_period=period)
             a = ops.attention(q, k, v, pos0=0, ring=False, context=self.context)
         else:

@@ -57,7 +57,32 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const RopeSplitParams p
 // workgroup whose early tiles finish after a fraction of the loop: 120 -> 102 us per launch only.
 constexpr int ATT_WAVES = 4, ATT_GROUP = 8;
 
-template <int D>
+// (cos, sin) of every (position, pair) of a whole-utterance pass, with the arithmetic of rope_split_kernel (modules/rope.py:37-62)
+__global__ __launch_bounds__(256) void rope_table_kernel_f32(float* __restrict__ tab, int T, int D, float rope_coef, long pos0) {
+    const int half = D / 2;
+    const long total = (long)T * half;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int i = (int)(idx % half);
+        const int t = (int)(idx / half);
+        const float fr = expf((float)i * rope_coef);
+        const float ang = fr * ((float)pos0 + (float)t);
+        tab[(long)t * D + 2 * i] = cosf(ang);
+        tab[(long)t * D + 2 * i + 1] = sinf(ang);
+    }
+}
+
+// two interleaved pairs (x0, x1), (x2, x3) rotated by (c0, s0), (c1, s1): the expressions of rope_split_kernel
+__device__ __forceinline__ f32x4 rope_piece(const f32x4 x, const f32x4 t) {
+    f32x4 y;
+    y[0] = x[0] * t[0] - x[1] * t[1];
+    y[1] = x[0] * t[1] + x[1] * t[0];
+    y[2] = x[2] * t[2] - x[3] * t[3];
+    y[3] = x[2] * t[3] + x[3] * t[2];
+    return y;
+}
+
+// QKV: the fused form (AttentionParams::row_stride / rope_tab) -- rows are `row_stride` floats apart and are rotated when they are loaded
+template <int D, bool QKV = false>
 __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const AttentionParams p) {
     constexpr int DT = D / 32;
     constexpr int KS = D / 8;
@@ -81,14 +106,26 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const Attenti
     const float scale = 1.0f / sqrtf((float)D);
     const float NEG_INF = -INFINITY;
 
-    const float* qb = p.q + ((b * p.H + head) * p.T) * (long)D;
-    const float* kb = p.k + ((b * p.H + head) * p.cap) * (long)D;
-    const float* vb = p.v + ((b * p.H + head) * p.cap) * (long)D;
+    const long RS = QKV ? (long)p.row_stride : (long)D;
+    const float* qb = QKV ? p.q + b * p.T * RS + (long)head * D : p.q + ((b * p.H + head) * p.T) * (long)D;
+    const float* kb = QKV ? p.k + b * p.T * RS + (long)head * D : p.k + ((b * p.H + head) * p.cap) * (long)D;
+    const float* vb = QKV ? p.v + b * p.T * RS + (long)head * D : p.v + ((b * p.H + head) * p.cap) * (long)D;
+    const bool rot = QKV && p.rope_tab != nullptr;
 
     f32x4 qf[KS];
+    {
+        const int qrow = min(q0 + j, p.T - 1);
+        f32x4 qt[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s)     // rows past T: a clamped (valid) row, never stored -- unconditional loads, all in flight at once
-        qf[s] = *reinterpret_cast<const f32x4*>(qb + (long)min(q0 + j, p.T - 1) * D + 8 * s + 4 * h);
+        for (int s = 0; s < KS; ++s) {   // rows past T: a clamped (valid) row, never stored -- unconditional loads, all in flight at once
+            qf[s] = *reinterpret_cast<const f32x4*>(qb + (long)qrow * RS + 8 * s + 4 * h);
+            if (QKV) qt[s] = *reinterpret_cast<const f32x4*>(p.rope_tab + (rot ? (long)qrow * D + 8 * s + 4 * h : 0));
+        }
+        if (QKV && rot) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) qf[s] = rope_piece(qf[s], qt[s]);
+        }
+    }
 
     // slots that can be visible: to this wave's tile [lo, hi], to any tile of the workgroup [lo_wg, hi_wg]
     // the last real tile of this workgroup's set ({0, 2, 5, 7} or {1, 3, 4, 6}): its end bounds the keys to stage
@@ -122,14 +159,15 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const Attenti
     // K / V tile at slots s0 .. s0 + 31 -> registers.  Slots beyond cap read the last slot again (finite data): their scores are masked
     // to -inf below, so the duplicate takes weight 0 -- every load is unconditional (a load under a per-lane condition is waited for
     // inside its branch); threads beyond the tile (D = 32) re-read its last piece and do not store it.
-    f32x4 kreg[LPT], vreg[LPT];
+    f32x4 kreg[LPT], vreg[LPT], treg[QKV ? LPT : 1];
     auto request = [&](int s0) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int idx = min(tid + NT * i, PIECES - 1);
             const int row = min(s0 + idx / (D / 4), p.cap - 1), c4 = (idx % (D / 4)) * 4;
-            kreg[i] = *reinterpret_cast<const f32x4*>(kb + (long)row * D + c4);
-            vreg[i] = *reinterpret_cast<const f32x4*>(vb + (long)row * D + c4);
+            kreg[i] = *reinterpret_cast<const f32x4*>(kb + (long)row * RS + c4);
+            vreg[i] = *reinterpret_cast<const f32x4*>(vb + (long)row * RS + c4);
+            if (QKV) treg[i] = *reinterpret_cast<const f32x4*>(p.rope_tab + (rot ? (long)row * D + c4 : 0));      // (slot = position: pos0 == 0)
         }
     };
     auto stage = [&](int buf) {
@@ -138,6 +176,7 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const Attenti
             const int idx = tid + NT * i;
             if (idx < PIECES) {
                 const int row = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
+                if (QKV && rot) kreg[i] = rope_piece(kreg[i], treg[i]);
                 *reinterpret_cast<f32x4*>(Ks[buf] + row * KLD + c4) = kreg[i];
                 *reinterpret_cast<f32x4*>(Vs[buf] + row * D + c4) = vreg[i];
             }
@@ -261,12 +300,34 @@ int rst_launch_rope_split(const RopeSplitParams& p, hipStream_t stream) {
     return rst_check_launch("rope_split");
 }
 
+int rst_launch_rope_table(float* tab, int T, int D, float rope_coef, long pos0, hipStream_t stream) {
+    RST_REQUIRE(tab && T > 0 && D > 0 && D % 2 == 0, "rope_table: bad arguments");
+    const long total = (long)T * (D / 2);
+    long g = (total + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(rope_table_kernel_f32, dim3((unsigned)g), dim3(256), 0, stream, tab, T, D, rope_coef, pos0);
+    return rst_check_launch("rope_table");
+}
+
 int rst_launch_attention(const AttentionParams& p, hipStream_t stream) {
     RST_REQUIRE(p.B >= 0 && p.T >= 0 && p.H > 0 && p.cap > 0, "attention: bad sizes");
     RST_REQUIRE(p.B <= 65535 && p.H <= 65535, "attention: grid too large");
     if (p.B == 0 || p.T == 0) return RST_OK;
     RST_REQUIRE(p.q && p.k && p.v && p.out, "attention: null pointer");
     const dim3 grid(2 * ((p.T + 32 * ATT_GROUP - 1) / (32 * ATT_GROUP)), p.H, p.B);
+    if (p.row_stride > 0) {
+        RST_REQUIRE(!p.ring && p.pos0 == 0 && !p.pos_dev && p.cap == p.T && p.row_stride >= p.D && p.row_stride % 4 == 0,
+                    "attention (fused qkv): whole-utterance passes only (ring = 0, pos0 = 0, cap = T)");
+        switch (p.D) {
+            case 32: hipLaunchKernelGGL((attention_kernel<32, true>), grid, dim3(64 * ATT_WAVES), 0, stream, p); break;
+            case 64: hipLaunchKernelGGL((attention_kernel<64, true>), grid, dim3(64 * ATT_WAVES), 0, stream, p); break;
+            case 128: hipLaunchKernelGGL((attention_kernel<128, true>), grid, dim3(64 * ATT_WAVES), 0, stream, p); break;
+            default:
+                rst_set_error("attention: head dim %d unsupported (32, 64, 128)", p.D);
+                return RST_ERR_UNSUPPORTED;
+        }
+        return rst_check_launch("attention_qkv");
+    }
     switch (p.D) {
         case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64 * ATT_WAVES), 0, stream, p); break;
         case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * ATT_WAVES), 0, stream, p); break;

@@ -163,6 +163,22 @@ int rst_attention_f32(const float* q, const float* k, const float* v, float* out
     AttentionParams p;
     p.q = q; p.k = k; p.v = v; p.out = out; p.pos_dev = (const long*)pos_dev; p.pos0 = pos0;
     p.B = B; p.T = T; p.H = H; p.D = D; p.cap = cap; p.ring = ring; p.context = context;
+    p.row_stride = 0; p.rope_tab = nullptr;
+    return rst_launch_attention(p, (hipStream_t)stream);
+}
+
+int rst_rope_table_f32(float* table, int T, int D, float rope_coef, int64_t pos0, rst_stream_t stream) {
+    return rst_launch_rope_table(table, T, D, rope_coef, pos0, (hipStream_t)stream);
+}
+
+int rst_attention_qkv_f32(const float* qkv, const float* rope_table, float* out, int B, int T, int H, int D, int context,
+                          rst_stream_t stream) {
+    RST_REQUIRE(qkv && out && B >= 0 && T >= 0 && H > 0 && D > 0, "attention_qkv: bad arguments");
+    RST_REQUIRE((uintptr_t)qkv % 16 == 0 && (!rope_table || (uintptr_t)rope_table % 16 == 0), "attention_qkv: pointers must be 16-byte aligned");
+    AttentionParams p;
+    p.q = qkv; p.k = qkv + (long)H * D; p.v = qkv + 2L * H * D; p.out = out; p.pos_dev = nullptr; p.pos0 = 0;
+    p.B = B; p.T = T; p.H = H; p.D = D; p.cap = T; p.ring = 0; p.context = context;
+    p.row_stride = 3 * H * D; p.rope_tab = rope_table;
     return rst_launch_attention(p, (hipStream_t)stream);
 }
 

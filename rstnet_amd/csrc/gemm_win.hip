@@ -966,6 +966,11 @@ static bool b3_dirw() {
     static const int v = rst_knob("RST_B3_DIRW", 1);
     return v != 0;
 }
+// (Round 5 also built the same stream with NO barrier per stage: the split activation planes in a ring of four LDS slots, every
+// condition a barrier enforces checked against per-slot arrival counters in LDS with a full stage of slack.  Parity-green and 5 - 15 %
+// SLOWER on every layer (181 vs 196 TFLOP/s, profiles/r05_b3_ring_vs_barrier.txt): waves that drift apart no longer share the weight
+// fragments in the L1, and the counter traffic costs more than the barrier it replaces.  The kernel is kept as
+// tools/probes/b3_ring_kernel.hip.inc, not in the library.)
 
 template <int TM, int TN, int WM, int WN, int KB = BK>
 int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {

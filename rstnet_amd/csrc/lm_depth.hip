@@ -348,12 +348,14 @@ __global__ __launch_bounds__(DF_THREADS) void depth_frame_kernel(const DepthFram
         });
         DF_STAMP(sk + 1 + DF_ST_LAYER * RST_DEPTH_MAX_L);
         if (k + 1 < dep_q) df_rows_issue<3, 2, false>(pq, p.in_proj[0] + (long)(k + 1) * 3 * E * E, 3 * E, E, gw, W, lane);
-        // ---- sampler (workgroup 0): utils/sampling.py:85-105
+        // ---- sampler: utils/sampling.py:85-105.  Workgroup b draws the token of batch row b (round 5: with the rows one after the other
+        // in workgroup 0 the second row's 14 us sat on every step's critical path at batch 2); the one-workgroup repair launch takes all rows
         ++eTOK;
-        if (wg == 0) {
-            df_gather<8>(gLOG, B * card, eLOG, lg, [](int i) { return i; }, sh, p.status, 64u);
+        if (SOLO || wg < B) {
+            const int b_lo = SOLO ? 0 : wg, b_hi = SOLO ? B : wg + 1;
+            df_gather<8>(gLOG + (long)b_lo * card, (b_hi - b_lo) * card, eLOG, lg + b_lo * card, [](int i) { return i; }, sh, p.status, 64u);
             DF_STAMP(sk + 2 + DF_ST_LAYER * RST_DEPTH_MAX_L);
-            for (int b = 0; b < B; ++b) {
+            for (int b = b_lo; b < b_hi; ++b) {
                 const float* nz = p.noise ? p.noise + (long)b * p.noise_stride + (long)k * p.top_k : nullptr;
                 const int limit = p.v_limit ? p.v_limit[k] : 0;
 #ifdef RST_ABLATION

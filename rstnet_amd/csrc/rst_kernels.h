@@ -145,8 +145,14 @@ struct AttentionParams {
     int B, T, H, D, cap;
     int ring;           // 0: slot s holds position s; 1: ring cache, end_offset = pos0 + T (RingKVCache.complete)
     int context;        // <= 0: unlimited
+    // fused-QKV form (whole-utterance pass, ring == 0, pos0 == 0, cap == T): q / k / v are read in place from the in-projection's output
+    // [B][T][3][H][D] (q = qkv, k = qkv + H*D, v = qkv + 2*H*D; row stride 3*H*D) and rotated on their way in by `rope_tab`
+    // ([T][D]: (cos, sin) of pair i of position t at [t][2i], [t][2i+1]; nullptr = no rotation) -- no rope_split launch, no q/k/v copies
+    int row_stride;     // floats between consecutive positions of q / k / v (D for the split layout)
+    const float* rope_tab;
 };
 int rst_launch_attention(const AttentionParams& p, hipStream_t stream);
+int rst_launch_rope_table(float* tab, int T, int D, float rope_coef, long pos0, hipStream_t stream);
 
 // ---- rvq.hip ----------------------------------------------------------------------------------
 // packed codebook for one level: [D/8][n_codes][2][4] floats followed by nothing; e2: [n_codes]

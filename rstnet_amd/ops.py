@@ -140,6 +140,9 @@ SKINNY_F32_MAX_ROWS = 128
 # instruction with every fp32 operand split into three bf16 planes (rst_gemm_win_b3_f32: six products per fp32 product, fp32
 # accuracy, 2.7x the f32 instruction's rate).  False: the f32 matrix instruction everywhere (the A/B switch of tools/ab.py).
 GEMM_B3 = True
+# End-to-end streaming (pipeline.StreamingPipeline): encode -> LM frame -> decode as ONE captured graph per frame once the delay line is
+# full.  False: the three module calls with their own graphs (the A/B switch of tools/ab.py).
+PIPELINE_FUSE = True
 _b3_weights = _PackedWeights()
 
 
@@ -457,6 +460,41 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, pos0: int = 
         return out
     _lib.check(_lib.lib().rst_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(pos_dev), pos0, B, T, H, D, cap,
                                             int(ring), int(context) if context else 0, _stream()))
+    return out
+
+
+_rope_tables: dict = {}
+# Whole-utterance passes of the codec transformers read q / k / v in place from the in-projection's output and rotate them on load
+# (rst_attention_qkv_f32).  False: rope_split + attention as two launches (the A/B switch of tools/ab.py; the streaming steps always do).
+ATTENTION_FUSED_QKV = True
+
+
+def rope_table(T: int, D: int, max_period: float, device) -> torch.Tensor:
+    """``[T, D]`` fp32: (cos, sin) of pair i of position t at ``[t, 2i]``, ``[t, 2i + 1]`` (rst_rope_table_f32; modules/rope.py:37-62).
+    Built once per (T, D, max_period, device): a whole-utterance pass launches nothing for its rotation."""
+    device = torch.device(device)
+    key = (T, D, float(max_period), device)
+    tab = _rope_tables.get(key)
+    if tab is None:
+        if len(_rope_tables) > 64:
+            _rope_tables.clear()
+        tab = torch.empty(T, D, device=device, dtype=torch.float32)
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().rst_rope_table_f32(_ptr(tab), T, D, rope_coef(max_period, D), 0, _stream()))
+        _rope_tables[key] = tab
+    return tab
+
+
+def attention_qkv(qkv: torch.Tensor, H: int, *, rope: bool = True, max_period: float = 10000.0, context: Optional[int] = None) -> torch.Tensor:
+    """qkv ``[B, T, 3*H*D]`` (the in-projection's output, "b t (p h d)") -> ``[B, T, H*D]``: causal (+ ``context``) attention over
+    positions 0 .. T-1 with interleaved RoPE applied as q / k are loaded -- the whole-utterance pass of
+    ``StreamingMultiheadAttention`` (modules/transformer.py:376-423) without the split / rotate launch and its q, k, v copies."""
+    _chk(qkv, "qkv")
+    B, T, E3 = qkv.shape
+    D = E3 // (3 * H)
+    out = torch.empty(B, T, H * D, device=qkv.device, dtype=torch.float32)
+    tab = rope_table(T, D, max_period, qkv.device) if rope else None
+    _lib.check(_lib.lib().rst_attention_qkv_f32(_ptr(qkv), _ptr(tab), _ptr(out), B, T, H, D, int(context) if context else 0, _stream()))
     return out
 
 

@@ -247,6 +247,55 @@ def test_streaming_generate_graphed_greedy_equals_eager():
     assert c["frames"].shape == a["frames"].shape and int(c["frames"][1:, 0].max()) < 30      # blanked ids never sampled at l = 0
 
 
+@pytest.mark.parametrize("B", [1, 2, 5])
+@pytest.mark.parametrize("name", ["gqa", "mha"])
+def test_gptgen_fused_step_equals_frame_then_advance(name, B, monkeypatch):
+    """`GPTGen.step` (round 5: advance of the completed frame + text sample + dep_q depth steps as ONE captured graph on a
+    device-resident token column) against the `frame` / `advance` pair `InferenceImp` uses -- sampled with the same injected noise
+    (eager), and the captured graph in greedy mode; batch 1 / 2 take the persistent depth launch, batch 5 the launch-per-op chain."""
+    from rstnet_amd.lm.generate import GPTGen
+    model, ocfg, osd, cfg_d = build(name)
+    n_codes = cfg_d["audio_card"] - 2
+    g = torch.Generator().manual_seed(B)
+    prompt = torch.randint(0, n_codes, (B, cfg_d["n_q"] + 1, 6), generator=g).to(DEV)
+    k_text, k_audio = 5, 8
+
+    def noise(kind, g_idx, l_idx):
+        gg = torch.Generator().manual_seed(1000 * g_idx + 10 * l_idx + (kind == "text"))
+        return -torch.log(torch.rand(B, k_text if kind == "text" else k_audio, generator=gg).clamp_min(1e-9))
+
+    def run(fused, use_sampling, hook):
+        gen = GPTGen(model, use_sampling=use_sampling, temp=0.8, temp_text=0.7, top_k=k_audio, top_k_text=k_text, n_audio_codes=n_codes,
+                     noise=hook)
+        gen.begin(B)
+        gen.set_blanking([False] + [True] * (cfg_d["dep_q"] - 1))
+        frames = []
+        try:
+            h, logits = gen.prefill(prompt)
+            if fused:
+                text, audio = gen.start(h, logits, 0)
+                frames.append(torch.cat([text[:, None], audio], 1).clone())
+                for _ in range(7):
+                    text, audio = gen.step()
+                    frames.append(torch.cat([text[:, None], audio], 1).clone())
+            else:
+                for g_idx in range(8):
+                    text, audio = gen.frame(h.contiguous(), logits.contiguous(), g_idx)
+                    frames.append(torch.cat([text[:, None], audio], 1).clone())
+                    h, logits = gen.advance(text, audio)
+        finally:
+            gen.end()
+        return torch.stack(frames).cpu()
+
+    ref = run(False, True, noise)
+    assert torch.equal(run(True, True, noise), ref)                 # same draws, same tokens (eager on both sides)
+    greedy = run(False, False, None)
+    assert torch.equal(run(True, False, None), greedy)              # the captured fused graph, greedy
+    monkeypatch.setenv("NO_CUDA_GRAPH", "1")
+    assert torch.equal(run(True, False, None), greedy)              # and the same function un-captured
+    assert int(greedy[:, :, 1].max()) < n_codes                     # the blanked ids of codebook 0 never come out
+
+
 def test_sampler_id_blanking():
     from oracle.gpt_generate_oracle import sample_token
     torch.manual_seed(3)
