@@ -626,13 +626,16 @@ void resblock128_b3_kernel(const ResblockB3Params p, const int tiles_u, const in
 
         // ---- GEMM2 (transposed): acc2[c][row] = sum_n W2[c][n] H[row][n]; wave (wm, wn) owns channel blocks 2 wn, 2 wn + 1
         f32x16 acc2[2], acc2x[2];                                // even / odd products: four chains
+        // the accumulators START at b2 + x (round 5): the skip operand is consumed here instead of riding through GEMM2 in 32 registers --
+        // with them the phase below needed more than the 256 a wave has, the compiler parked 5 of the 9 prefetched input vectors of the
+        // NEXT tile in scratch right behind their loads (a wait for HBM in front of GEMM1, and the tile's input through memory twice)
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(cst + 64 + 32 * wn + 32 * ci + 8 * g);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { acc2[ci][4 * g + j] = bv[j]; acc2x[ci][4 * g + j] = 0.f; }
+                for (int j = 0; j < 4; ++j) { acc2[ci][4 * g + j] = bv[j] + skip[ci * 4 + g][j]; acc2x[ci][4 * g + j] = 0.f; }
             }
         bf16x8 hb[3], w2[2][3];                                  // (one register set: a second one spills, and GEMM2 is four k-tiles)
         auto frags2 = [&](const int s, const int kl, bf16x8 (&hx)[3], bf16x8 (&w)[2][3]) {
@@ -664,7 +667,7 @@ void resblock128_b3_kernel(const ResblockB3Params p, const int tiles_u, const in
             __syncthreads();                                     // (s = 7: every wave is done with the hidden planes -> the next tile may stage)
         }
 
-        // ---- epilogue: y = x + acc2 (b2 is in the accumulators)
+        // ---- epilogue: y = acc2 (x and b2 are in the accumulators)
         const bool valid = FULL || (t_out >= 0 && t_out < T);
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
@@ -672,7 +675,7 @@ void resblock128_b3_kernel(const ResblockB3Params p, const int tiles_u, const in
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (acc2[ci][4 * g + j] + acc2x[ci][4 * g + j]) + skip[ci * 4 + g][j];
+                for (int j = 0; j < 4; ++j) v[j] = acc2[ci][4 * g + j] + acc2x[ci][4 * g + j];
                 if (p.elu_out) { v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]); }
                 if (valid) *reinterpret_cast<f32x4*>(p.y + ((long)b * T + t_out) * R8_C + 64 * wn + 32 * ci + 8 * g + 4 * h) = v;
             }

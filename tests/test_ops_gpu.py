@@ -217,6 +217,28 @@ def test_rope_attention_batch(T, context, H, D):
     assert rel_err(out, ref) < TOL
 
 
+@pytest.mark.parametrize("T,context,H,D,rope", [(250, 250, 8, 64, True), (77, 20, 2, 32, True), (300, 250, 4, 128, True), (130, None, 3, 64, False),
+                                               (1, 250, 8, 64, True), (513, 100, 2, 64, True)])
+def test_attention_fused_qkv_reads_the_projection_in_place(T, context, H, D, rope):
+    """rst_attention_qkv_f32 (round 5): the whole-utterance pass of StreamingMultiheadAttention (modules/transformer.py:376-423) with
+    q / k / v read in place from the in-projection's [B, T, 3*H*D] output and rotated on load, against the oracle's
+    rope + scaled_dot_product_attention and against the two-launch form (rope_split + attention)."""
+    g = torch.Generator().manual_seed(T + D)
+    B = 3
+    qkv = torch.randn(B, T, 3 * H * D, generator=g)
+    q, k, v = qkv.view(B, T, 3, H, D).permute(2, 0, 3, 1, 4)
+    qr, kr = (O.rope_interleaved(q.contiguous(), k.contiguous(), 0, 10000.0) if rope else (q.contiguous(), k.contiguous()))
+    ref = F.scaled_dot_product_attention(qr, kr, v, O.attention_mask(T, context)).permute(0, 2, 1, 3).reshape(B, T, H * D)
+    out = ops.attention_qkv(qkv.to(DEV), H, rope=rope, context=context)
+    assert rel_err(out, ref) < TOL
+    two = ops.attention(*ops.rope_split(qkv.to(DEV), H, rope=rope), context=context)
+    assert rel_err(out, two) < 2e-6
+    tab = ops.rope_table(T, D, 10000.0, DEV)                          # the table holds what rope_split evaluates per element
+    ang = torch.exp(torch.arange(D // 2, dtype=torch.float32) * ops.rope_coef(10000.0, D))[None] * torch.arange(T, dtype=torch.float32)[:, None]
+    # (an ulp of the frequency times positions up to T: ~T * 1e-7 on the angle)
+    assert rel_err(tab[:, 0::2], torch.cos(ang)) < 2e-4 and rel_err(tab[:, 1::2], torch.sin(ang)) < 2e-4
+
+
 def test_rvq_search_bit_exact_vs_c_oracle_and_reference():
     sd = synth.mimi_state_dict(cases.MIMI_SEED)
     cfg = O.MimiConfig()
