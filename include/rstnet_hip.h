@@ -204,6 +204,19 @@ int rst_rvq_search_f32(const float* x, const float* emb, const float* packed, co
                        float* dist, uint64_t* keys, int M, int F, int ldx, int D, int n_codes, int L, int n_groups,
                        const int* group_begin, const int* group_count, rst_stream_t stream);
 
+/* The few-frame streaming form as ONE launch for all levels (+ a one-workgroup finish launch): the workgroups of a (group, 32-frame
+ * tile) -- one per 128 codes, all resident -- hand every level's decision over in-kernel (each publishes its best (score, index) key
+ * per frame into its slot of `slots`, sweeps all slices' slots and takes the minimum; the residual stays in LDS).  Same k-ordered
+ * scores, same tie rule: codes and `dist` bit-identical to rst_rvq_search_f32.  slots: rst_rvq_chain_slot_elems(M, n_codes, L) uint64,
+ * all-ones before the first call, re-armed by every call.  status uint32[4] (zeroed once): [0] time-out code of a workgroup whose
+ * peers were not resident (waits are bounded by the wall clock), [1] calls the finish launch had to recompute on its own (outputs are
+ * right either way), [2] OR of their codes -- the convention of rst_depth_decode_frame.  Needs n_codes / 128 * n_groups * ceil(M / 32)
+ * <= CUs.  Replaces the residual loop of SplitResidualVectorQuantizer.encode per streamed frame (moshi/models/compression.py:368-389). */
+int rst_rvq_chain_slot_elems(int M, int n_codes, int L);   /* -1: bad sizes */
+int rst_rvq_search_chain_f32(const float* x, const float* emb, const float* packed, const float* e2, int64_t* codes, float* dist,
+                             uint64_t* slots, uint32_t* status, int M, int F, int ldx, int D, int n_codes, int L, int n_groups,
+                             const int* group_begin, const int* group_count, rst_stream_t stream);
+
 /* Sum of codebook rows per group = ResidualVectorQuantization.decode (core_vq.py:378-384): out [M][n_groups*D]. */
 int rst_rvq_gather_f32(const int64_t* codes, const float* emb, float* out, int M, int F, int D, int n_codes, int L,
                        int n_groups, const int* group_begin, const int* group_count, rst_stream_t stream);

@@ -111,6 +111,8 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const Attenti
     const float* kb = QKV ? p.k + b * p.T * RS + (long)head * D : p.k + ((b * p.H + head) * p.cap) * (long)D;
     const float* vb = QKV ? p.v + b * p.T * RS + (long)head * D : p.v + ((b * p.H + head) * p.cap) * (long)D;
     const bool rot = QKV && p.rope_tab != nullptr;
+    // (unconditional loads: without a table the same reads go to a valid address -- the first query row -- and are never used)
+    const float* const tabp = rot ? p.rope_tab : qb;
 
     f32x4 qf[KS];
     {
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const Attenti
 #pragma unroll
         for (int s = 0; s < KS; ++s) {   // rows past T: a clamped (valid) row, never stored -- unconditional loads, all in flight at once
             qf[s] = *reinterpret_cast<const f32x4*>(qb + (long)qrow * RS + 8 * s + 4 * h);
-            if (QKV) qt[s] = *reinterpret_cast<const f32x4*>(p.rope_tab + (rot ? (long)qrow * D + 8 * s + 4 * h : 0));
+            if (QKV) qt[s] = *reinterpret_cast<const f32x4*>(tabp + (rot ? (long)qrow * D + 8 * s + 4 * h : 0));
         }
         if (QKV && rot) {
 #pragma unroll
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64 * ATT_WAVES) void attention_kernel(const Attenti
             const int row = min(s0 + idx / (D / 4), p.cap - 1), c4 = (idx % (D / 4)) * 4;
             kreg[i] = *reinterpret_cast<const f32x4*>(kb + (long)row * RS + c4);
             vreg[i] = *reinterpret_cast<const f32x4*>(vb + (long)row * RS + c4);
-            if (QKV) treg[i] = *reinterpret_cast<const f32x4*>(p.rope_tab + (rot ? (long)row * D + c4 : 0));      // (slot = position: pos0 == 0)
+            if (QKV) treg[i] = *reinterpret_cast<const f32x4*>(tabp + (rot ? (long)row * D + c4 : 0));      // (slot = position: pos0 == 0)
         }
     };
     auto stage = [&](int buf) {

@@ -203,6 +203,27 @@ int rst_rvq_search_f32(const float* x, const float* emb, const float* packed, co
     return rst_launch_rvq_search(p, (hipStream_t)stream);
 }
 
+int rst_rvq_chain_slot_elems(int M, int n_codes, int L) {
+    if (M <= 0 || n_codes <= 0 || L <= 0 || (long)L * ((M + 31) / 32 * 32) * rst_rvq_chain_slices(n_codes) > 0x7fffffffL) return -1;
+    return L * ((M + 31) / 32 * 32) * rst_rvq_chain_slices(n_codes);
+}
+
+int rst_rvq_search_chain_f32(const float* x, const float* emb, const float* packed, const float* e2, int64_t* codes, float* dist,
+                             uint64_t* slots, uint32_t* status, int M, int F, int ldx, int D, int n_codes, int L, int n_groups,
+                             const int* group_begin, const int* group_count, rst_stream_t stream) {
+    RST_REQUIRE(n_groups >= 1 && n_groups <= 2 && group_begin && group_count, "rvq_search_chain: bad groups");
+    RvqSearchParams p;
+    p.x = x; p.emb = emb; p.packed = packed; p.e2 = e2; p.codes = (long*)codes; p.dist = dist;
+    p.M = M; p.F = F; p.ldx = ldx; p.D = D; p.n_codes = n_codes; p.L = L; p.n_groups = n_groups;
+    for (int g = 0; g < 2; ++g) {
+        p.group_begin[g] = g < n_groups ? group_begin[g] : 0;
+        p.group_count[g] = g < n_groups ? group_count[g] : 0;
+        RST_REQUIRE(p.group_begin[g] >= 0 && p.group_count[g] >= 0 && p.group_begin[g] + p.group_count[g] <= L,
+                    "rvq_search_chain: group %d out of range", g);
+    }
+    return rst_launch_rvq_search_chain(p, (unsigned long long*)slots, (unsigned*)status, (hipStream_t)stream);
+}
+
 int rst_rvq_gather_f32(const int64_t* codes, const float* emb, float* out, int M, int F, int D, int n_codes, int L,
                        int n_groups, const int* group_begin, const int* group_count, rst_stream_t stream) {
     RST_REQUIRE(n_groups >= 1 && n_groups <= 2 && group_begin && group_count, "rvq_gather: bad groups");

@@ -970,7 +970,7 @@ static bool b3_dirw() {
 // condition a barrier enforces checked against per-slot arrival counters in LDS with a full stage of slack.  Parity-green and 5 - 15 %
 // SLOWER on every layer (181 vs 196 TFLOP/s, profiles/r05_b3_ring_vs_barrier.txt): waves that drift apart no longer share the weight
 // fragments in the L1, and the counter traffic costs more than the barrier it replaces.  The kernel is kept as
-// tools/probes/b3_ring_kernel.hip.inc, not in the library.)
+// tools/probes/b3_ring_kernel.hip, not in the library.)
 
 template <int TM, int TN, int WM, int WN, int KB = BK>
 int launch_cfg(const GemmWinParams& p, bool vec, hipStream_t stream) {
@@ -1064,16 +1064,17 @@ int launch_stream_b3_cfg(const GemmWinParams& p, hipStream_t stream) {
     // launches run one after the other.)
     const bool lean = p.P == 0 && M % 128 == 0 && p.N % BN == 0 && (long)(p.T_out - 1) * p.S * p.C + p.K <= (long)p.T_in * p.C;
 #ifdef RST_ABLATION
+    // (the ablation instances of the SHIPPED form: weight fragments direct; RST_B3_DIRW=0 has no ablation instances)
     static const int dbg = rst_knob("RST_B3_DBG", 0);
-    if (dbg == 1) { go(gemm_win_b3_stream_kernel<false, true, NWN, 1>); return rst_check_launch("gemm_win_b3"); }
-    if (dbg == 2) { go(gemm_win_b3_stream_kernel<false, true, NWN, 2>); return rst_check_launch("gemm_win_b3"); }
-    if (dbg == 3) { go(gemm_win_b3_stream_kernel<false, true, NWN, 3>); return rst_check_launch("gemm_win_b3"); }
-    if (dbg == 4) { go(gemm_win_b3_stream_kernel<false, true, NWN, 4>); return rst_check_launch("gemm_win_b3"); }
-    if (dbg == 5) { go(gemm_win_b3_stream_kernel<false, true, NWN, 5>); return rst_check_launch("gemm_win_b3"); }
+    if (dirw && dbg == 1) { go(gemm_win_b3_stream_kernel<false, true, NWN, 1, true, true>); return rst_check_launch("gemm_win_b3"); }
+    if (dirw && dbg == 2) { go(gemm_win_b3_stream_kernel<false, true, NWN, 2, true, true>); return rst_check_launch("gemm_win_b3"); }
+    if (dirw && dbg == 3) { go(gemm_win_b3_stream_kernel<false, true, NWN, 3, true, true>); return rst_check_launch("gemm_win_b3"); }
+    if (dirw && dbg == 4) { go(gemm_win_b3_stream_kernel<false, true, NWN, 4, true, true>); return rst_check_launch("gemm_win_b3"); }
+    if (dirw && dbg == 5) { go(gemm_win_b3_stream_kernel<false, true, NWN, 5, true, true>); return rst_check_launch("gemm_win_b3"); }
     static const int bufl = rst_knob("RST_B3_BUF", 1);        // 0: plain global loads (64-bit addresses on the vector unit)
-    if (!bufl && p.act_in != 1) {
-        if (lean) go(gemm_win_b3_stream_kernel<false, false, NWN, 0, false>);
-        else go(gemm_win_b3_stream_kernel<false, true, NWN, 0, false>);
+    if (!bufl && dirw && p.act_in != 1) {
+        if (lean) go(gemm_win_b3_stream_kernel<false, false, NWN, 0, false, true>);
+        else go(gemm_win_b3_stream_kernel<false, true, NWN, 0, false, true>);
         return rst_check_launch("gemm_win_b3");
     }
 #endif

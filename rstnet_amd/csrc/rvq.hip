@@ -294,6 +294,206 @@ __global__ __launch_bounds__(256) void rvq_finalize_kernel(const RvqSearchParams
     }
 }
 
+// ---- few-frame path, ONE launch for all levels (round 5) ---------------------------------------------------------------------------
+// The per-level launches above cost a kernel boundary per residual level (7 dependent launches of ~13 us per 80 ms frame, ~26 us each
+// at 32 streams: every launch re-derives the residual from x with `step` gathers per element).  Here the workgroups of a (group, frame
+// tile) -- one per 128-code slice, all resident: at most a few dozen of them -- stay in the launch and hand the level's decision over
+// in-kernel, the data being the flag (persist.h's form): every workgroup publishes its slice's best (score, index) key per frame as ONE
+// 8-byte relaxed agent-scope store into its own slot, sweeps the slots of all slices until none is empty (all ones: no key is), and takes
+// the minimum itself -- lowest score, then lowest index, exactly the atomicMin's decision.  The residual stays in LDS and is updated
+// with ONE gather per element and level, in level order (the same sequence of exact subtractions).  Scores come from the same
+// k-ordered MFMA chain: codes and winning scores are bit-identical to the other two forms and to oracle/rvq_ref.c.
+// Every spin is bounded by the wall clock; a timed-out workgroup ORs a code into status[0].  The finish launch behind it (one
+// workgroup) re-arms the slots and, if status[0] is set, recomputes every (group, tile) alone -- all slices in a loop, minimum in
+// LDS: it waits for nobody -- before it counts the repair in status[1] (ops.persistent_poll retires the path on a device that repairs).
+constexpr long long RVQ_TIMEOUT_TICKS = 10000000;       // of the 100 MHz wall clock: 0.1 s
+#define RVQ_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// best key of frame j (lanes j and j + 32 of the wave agree) over the wave's 32 codes c0 .. c0 + 31 of level `lvl`
+__device__ __forceinline__ unsigned long long rvq_wave_best(const RvqSearchParams& p, const float* r_pk, int LD, int lvl, int c0, int lane) {
+    const int D = p.D;
+    const int j = lane & 31, h = lane >> 5;
+    const float* packed = p.packed + (long)lvl * p.n_codes * D;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const float* ap = packed + (long)(c0 + j) * 8 + h * 4;
+    const float* rrow = r_pk + j * LD + h * 4;
+    constexpr int UN = 16;
+    for (int kq0 = 0; kq0 < D / 8; kq0 += UN) {
+        f32x4 a[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            a[u] = kq0 + u < D / 8 ? *reinterpret_cast<const f32x4*>(ap + (long)(kq0 + u) * p.n_codes * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (kq0 + u < D / 8) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(rrow + (kq0 + u) * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], bq[e], acc, 0, 0, 0);
+            }
+        }
+    }
+    float best = INFINITY;
+    int bidx = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int code = c0 + rst_mfma32_row(r, lane);
+        const float sc = fmaf(-2.0f, acc[r], p.e2[(long)lvl * p.n_codes + code]);
+        if (sc < best) { best = sc; bidx = code; }
+    }
+    const float ob = __shfl_xor(best, 32);
+    const int oi = __shfl_xor(bidx, 32);
+    if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    return rvq_key(best, bidx);
+}
+
+// All levels of group g for the frame tile at m0.  SOLO: this workgroup takes every slice itself (the repair form); otherwise slice
+// `slice` of `ns`, hand-offs through `slots` [L][Mpad][ns].
+template <bool SOLO>
+__device__ __forceinline__ void rvq_chain_body(const RvqSearchParams& p, unsigned long long* slots, unsigned* status, float* smem,
+                                               const int g, const int m0, const int slice, const int ns, const int Mpad) {
+    const int D = p.D, LD = D + 4;
+    float* r_pk = smem;                                                        // [FR][LD]
+    unsigned long long* wbest = reinterpret_cast<unsigned long long*>(r_pk + FR * LD);     // [4 waves][FR]
+    unsigned long long* fbest = wbest + 4 * FR;                                // [FR] the level's decision
+    int* dead = reinterpret_cast<int*>(fbest + FR);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frv = min(FR, p.M - m0);
+    if (tid == 0) *dead = 0;
+    for (int idx = tid; idx < FR * D; idx += 256) {
+        const int f = idx / D, k = idx - f * D;
+        r_pk[f * LD + pk_off(k)] = f < frv ? p.x[(long)(m0 + f) * p.ldx + g * D + k] : 0.f;
+    }
+    __syncthreads();
+    for (int li = 0; li < p.group_count[g]; ++li) {
+        const int lvl = p.group_begin[g] + li;
+        // ---- this workgroup's best key per frame
+        if (SOLO) {
+            if (tid < FR) fbest[tid] = ~0ull;
+            __syncthreads();
+            for (int sl = 0; sl < ns; ++sl) {
+                const int c0 = (sl * 4 + wave) * 32;
+                unsigned long long k = ~0ull;
+                if (c0 < p.n_codes) k = rvq_wave_best(p, r_pk, LD, lvl, c0, lane);
+                if (lane < 32) wbest[wave * FR + lane] = k;
+                __syncthreads();
+                if (tid < FR) {
+                    unsigned long long k4 = fbest[tid];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) k4 = wbest[w * FR + tid] < k4 ? wbest[w * FR + tid] : k4;
+                    fbest[tid] = k4;
+                }
+                __syncthreads();
+            }
+        } else {
+            const int c0 = (slice * 4 + wave) * 32;
+            unsigned long long k = ~0ull;
+            if (c0 < p.n_codes) k = rvq_wave_best(p, r_pk, LD, lvl, c0, lane);
+            if (lane < 32) wbest[wave * FR + lane] = k;
+            __syncthreads();
+            unsigned long long* sl_base = slots + ((long)lvl * Mpad + m0) * ns;
+            if (tid < FR) {
+                unsigned long long k4 = wbest[tid];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) k4 = wbest[w * FR + tid] < k4 ? wbest[w * FR + tid] : k4;
+                __hip_atomic_store(sl_base + (long)tid * ns + slice, k4, RVQ_RLX);       // (a slice beyond the codebook cannot exist: ns = ceil(n_codes / 128))
+            }
+            // ---- the level's decision: minimum over the slices' slots.  Thread t: frame t / 8, slices (t % 8), (t % 8) + 8, ...
+            const int f = tid >> 3, s0 = tid & 7;
+            unsigned long long mine = ~0ull;
+            long long t0 = 0;
+            for (int sl = s0; sl < ns; sl += 8) {
+                unsigned long long v;
+                while (true) {
+                    v = __hip_atomic_load(sl_base + (long)f * ns + sl, RVQ_RLX);
+                    if (v != ~0ull) break;
+                    if (t0 == 0) t0 = wall_clock64();
+                    if (*(volatile int*)dead || wall_clock64() - t0 > RVQ_TIMEOUT_TICKS) {
+                        *dead = 1;
+                        atomicOr(status, 1u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                mine = v < mine ? v : mine;
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                const unsigned long long other = __shfl_xor(mine, o);
+                mine = other < mine ? other : mine;
+            }
+            if (s0 == 0) fbest[f] = mine;
+            __syncthreads();
+        }
+        // ---- codes / winning scores (one writer per frame), then the residual of the next level: one gather per element
+        if ((SOLO || slice == 0) && tid < frv) {
+            const unsigned long long kv = fbest[tid];
+            int code = (int)(kv & 0xffffffffu);
+            if (code < 0 || code >= p.n_codes) code = 0;        // only reachable with NaN inputs
+            const int m = m0 + tid;
+            const int b = m / p.F, fr = m - b * p.F;
+            p.codes[((long)b * p.L + lvl) * p.F + fr] = code;
+            if (p.dist) {
+                unsigned u = (unsigned)(kv >> 32);
+                u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+                p.dist[(long)lvl * p.M + m] = __uint_as_float(u);
+            }
+        }
+        if (li + 1 < p.group_count[g]) {
+            const float* emb = p.emb + (long)lvl * p.n_codes * D;
+            constexpr int U = 8;
+            for (int idx0 = tid; idx0 < frv * D; idx0 += 256 * U) {
+                float e[U];
+                int fk[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = min(idx0 + u * 256, frv * D - 1);
+                    const int f = idx / D, k = idx - f * D;
+                    int code = (int)(fbest[f] & 0xffffffffu);
+                    if (code < 0 || code >= p.n_codes) code = 0;
+                    fk[u] = f * LD + pk_off(k);
+                    e[u] = emb[(long)code * D + k];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (idx0 + u * 256 < frv * D) r_pk[fk[u]] -= e[u];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void rvq_chain_kernel(const RvqSearchParams p, unsigned long long* __restrict__ slots, unsigned* __restrict__ status,
+                                                        int ns, int Mpad) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < ns && p.group_count[blockIdx.y] > 0)
+        rvq_chain_body<false>(p, slots, status, smem, blockIdx.y, blockIdx.z * FR, blockIdx.x, ns, Mpad);
+}
+
+// one workgroup behind the chain launch: repair (if any workgroup timed out) and re-arm the slots for the next call
+__global__ __launch_bounds__(256) void rvq_chain_finish_kernel(const RvqSearchParams p, unsigned long long* __restrict__ slots, unsigned* __restrict__ status,
+                                                               int ns, int Mpad) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ unsigned code;
+    if (threadIdx.x == 0) code = __hip_atomic_load(status, RVQ_RLX);
+    __syncthreads();
+    if (code != 0) {
+        for (int g = 0; g < p.n_groups; ++g)
+            for (int m0 = 0; m0 < p.M; m0 += FR) {
+                rvq_chain_body<true>(p, slots, status, smem, g, m0, 0, ns, Mpad);
+                __syncthreads();
+            }
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(status + 1, 1u, RVQ_RLX);
+            __hip_atomic_fetch_or(status + 2, code, RVQ_RLX);
+            __hip_atomic_store(status, 0u, RVQ_RLX);
+        }
+    }
+    const long total = (long)p.L * Mpad * ns;
+    for (long i = threadIdx.x; i < total; i += 256) slots[i] = ~0ull;
+}
+
 __global__ __launch_bounds__(256) void rvq_gather_kernel(const RvqGatherParams p) {
     const int ND = p.n_groups * p.D;
     const long total = (long)p.M * ND;
@@ -364,6 +564,27 @@ int rst_launch_rvq_search_small(const RvqSearchParams& p, unsigned long long* ke
     long g = ((long)p.L * p.M + 255) / 256;
     hipLaunchKernelGGL(rvq_finalize_kernel, dim3((unsigned)(g > 64 ? 64 : g)), dim3(256), 0, stream, p, keys);
     return rst_check_launch("rvq_finalize");
+}
+
+int rst_rvq_chain_slices(int n_codes) { return (n_codes + 127) / 128; }
+
+int rst_launch_rvq_search_chain(const RvqSearchParams& p, unsigned long long* slots, unsigned* status, hipStream_t stream) {
+    if (p.M == 0) return RST_OK;
+    RST_REQUIRE(p.x && p.emb && p.packed && p.e2 && p.codes && slots && status, "rvq_search_chain: null pointer");
+    RST_REQUIRE(p.F > 0 && p.D > 0 && p.D % 8 == 0 && p.n_codes > 0 && p.n_codes % 32 == 0 && p.M % p.F == 0 &&
+                    p.n_groups >= 1 && p.n_groups <= 2,
+                "rvq_search_chain: need D %% 8 == 0 and n_codes %% 32 == 0 (D=%d n_codes=%d)", p.D, p.n_codes);
+    const int ns = rst_rvq_chain_slices(p.n_codes);
+    const int mt = (p.M + FR - 1) / FR;
+    // every workgroup waits for its peers of the same (group, tile): they must all be resident -- a few dozen on an idle device
+    RST_REQUIRE(ns <= 64 && (long)ns * p.n_groups * mt <= rst_cu_count(), "rvq_search_chain: %d x %d x %d workgroups exceed the CUs", ns, p.n_groups, mt);
+    const size_t lds = ((size_t)FR * (p.D + 4)) * sizeof(float) + (5 * FR) * sizeof(unsigned long long) + 16;
+    RST_REQUIRE(lds <= 64 * 1024, "rvq_search_chain: D=%d needs %zu bytes of LDS", p.D, lds);
+    hipLaunchKernelGGL(rvq_chain_kernel, dim3(ns, p.n_groups, mt), dim3(256), lds, stream, p, slots, status, ns, mt * FR);
+    int rc = rst_check_launch("rvq_chain");
+    if (rc) return rc;
+    hipLaunchKernelGGL(rvq_chain_finish_kernel, dim3(1), dim3(256), lds, stream, p, slots, status, ns, mt * FR);
+    return rst_check_launch("rvq_chain_finish");
 }
 
 int rst_launch_rvq_gather(const RvqGatherParams& p, hipStream_t stream) {

@@ -516,6 +516,12 @@ def _int_array(vals: Sequence[int]):
 _rvq_keys: dict = {}
 
 
+# Streaming RVQ (<= 64 frames per call): all residual levels in ONE launch with in-kernel hand-offs between the code slices'
+# workgroups (rst_rvq_search_chain_f32).  False: one launch per level (the A/B switch of tools/ab.py).
+RVQ_CHAIN = True
+_rvq_slots: dict = {}
+
+
 def rvq_search(x: torch.Tensor, emb: torch.Tensor, packed: torch.Tensor, e2: torch.Tensor, B: int, F: int,
                groups: Sequence[Tuple[int, int]], return_dist: bool = False):
     """x ``[B*F, n_groups*D]`` projected latents -> codes ``[B, L, F]`` int64 (levels outside ``groups`` untouched)."""
@@ -528,6 +534,16 @@ def rvq_search(x: torch.Tensor, emb: torch.Tensor, packed: torch.Tensor, e2: tor
     codes = (torch.empty if covered else torch.zeros)(B, L, F, device=x.device, dtype=torch.int64)
     dist = torch.zeros(L, M, device=x.device, dtype=torch.float32) if return_dist else None
     keys = None
+    if 0 < M <= 64 and RVQ_CHAIN and n_codes % 128 == 0 and depth_frame_enabled(x.device):
+        # streaming step, ONE launch for all levels (+ its one-workgroup finish launch): the slices' workgroups hand every level's
+        # decision over in-kernel (rst_rvq_search_chain_f32); a device that had to repair falls back to the launch-per-level form below
+        n_slots = int(_lib.lib().rst_rvq_chain_slot_elems(M, n_codes, L))
+        sc = _scratch(_rvq_slots, x.device, (L, M, n_codes),
+                      lambda: (torch.full((n_slots,), -1, device=x.device, dtype=torch.int64), new_persistent_status(x.device)))
+        _lib.check(_lib.lib().rst_rvq_search_chain_f32(_ptr(x), _ptr(emb), _ptr(packed), _ptr(e2), _ptr(codes), _ptr(dist), _ptr(sc[0]), _ptr(sc[1]),
+                                                       M, max(F, 1), x.shape[1], D, n_codes, L, len(groups), _int_array([g[0] for g in groups]),
+                                                       _int_array([g[1] for g in groups]), _stream()))
+        return (codes, dist) if return_dist else codes
     if 0 < M <= 64:     # streaming step: the few-frame form (codes spread over workgroups)
         keys = _scratch(_rvq_keys, x.device, (L, M), lambda: torch.full((L, M), -1, device=x.device, dtype=torch.int64))
     _lib.check(_lib.lib().rst_rvq_search_f32(_ptr(x), _ptr(emb), _ptr(packed), _ptr(e2), _ptr(codes), _ptr(dist), _ptr(keys), M, max(F, 1),

@@ -25,6 +25,7 @@ class StreamingPipeline:
         from . import ops
         self.fuse = bool(ops.PIPELINE_FUSE)     # one graph per frame once the delay line is full (False: the three module calls, as the reference loops)
         self._fused, self._fused_epoch = None, -1
+        self.last_codes: Optional[torch.Tensor] = None      # what the encoder emitted for the last frame, [B, K, 1] (valid until the next step)
 
     def __enter__(self):
         # encode touches only the encoder-side modules' states and decode only the decoder-side ones: one context serves both
@@ -44,6 +45,7 @@ class StreamingPipeline:
         cloning or re-staging of the codes / tokens between them."""
         B = self.batch_size
         codes = self.mimi.quantizer.encode_nlc(self.mimi.encode_latent(pcm))          # [B, K, 1]
+        self.last_codes = codes         # (inside the graph: a static buffer every replay refills)
         out, _ = self.lm_gen._frame(codes[:, :self.n_user, 0].contiguous())            # [B, 1 + dep_q]
         return self.mimi._decode(out[:, 1:].reshape(B, -1, 1))
 
@@ -73,6 +75,7 @@ class StreamingPipeline:
                 state.offset += 1
                 return wav.clone()
         codes = self.mimi.encode(pcm)                                   # [B, 8, 1]
+        self.last_codes = codes
         tokens = self.lm_gen.step(codes[:, :self.n_user].contiguous())  # [B, 1 + dep_q, 1] or None
         if tokens is None:
             return None

@@ -281,6 +281,45 @@ def test_rvq_search_ragged_sizes(M, F_):
     assert torch.equal(dist.cpu(), torch.from_numpy(d_ref))
 
 
+@pytest.mark.parametrize("M,F_,n_codes,D,groups", [(1, 1, 2048, 256, [(0, 1), (1, 7)]), (2, 2, 2048, 256, [(0, 1), (1, 7)]), (32, 1, 2048, 256, [(0, 1), (1, 7)]),
+                                                   (33, 33, 256, 16, [(0, 3)]), (64, 2, 2048, 256, [(0, 1), (1, 7)]), (5, 5, 128, 32, [(0, 4)])])
+def test_rvq_chain_one_launch_for_all_levels(M, F_, n_codes, D, groups, monkeypatch):
+    """rst_rvq_search_chain_f32 (round 5): the streaming form with ALL residual levels in one launch (in-kernel hand-offs between the code
+    slices' workgroups) against the C oracle and against the launch-per-level form -- codes AND winning scores bit for bit; then the
+    repair path: a time-out code planted in the status word makes the finish launch recompute everything alone, same bits, counted."""
+    g = torch.Generator().manual_seed(M + n_codes)
+    L = sum(n for _, n in groups)
+    emb = torch.randn(L, n_codes, D, generator=g)
+    x = torch.randn(M, len(groups) * D, generator=g)
+    embg = emb.to(DEV)
+    packed, e2 = ops.rvq_pack(embg)
+    monkeypatch.setattr(ops, "RVQ_CHAIN", True)
+    codes, dist = ops.rvq_search(x.to(DEV), embg, packed, e2, M // F_, F_, groups, return_dist=True)
+    key = next(k for k in ops._rvq_slots if k[-3:] == (L, M, n_codes) and k[1] != "graph")
+    slots, status = ops._rvq_slots[key]
+    torch.cuda.synchronize()
+    assert status.tolist() == [0, 0, 0, 0] and bool((slots == -1).all())          # nothing timed out; the slots are re-armed
+    refs = []
+    for gi, (g0, n) in enumerate(groups):
+        c_ref, d_ref = rvq_ref.rvq_search(x[:, gi * D:(gi + 1) * D].contiguous().numpy(), emb[g0:g0 + n].numpy())
+        refs.append((g0, n, torch.from_numpy(c_ref), torch.from_numpy(d_ref)))
+        assert torch.equal(codes[:, g0:g0 + n].cpu(), torch.from_numpy(c_ref).view(n, M // F_, F_).transpose(0, 1))
+        assert torch.equal(dist[g0:g0 + n].cpu(), torch.from_numpy(d_ref))
+    monkeypatch.setattr(ops, "RVQ_CHAIN", False)
+    codes2, dist2 = ops.rvq_search(x.to(DEV), embg, packed, e2, M // F_, F_, groups, return_dist=True)
+    assert torch.equal(codes, codes2) and torch.equal(dist, dist2)
+    # a second call reuses the re-armed slots; then the planted time-out
+    monkeypatch.setattr(ops, "RVQ_CHAIN", True)
+    codes3 = ops.rvq_search(x.to(DEV), embg, packed, e2, M // F_, F_, groups)
+    assert torch.equal(codes3, codes)
+    status[0] = 1
+    codes4, dist4 = ops.rvq_search(x.to(DEV), embg, packed, e2, M // F_, F_, groups, return_dist=True)
+    torch.cuda.synchronize()
+    assert torch.equal(codes4, codes) and torch.equal(dist4, dist)
+    assert status.tolist() == [0, 1, 1, 0] and bool((slots == -1).all())
+    status.zero_()
+
+
 def test_rvq_tie_takes_lowest_index():
     emb = torch.randn(1, 64, 16)
     emb[0, 40] = emb[0, 7]  # exact duplicate rows -> exact tie

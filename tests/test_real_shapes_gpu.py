@@ -383,13 +383,10 @@ def test_streaming_pipeline_32_streams_matches_composed_oracles():
     pcm = synth.synth_audio(B, frames * 1920, seed=77)
     outs, seen_codes = [], []
     with StreamingPipeline(mimi, gen, B) as pipe:
-        enc = pipe.mimi.encode
-        pipe.mimi.encode = lambda x: (lambda c: (seen_codes.append(c.cpu()), c)[1])(enc(x))      # record what the GPU encoder emitted
-        try:
-            for f in range(frames):
-                outs.append(pipe.step(pcm[:, :, f * 1920:(f + 1) * 1920].contiguous().to(DEV)))
-        finally:
-            del pipe.mimi.encode
+        for f in range(frames):
+            outs.append(pipe.step(pcm[:, :, f * 1920:(f + 1) * 1920].contiguous().to(DEV)))
+            seen_codes.append(pipe.last_codes.cpu().clone())                # what the GPU encoder emitted (module calls, then the fused frame graph)
+        assert pipe._fused is not None and pipe._fused.graph is not None     # the last frames ran as ONE captured graph (round 5)
     assert outs[0] is None and all(o is not None and o.shape == (B, 1, 1920) for o in outs[1:])
     got = torch.cat([o.cpu() for o in outs[1:]], -1)
     gpu_codes = torch.cat(seen_codes, -1)                                   # [B, 8, frames]

@@ -96,7 +96,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = codec ] || [ "$WHAT" = b3 ]; then
   need_ablation
   if [ -f rstnet_amd/librstnet_hip_ablation.so ]; then
     : > "$O/b3_ablation.txt"
-    for v in "RST_B3_DBG=0 full" "RST_B3_WGS=1 one_workgroup_per_cu_(128-wide_form)" "RST_B3_WIDE=0 128-wide_tiles_only" "RST_B3_DBG=5 lds_writes_of_unsplit_bits_(no_split_VALU)" "RST_B3_DBG=1 no_split_no_lds_writes" "RST_B3_DBG=2 no_global_loads" "RST_B3_DBG=3 matrix_instructions_only" "RST_B3_DBG=4 no_barriers" "RST_B3_BUF=0 plain_global_loads"; do
+    for v in "RST_B3_DBG=0 full" "RST_B3_DIRW=0 weights_staged_through_LDS_(round_4_form)" "RST_B3_WIDE=0 128-wide_tiles_only" "RST_B3_DBG=5 lds_writes_of_unsplit_bits_(no_split_VALU)" "RST_B3_DBG=1 no_split_no_lds_writes" "RST_B3_DBG=2 no_global_loads" "RST_B3_DBG=3 matrix_instructions_only" "RST_B3_DBG=4 no_barriers"; do
       set -- $v
       env "$1" python tools/ab.py LIB=rstnet_amd/librstnet_hip_ablation.so -- --steps 6 --warmup 2 --no-sub --no-cpu-baseline --no-check --timing-samples 1 2>/dev/null | python -c "
 import json,sys
