@@ -265,12 +265,21 @@ def _sample_steps(step, n):
     return out
 
 
+def _quiesce_host():
+    """Before a timed region: collect what earlier sub-benchmarks left behind NOW (captured graphs of a finished session are destroyed
+    when the cycle collector finds them -- tens of milliseconds if that happens inside the next timed loop)."""
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+
+
 def _timed_loop(step, warmup, steps, world, dev):
     """The contract's timing: `warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides,
     MAX over ranks.  `step(i)` runs step number i (0-based over warm-up + timed)."""
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
+    _quiesce_host()
     if _dist(world):
         import torch.distributed as dist
         dist.barrier()
@@ -509,6 +518,7 @@ def run_gpt(args, rank, world, dev, gpt=None, fp8=None, steps=None, warmup=None,
     for _ in range(warmup):
         h, logits = frame(h, logits)
     torch.cuda.synchronize()
+    _quiesce_host()
     if _dist(world):
         import torch.distributed as dist
         dist.barrier()
