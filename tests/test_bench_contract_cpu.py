@@ -25,6 +25,10 @@ def _last_json(path):
 def test_bench_lines_exist():
     names = {os.path.basename(p) for p in LINES}
     assert {f"{TAG}_{w}_bench.json" for w in ("codec", "lm", "gpt", "e2e1")} <= names
+    if TAG >= "r05":        # round 5: the batched lines and the fp8 line have their own standalone lines, traces and counter summaries
+        assert {f"{TAG}_{w}_bench.json" for w in ("lm32", "e2e32", "gpt_fp8")} <= names
+        for w in ("lm32", "e2e32", "gpt_fp8"):
+            assert os.path.exists(os.path.join(ROOT, "profiles", f"{TAG}_{w}_kernel_stats.csv")), w
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -103,6 +107,28 @@ def test_default_line_carries_every_baseline_config():
     assert "fp8" in d["gpt_b32_fp8"]["config"]["gemm_precision"] and "fp8" not in d["gpt_b32"]["config"]["gemm_precision"]
     one = d["cpu_baseline"]["single_thread"]
     assert one["cores"] == 1 and one["value"] > 0 and one["unit"] == "frames/s" and one["sample"]
+
+
+@pytest.mark.skipif(TAG < "r05", reason="trace-backed fractions for every line: round 5")
+def test_every_line_of_the_summary_has_a_trace_backed_fraction():
+    """all eight benchmark lines carry a non-null roofline fraction below 1 that follows from a kernel trace of THAT
+    workload committed under profiles/ (the event-pair figures of the 8-20 us launches, which exceed the graph-replayed step, moved
+    to `event_pairs` and are flagged)."""
+    d = _last_json(os.path.join(ROOT, "profiles", f"{TAG}_codec_bench.json"))
+    s = d["summary"]
+    for name in ("codec_b64", "lm_b1", "e2e_b1", "lm_ctx3000", "lm_b32", "e2e_b32", "gpt_b32", "gpt_b32_fp8"):
+        assert isinstance(s[f"{name}_frac"], float) and 0 < s[f"{name}_frac"] < 1, (name, s[f"{name}_frac"])
+    assert d["roofline"]["rocprof"]["source"] == f"profiles/{TAG}_codec_kernel_stats.csv"
+    want = {"lm_b1": "lm", "e2e_b1": "e2e1", "lm_ctx3000": "lm", "lm_b32": "lm32", "e2e_b32": "e2e32", "gpt_b32": "gpt", "gpt_b32_fp8": "gpt_fp8"}
+    for name, tag in want.items():
+        r = d[name]["roofline"]
+        src = f"profiles/{TAG}_{tag}_kernel_stats.csv"
+        assert os.path.exists(os.path.join(ROOT, src)), src
+        assert r["rocprof"]["source"] == src and src in r["frac_source"], (name, r.get("frac_source"))
+        assert abs(r["frac"] - r["rocprof"]["frac"]) < 1e-9 and r["kernel_ms_per_step"] < d[name]["ms_per_step"], name
+        ev = r.get("event_pairs")
+        if ev is not None and ev.get("kernel_ms_per_step") and ev["kernel_ms_per_step"] > d[name]["ms_per_step"]:
+            assert ev.get("exceeds_step") is True       # the inflated figure is labelled, and is not the headline
 
 
 # ---- host logic of bench.py itself (no GPU needed)
