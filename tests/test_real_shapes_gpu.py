@@ -212,6 +212,52 @@ def test_temporal_layers_at_the_moshi_shape_across_the_ring_wrap(B):
     assert worst["argmax_agree"] == B * steps, worst
 
 
+def test_moshi7b_full_depth_temporal_stack_and_depth_frame_vs_the_oracle_run_by_aten():
+    """the 7B model AS A MODEL -- all 32 temporal layers (the other tests cut the stack to two: a CPU step of the
+    full model takes minutes), then the depth transformer on its output.  The oracle here is the SAME `lm_oracle` code, but executed by
+    ATen on the GPU (fp32 `F.linear` / `scaled_dot_product_attention` through rocBLAS / hipBLASLt under `torch.device`), not on the CPU:
+    an independent arithmetic (none of this build's kernels), good for what this test is after -- an error that only compounds over 32
+    layers.  fp32 rings on both sides, 6 steps from position 0, batch 2; then the 8 depth steps of the last frame, teacher-forced."""
+    cfg = dict(synth.LM_MOSHI_7B)
+    sd = synth.lm_state_dict(cfg, seed=11, device=DEV)                      # bf16, on the device: the oracle widens a weight where it uses it
+    model = LMModel.from_state_dict(sd, cfg, kv_dtype=torch.float32)
+    ocfg = L.LMConfig(**cfg)
+    B, steps = 2, 6
+    g = torch.Generator().manual_seed(77)
+    worst = {"transformer_out": 0.0, "text_logits": 0.0, "argmax_agree": 0, "depth_logits": 0.0, "layers": cfg["num_layers"]}
+    assert len(model.transformer.layers) == 32
+    with model.streaming(B), torch.no_grad():
+        with torch.device(DEV):
+            st_o = L.new_transformer_state(B, cfg["num_layers"], cfg["num_heads"], cfg["dim"] // cfg["num_heads"], cfg["context"])
+        for s_ in range(steps):
+            toks = torch.randint(0, cfg["card"], (B, cfg["n_q"] + 1, 1), generator=g)
+            toks[:, 0] = torch.randint(0, cfg["text_card"], (B, 1), generator=g)
+            toks = toks.to(DEV)
+            out, logits = model.forward_text(toks)
+            with torch.device(DEV):
+                out_o, logits_o = L.forward_text(sd, ocfg, toks, st_o)
+            worst["transformer_out"] = max(worst["transformer_out"], rel_err(out, out_o))
+            worst["text_logits"] = max(worst["text_logits"], rel_err(logits, logits_o))
+            worst["argmax_agree"] += int((logits.view(B, -1).argmax(-1) == logits_o.view(B, -1).argmax(-1)).sum())
+        # the depth transformer on the last temporal output: teacher-forced tokens, every step's logits
+        prev = torch.randint(0, cfg["card"], (B, cfg["dep_q"] + 1), generator=g).to(DEV)
+        prev[:, 0] = torch.randint(0, cfg["text_card"], (B,), generator=g).to(DEV)
+        with torch.device(DEV):
+            dst_o = L.new_transformer_state(B, cfg["depformer_num_layers"], cfg["depformer_num_heads"],
+                                            cfg["depformer_dim"] // cfg["depformer_num_heads"], cfg["dep_q"])
+        with model.depformer.streaming(B):
+            for cb in range(cfg["dep_q"]):
+                lg = model.forward_depformer(cb, prev[:, cb].view(B, 1, 1), out)
+                with torch.device(DEV):
+                    lg_o = L.forward_depformer(sd, ocfg, cb, prev[:, cb].view(B, 1, 1), out_o, dst_o)
+                worst["depth_logits"] = max(worst["depth_logits"], rel_err(lg, lg_o))
+    _record("moshi7b_full_depth_vs_aten", worst)
+    del model, sd
+    torch.cuda.empty_cache()
+    assert worst["transformer_out"] < 1e-3 and worst["text_logits"] < 1e-3 and worst["depth_logits"] < 1e-3, worst
+    assert worst["argmax_agree"] == B * steps, worst
+
+
 def test_lmgen_greedy_frames_at_the_moshi_shape_across_the_ring_wrap(monkeypatch):
     """16 greedy `LMGen.step` frames (models/model.py:490-597: token ring, temporal step, text sample, 8 depth steps, delayed output) of
     the two-temporal-layer Moshi-7B-shaped model, one captured graph per frame, with the temporal rings seeded at offset 2990 (they wrap
@@ -306,6 +352,46 @@ def test_gpt_qwen_shape_batch_32_streamed_frames_match_the_oracle():
                     d_o = Gp.forward_codecformer(osd, ocfg, k, prev, h_o, cst)
                     worst["audio_logits"] = max(worst["audio_logits"], rel_err(d, d_o))
     _record("gpt_qwen_B32_bf16_hi_lo", worst)
+    assert worst["hidden"] < 1e-3 and worst["text_logits"] < 1e-3 and worst["audio_logits"] < 1e-3, worst
+    assert worst["text_argmax_agree"] >= 31 / 32, worst
+
+
+def test_gpt_qwen_full_depth_model_matches_the_oracle():
+    """the model AS A MODEL at full depth -- all 24 global blocks of the Qwen-1.5-0.5B shape (the other tests of this
+    file cut the stack to 3), the configured 3000-slot rings, LoRA merged, batch 32: two streamed frames with the eight codecformer steps
+    of each against `gpt_oracle` (the CPU side is a 5.8 GB fp32 copy; ~1 minute).  An error that only compounds over 24 layers would
+    show here."""
+    cfg_d = dict(synth.GPT_QWEN_0_5B)
+    sd = synth.gpt_state_dict(cfg_d, seed=6)
+    model = GPT.from_state_dict({k: v.to(DEV) for k, v in sd.items()}, Config.from_dict(cfg_d))
+    del sd
+    keep = set(Gp.GPTConfig.__dataclass_fields__)
+    ocfg = Gp.GPTConfig(**{k: v for k, v in cfg_d.items() if k in keep})
+    osd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    B, frames = 32, 2
+    toks = _gpt_tokens(cfg_d, B, frames, 23)
+    st = Gp.new_global_state(ocfg, B)
+    worst = {"hidden": 0.0, "text_logits": 0.0, "audio_logits": 0.0, "text_argmax_agree": 1.0, "layers": cfg_d["n_layer"]}
+    with model.streaming(B), torch.no_grad():
+        assert model.transformer._streaming_state.k[0].shape[2] == cfg_d["context"] and len(model.transformer.h) == 24
+        for t in range(frames):
+            frame = toks[:, :, t:t + 1]
+            h, lg = model.forward_global(frame.to(DEV))
+            h, lg = h.clone(), lg.clone()
+            h_o, lg_o = Gp.forward_global(osd, ocfg, frame, st, merged=True)
+            worst["hidden"] = max(worst["hidden"], rel_err(h, h_o))
+            worst["text_logits"] = max(worst["text_logits"], rel_err(lg, lg_o))
+            worst["text_argmax_agree"] = min(worst["text_argmax_agree"], float((lg.argmax(-1).cpu() == lg_o.argmax(-1)).float().mean()))
+            cst = Gp.new_codecformer_state(ocfg, B)
+            with model.codecformer.streaming(B):
+                for k in range(ocfg.dep_q):
+                    prev = toks[:, 0:1, t:t + 1] if k == 0 else toks[:, k:k + 1, t:t + 1]
+                    d = model.forward_codecformer(k, prev.to(DEV), h)
+                    d_o = Gp.forward_codecformer(osd, ocfg, k, prev, h_o, cst)
+                    worst["audio_logits"] = max(worst["audio_logits"], rel_err(d, d_o))
+    _record("gpt_qwen_full_depth_B32", worst)
+    del model, osd
+    torch.cuda.empty_cache()
     assert worst["hidden"] < 1e-3 and worst["text_logits"] < 1e-3 and worst["audio_logits"] < 1e-3, worst
     assert worst["text_argmax_agree"] >= 31 / 32, worst
 
