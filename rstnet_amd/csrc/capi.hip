@@ -24,7 +24,8 @@ int rst_check_launch(const char* what) {
 
 extern "C" {
 
-int rst_version(void) { return 105; }      // round 4: + three-plane residual blocks, rst_gemm_win_b3_supported (strict b3 route); 105: same ABI, decode-side kernels reworked
+int rst_version(void) { return 110; }      // round 5: three-plane weights in operand order (re-pack!), + rst_attention_qkv_f32 / rst_rope_table_f32,
+                                           // rst_rvq_search_chain_f32, rst_embed_sum_bf16(add_stride); 105: round 4
 const char* rst_last_error(void) { return g_err; }
 
 static int gemm_win_common(const float* x, const float* hist, const float* w, const uint16_t* w3, const float* bias, const float* res,

@@ -121,4 +121,6 @@ if [ "$WHAT" = all ] || [ "$WHAT" = codec ]; then
   publish rb
   run codec_bench python bench.py --steps 20 --warmup 5
 fi
+# the bench lines of the sections that ran -> profiles/TAG_<workload>_bench.json (what tests/test_bench_contract_cpu.py reads)
+for f in "$O"/*_bench.out; do [ -s "$f" ] && grep -q '^{' "$f" && cp "$f" "profiles/${TAG}_$(basename "${f%.out}").json"; done
 du -sh "$O"; ls "$O"
