@@ -459,7 +459,7 @@ class LLAMAStreamingTransformer(StreamingModule[_StepState]):
         shape = (batch_size, c.n_query_groups, capacity, c.head_size)
         scratch = None
         if capacity > 64:
-            splits = max(1, min(16, capacity // 128, 1024 // max(1, batch_size * c.n_head)))
+            splits = ops.lm_attn_splits(capacity, batch_size * c.n_head)
             scratch = (torch.empty(batch_size, c.n_head, splits, c.head_size + 2, device=dev),
                        torch.zeros(batch_size, c.n_head, device=dev, dtype=torch.int32))
         return _StepState([torch.zeros(shape, device=dev) for _ in self.h], [torch.zeros(shape, device=dev) for _ in self.h],

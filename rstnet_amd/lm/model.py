@@ -144,7 +144,7 @@ class StreamingTransformer(StreamingModule[_StepState]):
         shape = (batch_size, self.num_heads, cap, self.d_model // self.num_heads)
         scratch = None
         if cap > 64:
-            splits = max(1, min(16, cap // 128, 1024 // max(1, batch_size * self.num_heads)))
+            splits = ops.lm_attn_splits(cap, batch_size * self.num_heads)
             scratch = (torch.empty(batch_size, self.num_heads, splits, shape[3] + 2, device=dev),
                        torch.zeros(batch_size, self.num_heads, device=dev, dtype=torch.int32))
         kvd = self.kv_dtype if cap > 64 else torch.float32

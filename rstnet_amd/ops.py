@@ -976,6 +976,15 @@ def rmsnorm(x: torch.Tensor, alpha: torch.Tensor, eps: float = 1e-8) -> torch.Te
     return out
 
 
+# Workgroups a (stream, head) pair's ring is split over in the single-step decode attention (rst_lm_attn_decode_f32): at most this many,
+# at least 128 slots each, ~1024 workgroups per launch (the A/B switch of tools/ab.py).
+LM_ATTN_MAX_SPLITS = 16
+
+
+def lm_attn_splits(cap: int, pairs: int) -> int:
+    return max(1, min(int(LM_ATTN_MAX_SPLITS), cap // 128, 1024 // max(1, pairs)))
+
+
 def lm_rope_append(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos_dev: torch.Tensor, *, heads: int, rope: bool,
                    max_period: float = 10000.0, rope_dims: int = 0) -> torch.Tensor:
     """qkv ``[B, T, (H+2G)*D]`` (T new steps) -> rotated q ``[B, H, T, D]``; k/v appended to ring slots ``(pos+t) % cap`` of
@@ -1022,7 +1031,7 @@ def lm_attn_decode(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     if kv16 and cap <= 64:
         raise NotImplementedError("bf16 KV rings are served by the long-ring attention (capacity > 64)")
     if splits is None:
-        splits = 1 if cap <= 64 else max(1, min(16, cap // 128, 1024 // max(1, B * H)))
+        splits = 1 if cap <= 64 else lm_attn_splits(cap, B * H)
     ws = counters = None
     if splits > 1:
         if scratch is None:
