@@ -61,6 +61,8 @@ class GPTGen:
         self._saved = None
         self._limits: Optional[torch.Tensor] = None
         self._depth: Optional[_Graphed] = None
+        self._fused: Optional[_Graphed] = None       # `step`: the whole frame as one graph on the session's token column `_col`
+        self._col: Optional[torch.Tensor] = None
         self._regime = None
         self.B = 0
 
@@ -82,6 +84,7 @@ class GPTGen:
         m = self.model
         m.transformer._streaming_state, m._streaming_state, m.codecformer._streaming_state = self._saved
         self._saved = None
+        self._fused = self._col = None       # the fused frame graph of `start` / `step` belongs to the session that ends here
 
     def _exp_noise(self, kind: str, g_idx: int, l_idx: int, B: int, k: int) -> Optional[torch.Tensor]:
         if not self.use_sampling:

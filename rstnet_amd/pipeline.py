@@ -33,9 +33,11 @@ class StreamingPipeline:
         self._mimi_ctx.__enter__()
         self._lm_ctx = self.lm_gen.streaming(self.batch_size)
         self._lm_ctx.__enter__()
+        self._fused, self._fused_epoch, self.last_codes = None, -1, None     # a graph of an earlier session points at that session's states
         return self
 
     def __exit__(self, *exc):
+        self._fused, self.last_codes = None, None        # (the captured frame keeps the session's state tensors alive)
         self._lm_ctx.__exit__(*exc)
         self._mimi_ctx.__exit__(*exc)
         return False
