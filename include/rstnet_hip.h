@@ -92,8 +92,12 @@ int rst_gemm_win_b3_f32(const float* x, const float* hist, const float* w, const
  *     (modules/streaming.py:216-303, modules/transformer.py:395-562) is weight-bandwidth bound and goes through here.
  *     split_k > 1 (rst_skinny_f32_split_plan(M, N, K); 1 = none): K is also split over split_k workgroups per column tile --
  *     N / 32 workgroups alone stream a 6-33 MB layer at well under 1 TB/s; ws [split_k][M][N] floats and counters [ceil(N/32)]
- *     uint32 (zeroed once by the caller, self re-arming) carry the deterministic in-launch reduction. */
+ *     uint32 (zeroed once by the caller, self re-arming) carry the deterministic in-launch reduction.
+ *   rst_skinny_f32_pack_ln: the plain-linear case of the packing (rows x [M][K], no window) with nn.LayerNorm(K) applied on the way
+ *     (gamma, beta, eps; rst_layernorm_f32's arithmetic, so the operand equals LayerNorm followed by the pack bit for bit): the
+ *     norm1 / norm2 in front of in_proj / linear1 of a streamed transformer layer (modules/transformer.py:595-650) costs no launch. */
 int rst_skinny_f32_pack_weight(const float* w, float* wp, int N, int K, rst_stream_t stream);
+int rst_skinny_f32_pack_ln(const float* x, const float* gamma, const float* beta, float eps, float* xp, int M, int K, rst_stream_t stream);
 int rst_skinny_f32_pack_win(const float* x, const float* hist, float* xp, int B, int T_in, int T_out, int C, int K, int S, int P,
                             int pad_mode, int64_t x_bstride, int act_in, rst_stream_t stream);
 int rst_skinny_f32_split_plan(int M, int N, int K);

@@ -265,6 +265,10 @@ int rst_skinny_f32_pack_win(const float* x, const float* hist, float* xp, int B,
     return rst_launch_skinny_f32_pack_win(p, (hipStream_t)stream);
 }
 
+int rst_skinny_f32_pack_ln(const float* x, const float* gamma, const float* beta, float eps, float* xp, int M, int K, rst_stream_t stream) {
+    return rst_launch_skinny_f32_pack_ln(x, gamma, beta, xp, M, K, eps, (hipStream_t)stream);
+}
+
 int rst_skinny_f32_split_plan(int M, int N, int K) { return rst_skinny_f32_split_plan_impl(M, N, K); }
 
 int rst_gemm_skinny_f32(const float* xp, const float* wp, const float* bias, const float* res, const float* scale, float* y, int M,

@@ -42,6 +42,7 @@ struct SkinnyF32PackParams {      // the A operand of GemmWinParams, gathered + 
     int B, T_in, T_out, C, K, Kp, S, P, pad_mode, act_in;
     long x_bstride;
 };
+int rst_launch_skinny_f32_pack_ln(const float* x, const float* gamma, const float* beta, float* xp, int M, int K, float eps, hipStream_t stream);
 struct SkinnyF32Params {
     const float* xp;              // packed activation windows
     const float* wp;              // packed weights [ceil(N/32)][Kp/8][64][4]

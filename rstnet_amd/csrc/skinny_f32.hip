@@ -36,6 +36,58 @@ __global__ __launch_bounds__(256) void f32_pack_weight_kernel(const float* __res
 // rows of the packed activation buffer: the kernel is instantiated for 1, 2 or 4 row tiles
 __host__ __device__ inline int sf_rows(int M) { return M <= 32 ? 32 : (M <= 64 ? 64 : 128); }
 
+__device__ __forceinline__ float sf_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// LayerNorm + pack in ONE launch (round 5): the plain-linear case of the packing below (no window, K = C) with the row's LayerNorm
+// applied on the way -- `layernorm_kernel`'s arithmetic (one wave per row, fp32 statistics: sum in lane order, variance of the
+// centred values with fmaf, (x - mean) * rstd * gamma + beta), so the operand is bit-identical to LayerNorm followed by the pack.
+// Every streamed transformer layer of the codec at more than two streams had a LayerNorm launch in front of each of these packs.
+__global__ __launch_bounds__(256) void f32_pack_ln_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ xp, int M, int K, int Kp, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= sf_rows(M)) return;
+    const long tile = (long)(m >> 5) * (Kp >> 3);
+    if (m >= M) {            // pad rows of the batch tile: zeros
+        for (int k = lane * 4; k < Kp; k += 256)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xp[((tile + ((k + e) >> 3)) * 64 + ((k + e) & 1) * 32 + (m & 31)) * 4 + (((k + e) & 7) >> 1)] = 0.f;
+        return;
+    }
+    const float* xr = x + (long)m * K;
+    float s = 0.f;
+    for (int i = lane * 4; i < K; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = sf_wave_sum(s) / (float)K;
+    float q = 0.f;
+    for (int i = lane * 4; i < K; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q = fmaf(d, d, q); }
+    }
+    const float rstd = 1.0f / sqrtf(sf_wave_sum(q) / (float)K + eps);
+    for (int i = lane * 4; i < Kp; i += 256) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (i < K) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * g[e] + b[e];
+        }
+        // k = i .. i + 3 (i % 4 == 0): k & 1 alternates, (k & 7) >> 1 = (i & 7) / 2 + {0, 0, 1, 1}
+        const long base = (tile + (i >> 3)) * 64;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xp[(base + (e & 1) * 32 + (m & 31)) * 4 + (((i & 7) + e) >> 1)] = o[e];
+    }
+}
+
 // A(b, t, k) = xflat_b[(t * S - P) * C + k] with history / zero / replicate padding (the A operand of gemm_win_kernel), ELU on
 // load if asked, written in packed order; item = (row, q, h): the 4 floats of one lane.
 __global__ __launch_bounds__(256) void f32_pack_win_kernel(const SkinnyF32PackParams p) {
@@ -265,6 +317,15 @@ int rst_launch_skinny_f32_pack_win(const SkinnyF32PackParams& p, hipStream_t str
     const long total = (long)sf_rows(p.B * p.T_out) * (p.Kp / 8) * 2;
     hipLaunchKernelGGL(f32_pack_win_kernel, dim3(sf_grid(total, 4096)), dim3(256), 0, stream, p);
     return rst_check_launch("skinny_f32_pack_win");
+}
+
+int rst_launch_skinny_f32_pack_ln(const float* x, const float* gamma, const float* beta, float* xp, int M, int K, float eps, hipStream_t stream) {
+    RST_REQUIRE(x && gamma && beta && xp && M >= 1 && M <= 128 && K > 0 && K % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)gamma % 16 == 0 &&
+                    (uintptr_t)beta % 16 == 0,
+                "skinny_f32_pack_ln: bad arguments (1 <= M <= 128, K %% 4 == 0, 16-byte aligned rows; M=%d K=%d)", M, K);
+    const int Kp = (K + 7) / 8 * 8;
+    hipLaunchKernelGGL(f32_pack_ln_kernel, dim3((sf_rows(M) + 3) / 4), dim3(256), 0, stream, x, gamma, beta, xp, M, K, Kp, eps);
+    return rst_check_launch("skinny_f32_pack_ln");
 }
 
 int rst_skinny_f32_split_plan_impl(int M, int N, int K) {

@@ -194,13 +194,23 @@ def skinny_f32_pack_weight(w: torch.Tensor) -> torch.Tensor:
     return _skinny_f32_weights.get(w, build)
 
 
-def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, S, P, pad_mode, act_in, act_out) -> None:
-    """The streaming-step route of gemm_win / linear: gather + pack the activation windows, then the few-row fp32 skinny GEMM."""
+# LayerNorm in front of a few-row linear (streamed transformer layers at more than two streams): applied by the packing launch
+# (rst_skinny_f32_pack_ln) instead of a launch of its own.  False: LayerNorm, then pack (the A/B switch of tools/ab.py).
+SKINNY_F32_PACK_LN = True
+
+
+def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, S, P, pad_mode, act_in, act_out, ln=None) -> None:
+    """The streaming-step route of gemm_win / linear: gather + pack the activation windows, then the few-row fp32 skinny GEMM.
+    ``ln = (gamma, beta, eps)`` (plain linears only): the LayerNorm of the rows, applied while they are packed."""
     M = B * T_out
     wp = skinny_f32_pack_weight(w)
     xp = torch.empty(32 if M <= 32 else (64 if M <= 64 else 128), wp.shape[1], device=x.device, dtype=torch.float32)
-    _lib.check(_lib.lib().rst_skinny_f32_pack_win(_ptr(x), _ptr(hist), _ptr(xp), B, T_in, T_out, C_, K, S, P, pad_mode, T_in * C_, act_in,
-                                                 _stream()))
+    if ln is not None:
+        assert hist is None and S == 1 and P == 0 and T_in == T_out and C_ == K and act_in == ACT_NONE
+        _lib.check(_lib.lib().rst_skinny_f32_pack_ln(_ptr(x), _ptr(ln[0]), _ptr(ln[1]), float(ln[2]), _ptr(xp), M, K, _stream()))
+    else:
+        _lib.check(_lib.lib().rst_skinny_f32_pack_win(_ptr(x), _ptr(hist), _ptr(xp), B, T_in, T_out, C_, K, S, P, pad_mode, T_in * C_, act_in,
+                                                     _stream()))
     def build():
         sk = int(_lib.lib().rst_skinny_f32_split_plan(M, N, K))
         return (sk, torch.empty(sk, M, N, device=x.device, dtype=torch.float32),
@@ -284,14 +294,15 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         _lib.check(_lib.lib().rst_gemv_f32(_ptr(x), _ptr(g), _ptr(b), float(eps), _ptr(w), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out),
                                            M, N, K, act_out, _stream()))
         return out
-    if ln is not None:
+    fold_ln = ln is not None and SKINNY_F32_PACK_LN and _few_rows(M, N, K) and K % 4 == 0
+    if ln is not None and not fold_ln:
         x = layernorm(x, ln[0], ln[1], ln[2])
     prof = PROFILE
     if _few_rows(M, N, K):
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _gemm_few_rows(x, None, w, bias, res, scale, out, 1, M, M, K, K, N, 1, 0, 0, ACT_NONE, act_out)
+        _gemm_few_rows(x, None, w, bias, res, scale, out, 1, M, M, K, K, N, 1, 0, 0, ACT_NONE, act_out, ln=ln if fold_ln else None)
         if prof is not None:
             e1.record()
             prof.append(("gemm_skinny_f32", e0, e1, 2.0 * M * N * K, 4 * (w.numel() + x.numel() + out.numel()), (M, N, K)))

@@ -320,6 +320,28 @@ def test_rvq_chain_one_launch_for_all_levels(M, F_, n_codes, D, groups, monkeypa
     status.zero_()
 
 
+@pytest.mark.parametrize("M,K,N", [(6, 512, 1536), (33, 512, 2048), (64, 512, 1536), (128, 256, 512), (5, 520, 512)])
+def test_few_row_linear_applies_layernorm_while_packing(M, K, N, monkeypatch):
+    """rst_skinny_f32_pack_ln (round 5): nn.LayerNorm in front of a few-row linear (modules/transformer.py:595-650 for a streamed frame of
+    several streams) applied by the packing launch -- bit-identical to LayerNorm followed by the pack, and equal to torch's
+    layer_norm + linear within the GEMM's tolerance."""
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g) * 2 + 0.3
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    ref = F.linear(F.layer_norm(x, (K,), gamma, beta, 1e-5), w)
+    ln = (gamma.to(DEV), beta.to(DEV), 1e-5)
+    monkeypatch.setattr(ops, "SKINNY_F32_PACK_LN", True)
+    ops.PROFILE = []
+    y = ops.linear(x.to(DEV), w.to(DEV), ln=ln)
+    names, ops.PROFILE = [r[0] for r in ops.PROFILE], None
+    assert names == ["gemm_skinny_f32"]
+    monkeypatch.setattr(ops, "SKINNY_F32_PACK_LN", False)
+    y2 = ops.linear(x.to(DEV), w.to(DEV), ln=ln)
+    assert torch.equal(y, y2)
+    assert rel_err(y, ref) < TOL
+
+
 def test_rvq_tie_takes_lowest_index():
     emb = torch.randn(1, 64, 16)
     emb[0, 40] = emb[0, 7]  # exact duplicate rows -> exact tie
