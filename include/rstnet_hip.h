@@ -101,8 +101,10 @@ int rst_skinny_f32_pack_ln(const float* x, const float* gamma, const float* beta
 int rst_skinny_f32_pack_win(const float* x, const float* hist, float* xp, int B, int T_in, int T_out, int C, int K, int S, int P,
                             int pad_mode, int64_t x_bstride, int act_in, rst_stream_t stream);
 int rst_skinny_f32_split_plan(int M, int N, int K);
+/*     y_packed != 0 (N % 8 == 0, no residual): y [ceil(M/32)*32][N] is written in the packed order of rst_skinny_f32_pack_win, i.e. as the
+ *     operand `xp` of the NEXT few-row GEMM (linear1 -> GELU -> linear2 of a streamed layer: no packing launch between the two). */
 int rst_gemm_skinny_f32(const float* xp, const float* wp, const float* bias, const float* res, const float* scale, float* y, int M,
-                        int N, int K, int ldy, int act_out, int split_k, float* ws, uint32_t* counters, rst_stream_t stream);
+                        int N, int K, int ldy, int act_out, int split_k, float* ws, uint32_t* counters, int y_packed, rst_stream_t stream);
 
 /* Causal Conv1d.  Replaces F.conv1d in RawStreamingConv1d.forward (modules/streaming.py:216-244) together with the
  * padding logic of StreamingConv1d.forward (modules/conv.py:232-254).

@@ -31,7 +31,7 @@ class Linear(nn.Module):
         if self.bias is not None:
             nn.init.uniform_(self.bias, -1 / in_features ** 0.5, 1 / in_features ** 0.5)
 
-    def forward(self, x: torch.Tensor, **epilogue) -> torch.Tensor:
+    def forward(self, x, **epilogue):
         return ops.linear(x.contiguous(), self.weight, self.bias, **epilogue)
 
 
@@ -221,7 +221,9 @@ class StreamingTransformerLayer(StreamingModule[_LayerState]):
         # the two LayerNorms run as prologues of the in-projection / linear1 launches where that form exists
         if not self.skip_self_attn:
             x = self.self_attn(x, res=x, scale=self._scale(self.layer_scale_1), ln=self._ln(self.norm1))
-        h = self.linear1(x, act_out=ops.ACT_GELU, ln=self._ln(self.norm2))
+        # (few-row streaming steps: linear1 hands its GELU'd result to linear2 already in linear2's operand order)
+        chain = ops.linear_chains(x, self.linear1.weight, self.linear2.weight)
+        h = self.linear1(x, act_out=ops.ACT_GELU, ln=self._ln(self.norm2), **({"out_packed": True} if chain else {}))
         x = self.linear2(h, res=x, scale=self._scale(self.layer_scale_2))
         state = self._streaming_state
         if state:

@@ -272,10 +272,10 @@ int rst_skinny_f32_pack_ln(const float* x, const float* gamma, const float* beta
 int rst_skinny_f32_split_plan(int M, int N, int K) { return rst_skinny_f32_split_plan_impl(M, N, K); }
 
 int rst_gemm_skinny_f32(const float* xp, const float* wp, const float* bias, const float* res, const float* scale, float* y, int M,
-                        int N, int K, int ldy, int act_out, int split_k, float* ws, uint32_t* counters, rst_stream_t stream) {
+                        int N, int K, int ldy, int act_out, int split_k, float* ws, uint32_t* counters, int y_packed, rst_stream_t stream) {
     SkinnyF32Params p;
     p.xp = xp; p.wp = wp; p.bias = bias; p.res = res; p.scale = scale; p.y = y; p.M = M; p.N = N; p.Kp = (K + 7) / 8 * 8; p.ldy = ldy;
-    p.act_out = act_out; p.split_k = split_k; p.ws = ws; p.counters = counters;
+    p.act_out = act_out; p.split_k = split_k; p.ws = ws; p.counters = counters; p.Np_out = y_packed ? N : 0;
     return rst_launch_gemm_skinny_f32(p, (hipStream_t)stream);
 }
 

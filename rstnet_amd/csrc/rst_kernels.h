@@ -51,6 +51,7 @@ struct SkinnyF32Params {
     const float* scale;           // [N] or nullptr
     float* y;                     // [M][ldy]
     int M, N, Kp, ldy, act_out;   // act_out as GemmWinParams
+    int Np_out;                   // != 0 (= N, N % 8 == 0): y is written in the packed operand order of the NEXT few-row GEMM ([ceil(M/32)*32][N])
     int split_k;                  // > 1: K split over gridDim.y workgroups (rst_skinny_f32_split_plan_impl), partials in ws
     float* ws;                    // [split_k][M][N]
     unsigned* counters;           // [ceil(N/32)], zero before the first launch (self re-arming)

@@ -221,7 +221,13 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
         const long o = (long)m * p.ldy + n;
         if (p.res) v = rpre[c][q] + spre[c][q] * v;
         if (p.act_out == 2) v = rst_elu(v);
-        p.y[o] = v;
+        // Np_out: the result is the next few-row GEMM's operand -- written straight in its packed order (no packing launch between them)
+        if (p.Np_out) p.y[f32_packed_index(m, n, p.Np_out)] = v;
+        else p.y[o] = v;
+    };
+    // packed output: the pad rows of the last batch tile must read as zeros in the consumer
+    auto pad_zero = [&](int m, int n) {
+        if (p.Np_out && m >= M && m < NB * 32 && n < p.N) p.y[f32_packed_index(m, n, p.Np_out)] = 0.f;
     };
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -243,6 +249,8 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
                 for (int w = 0; w < SF_WAVES; ++w) v += red[w][m][nl];
                 if (nsplit == 1) epilogue(v, m, n, c, q);
                 else __hip_atomic_store(p.ws + ((long)blockIdx.y * M + m) * p.N + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (nsplit == 1) {
+                pad_zero(m, n);
             }
         }
     }
@@ -290,6 +298,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
             const int idx = tid + q * 64 * SF_WAVES;
             const int m = idx >> 5, n = (tile0 + c) * 32 + (idx & 31);
             if (m < M && n < p.N) epilogue(v[c][q], m, n, c, q);
+            else pad_zero(m, n);
         }
 }
 
@@ -344,6 +353,7 @@ int rst_launch_gemm_skinny_f32(const SkinnyF32Params& p, hipStream_t stream) {
     const int tiles = (p.N + 31) / 32;
     const int split = p.split_k > 1 ? p.split_k : 1;
     RST_REQUIRE(split == 1 || (p.ws && p.counters && tiles < 512), "gemm_skinny_f32: split-K needs the scratch buffers (and < 512 column tiles)");
+    RST_REQUIRE(p.Np_out == 0 || (p.Np_out == p.N && p.N % 8 == 0 && !p.res), "gemm_skinny_f32: packed output needs N %% 8 == 0, Np_out = N and no residual (N=%d)", p.N);
     const dim3 block(64 * SF_WAVES);
     const int nb = (p.M + 31) / 32;
     if (nb == 1) {

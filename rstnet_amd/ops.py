@@ -199,13 +199,46 @@ def skinny_f32_pack_weight(w: torch.Tensor) -> torch.Tensor:
 SKINNY_F32_PACK_LN = True
 
 
-def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, S, P, pad_mode, act_in, act_out, ln=None) -> None:
+class PackedRows:
+    """The result of a few-row linear kept in the packed operand order of the NEXT few-row linear (``ops.linear(..., out_packed=True)``):
+    ``xp [32 | 64 | 128, N]`` fp32 as rst_skinny_f32_pack_win lays rows out, ``shape`` the logical ``[..., N]``.  Only ``ops.linear``
+    consumes it."""
+
+    def __init__(self, xp: torch.Tensor, shape: tuple):
+        self.xp, self.shape = xp, tuple(shape)
+
+    def contiguous(self):
+        return self
+
+
+# linear1 -> GELU -> linear2 of a streamed transformer layer (few-row route): linear1 writes the operand of linear2 in packed order,
+# no packing launch between them.  False: row-major result + pack (the A/B switch of tools/ab.py).
+SKINNY_F32_CHAIN = True
+
+
+def linear_chains(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> bool:
+    """True when ``ops.linear(x, w1, out_packed=True)`` may feed ``ops.linear(., w2)``: both on the few-row skinny route."""
+    K = x.shape[-1]
+    M = x.numel() // K if K else 0
+    return bool(SKINNY_F32_CHAIN and x.is_cuda and M > 4 and _few_rows(M, w1.shape[0], K) and _few_rows(M, w2.shape[0], w1.shape[0])
+                and w1.shape[0] % 8 == 0 and w2.shape[1] == w1.shape[0])
+
+
+def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, S, P, pad_mode, act_in, act_out, ln=None,
+                   out_packed: bool = False) -> None:
     """The streaming-step route of gemm_win / linear: gather + pack the activation windows, then the few-row fp32 skinny GEMM.
-    ``ln = (gamma, beta, eps)`` (plain linears only): the LayerNorm of the rows, applied while they are packed."""
+    ``ln = (gamma, beta, eps)`` (plain linears only): the LayerNorm of the rows, applied while they are packed.  ``x`` may be a
+    ``PackedRows`` (no packing at all); ``out_packed``: ``out`` is the ``xp`` of a ``PackedRows``."""
     M = B * T_out
     wp = skinny_f32_pack_weight(w)
-    xp = torch.empty(32 if M <= 32 else (64 if M <= 64 else 128), wp.shape[1], device=x.device, dtype=torch.float32)
-    if ln is not None:
+    if isinstance(x, PackedRows):
+        xp = x.xp
+        assert xp.shape[1] == wp.shape[1] and ln is None and hist is None, (tuple(xp.shape), tuple(wp.shape))
+    else:
+        xp = torch.empty(32 if M <= 32 else (64 if M <= 64 else 128), wp.shape[1], device=x.device, dtype=torch.float32)
+    if isinstance(x, PackedRows):
+        pass
+    elif ln is not None:
         assert hist is None and S == 1 and P == 0 and T_in == T_out and C_ == K and act_in == ACT_NONE
         _lib.check(_lib.lib().rst_skinny_f32_pack_ln(_ptr(x), _ptr(ln[0]), _ptr(ln[1]), float(ln[2]), _ptr(xp), M, K, _stream()))
     else:
@@ -213,11 +246,11 @@ def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, 
                                                      _stream()))
     def build():
         sk = int(_lib.lib().rst_skinny_f32_split_plan(M, N, K))
-        return (sk, torch.empty(sk, M, N, device=x.device, dtype=torch.float32),
-                torch.zeros((N + 31) // 32, device=x.device, dtype=torch.int32)) if sk > 1 else (1, None, None)
-    sc = _scratch(_gemm_scratch, x.device, ("skinny", M, N, K), build)
+        return (sk, torch.empty(sk, M, N, device=xp.device, dtype=torch.float32),
+                torch.zeros((N + 31) // 32, device=xp.device, dtype=torch.int32)) if sk > 1 else (1, None, None)
+    sc = _scratch(_gemm_scratch, xp.device, ("skinny", M, N, K), build)
     _lib.check(_lib.lib().rst_gemm_skinny_f32(_ptr(xp), _ptr(wp), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, N, K, N, act_out,
-                                             sc[0], _ptr(sc[1]), _ptr(sc[2]), _stream()))
+                                             sc[0], _ptr(sc[1]), _ptr(sc[2]), int(out_packed), _stream()))
 
 
 def _few_rows(M: int, N: int, K: int) -> bool:
@@ -275,15 +308,46 @@ def gemm_win(x: torch.Tensor, w: torch.Tensor, *, B: int, T_in: int, T_out: int,
     return out
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, res: Optional[torch.Tensor] = None,
+def linear(x, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, res: Optional[torch.Tensor] = None,
            scale: Optional[torch.Tensor] = None, act_out: int = ACT_NONE,
-           ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> torch.Tensor:
+           ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, out_packed: bool = False):
     """``y = epi(LN(x) @ w.T + bias)`` over the last dim of ``x`` (rst_linear_f32).  ``ln = (gamma, beta, eps)``: the LayerNorm in
-    front of the linear; it is the prologue of the launch on the one/two-position GEMV route and a separate launch otherwise."""
-    for t, n in ((x, "x"), (w, "w"), (bias, "bias"), (res, "res"), (scale, "scale")):
+    front of the linear; it is the prologue of the launch on the one/two-position GEMV route, part of the packing launch on the
+    few-row route and a separate launch otherwise.  ``out_packed`` (only where ``linear_chains`` says so): returns a ``PackedRows`` --
+    the operand of the next few-row linear in its packed order; ``x`` may be one."""
+    for t, n in ((w, "w"), (bias, "bias"), (res, "res"), (scale, "scale")):
         _chk(t, n)
-    K = x.shape[-1]
     N = w.shape[0]
+    if isinstance(x, PackedRows) or out_packed:
+        K = x.shape[-1]
+        M = 1
+        for d in x.shape[:-1]:
+            M *= d
+        assert w.shape[1] == K and M > 4 and _few_rows(M, N, K), "packed rows travel between few-row linears only"
+        dev = x.xp.device if isinstance(x, PackedRows) else x.device
+        if not isinstance(x, PackedRows):
+            _chk(x, "x")
+        if out_packed:
+            assert res is None and N % 8 == 0
+            out = PackedRows(torch.empty(32 if M <= 32 else (64 if M <= 64 else 128), N, device=dev, dtype=torch.float32), (*x.shape[:-1], N))
+        else:
+            out = torch.empty(*x.shape[:-1], N, device=dev, dtype=torch.float32)
+        fold = ln is not None and SKINNY_F32_PACK_LN and K % 4 == 0
+        xin = x
+        if ln is not None and not fold:
+            xin = layernorm(x, ln[0], ln[1], ln[2])
+        prof = PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _gemm_few_rows(xin, None, w, bias, res, scale, out.xp if out_packed else out, 1, M, M, K, K, N, 1, 0, 0, ACT_NONE, act_out,
+                       ln=ln if fold else None, out_packed=out_packed)
+        if prof is not None:
+            e1.record()
+            prof.append(("gemm_skinny_f32", e0, e1, 2.0 * M * N * K, 4 * (w.numel() + M * K + M * N), (M, N, K)))
+        return out
+    _chk(x, "x")
+    K = x.shape[-1]
     assert w.shape[1] == K
     M = x.numel() // K if K else 0
     out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)

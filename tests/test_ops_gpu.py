@@ -342,6 +342,30 @@ def test_few_row_linear_applies_layernorm_while_packing(M, K, N, monkeypatch):
     assert rel_err(y, ref) < TOL
 
 
+@pytest.mark.parametrize("M", [5, 32, 64, 70, 128])
+def test_few_row_linears_chain_through_the_packed_operand(M, monkeypatch):
+    """linear1 -> GELU -> linear2 of a streamed transformer layer on the few-row route (round 5): linear1 writes its result in the
+    packed operand order of linear2 (`out_packed`, `ops.PackedRows`), pad rows of the last batch tile as zeros -- the same bits as the
+    row-major result followed by the packing launch, with and without the LayerNorm in front."""
+    g = torch.Generator().manual_seed(M)
+    K, Hd = 512, 2048
+    x = torch.randn(M, K, generator=g)
+    w1, w2 = torch.randn(Hd, K, generator=g) / K ** 0.5, torch.randn(K, Hd, generator=g) / Hd ** 0.5
+    gamma, beta, scale = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
+    xg, w1g, w2g, sg = x.to(DEV), w1.to(DEV), w2.to(DEV), scale.to(DEV)
+    ln = (gamma.to(DEV), beta.to(DEV), 1e-5)
+    assert ops.linear_chains(xg, w1g, w2g)
+    h = ops.linear(xg, w1g, act_out=ops.ACT_GELU, ln=ln, out_packed=True)
+    assert isinstance(h, ops.PackedRows) and h.shape == (M, Hd)
+    y = ops.linear(h, w2g, res=xg, scale=sg)
+    y2 = ops.linear(ops.linear(xg, w1g, act_out=ops.ACT_GELU, ln=ln), w2g, res=xg, scale=sg)
+    assert torch.equal(y, y2)
+    ref = x + scale * F.linear(F.gelu(F.linear(F.layer_norm(x, (K,), gamma, beta, 1e-5), w1)), w2)
+    assert rel_err(y, ref) < TOL
+    monkeypatch.setattr(ops, "SKINNY_F32_CHAIN", False)
+    assert not ops.linear_chains(xg, w1g, w2g)
+
+
 def test_rvq_tie_takes_lowest_index():
     emb = torch.randn(1, 64, 16)
     emb[0, 40] = emb[0, 7]  # exact duplicate rows -> exact tie
