@@ -375,6 +375,36 @@ int rst_depth_decode_frame(const uint16_t* const* in_proj, const uint16_t* const
     return rst_launch_depth_frame(p, (hipStream_t)stream);
 }
 
+int rst_temporal_frame_workspace_bytes(int E, int Hd, int H) {
+    if (H <= 0 || E % H) return -1;
+    return (int)(2 * rst_temporal_frame_workspace_granules(E, Hd, H, E / H) * 8);
+}
+
+int rst_temporal_frame_supported(int E, int H, int Hd, int L, int cap, int kv_bf16) {
+    if (H <= 0 || E % H) return 0;
+    TemporalFrameParams p = {};
+    p.E = E; p.H = H; p.D = E / H; p.Hd = Hd; p.L = L; p.cap = cap; p.kv_bf16 = kv_bf16;
+    return rst_temporal_frame_grid(p);
+}
+
+int rst_temporal_decode_frame(const uint16_t* const* in_proj, const uint16_t* const* out_proj, const uint16_t* const* gate_in,
+                              const uint16_t* const* gate_out, const float* const* norm1, const float* const* norm2, void* const* k_cache,
+                              void* const* v_cache, const float* x, float* y, const int64_t* pos_dev, const float* rope_cs, void* workspace,
+                              uint32_t* status, int E, int H, int Hd, int L, int cap, int context, int kv_bf16, float eps, rst_stream_t stream) {
+    RST_REQUIRE(in_proj && out_proj && gate_in && gate_out && norm1 && norm2 && k_cache && v_cache, "temporal_decode_frame: null table");
+    RST_REQUIRE(L >= 1 && L <= RST_TEMPORAL_MAX_L && H > 0 && E % H == 0, "temporal_decode_frame: L=%d (<= %d), H=%d, E=%d", L, RST_TEMPORAL_MAX_L, H, E);
+    RST_REQUIRE(x != y, "temporal_decode_frame: the repair launch re-reads x: y must be another buffer");
+    TemporalFrameParams p = {};
+    for (int l = 0; l < L; ++l) {
+        p.in_proj[l] = in_proj[l]; p.out_proj[l] = out_proj[l]; p.gate_in[l] = gate_in[l]; p.gate_out[l] = gate_out[l];
+        p.norm1[l] = norm1[l]; p.norm2[l] = norm2[l]; p.kc[l] = k_cache[l]; p.vc[l] = v_cache[l];
+    }
+    p.x = x; p.y = y; p.pos_dev = reinterpret_cast<const long*>(pos_dev); p.rope_cs = rope_cs;
+    p.gran = static_cast<unsigned long long*>(workspace); p.status = status;
+    p.E = E; p.H = H; p.D = E / H; p.Hd = Hd; p.L = L; p.cap = cap; p.context = context; p.kv_bf16 = kv_bf16; p.eps = eps;
+    return rst_launch_temporal_frame(p, (hipStream_t)stream);
+}
+
 int rst_codec_transformer_workspace_bytes(int rows, int E, int F) { return (int)(rst_codec_tr_workspace_granules(rows, E, F) * 16); }
 
 int rst_codec_transformer_supported(int B, int T, int E, int H, int F, int L, int cap) { return rst_codec_tr_grid(B, T, E, H, F, L, cap); }

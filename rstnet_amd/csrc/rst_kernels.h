@@ -313,6 +313,31 @@ long rst_depth_frame_workspace_bytes_impl(int B, int E, int Hd, int card);
 int rst_depth_frame_grid(const DepthFrameParams& p);       // workgroups of the persistent launch, 0 = shape not served
 int rst_launch_depth_frame(const DepthFrameParams& p, hipStream_t stream);
 
+// ---- lm_temporal.hip: the temporal transformer of one batch-1 LM step (all layers) as one persistent launch
+#define RST_TEMPORAL_MAX_L 40
+struct TemporalFrameParams {
+    const unsigned short* in_proj[RST_TEMPORAL_MAX_L];   // bf16 [3E][E]
+    const unsigned short* out_proj[RST_TEMPORAL_MAX_L];  // bf16 [E][E]
+    const unsigned short* gate_in[RST_TEMPORAL_MAX_L];   // bf16 [2 * Hd][E]  (rows u then v)
+    const unsigned short* gate_out[RST_TEMPORAL_MAX_L];  // bf16 [E][Hd]
+    const float* norm1[RST_TEMPORAL_MAX_L];              // fp32 RMSNorm gains [E]
+    const float* norm2[RST_TEMPORAL_MAX_L];
+    void* kc[RST_TEMPORAL_MAX_L];                        // KV rings [1][H][cap][D], bf16 (kv_bf16) or fp32; the new step is appended
+    void* vc[RST_TEMPORAL_MAX_L];
+    const float* x;                 // [E] input of the first layer
+    float* y;                       // [E] output of the last layer
+    const long* pos_dev;            // position of the new step (device scalar)
+    const float* rope_cs;           // [D/2][2] (cos, sin) of the step's rotation (rst_launch_lm_rope_table), nullptr: no rotation
+    unsigned long long* gran;       // 2 x rst_temporal_frame_workspace_granules(E, Hd, H, D) 8-byte words (persistent + repair launch)
+    unsigned* status;               // 4 device words, as DepthFrameParams::status
+    int E, H, D, Hd, L, cap, context, kv_bf16;
+    int thin;                       // one block per weight wave in flight across a hand-off instead of two (set by the launcher)
+    float eps;
+};
+long rst_temporal_frame_workspace_granules(int E, int Hd, int H, int D);
+int rst_temporal_frame_grid(const TemporalFrameParams& p);      // workgroups of the persistent launch, 0 = shape not served
+int rst_launch_temporal_frame(const TemporalFrameParams& p, hipStream_t stream);
+
 // ---- codec_tr.hip: one streaming step of a Mimi transformer (all layers) as one persistent launch
 #define RST_CTR_MAX_L 8
 struct CodecTrParams {

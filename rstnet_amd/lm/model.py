@@ -104,6 +104,8 @@ class _StepState:
     pos: torch.Tensor          # int64 [1] on device: steps appended so far (= position of the next step)
     scratch: Optional[tuple] = None   # (split workspace, arrival counters) of the long-ring attention kernel
     offset_cpu: int = 0
+    tables: object = None             # ops.TemporalFrameTables of the persistent batch-1 launch (built at the first step that takes it)
+    tables_key: object = None
 
     def reset(self) -> None:
         self.pos.zero_()
@@ -172,6 +174,13 @@ class StreamingTransformer(StreamingModule[_StepState]):
         if self.weights_per_step:
             k_idx = st.offset_cpu if step_index is None else step_index
         pos_t = st.pos if pos is None else pos
+        if B == 1 and x is not None and not self.weights_per_step and cap > 64:
+            y = self._persistent_step(st, x, pos_t, cap)
+            if y is not None:
+                if pos is None:
+                    st.pos.add_(1)
+                    st.offset_cpu += 1
+                return y
         # the step's rotation once for all layers (long rings: the attention launches read it instead of evaluating 24 libm calls per lane)
         rope_table = ops.lm_rope_table(pos_t, E // H, max_period=self.max_period) if self.rope and cap > 64 else None
         for l, layer in enumerate(self.layers):
@@ -202,6 +211,27 @@ class StreamingTransformer(StreamingModule[_StepState]):
             st.pos.add_(1)
             st.offset_cpu += 1
         return x
+
+
+    def _persistent_step(self, st: _StepState, x: torch.Tensor, pos_t: torch.Tensor, cap: int) -> Optional[torch.Tensor]:
+        """All layers of a batch-1 step as ONE persistent launch (csrc/lm_temporal.hip) when the library serves the shape and the
+        device's persistent launches are healthy; None -> the launch-per-op chain below."""
+        E, H = self.d_model, self.num_heads
+        Hd = self.layers[0].gating.linear_out.weight.shape[1]
+        w0 = self.layers[0].self_attn.in_proj_weight
+        if w0.dtype != torch.bfloat16 or not ops.temporal_frame_supported(1, E, H, Hd, len(self.layers), cap, st.k[0].dtype == torch.bfloat16, x.device):
+            return None
+        key = (ops.persistent_epoch(x.device),) + tuple((ly.self_attn.in_proj_weight.data_ptr(), ly.self_attn.in_proj_weight._version,
+                                                          ly.gating.linear_in.weight.data_ptr()) for ly in self.layers)
+        if st.tables is None or st.tables_key != key:
+            st.tables = ops.TemporalFrameTables(
+                [dict(in_proj=ly.self_attn.in_proj_weight, out_proj=ly.self_attn.out_proj.weight, gate_in=ly.gating.linear_in.weight,
+                      gate_out=ly.gating.linear_out.weight, norm1=ly.norm1.alpha_f32(), norm2=ly.norm2.alpha_f32(), k_cache=st.k[l],
+                      v_cache=st.v[l]) for l, ly in enumerate(self.layers)],
+                H=H, context=self.context, eps=self.layers[0].norm1.eps)
+            st.tables_key = key
+        rope_table = ops.lm_rope_table(pos_t, E // H, max_period=self.max_period) if self.rope else None
+        return ops.temporal_decode_frame(st.tables, x, pos_t, rope_table)
 
 
 class ModelConfig:

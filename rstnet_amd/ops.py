@@ -1382,6 +1382,91 @@ def depth_decode_frame(tables, h_all: torch.Tensor, tokens: torch.Tensor, noise:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# The temporal transformer of a batch-1 LM step as ONE persistent launch (rst_temporal_decode_frame)
+# ----------------------------------------------------------------------------------------------------------------------
+TEMPORAL_FRAME = False              # opt-in (tools/ab.py TEMPORAL_FRAME=True): measured 1.02 - 1.06x the five launches per layer it replaces (profiles/r06_temporal_persistent.txt)
+TEMPORAL_FRAME_MAX_L = 40
+_temporal_ws: dict = {}
+
+
+@functools.lru_cache(maxsize=64)
+def _temporal_frame_grid(dev: int, E: int, H: int, Hd: int, L: int, cap: int, kv16: int) -> int:
+    with torch.cuda.device(dev):
+        return int(_lib.lib().rst_temporal_frame_supported(E, H, Hd, L, cap, kv16))
+
+
+def temporal_frame_supported(B: int, E: int, H: int, Hd: int, L: int, cap: int, kv_bf16: bool, device=None) -> bool:
+    """Shapes ``rst_temporal_decode_frame`` serves -- the library's own answer (batch 1, E <= 4096, head dim 64 / 128, <= 40 layers, the
+    LDS footprint, a workgroup per head, the occupancy query) -- on a device whose persistent launches have not been retired."""
+    if not (TEMPORAL_FRAME and depth_frame_enabled(device) and B == 1 and 1 <= L <= TEMPORAL_FRAME_MAX_L and H >= 1 and E % max(H, 1) == 0):
+        return False
+    return _temporal_frame_grid(_device_index(device), E, H, Hd, L, cap, int(kv_bf16)) > 0
+
+
+class TemporalFrameTables:
+    """Host arrays of device pointers of ``rst_temporal_decode_frame`` for one streaming session: the layers' weights (bf16), norm gains
+    (fp32) and KV rings.  Keeps the tensors alive (a captured graph embeds the pointers)."""
+
+    def __init__(self, layers: Sequence[dict], *, H: int, context: Optional[int], eps: float):
+        """``layers``: dicts of device tensors ``in_proj [3E, E], out_proj [E, E], gate_in [2 Hd, E], gate_out [E, Hd]`` (bf16),
+        ``norm1, norm2 [E]`` (fp32), ``k_cache, v_cache [1, H, cap, D]`` (bf16 or fp32)."""
+        L = len(layers)
+        keep = []
+
+        def table(name, dtype):
+            arr = (C.c_void_p * L)()
+            for i, ly in enumerate(layers):
+                t = ly[name]
+                if not (t.is_cuda and t.is_contiguous() and t.dtype == dtype):
+                    raise ValueError(f"rstnet_amd.ops: temporal-frame table {name!r} needs contiguous {dtype} device tensors")
+                keep.append(t)
+                arr[i] = t.data_ptr()
+            return arr
+        E = layers[0]["out_proj"].shape[0]
+        self.L, self.E, self.H, self.Hd = L, E, H, layers[0]["gate_out"].shape[1]
+        kvd = layers[0]["k_cache"].dtype
+        self.kv_bf16 = kvd == torch.bfloat16
+        self.cap = layers[0]["k_cache"].shape[2]
+        for ly in layers:
+            assert tuple(ly["in_proj"].shape) == (3 * E, E) and tuple(ly["out_proj"].shape) == (E, E)
+            assert tuple(ly["gate_in"].shape) == (2 * self.Hd, E) and tuple(ly["gate_out"].shape) == (E, self.Hd)
+            assert tuple(ly["k_cache"].shape) == (1, H, self.cap, E // H) and ly["v_cache"].shape == ly["k_cache"].shape
+        self.in_proj, self.out_proj = table("in_proj", torch.bfloat16), table("out_proj", torch.bfloat16)
+        self.gate_in, self.gate_out = table("gate_in", torch.bfloat16), table("gate_out", torch.bfloat16)
+        self.norm1, self.norm2 = table("norm1", torch.float32), table("norm2", torch.float32)
+        self.k_cache, self.v_cache = table("k_cache", kvd), table("v_cache", kvd)
+        self.context, self.eps = context, float(eps)
+        self.status = new_persistent_status(layers[0]["in_proj"].device)
+        self._keep = keep
+
+
+def temporal_decode_frame(tables: "TemporalFrameTables", x: torch.Tensor, pos_dev: torch.Tensor, rope_table: Optional[torch.Tensor]) -> torch.Tensor:
+    """x fp32 ``[1, E]`` -> ``[1, E]`` through every layer of ``tables`` (one new step at position ``*pos_dev``, appended to the rings);
+    ``rope_table``: fp32 ``[D/2, 2]`` of `lm_rope_table` or None (no rotation)."""
+    _chk(x, "x")
+    _chk(pos_dev, "pos_dev", torch.int64)
+    _chk(rope_table, "rope_table")
+    t = tables
+    assert x.shape == (1, t.E)
+    y = torch.empty_like(x)
+    ws = _scratch(_temporal_ws, x.device, (t.E, t.Hd, t.H),
+                  lambda: torch.zeros(int(_lib.lib().rst_temporal_frame_workspace_bytes(t.E, t.Hd, t.H)) // 8, device=x.device, dtype=torch.int64))
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.lib().rst_temporal_decode_frame(
+        t.in_proj, t.out_proj, t.gate_in, t.gate_out, t.norm1, t.norm2, t.k_cache, t.v_cache, _ptr(x), _ptr(y), _ptr(pos_dev),
+        _ptr(rope_table), _ptr(ws), _ptr(t.status), t.E, t.H, t.Hd, t.L, t.cap, int(t.context) if t.context else 0, int(t.kv_bf16), t.eps,
+        _stream()))
+    if prof is not None:
+        e1.record()
+        n_w = t.L * (4 * t.E * t.E + 3 * t.Hd * t.E)
+        prof.append(("temporal_frame", e0, e1, 2.0 * n_w, 2 * n_w, (1, t.L, t.E)))
+    return y
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # One streaming step of a Mimi transformer as ONE persistent launch (rst_codec_transformer_frame)
 # ----------------------------------------------------------------------------------------------------------------------
 _ctr_ws: dict = {}
@@ -1449,7 +1534,7 @@ for _name in ("skinny_f32_pack_weight", "gemm_win", "linear", "seanet_resblock",
               "rvq_search", "rvq_gather", "convtr_depthwise", "activation", "transpose12", "mask_tail", "hist_update", "gemv_bf16",
               "gemv_attn", "gemv_embed", "skinny_pack_weight", "skinny_pack_act", "gemm_skinny", "skinny_pack_weight_fp8", "gemm_skinny_fp8", "lm_gated_pair",
               "lm_linear", "embed_sum", "rmsnorm", "lm_rope_append", "lm_rope_table", "lm_attn_decode", "lm_sample", "lm_ring_begin", "lm_ring_commit",
-              "depth_decode_frame", "codec_transformer_frame"):
+              "depth_decode_frame", "temporal_decode_frame", "codec_transformer_frame"):
     globals()[_name] = _on_tensor_device(globals()[_name])
 del _name
 

@@ -1,0 +1,101 @@
+"""rst_temporal_decode_frame (csrc/lm_temporal.hip): all layers of the temporal transformer of a batch-1 LM step as ONE persistent launch
+-- models/model.py:364-389 / modules/transformer.py:376-423, 551-592 -- against the launch-per-op chain (itself pinned to the reference by
+lm_tiny*.npz) at the Moshi-7B layer width, plus its in-stream repair launch."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DIM, HEADS, CAP = 4096, 32, 3000
+
+
+def _transformer(layers, kvd):
+    from rstnet_amd.lm.model import StreamingTransformer
+    torch.manual_seed(0)
+    return StreamingTransformer(DIM, HEADS, layers, int(4.125 * DIM), context=CAP, positional_embedding="rope", device="cuda:0",
+                                dtype=torch.bfloat16, kv_dtype=kvd)
+
+
+def _run(tr, xs, persistent, pos0=0, rings=None, plant=0):
+    from rstnet_amd import ops
+    old = ops.TEMPORAL_FRAME
+    ops.TEMPORAL_FRAME = persistent
+    try:
+        outs = []
+        with tr.streaming(1):
+            st = tr._streaming_state
+            if rings is not None:
+                for l in range(len(st.k)):
+                    st.k[l].copy_(rings[0][l]); st.v[l].copy_(rings[1][l])
+            st.pos.fill_(pos0)
+            for i, x in enumerate(xs):
+                if plant and i == 1:
+                    st.tables.status[0] = plant          # a time-out code as a timed-out hand-off leaves it
+                outs.append(tr.step(x).clone())
+            torch.cuda.synchronize()
+            assert (st.tables is not None) == persistent, "the persistent launch was not taken / was taken unasked"
+            status = st.tables.status.tolist() if st.tables is not None else None
+            kv = [st.k[0].clone(), st.v[0].clone()]
+        return outs, status, kv
+    finally:
+        ops.TEMPORAL_FRAME = old
+
+
+def _rel(a, b):
+    return max(((u - v).abs().max() / v.abs().max()).item() for u, v in zip(a, b))
+
+
+@pytest.mark.parametrize("kv", ["f32", "bf16"])
+def test_persistent_temporal_frame_equals_launch_per_op(kv):
+    from rstnet_amd import ops
+    kvd = torch.float32 if kv == "f32" else torch.bfloat16
+    tr = _transformer(2, kvd)
+    Hd = tr.layers[0].gating.linear_out.weight.shape[1]
+    assert Hd == 11264
+    old = ops.TEMPORAL_FRAME
+    ops.TEMPORAL_FRAME = True
+    try:
+        assert ops.temporal_frame_supported(1, DIM, HEADS, Hd, 2, CAP, kvd == torch.bfloat16, "cuda:0")
+    finally:
+        ops.TEMPORAL_FRAME = old
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    # 140 positions from an empty ring: one split, then two (128 slots per workgroup), the new step's own slot in every block position
+    xs = [torch.randn(1, DIM, device="cuda:0", generator=g) for _ in range(140)]
+    ref, _, kv_ref = _run(tr, xs, False)
+    got, status, kv_got = _run(tr, xs, True)
+    assert status == [0, 0, 0, 0]
+    # fp32 rings: the two paths differ in summation order only.  bf16 rings: a key / value that differs in its last fp32 bit between
+    # the paths now and then rounds to the other bf16 neighbour (2^-8 relative on one element of one slot) -- the reference's own cache
+    # precision; with few slots in the ring one such flip moves the output by ~1e-3 of its largest element
+    tol = 1e-5 if kv == "f32" else 4e-3
+    assert _rel(got, ref) < tol
+    assert torch.allclose(kv_got[0].float(), kv_ref[0].float(), atol=2e-2 if kv == "bf16" else 1e-5) and \
+        torch.allclose(kv_got[1].float(), kv_ref[1].float(), atol=2e-2 if kv == "bf16" else 1e-5)
+    # a full ring across its wrap (the `delta <= 0` slot of RingKVCache.complete, eight splits per head, the combine by the head's owner)
+    H, D = HEADS, DIM // HEADS
+    rings = ([(0.5 * torch.randn(1, H, CAP, D, device="cuda:0", generator=g)).to(kvd) for _ in range(2)],
+             [(0.5 * torch.randn(1, H, CAP, D, device="cuda:0", generator=g)).to(kvd) for _ in range(2)])
+    ref2, _, _ = _run(tr, xs[:20], False, pos0=CAP - 8, rings=rings)
+    got2, status2, _ = _run(tr, xs[:20], True, pos0=CAP - 8, rings=rings)
+    assert status2 == [0, 0, 0, 0]
+    assert _rel(got2, ref2) < (1e-5 if kv == "f32" else 1e-4)
+
+
+def test_persistent_temporal_frame_repair_launch():
+    """A planted time-out code: the one-workgroup launch behind the persistent one recomputes the step from the untouched input and the
+    rings, counts the repair and clears the code (csrc/persist.h).  Same arithmetic except that one workgroup walks a head's whole ring
+    (one split, the persistent launch uses up to eight and merges them): equal to rounding, not bit for bit."""
+    tr = _transformer(2, torch.bfloat16)
+    g = torch.Generator(device="cuda:0").manual_seed(2)
+    xs = [torch.randn(1, DIM, device="cuda:0", generator=g) for _ in range(3)]
+    clean, st0, kv0 = _run(tr, xs, True, pos0=200)
+    rep, st1, kv1 = _run(tr, xs, True, pos0=200, plant=8)
+    assert st0 == [0, 0, 0, 0] and st1 == [0, 1, 8, 0]
+    assert _rel(rep, clean) < 4e-3          # bf16 rings (see the parity test); fp32 rings below
+    assert torch.allclose(kv0[0].float(), kv1[0].float(), atol=2e-2) and torch.allclose(kv0[1].float(), kv1[1].float(), atol=2e-2)
+    tr = _transformer(1, torch.float32)
+    clean, st0, kv0 = _run(tr, xs, True, pos0=200)
+    rep, st1, kv1 = _run(tr, xs, True, pos0=200, plant=32)
+    assert st0 == [0, 0, 0, 0] and st1 == [0, 1, 32, 0]
+    assert _rel(rep, clean) < 1e-5
+    assert torch.allclose(kv0[0], kv1[0], atol=1e-5) and torch.allclose(kv0[1], kv1[1], atol=1e-5)
