@@ -730,6 +730,7 @@ __global__ __launch_bounds__(TF_THREADS) void temporal_frame_kernel(const Tempor
             {
                 float t[16];
                 wait_rows(l * NPH + 3);          // (the heads cannot be done before the in-projection rows are)
+                __builtin_amdgcn_s_sleep(48);    // ... nor before their owners have gathered q / k / v and walked a block: ~1.3 us without a sweep
                 tf_gather<16>(gATT, 0, E, l1, tc, ident, t, sh, p.status, 8u);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { const int k = tc + j * TF_CT; if (k < E) xB[k] = t[j]; }
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(TF_THREADS) void temporal_frame_kernel(const Tempor
             // ---- gated activation -> xD
             wait_rows(l * NPH + 2 * NH + 6);
             TF_STAMP(sl + 14);                                   // own ffn-in rows published
-            for (int first = 0; first < Hd; first += 8 * TF_CT) {
+            for (int first = 0; first < Hd; first += 8 * TF_CT) {       // (sweeps of 16 or of all 44 granules per thread made the compiler spill)
                 float t[8];
                 tf_gather<8>(gH, first, Hd, l1, tc, ident, t, sh, p.status, 32u);
 #pragma unroll
