@@ -233,14 +233,20 @@ def _dist(world: int) -> bool:
     return world > 1 or FORCE_DIST
 
 
+def _broadcast_stats(key: str):
+    b = MULTI.get(key)
+    return None if not b else {"bytes": int(b["bytes"]), "seconds": round(b["seconds"], 4),
+                               "gb_per_s": round(b["bytes"] / max(b["seconds"], 1e-9) / 1e9, 2),
+                               "note": "one flat blob per model, RCCL broadcast from rank 0; not in the timed region"}
+
+
 def _multi_gpu_block(world: int):
     if not _dist(world):
         return None
-    b = MULTI.get("broadcast")
     blk = {"per_rank_ms_per_step": MULTI.get("per_rank_ms_per_step"), "host": MULTI.get("host"),
-           "weight_broadcast": None if not b else {"bytes": int(b["bytes"]), "seconds": round(b["seconds"], 4),
-                                                   "gb_per_s": round(b["bytes"] / max(b["seconds"], 1e-9) / 1e9, 2),
-                                                   "note": "one flat blob per model, RCCL broadcast from rank 0; not in the timed region"},
+           "weight_broadcast": _broadcast_stats("broadcast"),
+           # the 15.4 GB LM blob (bf16) of the sharded end-to-end line: the one collective the multi-GPU design rests on
+           "lm_weight_broadcast": _broadcast_stats("broadcast_lm"),
            "forced_at_world_1": bool(FORCE_DIST and world == 1),
            "scaling_note": "no scaling curve has been measured on hardware by the builder: the driver computes efficiency from its own per-N runs"}
     return blk
@@ -339,7 +345,7 @@ def e2e_cpu_baseline(lm_cpu: dict, frames: int = 6):
                       f"oracle leg of lm_b1 ({lm_cpu['_seconds_per_frame'] * 1e3:.0f} ms / frame, Qwen-0.5B-sized temporal stack)"}
 
 
-def build_lm(args, rank, world, dev):
+def build_lm(args, rank, world, dev, stats_key="broadcast"):
     from rstnet_amd import synth
     from rstnet_amd.lm.model import LMModel
     cfg = dict(synth.LM_MOSHI_7B if args.lm_config == "moshi7b" else synth.LM_TINY)
@@ -348,7 +354,7 @@ def build_lm(args, rank, world, dev):
     sd = synth.lm_state_dict(cfg, seed=0, device=str(dev)) if rank == 0 else None
     if _dist(world):
         from rstnet_amd.parallel import broadcast_state_dict
-        sd = broadcast_state_dict(sd, dev, src=0, stats=MULTI.setdefault("broadcast", {}))
+        sd = broadcast_state_dict(sd, dev, src=0, stats=MULTI.setdefault(stats_key, {}))
     n_params = sum(v.numel() for v in sd.values())
     return cfg, LMModel.from_state_dict(sd, cfg, kv_dtype=torch.bfloat16 if args.kv_dtype == "bf16" else torch.float32), n_params
 
@@ -615,7 +621,7 @@ def run_gpt(args, rank, world, dev, gpt=None, fp8=None, steps=None, warmup=None,
     return result
 
 
-def run_e2e(args, rank, world, dev, lm=None, steps=None, warmup=None, lm_result=None):
+def run_e2e(args, rank, world, dev, lm=None, steps=None, warmup=None, lm_result=None, stats_key="broadcast"):
     """BASELINE configs[3] shape on one GPU: B concurrent streams, each frame = Mimi encode (1920 samples) -> LMGen.step ->
     Mimi decode; value = B * frames / time.  Returns the result dict on rank 0."""
     from rstnet_amd import synth
@@ -630,7 +636,7 @@ def run_e2e(args, rank, world, dev, lm=None, steps=None, warmup=None, lm_result=
     mimi_sd = synth.mimi_state_dict(0) if rank == 0 else None
     if _dist(world):
         from rstnet_amd.parallel import broadcast_state_dict
-        mimi_sd = broadcast_state_dict(mimi_sd, dev, src=0, stats=MULTI.setdefault("broadcast", {}))
+        mimi_sd = broadcast_state_dict(mimi_sd, dev, src=0, stats=MULTI.setdefault(stats_key, {}))
     mimi = MimiCodec.from_state_dict(mimi_sd).to(dev)
     gen = LMGen(model, use_sampling=not args.greedy)
     pcm = synth.synth_audio(B, 1920 * (warmup + steps + n_samples), seed=200 + rank).to(dev)
@@ -886,6 +892,30 @@ def main():
                                        f"codes vs its waveform, and the waveform the timed step decoded at batch {args.batch} vs the oracle's")
         if not args.no_cpu_baseline and not _dist(world):    # the CPU leg is timed on rank 0 of the single-GPU run only
             result["cpu_baseline"] = cpu_baseline(sd_cpu, args.seconds)
+    if _dist(world) and not args.no_sub:
+        # BASELINE configs[3] on the multi-GPU line: end-to-end streaming with 32 streams PER GPU (256 over 8 GPUs),
+        # streams sharded over the ranks, the LM's weights (15.4 GB of bf16) generated on rank 0 and handed to the others by ONE RCCL
+        # broadcast -- what MLLM_v2/moshi/models/loaders.py:142-159 does per process from disk and
+        # egs/pretraining/local/offline_codec_tokenization.py:45-51 does per rank.  No data-path collective: the timed frames touch
+        # the ranks' own streams only; value = all ranks' frames / the slowest rank's time.
+        del audio, last, codes, timed_wav
+        model = None
+        torch.cuda.empty_cache()
+        args.lm_batch = 32
+        lm = build_lm(args, rank, world, dev, stats_key="broadcast_lm")
+        e2e = run_e2e(args, rank, world, dev, lm=lm, steps=args.sub_steps, warmup=10, stats_key="broadcast_e2e_codec")
+        del lm
+        if rank == 0:
+            for k in ("metric", "higher_is_better", "scaling", "vs_baseline", "data"):
+                e2e.pop(k, None)
+            result["e2e_b32"] = e2e
+            lb = e2e["multi_gpu"].get("lm_weight_broadcast") or {}
+            result["summary"] = {"codec_b64_ms": result["ms_per_step"], "codec_b64_frames_s": result["value"],
+                                 "codec_per_rank_ms": (result.get("multi_gpu") or {}).get("per_rank_ms_per_step"),
+                                 "e2e_b32_ms": e2e["ms_per_step"], "e2e_b32_frames_s": e2e["value"], "e2e_b32_xrt": e2e["x_realtime_per_stream"],
+                                 "e2e_streams_total": 32 * world, "e2e_per_rank_ms": e2e["multi_gpu"].get("per_rank_ms_per_step"),
+                                 "lm_broadcast_gb": round(lb.get("bytes", 0) / 1e9, 2), "lm_broadcast_gb_s": lb.get("gb_per_s"),
+                                 "codec_broadcast_gb_s": ((result.get("multi_gpu") or {}).get("weight_broadcast") or {}).get("gb_per_s")}
     if not _dist(world) and not args.no_sub:
         # the north-star targets ride on the same line: batch-1 LM decode and the batch-1 end-to-end streaming frame
         del audio, last, codes, timed_wav

@@ -116,3 +116,25 @@ def test_bench_force_dist_takes_the_multi_gpu_path_and_agrees_with_the_plain_lin
     ratio = forced["ms_per_step"] / plain["ms_per_step"]
     print(f"force-dist {forced['ms_per_step']} ms vs plain {plain['ms_per_step']} ms per step: ratio {ratio:.4f}")
     assert 0.95 < ratio < 1.05, (forced["ms_per_step"], plain["ms_per_step"])
+
+
+def test_bench_multi_gpu_line_carries_the_sharded_end_to_end_run_and_the_lm_broadcast():
+    """The line `bench.py --gpus N` prints for N > 1 (here: the same code path at world size 1, --force-dist): behind the codec headline
+    the end-to-end streaming run of BASELINE configs[3] -- 32 streams per GPU, the 15.4 GB LM blob through `broadcast_state_dict` -- with
+    its per-rank times and both weight broadcasts in `multi_gpu` and in `summary`."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "2", "--batch", "8",
+           "--sub-steps", "8", "--no-check", "--no-cpu-baseline", "--timing-samples", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    e2e, summ = line["e2e_b32"], line["summary"]
+    assert e2e["config"]["streams_per_gpu"] == 32 and e2e["n_gpus"] == 1 and e2e["steps"] == 8
+    mg = e2e["multi_gpu"]
+    assert len(mg["per_rank_ms_per_step"]) == 1 and abs(mg["per_rank_ms_per_step"][0] - e2e["ms_per_step"]) < 0.05 * e2e["ms_per_step"]
+    assert mg["lm_weight_broadcast"]["bytes"] > 1.5e10 and mg["lm_weight_broadcast"]["seconds"] > 0          # 7.7 B parameters, bf16
+    assert line["multi_gpu"]["weight_broadcast"]["bytes"] > 2e8 and line["multi_gpu"]["lm_weight_broadcast"] is None   # codec blob only, taken before the LM came
+    assert summ["e2e_streams_total"] == 32 and summ["e2e_b32_ms"] == e2e["ms_per_step"] and summ["lm_broadcast_gb"] > 15
+    assert abs(e2e["value"] - 32 * 8 / (e2e["ms_per_step"] * 8e-3)) < 0.01 * e2e["value"]
+    # 12.5 frames per second per stream is real time
+    assert e2e["x_realtime_per_stream"] > 5
