@@ -39,6 +39,10 @@ typedef void* rst_stream_t;
 
 int rst_version(void);
 const char* rst_last_error(void);
+/* Build id: the first 16 hex digits of the SHA-256 of every source file the library was built from (csrc/Makefile), written to out
+ * (n >= 32 bytes, NUL-terminated); returns its length.  Measurement files under profiles/ carry the id of the build they were taken
+ * with (tools/profile_meta.py); bench.py quotes a committed kernel trace only for the library that produced it. */
+int rst_build_id(char* out, int n);
 
 /* Generic windowed GEMM:
  *   y[b*T_out + t][n] = epi( sum_{k<K} act_in(A(b,t,k)) * w[n][k] + bias[n] ),  A(b,t,k) = xflat_b[(t*S - P)*C + k]

@@ -19,6 +19,7 @@ _f = C.c_float
 
 # name -> argtypes (all functions return int); mirrors include/rstnet_hip.h one to one
 SIGNATURES = {
+    "rst_build_id": [_p, _i],
     "rst_gemm_win_split_plan": [_l, _i, _i],
     "rst_gemm_win_split_tiles": [_l, _i],
     "rst_gemm_win_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _l, _i, _i, _i, _i, _p, _p, _p],
@@ -127,3 +128,10 @@ def check(rc: int) -> None:
         if rc == -1:
             raise ValueError(f"librstnet_hip: {msg}")
         raise RstError(f"librstnet_hip error {rc}: {msg}")
+
+
+def build_id() -> str:
+    """The loaded library's build id (csrc/Makefile: hash of its sources)."""
+    buf = C.create_string_buffer(64)
+    n = lib().rst_build_id(buf, 64)
+    return buf.value.decode() if n > 0 else "unknown"

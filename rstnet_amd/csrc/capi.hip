@@ -28,6 +28,16 @@ int rst_version(void) { return 110; }      // round 5: three-plane weights in op
                                            // rst_rvq_search_chain_f32, rst_embed_sum_bf16(add_stride); 105: round 4
 const char* rst_last_error(void) { return g_err; }
 
+#ifndef RST_SRC_SHA
+#define RST_SRC_SHA "unknown"
+#endif
+int rst_build_id(char* out, int n) {
+    static const char id[] = RST_SRC_SHA;
+    if (!out || n < (int)sizeof(id)) return RST_ERR_INVALID_ARG;
+    for (int i = 0; i < (int)sizeof(id); ++i) out[i] = id[i];
+    return (int)sizeof(id) - 1;
+}
+
 static int gemm_win_common(const float* x, const float* hist, const float* w, const uint16_t* w3, const float* bias, const float* res,
                            const float* scale, float* y, int B, int T_in, int T_out, int C, int K, int N, int S, int P,
                            int pad_mode, int64_t x_bstride, int ldy, int act_in, int act_out, int split_k, float* ws,

@@ -191,3 +191,38 @@ def test_default_line_ends_with_the_summary():
     assert list(d)[-1] == "summary" and line.rstrip().endswith("}}")
     assert '"summary"' in line[-2000:]
     assert d["summary"]["e2e_b1_xrt"] >= 10.0 and d["summary"]["codec_b64_code_match"] is not None
+
+
+def _walk(obj, path=""):
+    if isinstance(obj, dict):
+        yield path, obj
+        for k, v in obj.items():
+            yield from _walk(v, f"{path}.{k}" if path else k)
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            yield from _walk(v, f"{path}[{i}]")
+
+
+@pytest.mark.skipif(TAG < "r06", reason="build ids next to the kernel traces exist since round 6")
+@pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
+def test_no_committed_line_quotes_a_stale_trace(path):
+    """Every trace-backed figure of a committed line names the build of the library it was taken with, that build is the one the line
+    itself ran (`loaded_build_id`), and no roofline block is marked stale (bench.py then quotes the whole-frame figure instead)."""
+    d = _last_json(path)
+    for where, blk in _walk(d):
+        assert blk.get("stale") is not True, f"{os.path.basename(path)}: {where} is stale"
+        if "loaded_build_id" in blk:
+            assert blk["build_id"] == blk["loaded_build_id"], (where, blk["build_id"], blk["loaded_build_id"])
+
+
+@pytest.mark.skipif(TAG < "r06", reason="build ids next to the kernel traces exist since round 6")
+def test_committed_traces_belong_to_the_library_in_the_tree():
+    """profiles/rNN_*_kernel_stats.meta.json (tools/profile_meta.py) vs rst_build_id of the library built from THIS tree: a kernel change
+    after the collection run shows up here, not as a silently stale fraction on the driver's line."""
+    from rstnet_amd import _lib
+    mine = _lib.build_id()
+    metas = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{TAG}_*_kernel_stats.meta.json")))
+    assert metas, "no build ids next to the committed kernel traces"
+    for m in metas:
+        with open(m) as f:
+            assert json.load(f)["build_id"] == mine, (os.path.basename(m), mine)

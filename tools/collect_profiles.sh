@@ -35,7 +35,9 @@ prof_trace() { local n=$1; shift
 need_ablation() { [ -f rstnet_amd/librstnet_hip_ablation.so ] || make -C rstnet_amd/csrc -j32 ablation > "$O/ablation_build.log" 2>&1 || tail -5 "$O/ablation_build.log"; }
 # the bench lines quote the trace / counter summaries of the SAME code: each workload is profiled first, its summaries are copied
 # into this box's profiles/ under the tag, and only then the bench line is taken
-publish() { for f in "$O"/$1_*; do case "$f" in *.out|*.err|*_bench.json) ;; *) cp "$f" "profiles/${TAG}_$(basename "$f")";; esac; done; }
+publish() { for f in "$O"/$1_*; do case "$f" in *.out|*.err|*_bench.json) ;; *) cp "$f" "profiles/${TAG}_$(basename "$f")";; esac; done
+  # every published kernel-trace summary names the build of the library it was taken with (bench.py quotes it for that build only)
+  for f in profiles/${TAG}_$1_kernel_stats.csv; do [ -f "$f" ] && python tools/profile_meta.py "${f%.csv}" > /dev/null; done; }
 if [ "$WHAT" = all ] || [ "$WHAT" = lm ]; then
   prof lm python bench.py --workload lm --steps 6 --warmup 2 --no-cpu-baseline --timing-samples 2
   db=$(find "$RAW/lm_trace" -name "*.db" | head -1); [ -n "$db" ] && python tools/frame_timeline.py "$db" "$O/lm_timeline.csv" lm_ring_begin_kernel 2
