@@ -36,12 +36,13 @@ CONV_CASES = {
     "stride6": (1, 64, 128, 40, 12, 6),
     "stride8": (2, 128, 256, 35, 16, 8),
 }
-# name -> (B, Cin, Cout, T, K, stride); first four = conv_test.py:30-48
+# name -> (B, Cin, Cout, T, K, stride); first three = conv_test.py:30-48 (its fourth set, 512 -> 512 channels x 256 steps at K = 7, S = 2, is
+# small2's geometry at 1 MB of output: dropped from the fixtures in round 6 -- the 512-wide layers are covered by CONV_CASES["large1"],
+# RESBLOCK_CASES["dim512"] and the end-to-end fixtures)
 CONVTR_CASES = {
     "small1": (3, 4, 5, 10, 6, 1),
     "small2": (4, 5, 6, 10, 7, 2),
     "small3": (5, 6, 7, 10, 4, 3),
-    "large1": (1, 512, 512, 256, 7, 2),
     "stride8": (2, 256, 128, 9, 16, 8),
     "stride6": (1, 128, 64, 21, 12, 6),
     "stride5": (2, 64, 32, 33, 10, 5),

@@ -249,7 +249,10 @@ def gen_gpt_tiny():
         merge_lora_weights(m)
         h_m, logits_m = m.forward_global(toks[:, :, :T])
         out[f"{name}.merged.logits"] = logits_m.numpy()
-        out[f"{name}.merged.qkv0"] = m.transformer.h[0].attn.attn.linear.weight.detach().numpy()
+        # the merged fused-QKV weight of block 0 through its row and column sums (the matrix itself was 1.3 MB of the fixture set; the
+        # merged logits above pin the merge as well)
+        w0 = m.transformer.h[0].attn.attn.linear.weight.detach().double()
+        out[f"{name}.merged.qkv0_rowsum"], out[f"{name}.merged.qkv0_colsum"] = w0.sum(1).float().numpy(), w0.sum(0).float().numpy()
         print("gpt_tiny", name, logits_full.shape, out[f"{name}.stream.dep_logits"].shape, local.shape,
               float((logits_m - logits_full).abs().max()))
     np.savez(os.path.join(HERE, "gpt_tiny.npz"), **out)
