@@ -362,10 +362,11 @@ int rst_depth_decode_frame(const uint16_t* const* in_proj, const uint16_t* const
  * LMModel.forward_text's `self.transformer(input_)` at T = 1 in streaming mode (models/model.py:364-389), i.e. L x
  * StreamingTransformerLayer (modules/transformer.py:551-592: rms_norm_f32 -> StreamingMultiheadAttention :376-423 with RoPE
  * (modules/rope.py:37-62) and the RingKVCache of :211-278 -> + x; rms_norm_f32 -> ActivationGating (modules/gating.py:12-51) -> + x).
- * Tables are HOST arrays of L device pointers: in_proj[l] bf16 [3E][E], out_proj[l] bf16 [E][E], gate_in[l] bf16 [2 Hd][E] (rows u then
- * v), gate_out[l] bf16 [E][Hd], norm1[l] / norm2[l] fp32 [E], k_cache[l] / v_cache[l] the rings [1][H][cap][E / H] (bf16 when kv_bf16,
- * else fp32; the new step is appended at slot *pos_dev % cap).  x fp32 [E] -> y fp32 [E] (y != x).  rope_cs: fp32 [D / 2][2] (cos, sin)
- * of the step's rotation (rst_lm_rope_table_f32) or NULL (no rotation).  context <= 0: none.  workspace:
+ * dev_tables: a DEVICE array [8][L] of device pointers (uint64), row 0 in_proj[l] bf16 [3E][E], 1 out_proj[l] bf16 [E][E], 2 gate_in[l]
+ * bf16 [2 Hd][E] (rows u then v), 3 gate_out[l] bf16 [E][Hd], 4 norm1[l] / 5 norm2[l] fp32 [E], 6 k_cache[l] / 7 v_cache[l] the rings
+ * [1][H][cap][E / H] (bf16 when kv_bf16, else fp32; the new step is appended at slot *pos_dev % cap) -- built once per session by the caller
+ * (a layer's pointers are then one indexed scalar load inside the launch).  x fp32 [E] -> y fp32 [E] (y != x).  rope_cs: fp32 [D / 2][2]
+ * (cos, sin) of the step's rotation (rst_lm_rope_table_f32) or NULL (no rotation).  context <= 0: none.  workspace:
  * rst_temporal_frame_workspace_bytes(E, Hd, H) bytes of 8-byte {epoch, value} granules, zeroed by the call on `stream`.
  * Weights stream continuously across op and layer boundaries (each weight wave keeps 32 KB in flight in registers, requested before the
  * hand-off that produces the op's input); the op boundaries are in-launch all-to-all hand-offs.  Residency, bounded waits, the
@@ -374,9 +375,7 @@ int rst_depth_decode_frame(const uint16_t* const* in_proj, const uint16_t* const
  * the occupancy query), else 0 -- callers then run the launch-per-op chain. */
 int rst_temporal_frame_workspace_bytes(int E, int Hd, int H);
 int rst_temporal_frame_supported(int E, int H, int Hd, int L, int cap, int kv_bf16);
-int rst_temporal_decode_frame(const uint16_t* const* in_proj, const uint16_t* const* out_proj, const uint16_t* const* gate_in,
-                              const uint16_t* const* gate_out, const float* const* norm1, const float* const* norm2, void* const* k_cache,
-                              void* const* v_cache, const float* x, float* y, const int64_t* pos_dev, const float* rope_cs, void* workspace,
+int rst_temporal_decode_frame(const uint64_t* dev_tables, const float* x, float* y, const int64_t* pos_dev, const float* rope_cs, void* workspace,
                               uint32_t* status, int E, int H, int Hd, int L, int cap, int context, int kv_bf16, float eps, rst_stream_t stream);
 
 /* The same contraction for 4 < B <= 64 on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), in three entry points.

@@ -69,7 +69,7 @@ SIGNATURES = {
     "rst_depth_decode_frame": [C.POINTER(_p)] * 9 + [C.POINTER(_i), _p, _p, _p, _p, _p, _p] + [_i] * 12 + [_f, _f, _i, _i, _p],
     "rst_temporal_frame_workspace_bytes": [_i, _i, _i],
     "rst_temporal_frame_supported": [_i, _i, _i, _i, _i, _i],
-    "rst_temporal_decode_frame": [C.POINTER(_p)] * 8 + [_p] * 6 + [_i] * 7 + [_f, _p],
+    "rst_temporal_decode_frame": [_p] * 7 + [_i] * 7 + [_f, _p],
     "rst_skinny_pack_weight_bf16": [_p, _p, _i, _i, _i, _p],
     "rst_skinny_pack_act_f32": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     "rst_skinny_pack_weight_fp8": [_p, _p, _p, _i, _i, _p],

@@ -397,18 +397,13 @@ int rst_temporal_frame_supported(int E, int H, int Hd, int L, int cap, int kv_bf
     return rst_temporal_frame_grid(p);
 }
 
-int rst_temporal_decode_frame(const uint16_t* const* in_proj, const uint16_t* const* out_proj, const uint16_t* const* gate_in,
-                              const uint16_t* const* gate_out, const float* const* norm1, const float* const* norm2, void* const* k_cache,
-                              void* const* v_cache, const float* x, float* y, const int64_t* pos_dev, const float* rope_cs, void* workspace,
+int rst_temporal_decode_frame(const uint64_t* dev_tables, const float* x, float* y, const int64_t* pos_dev, const float* rope_cs, void* workspace,
                               uint32_t* status, int E, int H, int Hd, int L, int cap, int context, int kv_bf16, float eps, rst_stream_t stream) {
-    RST_REQUIRE(in_proj && out_proj && gate_in && gate_out && norm1 && norm2 && k_cache && v_cache, "temporal_decode_frame: null table");
+    RST_REQUIRE(dev_tables, "temporal_decode_frame: null pointer table");
     RST_REQUIRE(L >= 1 && L <= RST_TEMPORAL_MAX_L && H > 0 && E % H == 0, "temporal_decode_frame: L=%d (<= %d), H=%d, E=%d", L, RST_TEMPORAL_MAX_L, H, E);
     RST_REQUIRE(x != y, "temporal_decode_frame: the repair launch re-reads x: y must be another buffer");
     TemporalFrameParams p = {};
-    for (int l = 0; l < L; ++l) {
-        p.in_proj[l] = in_proj[l]; p.out_proj[l] = out_proj[l]; p.gate_in[l] = gate_in[l]; p.gate_out[l] = gate_out[l];
-        p.norm1[l] = norm1[l]; p.norm2[l] = norm2[l]; p.kc[l] = k_cache[l]; p.vc[l] = v_cache[l];
-    }
+    p.tab = reinterpret_cast<const unsigned long long*>(dev_tables);
     p.x = x; p.y = y; p.pos_dev = reinterpret_cast<const long*>(pos_dev); p.rope_cs = rope_cs;
     p.gran = static_cast<unsigned long long*>(workspace); p.status = status;
     p.E = E; p.H = H; p.D = E / H; p.Hd = Hd; p.L = L; p.cap = cap; p.context = context; p.kv_bf16 = kv_bf16; p.eps = eps;

@@ -217,6 +217,14 @@ __global__ __launch_bounds__(TF_THREADS) void temporal_frame_kernel(const Tempor
     u64* gH = gATT + E;
     u64* gPART = gH + Hd;
 
+    // row `arr` of the device pointer table (TemporalFrameParams::tab): 0 in_proj, 1 out_proj, 2 gate_in, 3 gate_out, 4 norm1, 5 norm2, 6 K, 7 V
+    // (read through the CONSTANT address space: the table is invariant, so the load is a scalar one.  As an ordinary global load it became a
+    // vector-memory load in the weight waves' code, and the compiler's wait for it -- counted without the weight stream's asm loads it does
+    // not know about -- could be satisfied before the pointer had arrived: a memory fault, tools/check_asm_loads.py now refuses any
+    // compiler-generated vector load there)
+    typedef const unsigned long long __attribute__((address_space(4))) * tf_cptr;
+    const tf_cptr tabc = (tf_cptr)p.tab;
+    auto tptr = [&](int arr, int l) __attribute__((always_inline)) { return reinterpret_cast<const char*>(tabc[arr * L + l]); };
     // ---- attention geometry (the same for every layer: the position is the frame's)
     const long pos = *p.pos_dev;
     const int S = SOLO ? 1 : min(TF_MAX_SPLITS, G / H);            // splits per head
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(TF_THREADS) void temporal_frame_kernel(const Tempor
         auto next = [&](TfBlk& b) __attribute__((always_inline)) {
             if (gt >= nL) { gt = 0; gl = gl + 1; }
             if (gl >= L) {
-                b.meta = TF_END; b.p0 = b.p1 = reinterpret_cast<const char*>(p.in_proj[0]); b.kb = 0; b.r0 = 0; b.need = L * NPH;
+                b.meta = TF_END; b.p0 = b.p1 = tptr(0, 0); b.kb = 0; b.r0 = 0; b.need = L * NPH;
                 return;
             }
             const int t = gt;
@@ -292,8 +300,8 @@ __global__ __launch_bounds__(TF_THREADS) void temporal_frame_kernel(const Tempor
                 kv_range(gh, s_lo, s_hi, on);
                 const int h = SOLO ? gh : wg / S;
                 b.kb = s_lo + (i * TF_WW + wave) * KV::SPB;
-                b.p0 = static_cast<const char*>(p.kc[gl]) + (long)h * cap * KV::ROWB;
-                b.p1 = static_cast<const char*>(p.vc[gl]) + (long)h * cap * KV::ROWB;
+                b.p0 = tptr(6, gl) + (long)h * cap * KV::ROWB;
+                b.p1 = tptr(7, gl) + (long)h * cap * KV::ROWB;
                 b.r0 = s_hi;
                 b.meta = TF_OP_KV | (((i == 0 ? 1 : 0) | (i == kvb - 1 ? 2 : 0)) << 3) | (gl << 16);
                 b.need = base + 3 + 2 * gh;
@@ -302,11 +310,11 @@ __global__ __launch_bounds__(TF_THREADS) void temporal_frame_kernel(const Tempor
             const unsigned short* w;
             int K = E, kb = 0, r0, flags = 3;
             bool has1 = false;
-            if (gop == TF_OP_A) { w = p.in_proj[gl]; r0 = gw + 2 * i * W; has1 = 2 * i + 1 < rowsA; b.need = base + 2; }
-            else if (gop == TF_OP_B) { w = p.out_proj[gl]; r0 = gw + 2 * i * W; has1 = 2 * i + 1 < rowsB; b.need = base + 2 * NH + 3; }
-            else if (gop == TF_OP_C) { w = p.gate_in[gl]; r0 = gw + i * W; b.need = base + 2 * NH + 5; }
+            if (gop == TF_OP_A) { w = reinterpret_cast<const unsigned short*>(tptr(0, gl)); r0 = gw + 2 * i * W; has1 = 2 * i + 1 < rowsA; b.need = base + 2; }
+            else if (gop == TF_OP_B) { w = reinterpret_cast<const unsigned short*>(tptr(1, gl)); r0 = gw + 2 * i * W; has1 = 2 * i + 1 < rowsB; b.need = base + 2 * NH + 3; }
+            else if (gop == TF_OP_C) { w = reinterpret_cast<const unsigned short*>(tptr(2, gl)); r0 = gw + i * W; b.need = base + 2 * NH + 5; }
             else {
-                w = p.gate_out[gl]; K = Hd;
+                w = reinterpret_cast<const unsigned short*>(tptr(3, gl)); K = Hd;
                 const int ip = KBd == 3 ? i / 3 : i / KBd, kblk = i - ip * KBd;      // (a division by a constant is a multiply)
                 r0 = gw + 2 * ip * W; has1 = 2 * ip + 1 < rowsB;
                 kb = kblk << 12;
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(TF_THREADS) void temporal_frame_kernel(const Tempor
 #endif
             TF_STAMP(sl + 0);                                    // layer start
             // ---- layer input -> xres0, norm1 -> xA
-            load_alpha(p.norm1[l]);
+            load_alpha(reinterpret_cast<const float*>(tptr(4, l)));
             if (l == 0) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
@@ -649,11 +657,11 @@ __global__ __launch_bounds__(TF_THREADS) void temporal_frame_kernel(const Tempor
                                 const unsigned short ha = tf_bf16_rne(a), hc = tf_bf16_rne(c);
                                 a = __uint_as_float((unsigned)ha << 16); c = __uint_as_float((unsigned)hc << 16);
                                 if (split == 0) {
-                                    unsigned short* ring = static_cast<unsigned short*>(part == 1 ? p.kc[l] : p.vc[l]);
+                                    unsigned short* ring = reinterpret_cast<unsigned short*>(const_cast<char*>(tptr(part == 1 ? 6 : 7, l)));
                                     *reinterpret_cast<unsigned*>(ring + ((long)h * cap + slot_cur) * D + d) = (unsigned)ha | ((unsigned)hc << 16);
                                 }
                             } else if (split == 0) {
-                                float* ring = static_cast<float*>(part == 1 ? p.kc[l] : p.vc[l]);
+                                float* ring = reinterpret_cast<float*>(const_cast<char*>(tptr(part == 1 ? 6 : 7, l)));
                                 float* dst = ring + ((long)h * cap + slot_cur) * D + d;
                                 dst[0] = a; dst[1] = c;
                             }
@@ -735,7 +743,7 @@ __global__ __launch_bounds__(TF_THREADS) void temporal_frame_kernel(const Tempor
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { const int k = tc + j * TF_CT; if (k < E) xB[k] = t[j]; }
             }
-            load_alpha(p.norm2[l]);
+            load_alpha(reinterpret_cast<const float*>(tptr(5, l)));
             TF_STAMP(sl + 5);                                    // attention output of all heads gathered
             tf_barrier();                                        // barrier 5: xB staged -> out-projection rows
             // ---- x after the attention block -> xres1, norm2 -> xA
@@ -829,12 +837,9 @@ int rst_temporal_frame_grid(const TemporalFrameParams& p) {
 }
 
 int rst_launch_temporal_frame(const TemporalFrameParams& p, hipStream_t stream) {
-    RST_REQUIRE(p.x && p.y && p.pos_dev && p.gran && p.status, "temporal_frame: null buffers");
+    RST_REQUIRE(p.tab && p.x && p.y && p.pos_dev && p.gran && p.status, "temporal_frame: null buffers");
     const int G = rst_temporal_frame_grid(p);
     RST_REQUIRE(G > 0, "temporal_frame: unsupported shape (E=%d Hd=%d H=%d D=%d L=%d cap=%d) or no resident grid for it", p.E, p.Hd, p.H, p.D, p.L, p.cap);
-    for (int l = 0; l < p.L; ++l)
-        RST_REQUIRE(p.in_proj[l] && p.out_proj[l] && p.gate_in[l] && p.gate_out[l] && p.norm1[l] && p.norm2[l] && p.kc[l] && p.vc[l],
-                    "temporal_frame: layer %d pointers", l);
     const size_t lds = tf_lds_bytes(p);
     TemporalFrameParams pk = p;
     static const int thin = rst_knob("RST_TF_THIN", 0);      // tools build only (A/B)

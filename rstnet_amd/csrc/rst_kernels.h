@@ -316,14 +316,11 @@ int rst_launch_depth_frame(const DepthFrameParams& p, hipStream_t stream);
 // ---- lm_temporal.hip: the temporal transformer of one batch-1 LM step (all layers) as one persistent launch
 #define RST_TEMPORAL_MAX_L 40
 struct TemporalFrameParams {
-    const unsigned short* in_proj[RST_TEMPORAL_MAX_L];   // bf16 [3E][E]
-    const unsigned short* out_proj[RST_TEMPORAL_MAX_L];  // bf16 [E][E]
-    const unsigned short* gate_in[RST_TEMPORAL_MAX_L];   // bf16 [2 * Hd][E]  (rows u then v)
-    const unsigned short* gate_out[RST_TEMPORAL_MAX_L];  // bf16 [E][Hd]
-    const float* norm1[RST_TEMPORAL_MAX_L];              // fp32 RMSNorm gains [E]
-    const float* norm2[RST_TEMPORAL_MAX_L];
-    void* kc[RST_TEMPORAL_MAX_L];                        // KV rings [1][H][cap][D], bf16 (kv_bf16) or fp32; the new step is appended
-    void* vc[RST_TEMPORAL_MAX_L];
+    // device table of device pointers [8][L]: row 0 in_proj (bf16 [3E][E]), 1 out_proj (bf16 [E][E]), 2 gate_in (bf16 [2 Hd][E], rows u then
+    // v), 3 gate_out (bf16 [E][Hd]), 4 norm1, 5 norm2 (fp32 RMSNorm gains [E]), 6 / 7 the K / V rings [1][H][cap][D] (bf16 when kv_bf16, else
+    // fp32; the new step is appended).  In device memory so that a layer's pointers are one indexed scalar load (kernel-argument
+    // arrays indexed at run time were compiled into per-op address arithmetic and branches in front of every block of the weight stream)
+    const unsigned long long* tab;
     const float* x;                 // [E] input of the first layer
     float* y;                       // [E] output of the last layer
     const long* pos_dev;            // position of the new step (device scalar)

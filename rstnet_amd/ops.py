@@ -1413,15 +1413,15 @@ class TemporalFrameTables:
         L = len(layers)
         keep = []
 
-        def table(name, dtype):
-            arr = (C.c_void_p * L)()
-            for i, ly in enumerate(layers):
+        def column(name, dtype):
+            out = []
+            for ly in layers:
                 t = ly[name]
                 if not (t.is_cuda and t.is_contiguous() and t.dtype == dtype):
                     raise ValueError(f"rstnet_amd.ops: temporal-frame table {name!r} needs contiguous {dtype} device tensors")
                 keep.append(t)
-                arr[i] = t.data_ptr()
-            return arr
+                out.append(t.data_ptr())
+            return out
         E = layers[0]["out_proj"].shape[0]
         self.L, self.E, self.H, self.Hd = L, E, H, layers[0]["gate_out"].shape[1]
         kvd = layers[0]["k_cache"].dtype
@@ -1431,10 +1431,11 @@ class TemporalFrameTables:
             assert tuple(ly["in_proj"].shape) == (3 * E, E) and tuple(ly["out_proj"].shape) == (E, E)
             assert tuple(ly["gate_in"].shape) == (2 * self.Hd, E) and tuple(ly["gate_out"].shape) == (E, self.Hd)
             assert tuple(ly["k_cache"].shape) == (1, H, self.cap, E // H) and ly["v_cache"].shape == ly["k_cache"].shape
-        self.in_proj, self.out_proj = table("in_proj", torch.bfloat16), table("out_proj", torch.bfloat16)
-        self.gate_in, self.gate_out = table("gate_in", torch.bfloat16), table("gate_out", torch.bfloat16)
-        self.norm1, self.norm2 = table("norm1", torch.float32), table("norm2", torch.float32)
-        self.k_cache, self.v_cache = table("k_cache", kvd), table("v_cache", kvd)
+        rows = [column("in_proj", torch.bfloat16), column("out_proj", torch.bfloat16), column("gate_in", torch.bfloat16),
+                column("gate_out", torch.bfloat16), column("norm1", torch.float32), column("norm2", torch.float32), column("k_cache", kvd),
+                column("v_cache", kvd)]
+        # the [8][L] pointer table lives in device memory (addresses fit int64: the top bit of a device pointer is clear)
+        self.dev_tables = torch.tensor(rows, dtype=torch.int64, device=layers[0]["in_proj"].device)
         self.context, self.eps = context, float(eps)
         self.status = new_persistent_status(layers[0]["in_proj"].device)
         self._keep = keep
@@ -1456,9 +1457,8 @@ def temporal_decode_frame(tables: "TemporalFrameTables", x: torch.Tensor, pos_de
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.check(_lib.lib().rst_temporal_decode_frame(
-        t.in_proj, t.out_proj, t.gate_in, t.gate_out, t.norm1, t.norm2, t.k_cache, t.v_cache, _ptr(x), _ptr(y), _ptr(pos_dev),
-        _ptr(rope_table), _ptr(ws), _ptr(t.status), t.E, t.H, t.Hd, t.L, t.cap, int(t.context) if t.context else 0, int(t.kv_bf16), t.eps,
-        _stream()))
+        _ptr(t.dev_tables), _ptr(x), _ptr(y), _ptr(pos_dev), _ptr(rope_table), _ptr(ws), _ptr(t.status), t.E, t.H, t.Hd, t.L, t.cap,
+        int(t.context) if t.context else 0, int(t.kv_bf16), t.eps, _stream()))
     if prof is not None:
         e1.record()
         n_w = t.L * (4 * t.E * t.E + 3 * t.Hd * t.E)

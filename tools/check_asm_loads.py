@@ -6,7 +6,7 @@ The weight waves load into FIXED registers v128 .. v255 through inline asm and t
 statement that first waits for it; "pin" variables defined in exactly those registers keep the compiler out of them while a block is
 in flight.  The checker makes sure of exactly that, on the weight waves' code (from the first asm load to the final drain): (1) no
 compiler-generated instruction mentions v128 .. v255, (2) every asm load targets that range, (3) the kernel spills no VGPR and uses no
-scratch, (4) a piece is only read by a statement that starts with its own s_waitcnt, and nothing inside an asm block writes the range
+scratch, and the compiler issues no vector-memory LOAD of its own there (it would wait for it with a count that ignores the asm loads), (4) a piece is only read by a statement that starts with its own s_waitcnt, and nothing inside an asm block writes the range
 but the loads."""
 import os
 import re
@@ -54,6 +54,9 @@ def check_kernel(lines):
         if not in_asm:
             if hi:
                 bad.append(f"compiler-generated `{t}` touches the stream's registers")
+            if re.match(r"(global|flat|buffer|scratch)_load", t):
+                # the compiler waits for its own loads with counts that ignore the stream's asm loads: such a wait can be satisfied early
+                bad.append(f"compiler-generated vector-memory load `{t}` inside the weight waves' code")
             continue
         if t.startswith("s_waitcnt"):
             waited = True
