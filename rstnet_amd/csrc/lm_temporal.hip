@@ -30,6 +30,7 @@ constexpr int TF_WW = 4, TF_CW = 4;
 constexpr int TF_THREADS = 64 * (TF_WW + TF_CW), TF_CT = 64 * TF_CW;
 constexpr int TF_HDR = 64;         // floats in front of the LDS carve: TfShared
 constexpr int TF_MAX_SPLITS = 8;
+constexpr int TF_TAB_MAX = 48;     // block descriptors of one layer per weight wave kept in LDS (7B shape: 25 - 28)
 
 struct TfShared {
     float red[4];
@@ -80,6 +81,10 @@ typedef unsigned int tf_pin_t __attribute__((ext_vector_type(32)));
 template <int REG>
 __device__ __forceinline__ void tf_load(unsigned voff, unsigned long long sbase) {
     asm volatile("global_load_dwordx4 v[%c2:%c3], %0, %1 nt" ::"v"(voff), "s"(sbase), "n"(REG), "n"(REG + 3));
+}
+template <int REG, int IMM>
+__device__ __forceinline__ void tf_load_imm(unsigned voff, unsigned long long sbase) {
+    asm volatile("global_load_dwordx4 v[%c2:%c3], %0, %1 offset:%c4 nt" ::"v"(voff), "s"(sbase), "n"(REG), "n"(REG + 3), "n"(IMM));
 }
 template <int REG, int N>      // 8 bf16 -> fp32 (the shifts / masks the multiply needs anyway)
 __device__ __forceinline__ void tf_take_bf16(float (&o)[8]) {
@@ -198,10 +203,11 @@ __global__ __launch_bounds__(TF_THREADS) void temporal_frame_kernel(const Tempor
     // and multiplies zeros, so the multiply needs no per-piece condition
     const int EP = (E + 4095) & ~4095, HdP = (Hd + 4095) & ~4095;
     // LDS carve (floats): header | xA [EP] (norm1 / norm2 output) | xB [EP] (attention output) | xD [HdP] (gated activation) |
-    //                     xres0 [E] (layer input) | xres1 [E] (after the attention block) | qh [3D] | pw_o [TF_WW][D]
+    //                     xres0 [E] (layer input) | xres1 [E] (after the attention block) | qh [3D] | pw_o [TF_WW][D] |
+    //                     block descriptors [TF_WW][TF_TAB_MAX][8] (words)
     // (offsets into `lds`, not pointers: a pointer selected at run time loses its address space and turns every access into a flat one,
     // which counts against BOTH wait counters and drains the weight stream at every LDS read)
-    const int oA = TF_HDR, oB = oA + EP, oD = oB + EP, oR0 = oD + HdP, oR1 = oR0 + E, oQ = oR1 + E, oPW = oQ + 3 * D;
+    const int oA = TF_HDR, oB = oA + EP, oD = oB + EP, oR0 = oD + HdP, oR1 = oR0 + E, oQ = oR1 + E, oPW = oQ + 3 * D, oTAB = oPW + TF_WW * D;
 #define xA (lds + oA)
 #define xB (lds + oB)
 #define xD (lds + oD)
@@ -282,6 +288,64 @@ __global__ __launch_bounds__(TF_THREADS) void temporal_frame_kernel(const Tempor
             kvb = on && span > 0 ? (span + TF_WW * KV::SPB - 1) / (TF_WW * KV::SPB) : 0;
         }
         const int cA = nA, cKV = cA + NH * kvb, cB = cKV + nB, cC = cB + nC, nL = cC + nD;      // prefix sums of a layer's blocks
+        // block t of a layer, as everything but the layer: what `next` needs to form its descriptor
+        struct TfDec { int meta, kb, r0, need_rel, arr0, arr1; long off0, off1; };
+        auto decode = [&](int t, TfDec& d) __attribute__((always_inline)) {
+            const int gop = t < cA ? TF_OP_A : (t < cKV ? TF_OP_KV : (t < cB ? TF_OP_B : (t < cC ? TF_OP_C : TF_OP_D)));
+            int i = t - (t < cA ? 0 : (t < cKV ? cA : (t < cB ? cKV : (t < cC ? cB : cC))));
+            if (gop == TF_OP_KV) {
+                int gh = 0;
+                if (SOLO) { gh = i / kvb; i -= gh * kvb; }
+                int s_lo, s_hi; bool on;
+                kv_range(gh, s_lo, s_hi, on);
+                const int h = SOLO ? gh : wg / S;
+                d.kb = s_lo + (i * TF_WW + wave) * KV::SPB;
+                d.arr0 = 6; d.arr1 = 7;
+                d.off0 = d.off1 = (long)h * cap * KV::ROWB;
+                d.r0 = s_hi;
+                d.meta = TF_OP_KV | (((i == 0 ? 1 : 0) | (i == kvb - 1 ? 2 : 0)) << 3);
+                d.need_rel = 3 + 2 * gh;
+                return;
+            }
+            int K = E, kb = 0, r0, flags = 3;
+            bool has1 = false;
+            if (gop == TF_OP_A) { d.arr0 = 0; r0 = gw + 2 * i * W; has1 = 2 * i + 1 < rowsA; d.need_rel = 2; }
+            else if (gop == TF_OP_B) { d.arr0 = 1; r0 = gw + 2 * i * W; has1 = 2 * i + 1 < rowsB; d.need_rel = 2 * NH + 3; }
+            else if (gop == TF_OP_C) { d.arr0 = 2; r0 = gw + i * W; d.need_rel = 2 * NH + 5; }
+            else {
+                d.arr0 = 3; K = Hd;
+                const int ip = i / KBd, kblk = i - ip * KBd;
+                r0 = gw + 2 * ip * W; has1 = 2 * ip + 1 < rowsB;
+                kb = kblk << 12;
+                flags = (kblk == 0 ? 1 : 0) | (kblk == KBd - 1 ? 2 : 0);
+                d.need_rel = 2 * NH + 6;
+            }
+            d.arr1 = d.arr0;
+            const int rem = min(K - kb, 4096);
+            d.kb = kb;
+            d.meta = gop | ((flags | (has1 ? 4 : 0)) << 3) | (((rem + 511) >> 9) << 6);
+            d.off0 = ((long)r0 * K + kb) * 2;
+            d.off1 = gop == TF_OP_C ? (((long)Hd + r0) * K) * 2 : (has1 ? d.off0 + (long)W * K * 2 : d.off0);
+            d.r0 = r0;
+        };
+        // The descriptors of ONE layer of this wave in LDS (8 words per block), written once: `next` then costs two broadcast LDS reads,
+        // six v_readfirstlane and two scalar loads of the layer's pointers instead of ~100 scalar instructions of decoding in front of
+        // every block (a lone wave per SIMD hides none of it).  The repair launch (many more blocks per layer) decodes as it goes.
+        const bool use_tab = !SOLO && nL <= TF_TAB_MAX;
+        unsigned* const mytab = reinterpret_cast<unsigned*>(lds) + oTAB + wave * (TF_TAB_MAX * 8);
+        if (use_tab) {
+            for (int t = 0; t < nL; ++t) {
+                TfDec d;
+                decode(t, d);
+                if (lane == 0) {
+                    unsigned* e = mytab + t * 8;
+                    e[0] = (unsigned)d.meta; e[1] = (unsigned)d.kb; e[2] = (unsigned)d.r0; e[3] = (unsigned)(d.need_rel | (d.arr0 << 8) | (d.arr1 << 12));
+                    e[4] = (unsigned)d.off0; e[5] = (unsigned)((unsigned long long)d.off0 >> 32);
+                    e[6] = (unsigned)d.off1; e[7] = (unsigned)((unsigned long long)d.off1 >> 32);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's own writes, read back by this wave only
+        }
         auto next = [&](TfBlk& b) __attribute__((always_inline)) {
             if (gt >= nL) { gt = 0; gl = gl + 1; }
             if (gl >= L) {
@@ -290,43 +354,22 @@ __global__ __launch_bounds__(TF_THREADS) void temporal_frame_kernel(const Tempor
             }
             const int t = gt;
             gt = t + 1;
-            const int gop = t < cA ? TF_OP_A : (t < cKV ? TF_OP_KV : (t < cB ? TF_OP_B : (t < cC ? TF_OP_C : TF_OP_D)));
-            int i = t - (t < cA ? 0 : (t < cKV ? cA : (t < cB ? cKV : (t < cC ? cB : cC))));
-            const int base = gl * NPH;
-            if (gop == TF_OP_KV) {
-                int gh = 0;
-                if (SOLO) { gh = i / kvb; i -= gh * kvb; }
-                int s_lo, s_hi; bool on;
-                kv_range(gh, s_lo, s_hi, on);
-                const int h = SOLO ? gh : wg / S;
-                b.kb = s_lo + (i * TF_WW + wave) * KV::SPB;
-                b.p0 = tptr(6, gl) + (long)h * cap * KV::ROWB;
-                b.p1 = tptr(7, gl) + (long)h * cap * KV::ROWB;
-                b.r0 = s_hi;
-                b.meta = TF_OP_KV | (((i == 0 ? 1 : 0) | (i == kvb - 1 ? 2 : 0)) << 3) | (gl << 16);
-                b.need = base + 3 + 2 * gh;
-                return;
+            int meta, kb, r0, misc;
+            long off0, off1;
+            if (use_tab) {
+                const u32x4 ea = *reinterpret_cast<const u32x4*>(mytab + t * 8), eb = *reinterpret_cast<const u32x4*>(mytab + t * 8 + 4);
+                meta = __builtin_amdgcn_readfirstlane((int)ea[0]); kb = __builtin_amdgcn_readfirstlane((int)ea[1]);
+                r0 = __builtin_amdgcn_readfirstlane((int)ea[2]); misc = __builtin_amdgcn_readfirstlane((int)ea[3]);
+                off0 = (long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)eb[1]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)eb[0]));
+                off1 = (long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)eb[3]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)eb[2]));
+            } else {
+                TfDec d;
+                decode(t, d);
+                meta = d.meta; kb = d.kb; r0 = d.r0; misc = d.need_rel | (d.arr0 << 8) | (d.arr1 << 12); off0 = d.off0; off1 = d.off1;
             }
-            const unsigned short* w;
-            int K = E, kb = 0, r0, flags = 3;
-            bool has1 = false;
-            if (gop == TF_OP_A) { w = reinterpret_cast<const unsigned short*>(tptr(0, gl)); r0 = gw + 2 * i * W; has1 = 2 * i + 1 < rowsA; b.need = base + 2; }
-            else if (gop == TF_OP_B) { w = reinterpret_cast<const unsigned short*>(tptr(1, gl)); r0 = gw + 2 * i * W; has1 = 2 * i + 1 < rowsB; b.need = base + 2 * NH + 3; }
-            else if (gop == TF_OP_C) { w = reinterpret_cast<const unsigned short*>(tptr(2, gl)); r0 = gw + i * W; b.need = base + 2 * NH + 5; }
-            else {
-                w = reinterpret_cast<const unsigned short*>(tptr(3, gl)); K = Hd;
-                const int ip = KBd == 3 ? i / 3 : i / KBd, kblk = i - ip * KBd;      // (a division by a constant is a multiply)
-                r0 = gw + 2 * ip * W; has1 = 2 * ip + 1 < rowsB;
-                kb = kblk << 12;
-                flags = (kblk == 0 ? 1 : 0) | (kblk == KBd - 1 ? 2 : 0);
-                b.need = base + 2 * NH + 6;
-            }
-            const int rem = min(K - kb, 4096);
-            b.kb = kb;
-            b.meta = gop | ((flags | (has1 ? 4 : 0)) << 3) | (((rem + 511) >> 9) << 6) | (gl << 16);
-            b.p0 = reinterpret_cast<const char*>(w + (long)r0 * K + kb);
-            b.p1 = gop == TF_OP_C ? reinterpret_cast<const char*>(w + ((long)Hd + r0) * K) : (has1 ? b.p0 + (long)W * K * 2 : b.p0);
-            b.r0 = r0;
+            b.meta = meta | (gl << 16); b.kb = kb; b.r0 = r0; b.need = gl * NPH + (misc & 255);
+            b.p0 = tptr((misc >> 8) & 15, gl) + off0;
+            b.p1 = tptr((misc >> 12) & 15, gl) + off1;
         };
         // v128 .. v255 belong to the weight stream for the whole life of a weight wave: the pins are live from here to the drain behind the loop
         tf_pin_t pin00, pin01, pin10, pin11;
@@ -348,12 +391,23 @@ __global__ __launch_bounds__(TF_THREADS) void temporal_frame_kernel(const Tempor
                                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a0);
             const unsigned long long s1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a1 >> 32)) << 32) |
                                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a1);
-            tf_for<8>([&](auto JC) __attribute__((always_inline)) {
-                constexpr int j = decltype(JC)::value;
-                const unsigned o = min(off0 + j * jstride, clampv) + tail;
-                tf_load<tf_reg(B, j, 0)>(o, s0);
-                tf_load<tf_reg(B, j, 1)>(o, s1);
-            });
+            if (b.type() != TF_OP_KV && b.nch() == 8) {
+                // a whole 2 x 8-piece block of two weight rows: piece j sits j KB behind the lane's 16 bytes -- immediate offsets, no
+                // per-piece address arithmetic
+                const unsigned v0 = lane * 16, v1 = v0 + 4096;
+                tf_for<8>([&](auto JC) __attribute__((always_inline)) {
+                    constexpr int j = decltype(JC)::value;
+                    tf_load_imm<tf_reg(B, j, 0), (j & 3) * 1024>(j < 4 ? v0 : v1, s0);
+                    tf_load_imm<tf_reg(B, j, 1), (j & 3) * 1024>(j < 4 ? v0 : v1, s1);
+                });
+            } else {
+                tf_for<8>([&](auto JC) __attribute__((always_inline)) {
+                    constexpr int j = decltype(JC)::value;
+                    const unsigned o = min(off0 + j * jstride, clampv) + tail;
+                    tf_load<tf_reg(B, j, 0)>(o, s0);
+                    tf_load<tf_reg(B, j, 1)>(o, s1);
+                });
+            }
         };
 
         int phase = 0;
@@ -799,7 +853,7 @@ int tf_cu_count() { return rst_cu_count(); }
 size_t tf_lds_bytes(const TemporalFrameParams& p) {
     const int EP = (p.E + 4095) & ~4095, HdP = (p.Hd + 4095) & ~4095;
     static_assert(sizeof(TfShared) <= TF_HDR * 4, "LDS header too small");
-    return (size_t)(TF_HDR + 2 * EP + HdP + 2 * p.E + 3 * p.D + TF_WW * p.D) * sizeof(float);
+    return (size_t)(TF_HDR + 2 * EP + HdP + 2 * p.E + 3 * p.D + TF_WW * p.D + TF_WW * TF_TAB_MAX * 8) * sizeof(float);
 }
 
 }  // namespace

@@ -38,6 +38,7 @@ def main():
     dim, heads, cap = 4096, 32, 3000
     tr = StreamingTransformer(dim, heads, a.layers, int(4.125 * dim), context=cap, positional_embedding="rope", device=dev, dtype=torch.bfloat16,
                               kv_dtype=torch.bfloat16)
+    ops.TEMPORAL_FRAME = True
     lib = _lib.lib()
     lib.rst_debug_temporal_frame_stamps.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.rst_debug_temporal_frame_stamps.restype = C.c_int
