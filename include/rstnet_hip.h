@@ -223,6 +223,7 @@ int rst_rvq_search_f32(const float* x, const float* emb, const float* packed, co
  * right either way), [2] OR of their codes -- the convention of rst_depth_decode_frame.  Needs n_codes / 128 * n_groups * ceil(M / 32)
  * <= CUs.  Replaces the residual loop of SplitResidualVectorQuantizer.encode per streamed frame (moshi/models/compression.py:368-389). */
 int rst_rvq_chain_slot_elems(int M, int n_codes, int L);   /* -1: bad sizes */
+int rst_rvq_chain_supported(int M, int n_codes, int L, int D, int n_groups);   /* 1: the chain serves the shape on this device, 0: use rst_rvq_search_f32 */
 int rst_rvq_search_chain_f32(const float* x, const float* emb, const float* packed, const float* e2, int64_t* codes, float* dist,
                              uint64_t* slots, uint32_t* status, int M, int F, int ldx, int D, int n_codes, int L, int n_groups,
                              const int* group_begin, const int* group_count, rst_stream_t stream);

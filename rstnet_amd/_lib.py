@@ -44,6 +44,7 @@ SIGNATURES = {
     "rst_rvq_pack_f32": [_p, _p, _p, _i, _i, _p],
     "rst_rvq_search_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _p],
     "rst_rvq_chain_slot_elems": [_i, _i, _i],
+    "rst_rvq_chain_supported": [_i, _i, _i, _i, _i],
     "rst_rvq_search_chain_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _p],
     "rst_rvq_gather_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _p],
     "rst_convtr_depthwise_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

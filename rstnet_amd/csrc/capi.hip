@@ -214,6 +214,8 @@ int rst_rvq_search_f32(const float* x, const float* emb, const float* packed, co
     return rst_launch_rvq_search(p, (hipStream_t)stream);
 }
 
+int rst_rvq_chain_supported(int M, int n_codes, int L, int D, int n_groups) { return rst_rvq_chain_supported_impl(M, n_codes, L, D, n_groups); }
+
 int rst_rvq_chain_slot_elems(int M, int n_codes, int L) {
     if (M <= 0 || n_codes <= 0 || L <= 0 || (long)L * ((M + 31) / 32 * 32) * rst_rvq_chain_slices(n_codes) > 0x7fffffffL) return -1;
     return L * ((M + 31) / 32 * 32) * rst_rvq_chain_slices(n_codes);

@@ -175,6 +175,7 @@ int rst_launch_rvq_search(const RvqSearchParams& p, hipStream_t stream);
 // few-frame variant: codes spread over workgroups, one launch per level; keys [L][M] uint64, all-ones before the first call
 int rst_launch_rvq_search_small(const RvqSearchParams& p, unsigned long long* keys, hipStream_t stream);
 int rst_rvq_chain_slices(int n_codes);
+int rst_rvq_chain_supported_impl(int M, int n_codes, int L, int D, int n_groups);
 int rst_launch_rvq_search_chain(const RvqSearchParams& p, unsigned long long* slots, unsigned* status, hipStream_t stream);
 struct RvqGatherParams {
     const long* codes;     // [B][L][F]

@@ -568,6 +568,16 @@ int rst_launch_rvq_search_small(const RvqSearchParams& p, unsigned long long* ke
 
 int rst_rvq_chain_slices(int n_codes) { return (n_codes + 127) / 128; }
 
+// shapes the one-launch chain serves (the checks of the launcher below): the library's answer, so that callers pick the per-level launches
+// instead of catching an error
+int rst_rvq_chain_supported_impl(int M, int n_codes, int L, int D, int n_groups) {
+    if (!(M > 0 && L > 0 && D > 0 && D % 8 == 0 && n_codes > 0 && n_codes % 32 == 0 && n_groups >= 1 && n_groups <= 2)) return 0;
+    const int ns = rst_rvq_chain_slices(n_codes), mt = (M + FR - 1) / FR;
+    if (ns > 64 || (long)ns * n_groups * mt > rst_cu_count()) return 0;
+    const size_t lds = ((size_t)FR * (D + 4)) * sizeof(float) + (5 * FR) * sizeof(unsigned long long) + 16;
+    return lds <= 64 * 1024 ? 1 : 0;
+}
+
 int rst_launch_rvq_search_chain(const RvqSearchParams& p, unsigned long long* slots, unsigned* status, hipStream_t stream) {
     if (p.M == 0) return RST_OK;
     RST_REQUIRE(p.x && p.emb && p.packed && p.e2 && p.codes && slots && status, "rvq_search_chain: null pointer");

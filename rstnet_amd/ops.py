@@ -233,13 +233,17 @@ def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, 
     wp = skinny_f32_pack_weight(w)
     if isinstance(x, PackedRows):
         xp = x.xp
-        assert xp.shape[1] == wp.shape[1] and ln is None and hist is None, (tuple(xp.shape), tuple(wp.shape))
+        if not (xp.shape[1] == wp.shape[1] and ln is None and hist is None):
+            raise ValueError(f"rstnet_amd.ops: a PackedRows operand of {tuple(xp.shape)} does not fit packed weights {tuple(wp.shape)} / takes no LayerNorm or history")
     else:
         xp = torch.empty(32 if M <= 32 else (64 if M <= 64 else 128), wp.shape[1], device=x.device, dtype=torch.float32)
     if isinstance(x, PackedRows):
         pass
     elif ln is not None:
-        assert hist is None and S == 1 and P == 0 and T_in == T_out and C_ == K and act_in == ACT_NONE
+        if not (hist is None and S == 1 and P == 0 and T_in == T_out and C_ == K and act_in == ACT_NONE):
+            raise ValueError("rstnet_amd.ops: a LayerNorm can only be folded into the packing launch of a plain linear")
+        _chk(ln[0], "ln gamma")
+        _chk(ln[1], "ln beta")
         _lib.check(_lib.lib().rst_skinny_f32_pack_ln(_ptr(x), _ptr(ln[0]), _ptr(ln[1]), float(ln[2]), _ptr(xp), M, K, _stream()))
     else:
         _lib.check(_lib.lib().rst_skinny_f32_pack_win(_ptr(x), _ptr(hist), _ptr(xp), B, T_in, T_out, C_, K, S, P, pad_mode, T_in * C_, act_in,
@@ -546,18 +550,25 @@ ATTENTION_FUSED_QKV = True
 
 def rope_table(T: int, D: int, max_period: float, device) -> torch.Tensor:
     """``[T, D]`` fp32: (cos, sin) of pair i of position t at ``[t, 2i]``, ``[t, 2i + 1]`` (rst_rope_table_f32; modules/rope.py:37-62).
-    Built once per (T, D, max_period, device): a whole-utterance pass launches nothing for its rotation."""
+    ONE table per (D, max_period, device), grown to the longest pass seen (rounded up to 256 positions) and read by shorter passes as a
+    prefix -- variable-length utterances launch nothing for their rotation once the longest has passed.  A table is built on the stream
+    that first needs it; readers on other streams wait for the build's event, and a table replaced by a longer one stays alive with the
+    tensors that reference it."""
     device = torch.device(device)
-    key = (T, D, float(max_period), device)
-    tab = _rope_tables.get(key)
-    if tab is None:
-        if len(_rope_tables) > 64:
-            _rope_tables.clear()
-        tab = torch.empty(T, D, device=device, dtype=torch.float32)
+    key = (D, float(max_period), device)
+    hit = _rope_tables.get(key)
+    if hit is None or hit[0].shape[0] < T:
+        Tp = (T + 255) // 256 * 256
+        tab = torch.empty(Tp, D, device=device, dtype=torch.float32)
         with torch.cuda.device(device):
-            _lib.check(_lib.lib().rst_rope_table_f32(_ptr(tab), T, D, rope_coef(max_period, D), 0, _stream()))
-        _rope_tables[key] = tab
-    return tab
+            _lib.check(_lib.lib().rst_rope_table_f32(_ptr(tab), Tp, D, rope_coef(max_period, D), 0, _stream()))
+            ev = torch.cuda.Event()
+            ev.record()
+            hit = _rope_tables[key] = (tab, ev, torch.cuda.current_stream())
+    tab, ev, built_on = hit
+    if torch.cuda.current_stream(device) != built_on and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(device).wait_event(ev)
+    return tab[:T]
 
 
 def attention_qkv(qkv: torch.Tensor, H: int, *, rope: bool = True, max_period: float = 10000.0, context: Optional[int] = None) -> torch.Tensor:
@@ -597,6 +608,13 @@ RVQ_CHAIN = True
 _rvq_slots: dict = {}
 
 
+@functools.lru_cache(maxsize=64)
+def _rvq_chain_supported(dev: int, M: int, n_codes: int, L: int, D: int, n_groups: int) -> bool:
+    # the library's own answer (slices x groups x frame tiles within the CUs, LDS footprint): other shapes take the per-level launches
+    with torch.cuda.device(dev):
+        return bool(_lib.lib().rst_rvq_chain_supported(M, n_codes, L, D, n_groups))
+
+
 def rvq_search(x: torch.Tensor, emb: torch.Tensor, packed: torch.Tensor, e2: torch.Tensor, B: int, F: int,
                groups: Sequence[Tuple[int, int]], return_dist: bool = False):
     """x ``[B*F, n_groups*D]`` projected latents -> codes ``[B, L, F]`` int64 (levels outside ``groups`` untouched)."""
@@ -609,7 +627,8 @@ def rvq_search(x: torch.Tensor, emb: torch.Tensor, packed: torch.Tensor, e2: tor
     codes = (torch.empty if covered else torch.zeros)(B, L, F, device=x.device, dtype=torch.int64)
     dist = torch.zeros(L, M, device=x.device, dtype=torch.float32) if return_dist else None
     keys = None
-    if 0 < M <= 64 and RVQ_CHAIN and n_codes % 128 == 0 and depth_frame_enabled(x.device):
+    if 0 < M <= 64 and RVQ_CHAIN and n_codes % 128 == 0 and depth_frame_enabled(x.device) and \
+            _rvq_chain_supported(_device_index(x.device), M, n_codes, L, D, len(groups)):
         # streaming step, ONE launch for all levels (+ its one-workgroup finish launch): the slices' workgroups hand every level's
         # decision over in-kernel (rst_rvq_search_chain_f32); a device that had to repair falls back to the launch-per-level form below
         n_slots = int(_lib.lib().rst_rvq_chain_slot_elems(M, n_codes, L))

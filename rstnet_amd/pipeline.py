@@ -71,7 +71,10 @@ class StreamingPipeline:
                 ops.persistent_poll(pcm.device)
             epoch = ops.persistent_epoch(pcm.device)
             if self._fused is None or self._fused_epoch != epoch:
-                self._fused, self._fused_epoch = Graphed(self._frame_fn, warmup=0), epoch
+                # the first capture follows the modules' own eager frames (the delay line: max_delay + 2 of them).  A RE-capture after the
+                # device's persistent launches were retired takes launch-per-op paths that have not run in this session yet: one eager
+                # frame first, so that their lazily created state and scratch exist before the capture
+                self._fused, self._fused_epoch = Graphed(self._frame_fn, warmup=0 if self._fused is None else 1), epoch
             if not self._fused.disable:
                 wav = self._fused(pcm.contiguous())
                 state.offset += 1
