@@ -1062,8 +1062,12 @@ int launch_stream_b3_cfg(const GemmWinParams& p, hipStream_t stream) {
     // (Measured: walking the interior tiles with the lean kernel and the others with the masked one as two launches gains 2 - 9 % on
     // the 24 kHz / 4.8 kHz layers, whose edge tiles are few, and loses 20 - 40 % on the layers below, where the two half-filled
     // launches run one after the other.)
-    const bool lean = p.P == 0 && M % 128 == 0 && p.N % BN == 0 && (long)(p.T_out - 1) * p.S * p.C + p.K <= (long)p.T_in * p.C;
+    bool lean = p.P == 0 && M % 128 == 0 && p.N % BN == 0 && (long)(p.T_out - 1) * p.S * p.C + p.K <= (long)p.T_in * p.C;
 #ifdef RST_ABLATION
+    // RST_B3_FORCE_MASK=1 (tools build): the masked instance (9 - 33 spilled registers, scratch) on the edge-free launches too -- what do
+    // its spills cost on a shape that never takes an edge path?  (VERDICT r5 #6d; profiles/r06_b3_masked_vs_lean.txt)
+    static const int force_mask = rst_knob("RST_B3_FORCE_MASK", 0);
+    if (force_mask) lean = false;
     // (the ablation instances of the SHIPPED form: weight fragments direct; RST_B3_DIRW=0 has no ablation instances)
     static const int dbg = rst_knob("RST_B3_DBG", 0);
     if (dirw && dbg == 1) { go(gemm_win_b3_stream_kernel<false, true, NWN, 1, true, true>); return rst_check_launch("gemm_win_b3"); }

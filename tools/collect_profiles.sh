@@ -37,7 +37,7 @@ need_ablation() { [ -f rstnet_amd/librstnet_hip_ablation.so ] || make -C rstnet_
 # into this box's profiles/ under the tag, and only then the bench line is taken
 publish() { for f in "$O"/$1_*; do case "$f" in *.out|*.err|*_bench.json) ;; *) cp "$f" "profiles/${TAG}_$(basename "$f")";; esac; done
   # every published kernel-trace summary names the build of the library it was taken with (bench.py quotes it for that build only)
-  for f in profiles/${TAG}_$1_kernel_stats.csv; do [ -f "$f" ] && python tools/profile_meta.py "${f%.csv}" > /dev/null; done; }
+  for f in profiles/${TAG}_$1_kernel_stats.csv; do [ -f "$f" ] && python tools/profile_meta.py "${f%.csv}" > /dev/null && cp "${f%.csv}.meta.json" "$O/$1_kernel_stats.meta.json"; done; }
 if [ "$WHAT" = all ] || [ "$WHAT" = lm ]; then
   prof lm python bench.py --workload lm --steps 6 --warmup 2 --no-cpu-baseline --timing-samples 2
   db=$(find "$RAW/lm_trace" -name "*.db" | head -1); [ -n "$db" ] && python tools/frame_timeline.py "$db" "$O/lm_timeline.csv" lm_ring_begin_kernel 2
@@ -76,6 +76,8 @@ if [ "$WHAT" = all ] || [ "$WHAT" = phases ]; then
   # op-boundary stamps of the two persistent kernels (tools build: librstnet_hip_ablation.so)
   (python tools/probes/codec_tr_phases.py 1 2; python tools/probes/codec_tr_phases.py 1 1; python tools/probes/codec_tr_phases.py 2 2) 2>&1 | grep -v amdgpu.ids > "$O/codec_tr_phases.txt"
   (python tools/probes/depth_frame_phases.py 1; python tools/probes/depth_frame_phases.py 2) 2>&1 | grep -v amdgpu.ids > "$O/depth_frame_phases.txt"
+  (python tools/probes/temporal_frame_phases.py --layers 8 --pos 10 --wg 133; python tools/probes/temporal_frame_phases.py --layers 8 --pos 3100 --wg 133) 2>&1 | grep -v amdgpu.ids > "$O/temporal_frame_phases.txt"
+  cp "$O/temporal_frame_phases.txt" "profiles/${TAG}_temporal_frame_phases.txt" 2>/dev/null
   cp "$O/codec_tr_phases.txt" "$O/depth_frame_phases.txt" profiles/ 2>/dev/null; for f in codec_tr_phases depth_frame_phases; do mv "profiles/$f.txt" "profiles/${TAG}_$f.txt"; done
 fi
 # the codec workload last: its default line carries the LM / GPT / end-to-end sub-objects, which quote the summaries published above
@@ -98,7 +100,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = codec ] || [ "$WHAT" = b3 ]; then
   need_ablation
   if [ -f rstnet_amd/librstnet_hip_ablation.so ]; then
     : > "$O/b3_ablation.txt"
-    for v in "RST_B3_DBG=0 full" "RST_B3_DIRW=0 weights_staged_through_LDS_(round_4_form)" "RST_B3_WIDE=0 128-wide_tiles_only" "RST_B3_DBG=5 lds_writes_of_unsplit_bits_(no_split_VALU)" "RST_B3_DBG=1 no_split_no_lds_writes" "RST_B3_DBG=2 no_global_loads" "RST_B3_DBG=3 matrix_instructions_only" "RST_B3_DBG=4 no_barriers"; do
+    for v in "RST_B3_DBG=0 full" "RST_B3_FORCE_MASK=1 masked_instance_on_the_edge-free_launches_too" "RST_B3_DIRW=0 weights_staged_through_LDS_(round_4_form)" "RST_B3_WIDE=0 128-wide_tiles_only" "RST_B3_DBG=5 lds_writes_of_unsplit_bits_(no_split_VALU)" "RST_B3_DBG=1 no_split_no_lds_writes" "RST_B3_DBG=2 no_global_loads" "RST_B3_DBG=3 matrix_instructions_only" "RST_B3_DBG=4 no_barriers"; do
       set -- $v
       env "$1" python tools/ab.py LIB=rstnet_amd/librstnet_hip_ablation.so -- --steps 6 --warmup 2 --no-sub --no-cpu-baseline --no-check --timing-samples 1 2>/dev/null | python -c "
 import json,sys
