@@ -24,7 +24,7 @@ int rst_check_launch(const char* what) {
 
 extern "C" {
 
-int rst_version(void) { return 110; }      // round 5: three-plane weights in operand order (re-pack!), + rst_attention_qkv_f32 / rst_rope_table_f32,
+int rst_version(void) { return 120; }      // round 6: + rst_temporal_decode_frame / _supported / _workspace_bytes, rst_build_id, rst_rvq_chain_supported; 110 = round 5: three-plane weights in operand order (re-pack!), + rst_attention_qkv_f32 / rst_rope_table_f32,
                                            // rst_rvq_search_chain_f32, rst_embed_sum_bf16(add_stride); 105: round 4
 const char* rst_last_error(void) { return g_err; }
 

@@ -174,7 +174,7 @@ class StreamingTransformer(StreamingModule[_StepState]):
         if self.weights_per_step:
             k_idx = st.offset_cpu if step_index is None else step_index
         pos_t = st.pos if pos is None else pos
-        if B == 1 and x is not None and not self.weights_per_step and cap > 64:
+        if B == 1 and x is not None and not self.weights_per_step and cap > 64 and ops.temporal_frame_wanted(st.offset_cpu):
             y = self._persistent_step(st, x, pos_t, cap)
             if y is not None:
                 if pos is None:
@@ -417,10 +417,13 @@ class _LMGenState:
     offset: int = 0
     persist_epoch: int = 0                 # ops.persistent_epoch(device) when the frame graph was captured
     tables: object = None                  # the DepthFrameTables the captured frame points at (kept alive with the graph)
+    temporal_base: Optional[int] = None    # host-side position of the temporal rings at frame 0 of this session
+    temporal_choice: Optional[bool] = None  # whether the captured frame takes the persistent temporal launch
 
     def reset(self) -> None:
         self.offset = 0
         self.offset_dev.zero_()
+        self.temporal_base = None       # (the temporal rings were reset with the session: re-read their position at the next frame)
 
 
 class LMGen(StreamingModule[_LMGenState]):
@@ -524,7 +527,22 @@ class LMGen(StreamingModule[_LMGenState]):
             if state.persist_epoch != ops.persistent_epoch(lm.device):
                 state.persist_epoch = ops.persistent_epoch(lm.device)
                 state.graphed_frame = _Graphed(self._frame)
+        tst = lm.transformer._streaming_state
+        if tst is not None:
+            # the temporal rings' fill as the host knows it (graph replays do not run the Python that counts steps): the persistent
+            # temporal launch is chosen by it (ops.temporal_frame_wanted), and a frame captured under the other choice is re-captured
+            if state.temporal_base is None:
+                state.temporal_base = tst.offset_cpu - state.offset
+            tst.offset_cpu = state.temporal_base + state.offset
+            want = B == 1 and ops.temporal_frame_wanted(tst.offset_cpu)
+            if state.temporal_choice is None:
+                state.temporal_choice = want
+            elif want != state.temporal_choice:
+                state.temporal_choice = want
+                state.graphed_frame = _Graphed(self._frame)
         out, input_ = state.graphed_frame(input_tokens.reshape(B, Ki).contiguous())
+        if tst is not None:
+            tst.offset_cpu = state.temporal_base + state.offset + 1
         if self.check:
             if lm._depth_tables._val is not None:
                 lm._depth_tables._val.check()       # a timed-out hand-off of the persistent depth launch

@@ -1403,7 +1403,21 @@ def depth_decode_frame(tables, h_all: torch.Tensor, tokens: torch.Tensor, noise:
 # ----------------------------------------------------------------------------------------------------------------------
 # The temporal transformer of a batch-1 LM step as ONE persistent launch (rst_temporal_decode_frame)
 # ----------------------------------------------------------------------------------------------------------------------
-TEMPORAL_FRAME = False              # opt-in (tools/ab.py TEMPORAL_FRAME=True): measured 1.02 - 1.06x the five launches per layer it replaces (profiles/r06_temporal_persistent.txt)
+# "auto": the persistent launch once the temporal rings hold at least TEMPORAL_FRAME_AUTO_POS steps.  Measured per frame (lm_b1, launch per
+# op vs persistent, profiles/r06_temporal_persistent.txt): ring offset 0: 3.78 / 3.78 ms, 500: 3.90 / 3.95, 1000: 4.02 / 3.99, 2000: 4.08 /
+# 4.08, 3000 (full): 4.20 / 4.14 -- the ring rows are part of its weight stream, so it gains where they are many.  True / False: always /
+# never (tools/ab.py TEMPORAL_FRAME=True).
+TEMPORAL_FRAME = "auto"
+TEMPORAL_FRAME_AUTO_POS = 2048
+
+
+def temporal_frame_wanted(host_pos: int) -> bool:
+    """Whether a batch-1 temporal step at (host-side) position ``host_pos`` should take the persistent launch."""
+    if TEMPORAL_FRAME == "auto":
+        return host_pos >= TEMPORAL_FRAME_AUTO_POS
+    return bool(TEMPORAL_FRAME)
+
+
 TEMPORAL_FRAME_MAX_L = 40
 _temporal_ws: dict = {}
 

@@ -99,3 +99,39 @@ def test_persistent_temporal_frame_repair_launch():
     assert st0 == [0, 0, 0, 0] and st1 == [0, 1, 32, 0]
     assert _rel(rep, clean) < 1e-5
     assert torch.allclose(kv0[0], kv1[0], atol=1e-5) and torch.allclose(kv0[1], kv1[1], atol=1e-5)
+
+
+def test_auto_mode_switches_the_captured_frame_at_the_threshold():
+    """`ops.TEMPORAL_FRAME = "auto"` (the default): an `LMGen` session takes the launch-per-op chain while the temporal rings are short and
+    re-captures its frame onto the persistent launch when the host-side position crosses `TEMPORAL_FRAME_AUTO_POS` -- token streams equal
+    to the always-off session's (greedy; the two paths agree to rounding, far from the ties of a random model)."""
+    from rstnet_amd import ops, synth
+    from rstnet_amd.lm.model import LMGen, LMModel
+    cfg = dict(synth.LM_MOSHI_7B, num_layers=2, depformer_num_layers=2)
+    sd = synth.lm_state_dict(cfg, seed=5, device="cuda:0")
+    model = LMModel.from_state_dict(sd, cfg, kv_dtype=torch.float32)
+    g = torch.Generator(device="cuda:0").manual_seed(9)
+    n = 12
+    user = torch.randint(0, cfg["card"], (n, 1, cfg["n_q"] - cfg["dep_q"], 1), generator=g, device="cuda:0")
+    old, old_pos = ops.TEMPORAL_FRAME, ops.TEMPORAL_FRAME_AUTO_POS
+
+    def run(mode, threshold):
+        ops.TEMPORAL_FRAME, ops.TEMPORAL_FRAME_AUTO_POS = mode, threshold
+        gen = LMGen(model, use_sampling=False)
+        outs, choices = [], []
+        with gen.streaming(1):
+            for s in range(n):
+                o = gen.step(user[s])
+                outs.append(None if o is None else o.clone())
+                choices.append(gen._streaming_state.temporal_choice)
+            tabs = model.transformer._streaming_state.tables
+        return outs, choices, tabs
+    try:
+        ref, ch0, tabs0 = run(False, 1024)
+        got, ch1, tabs1 = run("auto", 6)
+    finally:
+        ops.TEMPORAL_FRAME, ops.TEMPORAL_FRAME_AUTO_POS = old, old_pos
+    assert tabs0 is None and not any(ch0)
+    assert ch1[:6] == [False] * 6 and all(ch1[6:]) and tabs1 is not None and tabs1.status.tolist() == [0, 0, 0, 0]
+    for a, b in zip(got, ref):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
