@@ -17,6 +17,7 @@ def _transformer(layers, kvd):
 
 
 def _run(tr, xs, persistent, pos0=0, rings=None, plant=0):
+    DIM_ = tr.d_model
     from rstnet_amd import ops
     old = ops.TEMPORAL_FRAME
     ops.TEMPORAL_FRAME = persistent
@@ -135,3 +136,30 @@ def test_auto_mode_switches_the_captured_frame_at_the_threshold():
     assert ch1[:6] == [False] * 6 and all(ch1[6:]) and tabs1 is not None and tabs1.status.tolist() == [0, 0, 0, 0]
     for a, b in zip(got, ref):
         assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+
+
+@pytest.mark.parametrize("dim,heads,cap,layers,kv", [(2048, 32, 300, 3, "bf16"), (1024, 16, 130, 3, "f32"), (1536, 12, 96, 2, "f32")])
+def test_other_shapes(dim, heads, cap, layers, kv):
+    """Head dim 64 and 128 away from the 7B width: fewer rows per wave than waves in places (1536 / 1024 wide: some waves own no row of
+    the narrow ops), vectors that are not whole 4096-k blocks (zero-padded staging), a hidden width that is not a multiple of 512, short
+    rings crossing their wrap."""
+    from rstnet_amd import ops
+    from rstnet_amd.lm.model import StreamingTransformer
+    kvd = torch.float32 if kv == "f32" else torch.bfloat16
+    torch.manual_seed(3)
+    tr = StreamingTransformer(dim, heads, layers, int(4.125 * dim), context=cap, positional_embedding="rope", device="cuda:0", dtype=torch.bfloat16,
+                              kv_dtype=kvd)
+    Hd = tr.layers[0].gating.linear_out.weight.shape[1]
+    old = ops.TEMPORAL_FRAME
+    ops.TEMPORAL_FRAME = True
+    try:
+        if not ops.temporal_frame_supported(1, dim, heads, Hd, layers, cap, kvd == torch.bfloat16, "cuda:0"):
+            pytest.skip("shape not served by the persistent launch")
+    finally:
+        ops.TEMPORAL_FRAME = old
+    g = torch.Generator(device="cuda:0").manual_seed(4)
+    xs = [torch.randn(1, dim, device="cuda:0", generator=g) for _ in range(cap + 40)]
+    ref, _, _ = _run(tr, xs, False)
+    got, status, _ = _run(tr, xs, True)
+    assert status == [0, 0, 0, 0]
+    assert _rel(got, ref) < (1e-5 if kv == "f32" else 4e-3)
