@@ -448,6 +448,9 @@ def run_lm(args, rank, world, dev, lm=None, steps=None, warmup=None, cpu=True):
             st.offset_cpu = args.lm_context
         elapsed = _timed_loop(lambda i: gen.step(user[i]), warmup, steps, world, dev)
         samples = _sample_steps(lambda i: gen.step(user[warmup + steps + i]), n_samples)
+        # which form the timed frames' temporal stack took (ops.TEMPORAL_FRAME = "auto": the persistent launch from 2048 ring steps on)
+        temporal_path = ("one persistent launch (rst_temporal_decode_frame)" if getattr(model.transformer._streaming_state, "tables", None) is not None
+                         else "five launches per layer")
     if rank != 0:
         return None
     # roofline of the dominant kernel (weight-streaming GEMV): one extra frame, eager (no graph), HIP events per launch
@@ -492,7 +495,7 @@ def run_lm(args, rank, world, dev, lm=None, steps=None, warmup=None, cpu=True):
                    "batch_per_gpu": B, "params": n_params, "context_frames": args.lm_context + warmup + steps,
                    "kv_dtype": str(model.kv_dtype).replace("torch.", "") if hasattr(model, "kv_dtype") else "float32",
                    "sampling": "greedy" if args.greedy else "temp 0.8/0.7 top-k 250/25", "hip_graphs": True,
-                   "parallelism": f"replica x{world}"},
+                   "temporal_stack": temporal_path, "parallelism": f"replica x{world}"},
         "x_realtime_per_stream": round(steps / elapsed / 12.5, 2),
         "timing": timing,
         "roofline": {"bound": "hbm", "kernel": ("gemv_kernel / gemv_norm_kernel / gemv_ksplit_kernel" if B <= 2 else "gemm_skinny_kernel / gemm_skinny_x32_kernel") + " (bf16 weight streaming)",
