@@ -258,6 +258,47 @@ def test_moshi7b_full_depth_temporal_stack_and_depth_frame_vs_the_oracle_run_by_
     assert worst["argmax_agree"] == B * steps, worst
 
 
+def test_moshi7b_full_depth_persistent_temporal_launch_vs_the_oracle_run_by_aten():
+    """Round 6: the 32 temporal layers of the 7B shape through ONE persistent launch (`rst_temporal_decode_frame`, csrc/lm_temporal.hip;
+    `ops.TEMPORAL_FRAME = True`) against the `lm_oracle` code executed by ATen on the GPU -- as the test above does for the
+    launch-per-op chain -- batch 1, fp32 rings, 6 steps from position 0; no hand-off may time out."""
+    from rstnet_amd import ops
+    cfg = dict(synth.LM_MOSHI_7B)
+    sd = synth.lm_state_dict(cfg, seed=11, device=DEV)
+    model = LMModel.from_state_dict(sd, cfg, kv_dtype=torch.float32)
+    ocfg = L.LMConfig(**cfg)
+    B, steps = 1, 6
+    g = torch.Generator().manual_seed(78)
+    worst = {"transformer_out": 0.0, "text_logits": 0.0, "argmax_agree": 0, "layers": cfg["num_layers"]}
+    old = ops.TEMPORAL_FRAME
+    ops.TEMPORAL_FRAME = True
+    try:
+        with model.streaming(B), torch.no_grad():
+            with torch.device(DEV):
+                st_o = L.new_transformer_state(B, cfg["num_layers"], cfg["num_heads"], cfg["dim"] // cfg["num_heads"], cfg["context"])
+            for s_ in range(steps):
+                toks = torch.randint(0, cfg["card"], (B, cfg["n_q"] + 1, 1), generator=g)
+                toks[:, 0] = torch.randint(0, cfg["text_card"], (B, 1), generator=g)
+                toks = toks.to(DEV)
+                out, logits = model.forward_text(toks)
+                with torch.device(DEV):
+                    out_o, logits_o = L.forward_text(sd, ocfg, toks, st_o)
+                worst["transformer_out"] = max(worst["transformer_out"], rel_err(out, out_o))
+                worst["text_logits"] = max(worst["text_logits"], rel_err(logits, logits_o))
+                worst["argmax_agree"] += int((logits.view(B, -1).argmax(-1) == logits_o.view(B, -1).argmax(-1)).sum())
+            tables = model.transformer._streaming_state.tables
+            assert tables is not None, "the persistent launch was not taken"
+            worst["status"] = tables.status.tolist()
+    finally:
+        ops.TEMPORAL_FRAME = old
+    _record("moshi7b_persistent_temporal_vs_aten", worst)
+    del model, sd
+    torch.cuda.empty_cache()
+    assert worst["status"] == [0, 0, 0, 0], worst
+    assert worst["transformer_out"] < 1e-3 and worst["text_logits"] < 1e-3, worst
+    assert worst["argmax_agree"] == B * steps, worst
+
+
 def test_lmgen_greedy_frames_at_the_moshi_shape_across_the_ring_wrap(monkeypatch):
     """16 greedy `LMGen.step` frames (models/model.py:490-597: token ring, temporal step, text sample, 8 depth steps, delayed output) of
     the two-temporal-layer Moshi-7B-shaped model, one captured graph per frame, with the temporal rings seeded at offset 2990 (they wrap

@@ -9,6 +9,21 @@ pytestmark = pytest.mark.gpu
 DIM, HEADS, CAP = 4096, 32, 3000
 
 
+@pytest.fixture
+def clean_health():
+    """The repair counters these tests provoke must not retire the device's persistent launches for the tests that follow."""
+    yield
+    from rstnet_amd import ops
+    torch.cuda.synchronize()
+    ops._persist_off.clear()
+    ops._persist_pending.clear()
+    for refs in ops._persist_status.values():
+        for r in refs:
+            t = r()
+            if t is not None:
+                t.zero_()
+
+
 def _transformer(layers, kvd):
     from rstnet_amd.lm.model import StreamingTransformer
     torch.manual_seed(0)
@@ -82,7 +97,7 @@ def test_persistent_temporal_frame_equals_launch_per_op(kv):
     assert _rel(got2, ref2) < (1e-5 if kv == "f32" else 1e-4)
 
 
-def test_persistent_temporal_frame_repair_launch():
+def test_persistent_temporal_frame_repair_launch(clean_health):
     """A planted time-out code: the one-workgroup launch behind the persistent one recomputes the step from the untouched input and the
     rings, counts the repair and clears the code (csrc/persist.h).  Same arithmetic except that one workgroup walks a head's whole ring
     (one split, the persistent launch uses up to eight and merges them): equal to rounding, not bit for bit."""
@@ -163,3 +178,43 @@ def test_other_shapes(dim, heads, cap, layers, kv):
     got, status, _ = _run(tr, xs, True)
     assert status == [0, 0, 0, 0]
     assert _rel(got, ref) < (1e-5 if kv == "f32" else 4e-3)
+
+
+def test_temporal_frame_without_full_residency_is_repaired(clean_health):
+    """A REAL loss of residency: a helper kernel (tests/helpers/occupy.hip) holds 150 KB of LDS on all but 12 CUs while one step is
+    launched, so most of the persistent launch's workgroups cannot start: the comm waves' sweeps time out (bounded spins, 0.1 s), the
+    launch drains, and the one-workgroup launch behind it recomputes the step -- outputs and rings equal to an undisturbed run to
+    rounding, status = [0, 1, codes, 0]; the later steps run on the rings the repair appended to."""
+    import time
+    from tests.test_persistent_safety_gpu import _hold_cus, _occ
+    tr = _transformer(2, torch.float32)
+    g = torch.Generator(device="cuda:0").manual_seed(6)
+    xs = [torch.randn(1, DIM, device="cuda:0", generator=g) for _ in range(5)]
+    lib, side = _occ(), torch.cuda.Stream()
+    from rstnet_amd import ops
+    old = ops.TEMPORAL_FRAME
+    ops.TEMPORAL_FRAME = True
+
+    def stream(disturb_at=None):
+        outs = []
+        with tr.streaming(1):
+            st = tr._streaming_state
+            st.pos.fill_(150)
+            for i, x in enumerate(xs):
+                keep = _hold_cus(lib, side, ms=2500) if disturb_at == i else None
+                outs.append(tr.step(x).clone())
+                torch.cuda.synchronize()
+                if keep is not None:
+                    side.synchronize()
+            return outs, st.tables.status.tolist(), [st.k[1].clone(), st.v[1].clone()]
+    try:
+        want, st0, kv0 = stream()
+        t0 = time.perf_counter()
+        got, st1, kv1 = stream(disturb_at=2)
+        took = time.perf_counter() - t0
+    finally:
+        ops.TEMPORAL_FRAME = old
+    assert st0 == [0, 0, 0, 0]
+    assert st1[0] == 0 and st1[1] == 1 and st1[2] != 0, f"status {st1}: the step was expected to time out and be repaired ({took:.2f} s)"
+    assert _rel(got, want) < 1e-5
+    assert torch.allclose(kv0[0], kv1[0], atol=1e-5) and torch.allclose(kv0[1], kv1[1], atol=1e-5)
