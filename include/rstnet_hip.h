@@ -109,6 +109,16 @@ int rst_skinny_f32_split_plan(int M, int N, int K);
  *     operand `xp` of the NEXT few-row GEMM (linear1 -> GELU -> linear2 of a streamed layer: no packing launch between the two). */
 int rst_gemm_skinny_f32(const float* xp, const float* wp, const float* bias, const float* res, const float* scale, float* y, int M,
                         int N, int K, int ldy, int act_out, int split_k, float* ws, uint32_t* counters, int y_packed, rst_stream_t stream);
+/*   rst_linear_few_rows_f32 (round 6): the plain-linear case of the few-row GEMM WITHOUT a packing launch -- the rows x [M][ldx]
+ *     (K % 8 == 0, ldx % 4 == 0, 16-byte aligned) are read row-major inside the GEMM, a lane picking its four k of every 8-k chunk; with
+ *     ln_gamma / ln_beta [K] (both or neither) the nn.LayerNorm(K, ln_eps) in front of the linear is applied on the way, its statistics
+ *     computed per workgroup with rst_skinny_f32_pack_ln's arithmetic: the result equals rst_skinny_f32_pack_ln (or _pack_win) followed by
+ *     rst_gemm_skinny_f32 bit for bit.  Every Linear of a streamed transformer layer at more than two streams
+ *     (modules/transformer.py:395-423 in_proj / out_proj, :540-569 norm -> linear1 -> GELU -> linear2) is one launch instead of two.
+ *     wp, bias, res, scale, act_out, split_k, ws, counters, y_packed as rst_gemm_skinny_f32. */
+int rst_linear_few_rows_f32(const float* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* wp,
+                            const float* bias, const float* res, const float* scale, float* y, int M, int N, int K, int ldy, int act_out,
+                            int split_k, float* ws, uint32_t* counters, int y_packed, rst_stream_t stream);
 
 /* Causal Conv1d.  Replaces F.conv1d in RawStreamingConv1d.forward (modules/streaming.py:216-244) together with the
  * padding logic of StreamingConv1d.forward (modules/conv.py:232-254).
@@ -476,6 +486,16 @@ int rst_lm_attn_decode_f32(const float* qkv, void* k, void* v, float* ws, uint32
 int rst_attn_decode_multi_f32(const float* q, const float* k, const float* v, float* ws, uint32_t* counters, float* out,
                               const int64_t* pos_dev, int B, int T, int H, int D, int cap, int context, int splits,
                               int kv_heads, rst_stream_t stream);
+
+/* One streaming step of a codec transformer layer's attention as ONE launch (round 6; rst_rope_split_f32(ring = 1) +
+ * rst_attn_decode_multi_f32 in one workgroup per (stream, head)): qkv [B][T][3][H][D] is the in-projection's output of the T new steps
+ * ("b t (p h d)", modules/transformer.py:376-388); q and k are rotated (interleaved RoPE at positions *pos_dev + t, modules/rope.py:37-62;
+ * rope = 0: none), k / v appended to ring slots (*pos_dev + t) % cap of [B][H][cap][D] (RingKVCache.complete, transformer.py:255-262), and
+ * the T queries run against the ring with the mask / slot map of rst_attention_f32(ring = 1), end_offset = *pos_dev + T.  out [B][T][H*D].
+ * Served shapes (rst_attention_step_supported): 1 <= T <= 4, D in {32, 64, 128}, the ring's scores in LDS (cap up to ~4000 at T = 4). */
+int rst_attention_step_supported(int T, int D, int cap);
+int rst_attention_step_f32(const float* qkv, float* k, float* v, float* out, const int64_t* pos_dev, int B, int T, int H, int D, int cap,
+                           int context, int rope, float rope_coef, rst_stream_t stream);
 
 /* sample_token (utils/sampling.py:85-105): greedy argmax, or softmax(logits/temp) -> top-k (sorted descending) ->
  * argmax_j p_j / noise_j with caller-provided Exp(1) noise [B][noise_stride] (the reference draws it with

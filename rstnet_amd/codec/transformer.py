@@ -155,9 +155,13 @@ class StreamingMultiheadAttention(StreamingModule[_MHAState]):
         else:
             # position from the device-side counter (graph-replay safe), mirrored on the host in offset_cpu
             pos_dev = state.shared if state.shared is not None else state.offset
-            q, k, v = ops.rope_split(qkv, H, k=state.k_cache, v=state.v_cache, pos0=offset, pos_dev=pos_dev, ring=True,
-                                     rope=use_rope, max_period=period)
-            a = ops.attention(q, k, v, pos0=offset, pos_dev=pos_dev, ring=True, context=self.context)
+            if ops.attention_step_supported(qkv, H, state.k_cache.shape[2]):
+                # a few new positions: split, rotation, ring append and the queries against the ring in one launch
+                a = ops.attention_step(qkv, H, state.k_cache, state.v_cache, pos_dev, context=self.context, rope=use_rope, max_period=period)
+            else:
+                q, k, v = ops.rope_split(qkv, H, k=state.k_cache, v=state.v_cache, pos0=offset, pos_dev=pos_dev, ring=True,
+                                         rope=use_rope, max_period=period)
+                a = ops.attention(q, k, v, pos0=offset, pos_dev=pos_dev, ring=True, context=self.context)
         out = self._project(self.out_proj.weight, a, offset, res=res, scale=scale)
         if state is not None:
             if state.shared is None:

@@ -24,7 +24,7 @@ int rst_check_launch(const char* what) {
 
 extern "C" {
 
-int rst_version(void) { return 120; }      // round 6: + rst_temporal_decode_frame / _supported / _workspace_bytes, rst_build_id, rst_rvq_chain_supported; 110 = round 5: three-plane weights in operand order (re-pack!), + rst_attention_qkv_f32 / rst_rope_table_f32,
+int rst_version(void) { return 121; }      // 121: + rst_linear_few_rows_f32, rst_attention_step_f32 / _supported; 120 = round 6: + rst_temporal_decode_frame / _supported / _workspace_bytes, rst_build_id, rst_rvq_chain_supported; 110 = round 5: three-plane weights in operand order (re-pack!), + rst_attention_qkv_f32 / rst_rope_table_f32,
                                            // rst_rvq_search_chain_f32, rst_embed_sum_bf16(add_stride); 105: round 4
 const char* rst_last_error(void) { return g_err; }
 
@@ -285,10 +285,31 @@ int rst_skinny_f32_split_plan(int M, int N, int K) { return rst_skinny_f32_split
 
 int rst_gemm_skinny_f32(const float* xp, const float* wp, const float* bias, const float* res, const float* scale, float* y, int M,
                         int N, int K, int ldy, int act_out, int split_k, float* ws, uint32_t* counters, int y_packed, rst_stream_t stream) {
-    SkinnyF32Params p;
+    SkinnyF32Params p = {};
     p.xp = xp; p.wp = wp; p.bias = bias; p.res = res; p.scale = scale; p.y = y; p.M = M; p.N = N; p.Kp = (K + 7) / 8 * 8; p.ldy = ldy;
     p.act_out = act_out; p.split_k = split_k; p.ws = ws; p.counters = counters; p.Np_out = y_packed ? N : 0;
     return rst_launch_gemm_skinny_f32(p, (hipStream_t)stream);
+}
+
+int rst_linear_few_rows_f32(const float* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* wp, const float* bias,
+                            const float* res, const float* scale, float* y, int M, int N, int K, int ldy, int act_out, int split_k, float* ws,
+                            uint32_t* counters, int y_packed, rst_stream_t stream) {
+    RST_REQUIRE(x && K > 0 && K % 8 == 0, "linear_few_rows: K %% 8 == 0 required (K=%d)", K);
+    SkinnyF32Params p = {};
+    p.xr = x; p.ldx = ldx; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps;
+    p.wp = wp; p.bias = bias; p.res = res; p.scale = scale; p.y = y; p.M = M; p.N = N; p.Kp = K; p.ldy = ldy;
+    p.act_out = act_out; p.split_k = split_k; p.ws = ws; p.counters = counters; p.Np_out = y_packed ? N : 0;
+    return rst_launch_gemm_skinny_f32(p, (hipStream_t)stream);
+}
+
+int rst_attention_step_supported(int T, int D, int cap) { return rst_attn_step_supported_impl(T, D, cap); }
+
+int rst_attention_step_f32(const float* qkv, float* k, float* v, float* out, const int64_t* pos_dev, int B, int T, int H, int D, int cap,
+                           int context, int rope, float rope_coef, rst_stream_t stream) {
+    AttnStepParams p = {};
+    p.qkv = qkv; p.k = k; p.v = v; p.out = out; p.pos_dev = reinterpret_cast<const long*>(pos_dev);
+    p.B = B; p.T = T; p.H = H; p.D = D; p.cap = cap; p.context = context; p.rope = rope; p.rope_coef = rope_coef;
+    return rst_launch_attn_step(p, (hipStream_t)stream);
 }
 
 int rst_hist_update_batch_f32(const float* const* x, float* const* hist, const int* T_in, const int* P, const int* C, int n, int B,

@@ -44,7 +44,12 @@ struct SkinnyF32PackParams {      // the A operand of GemmWinParams, gathered + 
 };
 int rst_launch_skinny_f32_pack_ln(const float* x, const float* gamma, const float* beta, float* xp, int M, int K, float eps, hipStream_t stream);
 struct SkinnyF32Params {
-    const float* xp;              // packed activation windows
+    const float* xp;              // packed activation windows (nullptr: the rows come row-major, below)
+    const float* xr;              // row-major rows x [M][ldx] of a plain linear (Kp = K, K % 8 == 0): no packing launch in front of the GEMM
+    const float* ln_g;            // xr only, optional: nn.LayerNorm(K, ln_eps) applied to the rows on their way in (gamma, beta [K])
+    const float* ln_b;
+    int ldx;
+    float ln_eps;
     const float* wp;              // packed weights [ceil(N/32)][Kp/8][64][4]
     const float* bias;            // [N] or nullptr
     const float* res;             // [M][ldy] or nullptr
@@ -60,6 +65,19 @@ int rst_skinny_f32_split_plan_impl(int M, int N, int K);
 int rst_launch_skinny_f32_pack_weight(const float* w, float* wp, int N, int K, hipStream_t stream);
 int rst_launch_skinny_f32_pack_win(const SkinnyF32PackParams& p, hipStream_t stream);
 int rst_launch_gemm_skinny_f32(const SkinnyF32Params& p, hipStream_t stream);
+
+// ---- codec_attn.hip -------------------------------------------------------------------------------
+struct AttnStepParams {
+    const float* qkv;             // [B][T][3][H][D]: the in-projection's output of the T new steps
+    float* k;                     // rings [B][H][cap][D]
+    float* v;
+    float* out;                   // [B][T][H*D]
+    const long* pos_dev;          // position of the first new step
+    int B, T, H, D, cap, context, rope;
+    float rope_coef;
+};
+int rst_attn_step_supported_impl(int T, int D, int cap);
+int rst_launch_attn_step(const AttnStepParams& p, hipStream_t stream);
 
 // ---- resblock.hip ---------------------------------------------------------------------------------
 struct ResblockParams {

@@ -42,10 +42,63 @@ __device__ __forceinline__ float sf_wave_sum(float v) {
     return v;
 }
 
+// nn.LayerNorm statistics of one row by one wave -- `layernorm_kernel`'s arithmetic (fp32: the lane's sum in column order, the wave's
+// sum in butterfly order, variance of the centred values with fmaf) -- and its application to one element.  Shared by the packing launch
+// below and by the GEMM's row-major operand path, so that both give the bits of LayerNorm followed by the pack.
+__device__ __forceinline__ float sf_ln_apply(float v, float mean, float rstd, float g, float b) { return (v - mean) * rstd * g + b; }
+
+__device__ __forceinline__ void sf_row_stats(const float* xr, int K, int lane, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+    for (int i = lane * 4; i < K; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    mean = sf_wave_sum(s) / (float)K;
+    float q = 0.f;
+    for (int i = lane * 4; i < K; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q = fmaf(d, d, q); }
+    }
+    rstd = 1.0f / sqrtf(sf_wave_sum(q) / (float)K + eps);
+}
+
+// The same statistics for RB rows of K <= 256 KP columns at once: every row's pieces are requested before any is used (one memory
+// round trip for the batch instead of two per row), then the per-row arithmetic of sf_row_stats in the same order.
+template <int RB, int KP>
+__device__ __forceinline__ void sf_rows_stats(const float* x, int ldx, int m0, int dm, int M, int K, int lane, float eps, float (&mean)[RB], float (&rstd)[RB]) {
+    f32x4 v[RB][KP];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const float* xr = x + (long)min(m0 + r * dm, M - 1) * ldx;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) v[r][j] = *reinterpret_cast<const f32x4*>(xr + min(lane * 4 + 256 * j, K - 4));       // clamped: unconditional loads
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+            if (lane * 4 + 256 * j < K) s += (v[r][j][0] + v[r][j][1]) + (v[r][j][2] + v[r][j][3]);
+        mean[r] = sf_wave_sum(s) / (float)K;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+            if (lane * 4 + 256 * j < K) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[r][j][e] - mean[r]; q = fmaf(d, d, q); }
+            }
+        rstd[r] = 1.0f / sqrtf(sf_wave_sum(q) / (float)K + eps);
+    }
+}
+
 // LayerNorm + pack in ONE launch (round 5): the plain-linear case of the packing below (no window, K = C) with the row's LayerNorm
-// applied on the way -- `layernorm_kernel`'s arithmetic (one wave per row, fp32 statistics: sum in lane order, variance of the
-// centred values with fmaf, (x - mean) * rstd * gamma + beta), so the operand is bit-identical to LayerNorm followed by the pack.
+// applied on the way, so the operand is bit-identical to LayerNorm followed by the pack.
 // Every streamed transformer layer of the codec at more than two streams had a LayerNorm launch in front of each of these packs.
+// (Round 6: plain linears read their rows row-major inside the GEMM itself -- SkinnyF32Params::xr -- and this launch is the A/B form.)
 __global__ __launch_bounds__(256) void f32_pack_ln_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ xp, int M, int K, int Kp, float eps) {
     const int lane = threadIdx.x & 63;
@@ -59,19 +112,8 @@ __global__ __launch_bounds__(256) void f32_pack_ln_kernel(const float* __restric
         return;
     }
     const float* xr = x + (long)m * K;
-    float s = 0.f;
-    for (int i = lane * 4; i < K; i += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);
-        s += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    const float mean = sf_wave_sum(s) / (float)K;
-    float q = 0.f;
-    for (int i = lane * 4; i < K; i += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q = fmaf(d, d, q); }
-    }
-    const float rstd = 1.0f / sqrtf(sf_wave_sum(q) / (float)K + eps);
+    float mean, rstd;
+    sf_row_stats(xr, K, lane, eps, mean, rstd);
     for (int i = lane * 4; i < Kp; i += 256) {
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
         if (i < K) {
@@ -79,7 +121,7 @@ __global__ __launch_bounds__(256) void f32_pack_ln_kernel(const float* __restric
             const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i);
             const f32x4 b = *reinterpret_cast<const f32x4*>(beta + i);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * g[e] + b[e];
+            for (int e = 0; e < 4; ++e) o[e] = sf_ln_apply(v[e], mean, rstd, g[e], b[e]);
         }
         // k = i .. i + 3 (i % 4 == 0): k & 1 alternates, (k & 7) >> 1 = (i & 7) / 2 + {0, 0, 1, 1}
         const long base = (tile + (i >> 3)) * 64;
@@ -150,11 +192,17 @@ constexpr int SF_WAVES = 8;
 // behind N / 32 = 16 or 32 workgroups streams at well under 1 TB/s (measured 62 us for the 33 MB 512 -> 1024 k16 convolution);
 // the partial tiles go to `ws` with write-through stores, one arrival counter per column tile, and the LAST workgroup to arrive
 // sums them in split order (deterministic) and runs the epilogue (the protocol of gemm_win's split-K: cdna_hip_programming.md G16).
-template <int NB, int CT>
+// ROWS (round 6): the activation operand is NOT packed -- the rows of a plain linear are read row-major (p.xr [M][ldx], K % 8 == 0), a
+// lane picking its four k of every 8-k chunk out of two 16-byte loads, with the LayerNorm in front of the linear (p.ln_g / p.ln_b)
+// applied on the way: its statistics are computed by every workgroup for all M rows (one wave per row, a batch of rows per memory
+// round trip; M x K x 4 bytes out of L2) with the packing launch's arithmetic, so the products are the bits of LayerNorm -> pack ->
+// GEMM.  A few-row linear of a streamed transformer layer is then ONE launch instead of two (16 x 4 launches per 80 ms frame).
+template <int NB, int CT, bool ROWS = false>
 __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const SkinnyF32Params p) {
     __shared__ float red[SF_WAVES][NB * 32][33];
     __shared__ int sm_last;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float ln_stat[ROWS ? NB * 32 : 1][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = ROWS ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int tiles = (p.N + 31) / 32;
     const int tile0 = blockIdx.x * CT;
     const int chunks = p.Kp / 8;
@@ -189,8 +237,19 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
             spre[c][q] = p.scale ? p.scale[n] : 1.0f;
         }
     constexpr int UN = NB * CT <= 2 ? 4 : 2;
-    for (int s = s0; s < s1; s += UN) {
-        f32x4 a[UN][CT], bx[UN][NB];
+    // One pass of the K loop: UN chunks of weights and activations requested together, then multiplied.  ROWS: the requests of the
+    // wave's FIRST pass (weights from HBM, the rows, gamma / beta) go out before the LayerNorm statistics, whose own round trip and
+    // reductions then run under them -- the rows' raw values wait in registers for mean / rstd.
+    f32x4 a[UN][CT], bx[UN][NB];
+    f32x4 xlo[ROWS ? UN : 1][NB], xhi[ROWS ? UN : 1][NB], g4[ROWS ? UN : 1], b4[ROWS ? UN : 1];
+    const float* xrow[NB];
+    const bool has_ln = ROWS && p.ln_g != nullptr;
+    const bool odd = (lane >> 5) != 0;
+    if (ROWS) {
+#pragma unroll
+        for (int t = 0; t < NB; ++t) xrow[t] = p.xr + (long)min(32 * t + (lane & 31), p.M - 1) * p.ldx;      // rows past M: row M - 1, cleared below
+    }
+    auto issue = [&](const int s) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const bool ok = s + u < s1;
@@ -198,9 +257,85 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
 #pragma unroll
             for (int c = 0; c < CT; ++c)
                 a[u][c] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wt[c] + so)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!ROWS) {
 #pragma unroll
-            for (int t = 0; t < NB; ++t)
-                bx[u][t] = ok ? *reinterpret_cast<const f32x4*>(xq + (long)t * chunks * 256 + so) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < NB; ++t)
+                    bx[u][t] = ok ? *reinterpret_cast<const f32x4*>(xq + (long)t * chunks * 256 + so) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                // chunk s + u = columns 8 (s + u) .. + 7; this lane's four are k = 8 (s + u) + 2 e + (lane >> 5).  (Past the wave's range:
+                // the last chunk once more -- a valid address, unconditional loads -- against zero weights.)
+                const int k0 = 8 * min(s + u, chunks - 1);
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    xlo[u][t] = *reinterpret_cast<const f32x4*>(xrow[t] + k0);
+                    xhi[u][t] = *reinterpret_cast<const f32x4*>(xrow[t] + k0 + 4);
+                }
+                if (has_ln) {
+                    const f32x4 glo = *reinterpret_cast<const f32x4*>(p.ln_g + k0), ghi = *reinterpret_cast<const f32x4*>(p.ln_g + k0 + 4);
+                    const f32x4 blo = *reinterpret_cast<const f32x4*>(p.ln_b + k0), bhi = *reinterpret_cast<const f32x4*>(p.ln_b + k0 + 4);
+                    g4[u] = odd ? f32x4{glo[1], glo[3], ghi[1], ghi[3]} : f32x4{glo[0], glo[2], ghi[0], ghi[2]};
+                    b4[u] = odd ? f32x4{blo[1], blo[3], bhi[1], bhi[3]} : f32x4{blo[0], blo[2], bhi[0], bhi[2]};
+                }
+            }
+        }
+    };
+    float r_mean[NB], r_rstd[NB];
+    if (ROWS) {
+        issue(s0);
+        if (has_ln) {
+            const int K = p.Kp;
+            if (K <= 512) {              // all rows of a wave in one round trip (M <= 64), or two
+                for (int m0 = wave; m0 < p.M; m0 += 8 * SF_WAVES) {
+                    float mean[8], rstd[8];
+                    sf_rows_stats<8, 2>(p.xr, p.ldx, m0, SF_WAVES, p.M, K, lane, p.ln_eps, mean, rstd);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r)
+                            if (m0 + r * SF_WAVES < p.M) { ln_stat[m0 + r * SF_WAVES][0] = mean[r]; ln_stat[m0 + r * SF_WAVES][1] = rstd[r]; }
+                    }
+                }
+            } else if (K <= 1024) {
+                for (int m0 = wave; m0 < p.M; m0 += 4 * SF_WAVES) {
+                    float mean[4], rstd[4];
+                    sf_rows_stats<4, 4>(p.xr, p.ldx, m0, SF_WAVES, p.M, K, lane, p.ln_eps, mean, rstd);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (m0 + r * SF_WAVES < p.M) { ln_stat[m0 + r * SF_WAVES][0] = mean[r]; ln_stat[m0 + r * SF_WAVES][1] = rstd[r]; }
+                    }
+                }
+            } else {
+                for (int m = wave; m < p.M; m += SF_WAVES) {
+                    float mean, rstd;
+                    sf_row_stats(p.xr + (long)m * p.ldx, K, lane, p.ln_eps, mean, rstd);
+                    if (lane == 0) { ln_stat[m][0] = mean; ln_stat[m][1] = rstd; }
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const int row = min(32 * t + (lane & 31), p.M - 1);
+            r_mean[t] = has_ln ? ln_stat[row][0] : 0.f;
+            r_rstd[t] = has_ln ? ln_stat[row][1] : 1.f;
+        }
+    }
+    for (int s = s0; s < s1; s += UN) {
+        if (!ROWS || s != s0) issue(s);
+        if (ROWS) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    const f32x4 lo = xlo[u][t], hi = xhi[u][t];
+                    f32x4 x4 = odd ? f32x4{lo[1], lo[3], hi[1], hi[3]} : f32x4{lo[0], lo[2], hi[0], hi[2]};
+                    if (has_ln) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x4[e] = sf_ln_apply(x4[e], r_mean[t], r_rstd[t], g4[u][e], b4[u][e]);
+                    }
+                    if (s + u >= s1 || 32 * t + (lane & 31) >= p.M) x4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    bx[u][t] = x4;
+                }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u)
@@ -348,7 +483,7 @@ int rst_skinny_f32_split_plan_impl(int M, int N, int K) {
 }
 
 int rst_launch_gemm_skinny_f32(const SkinnyF32Params& p, hipStream_t stream) {
-    RST_REQUIRE(p.xp && p.wp && p.y && p.M >= 1 && p.M <= 128 && p.N > 0 && p.Kp > 0 && p.Kp % 8 == 0 && p.act_out >= 0 && p.act_out <= 2,
+    RST_REQUIRE((p.xp || p.xr) && p.wp && p.y && p.M >= 1 && p.M <= 128 && p.N > 0 && p.Kp > 0 && p.Kp % 8 == 0 && p.act_out >= 0 && p.act_out <= 2,
                 "gemm_skinny_f32: bad arguments (1 <= M <= 128, Kp %% 8 == 0; M=%d Kp=%d)", p.M, p.Kp);
     const int tiles = (p.N + 31) / 32;
     const int split = p.split_k > 1 ? p.split_k : 1;
@@ -356,6 +491,16 @@ int rst_launch_gemm_skinny_f32(const SkinnyF32Params& p, hipStream_t stream) {
     RST_REQUIRE(p.Np_out == 0 || (p.Np_out == p.N && p.N % 8 == 0 && !p.res), "gemm_skinny_f32: packed output needs N %% 8 == 0, Np_out = N and no residual (N=%d)", p.N);
     const dim3 block(64 * SF_WAVES);
     const int nb = (p.M + 31) / 32;
+    if (p.xr) {
+        // row-major rows of a plain linear (+ LayerNorm): no packing launch
+        RST_REQUIRE(!p.xp && p.ldx >= p.Kp && p.ldx % 4 == 0 && (uintptr_t)p.xr % 16 == 0 && (!p.ln_g == !p.ln_b) &&
+                        (!p.ln_g || ((uintptr_t)p.ln_g % 16 == 0 && (uintptr_t)p.ln_b % 16 == 0)),
+                    "linear_few_rows: rows must be 16-byte aligned with K %% 8 == 0 and ldx %% 4 == 0; gamma and beta come together (K=%d ldx=%d)", p.Kp, p.ldx);
+        if (nb == 1) hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 1, true>), dim3(tiles, split), block, 0, stream, p);
+        else if (nb == 2) hipLaunchKernelGGL((gemm_skinny_f32_kernel<2, 1, true>), dim3(tiles, split), block, 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_f32_kernel<4, 1, true>), dim3(tiles, split), block, 0, stream, p);
+        return rst_check_launch("linear_few_rows");
+    }
     if (nb == 1) {
         if (tiles >= 512) hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 2>), dim3((tiles + 1) / 2), block, 0, stream, p);
         else hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 1>), dim3(tiles, split), block, 0, stream, p);

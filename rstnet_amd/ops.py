@@ -194,6 +194,17 @@ def skinny_f32_pack_weight(w: torch.Tensor) -> torch.Tensor:
     return _skinny_f32_weights.get(w, build)
 
 
+# K split of the few-row GEMMs across workgroups: None = rst_skinny_f32_split_plan; an int overrides it (probes / A/B runs only)
+SKINNY_F32_SPLIT = None
+
+# Plain few-row linears (no window: the Linears of a streamed transformer layer at more than two streams) read their rows row-major
+# inside the GEMM (rst_linear_few_rows_f32): no packing launch.  "plain" (default): the linears WITHOUT a LayerNorm in front (the
+# out-projection); True: those with one too -- the same bits, but measured SLOWER (64 rows, 512 -> 1536: 15.9 us against 11.3 us for
+# LayerNorm + pack followed by the GEMM; the statistics of all rows by every workgroup are a second memory round trip plus two
+# cross-lane reductions in front of the matrix instructions, and a 3 us packing launch is all they replace;
+# tools/probes/few_row_linear_probe.py, profiles/r06_few_row_linear_probe.txt); False: never (the A/B switch).
+SKINNY_F32_ROWS = "plain"
+
 # LayerNorm in front of a few-row linear (streamed transformer layers at more than two streams): applied by the packing launch
 # (rst_skinny_f32_pack_ln) instead of a launch of its own.  False: LayerNorm, then pack (the A/B switch of tools/ab.py).
 SKINNY_F32_PACK_LN = True
@@ -231,6 +242,23 @@ def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, 
     ``PackedRows`` (no packing at all); ``out_packed``: ``out`` is the ``xp`` of a ``PackedRows``."""
     M = B * T_out
     wp = skinny_f32_pack_weight(w)
+    dev = x.xp.device if isinstance(x, PackedRows) else x.device
+
+    def build():
+        sk = int(_lib.lib().rst_skinny_f32_split_plan(M, N, K)) if SKINNY_F32_SPLIT is None else int(SKINNY_F32_SPLIT)
+        return (sk, torch.empty(sk, M, N, device=dev, dtype=torch.float32),
+                torch.zeros((N + 31) // 32, device=dev, dtype=torch.int32)) if sk > 1 else (1, None, None)
+    sc = _scratch(_gemm_scratch, dev, ("skinny", M, N, K, SKINNY_F32_SPLIT), build)
+    plain = hist is None and S == 1 and P == 0 and T_in == T_out and C_ == K and act_in == ACT_NONE
+    if (SKINNY_F32_ROWS and plain and not isinstance(x, PackedRows) and K % 8 == 0 and x.data_ptr() % 16 == 0 and
+            (ln is None or (SKINNY_F32_ROWS is True and ln[0].data_ptr() % 16 == 0 and ln[1].data_ptr() % 16 == 0))):
+        # the rows as they are: one launch
+        g, b, eps = ln if ln is not None else (None, None, 0.0)
+        _chk(g, "ln gamma")
+        _chk(b, "ln beta")
+        _lib.check(_lib.lib().rst_linear_few_rows_f32(_ptr(x), K, _ptr(g), _ptr(b), float(eps), _ptr(wp), _ptr(bias), _ptr(res), _ptr(scale),
+                                                     _ptr(out), M, N, K, N, act_out, sc[0], _ptr(sc[1]), _ptr(sc[2]), int(out_packed), _stream()))
+        return
     if isinstance(x, PackedRows):
         xp = x.xp
         if not (xp.shape[1] == wp.shape[1] and ln is None and hist is None):
@@ -248,11 +276,6 @@ def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, 
     else:
         _lib.check(_lib.lib().rst_skinny_f32_pack_win(_ptr(x), _ptr(hist), _ptr(xp), B, T_in, T_out, C_, K, S, P, pad_mode, T_in * C_, act_in,
                                                      _stream()))
-    def build():
-        sk = int(_lib.lib().rst_skinny_f32_split_plan(M, N, K))
-        return (sk, torch.empty(sk, M, N, device=xp.device, dtype=torch.float32),
-                torch.zeros((N + 31) // 32, device=xp.device, dtype=torch.int32)) if sk > 1 else (1, None, None)
-    sc = _scratch(_gemm_scratch, xp.device, ("skinny", M, N, K), build)
     _lib.check(_lib.lib().rst_gemm_skinny_f32(_ptr(xp), _ptr(wp), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, N, K, N, act_out,
                                              sc[0], _ptr(sc[1]), _ptr(sc[2]), int(out_packed), _stream()))
 
@@ -539,6 +562,34 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, pos0: int = 
         return out
     _lib.check(_lib.lib().rst_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(pos_dev), pos0, B, T, H, D, cap,
                                             int(ring), int(context) if context else 0, _stream()))
+    return out
+
+
+# A streaming step of a codec transformer layer's attention (a few new positions of many streams) as ONE launch: split + RoPE + ring
+# append + the queries against the ring (rst_attention_step_f32).  False: rope_split + attention, two launches (the A/B switch).
+ATTENTION_STEP = True
+
+
+def attention_step_supported(qkv: torch.Tensor, H: int, cap: int) -> bool:
+    B, T, E3 = qkv.shape
+    return bool(ATTENTION_STEP and qkv.is_cuda and E3 % (3 * H) == 0 and qkv.data_ptr() % 16 == 0 and
+                _lib.lib().rst_attention_step_supported(T, E3 // (3 * H), cap))
+
+
+def attention_step(qkv: torch.Tensor, H: int, k: torch.Tensor, v: torch.Tensor, pos_dev: torch.Tensor, *, context: Optional[int] = None,
+                   rope: bool = True, max_period: float = 10000.0) -> torch.Tensor:
+    """qkv ``[B,T,3*H*D]`` (the in-projection of the T new steps) -> ``[B,T,H*D]``; k / v ``[B,H,cap,D]`` rings, appended in place at
+    slots ``(pos_dev + t) % cap``."""
+    for t, n in ((qkv, "qkv"), (k, "k"), (v, "v")):
+        _chk(t, n)
+    _chk(pos_dev, "pos_dev", torch.int64)
+    B, T, E3 = qkv.shape
+    D = E3 // (3 * H)
+    if k.shape != v.shape or k.shape[0] != B or k.shape[1] != H or k.shape[3] != D:
+        raise ValueError(f"rstnet_amd.ops: rings {tuple(k.shape)} / {tuple(v.shape)} do not belong to qkv {tuple(qkv.shape)} with {H} heads")
+    out = torch.empty(B, T, H * D, device=qkv.device, dtype=torch.float32)
+    _lib.check(_lib.lib().rst_attention_step_f32(_ptr(qkv), _ptr(k), _ptr(v), _ptr(out), _ptr(pos_dev), B, T, H, D, k.shape[2],
+                                                 int(context) if context else 0, int(rope), rope_coef(max_period, D), _stream()))
     return out
 
 

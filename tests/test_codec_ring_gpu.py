@@ -100,6 +100,28 @@ def test_projected_transformer_streamed_across_the_wrap(chunk, persistent, monke
     assert ops.codec_transformer_status(torch.device(DEV)).tolist()[:3] == [0, 0, 0], "a hand-off of the persistent transformer launch timed out"
 
 
+@pytest.mark.parametrize("streams,chunk,one_launch", [(5, 2, True), (5, 2, False), (3, 3, True), (9, 1, True)])
+def test_projected_transformer_many_streams_across_the_wrap(streams, chunk, one_launch, monkeypatch):
+    """More than two streams per step: the layer loop on the few-row route (round 6: every attention step as ONE launch,
+    rst_attention_step_f32, and the out-projection reading its rows in place, rst_linear_few_rows_f32 -- or the launches they replace
+    with the switches off) vs the oracle's TransformerStream for 300 positions (the ring wraps at 250)."""
+    monkeypatch.setattr(ops, "ATTENTION_STEP", one_launch)
+    monkeypatch.setattr(ops, "SKINNY_F32_ROWS", "plain" if one_launch else False)
+    sd = synth.mimi_state_dict(cases.MIMI_SEED, layer_scale=cases.TRANSFORMER_LAYER_SCALE)
+    model, tr = _transformer(sd)
+    x = cases.transformer_input(batch=streams)
+    ts = O.TransformerStream(sd, "encoder_transformer", O.MimiConfig(), streams)
+    worst = 0.0
+    with tr.streaming(streams):
+        for i in range(0, x.shape[-1], chunk):
+            xc = x[:, :, i:i + chunk].contiguous()
+            with torch.no_grad():
+                ref = ts.step(xc)
+            y = tr(xc.to(DEV))[0]
+            worst = max(worst, rel_err(y, ref))
+    assert worst < 1e-3, worst
+
+
 def test_codec_transformer_frame_mixed_with_layer_loop():
     """One session that alternates between the persistent launch (chunks of 2 positions) and the layer loop (a chunk of 7): both
     append to the same rings and advance the same position counter."""

@@ -331,6 +331,7 @@ def test_few_row_linear_applies_layernorm_while_packing(M, K, N, monkeypatch):
     gamma, beta = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
     ref = F.linear(F.layer_norm(x, (K,), gamma, beta, 1e-5), w)
     ln = (gamma.to(DEV), beta.to(DEV), 1e-5)
+    monkeypatch.setattr(ops, "SKINNY_F32_ROWS", False)       # (the packed-operand route: round 6 reads plain rows inside the GEMM, below)
     monkeypatch.setattr(ops, "SKINNY_F32_PACK_LN", True)
     ops.PROFILE = []
     y = ops.linear(x.to(DEV), w.to(DEV), ln=ln)
@@ -364,6 +365,72 @@ def test_few_row_linears_chain_through_the_packed_operand(M, monkeypatch):
     assert rel_err(y, ref) < TOL
     monkeypatch.setattr(ops, "SKINNY_F32_CHAIN", False)
     assert not ops.linear_chains(xg, w1g, w2g)
+
+
+@pytest.mark.parametrize("M", [5, 33, 64, 100, 128])
+@pytest.mark.parametrize("N,K", [(1536, 512), (512, 512), (2048, 512), (512, 2048), (96, 1280)])
+def test_few_row_linear_reads_its_rows_in_place(M, N, K, monkeypatch):
+    """rst_linear_few_rows_f32 (round 6): a plain few-row linear reads its rows row-major inside the GEMM -- with the LayerNorm in front of
+    it, the residual / LayerScale / GELU epilogue and the packed output for the next linear -- and gives the bits of the packing launch
+    followed by the GEMM on the packed operand (modules/transformer.py:395-423,540-569 at more than two streams per step)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 2 + 0.3).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    res, scale = torch.randn(M, N, generator=g).to(DEV), torch.rand(N, generator=g).to(DEV)
+    ln = ((1 + 0.1 * torch.randn(K, generator=g)).to(DEV), (0.1 * torch.randn(K, generator=g)).to(DEV), 1e-5)
+    cases = [dict(), dict(ln=ln), dict(res=res, scale=scale), dict(ln=ln, act_out=ops.ACT_GELU), dict(ln=ln, res=res, scale=scale, act_out=ops.ACT_GELU)]
+    got, want = [], []
+    for rows, dst in ((True, got), (False, want)):
+        monkeypatch.setattr(ops, "SKINNY_F32_ROWS", rows)
+        for kw in cases:
+            for _ in range(2):         # twice: the split-K arrival counters re-arm
+                y = ops.linear(x, w, **kw)
+            dst.append(y)
+        if N % 8 == 0 and M > 4:
+            h = ops.linear(x, w, ln=ln, act_out=ops.ACT_GELU, out_packed=True)
+            assert isinstance(h, ops.PackedRows)
+            dst.append(h.xp)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    xc, wc = x.cpu(), w.cpu()
+    ref = res.cpu() + scale.cpu() * F.gelu(F.linear(F.layer_norm(xc, (K,), ln[0].cpu(), ln[1].cpu(), 1e-5), wc))
+    assert rel_err(got[4], ref) < TOL
+    assert rel_err(got[0], F.linear(xc, wc)) < TOL
+
+
+@pytest.mark.parametrize("T,D,H,cap,context", [(2, 64, 8, 250, 250), (1, 64, 8, 250, 250), (4, 32, 4, 64, 40), (3, 128, 2, 300, None), (2, 64, 8, 250, 100)])
+def test_attention_step_is_rope_split_plus_ring_attention(T, D, H, cap, context, monkeypatch):
+    """rst_attention_step_f32 (round 6): split of the in-projection's output, interleaved RoPE, ring append and the T new queries against the
+    ring in ONE launch vs rst_rope_split_f32 + rst_attn_decode_multi_f32 -- same ring contents, same outputs (to the summation order of the
+    softmax), from an empty ring, across the wrap and deep into steady state (modules/transformer.py:376-416, RingKVCache.complete)."""
+    B = 5
+    g = torch.Generator().manual_seed(T * 100 + D)
+    E = H * D
+    for pos0 in (0, cap - 2 * T - 1, 7 * cap + 3):
+        k1, v1 = (torch.randn(B, H, cap, D, generator=g).to(DEV) for _ in range(2))
+        k2, v2 = k1.clone(), v1.clone()
+        if pos0 == 0:
+            k1.fill_(float("nan")); v1.fill_(float("nan"))      # an empty ring is never read by the one-launch step
+            k2.zero_(); v2.zero_()
+        pos1, pos2 = (torch.tensor([pos0], device=DEV, dtype=torch.long) for _ in range(2))
+        off = pos0
+        for step in range(6):
+            qkv = torch.randn(B, T, 3 * E, generator=g).to(DEV)
+            assert ops.attention_step_supported(qkv, H, cap)
+            a = ops.attention_step(qkv, H, k1, v1, pos1, context=context, rope=True, max_period=10000.0)
+            q, kk, vv = ops.rope_split(qkv, H, k=k2, v=v2, pos0=off, pos_dev=pos2, ring=True, rope=True, max_period=10000.0)
+            b = ops.attention(q, kk, vv, pos0=off, pos_dev=pos2, ring=True, context=context)
+            pos1.add_(T); pos2.add_(T); off += T
+            used = min(cap, off)
+            if pos0 == 0:
+                sl = torch.arange(used, device=DEV)
+                assert torch.allclose(k1[:, :, sl], k2[:, :, sl], rtol=0, atol=1e-6) and torch.equal(v1[:, :, sl], v2[:, :, sl])
+            else:
+                assert torch.allclose(k1, k2, rtol=0, atol=1e-6) and torch.equal(v1, v2)
+            assert torch.isfinite(a).all()
+            assert rel_err(a, b.cpu()) < 2e-6, (pos0, step)
+    monkeypatch.setattr(ops, "ATTENTION_STEP", False)
+    assert not ops.attention_step_supported(qkv, H, cap)
 
 
 def test_rvq_tie_takes_lowest_index():
