@@ -95,8 +95,10 @@ int rst_gemm_win_b3_f32(const float* x, const float* hist, const float* w, const
  *     v_mfma_f32_32x32x2_f32 with k ascending per wave.  Every Conv1d / ConvTranspose1d / Linear of a streaming step
  *     (modules/streaming.py:216-303, modules/transformer.py:395-562) is weight-bandwidth bound and goes through here.
  *     split_k > 1 (rst_skinny_f32_split_plan(M, N, K); 1 = none): K is also split over split_k workgroups per column tile --
- *     N / 32 workgroups alone stream a 6-33 MB layer at well under 1 TB/s; ws [split_k][M][N] floats and counters [ceil(N/32)]
- *     uint32 (zeroed once by the caller, self re-arming) carry the deterministic in-launch reduction.
+ *     N / 32 workgroups alone stream a 6-33 MB layer at well under 1 TB/s; ws [split_k][M][N] floats and counters
+ *     [ceil(M/32)][ceil(N/32)] uint32 (zeroed once by the caller, self re-arming) carry the deterministic in-launch reduction.
+ *     More than 32 rows: every 32-row tile of the batch is a workgroup of its own per column tile (same arithmetic per element, so
+ *     the same bits as the one-workgroup form of rounds 2 - 5; the weights cross L2 once per row tile).
  *   rst_skinny_f32_pack_ln: the plain-linear case of the packing (rows x [M][K], no window) with nn.LayerNorm(K) applied on the way
  *     (gamma, beta, eps; rst_layernorm_f32's arithmetic, so the operand equals LayerNorm followed by the pack bit for bit): the
  *     norm1 / norm2 in front of in_proj / linear1 of a streamed transformer layer (modules/transformer.py:595-650) costs no launch. */

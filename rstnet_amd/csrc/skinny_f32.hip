@@ -211,7 +211,10 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
     const int c_lo = blockIdx.y * per_split, c_hi = min(chunks, c_lo + per_split);
     const int per = (max(c_hi - c_lo, 0) + SF_WAVES - 1) / SF_WAVES;
     const int s0 = c_lo + wave * per, s1 = min(c_hi, s0 + per);
-    const float* xq = p.xp + (long)lane * 4;
+    // gridDim.z > 1: the NB row tiles of this workgroup are tiles blockIdx.z * NB .. of the batch (rows mz .. mz + 32 NB - 1) -- 64 rows
+    // as two one-tile workgroups per column tile cost what 32 rows do (the weights cross L2 twice, the launch is a round trip shorter)
+    const int mz = blockIdx.z * NB * 32;
+    const float* xq = p.xp + (long)blockIdx.z * NB * chunks * 256 + (long)lane * 4;
     const float* wt[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) wt[c] = p.wp + ((long)min(tile0 + c, tiles - 1) * chunks * 64 + lane) * 4;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
 #pragma unroll
         for (int q = 0; q < EP; ++q) {
             const int idx = tid + q * 64 * SF_WAVES;
-            const int m = min(idx >> 5, p.M - 1), n = min((tile0 + c) * 32 + (idx & 31), p.N - 1);
+            const int m = min(mz + (idx >> 5), p.M - 1), n = min((tile0 + c) * 32 + (idx & 31), p.N - 1);
             rpre[c][q] = p.res ? p.res[(long)m * p.ldy + n] : 0.f;
             bpre[c][q] = p.bias ? p.bias[n] : 0.f;
             spre[c][q] = p.scale ? p.scale[n] : 1.0f;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
     const bool odd = (lane >> 5) != 0;
     if (ROWS) {
 #pragma unroll
-        for (int t = 0; t < NB; ++t) xrow[t] = p.xr + (long)min(32 * t + (lane & 31), p.M - 1) * p.ldx;      // rows past M: row M - 1, cleared below
+        for (int t = 0; t < NB; ++t) xrow[t] = p.xr + (long)min(mz + 32 * t + (lane & 31), p.M - 1) * p.ldx;      // rows past M: row M - 1, cleared below
     }
     auto issue = [&](const int s) {
 #pragma unroll
@@ -284,38 +287,39 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
         issue(s0);
         if (has_ln) {
             const int K = p.Kp;
-            if (K <= 512) {              // all rows of a wave in one round trip (M <= 64), or two
-                for (int m0 = wave; m0 < p.M; m0 += 8 * SF_WAVES) {
+            const int m_end = min(p.M, mz + NB * 32);       // this workgroup's rows: mz .. m_end - 1 (ln_stat is indexed from mz)
+            if (K <= 512) {              // all rows of a wave in one round trip (<= 64 rows), or two
+                for (int m0 = mz + wave; m0 < m_end; m0 += 8 * SF_WAVES) {
                     float mean[8], rstd[8];
                     sf_rows_stats<8, 2>(p.xr, p.ldx, m0, SF_WAVES, p.M, K, lane, p.ln_eps, mean, rstd);
                     if (lane == 0) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r)
-                            if (m0 + r * SF_WAVES < p.M) { ln_stat[m0 + r * SF_WAVES][0] = mean[r]; ln_stat[m0 + r * SF_WAVES][1] = rstd[r]; }
+                            if (m0 + r * SF_WAVES < m_end) { ln_stat[m0 + r * SF_WAVES - mz][0] = mean[r]; ln_stat[m0 + r * SF_WAVES - mz][1] = rstd[r]; }
                     }
                 }
             } else if (K <= 1024) {
-                for (int m0 = wave; m0 < p.M; m0 += 4 * SF_WAVES) {
+                for (int m0 = mz + wave; m0 < m_end; m0 += 4 * SF_WAVES) {
                     float mean[4], rstd[4];
                     sf_rows_stats<4, 4>(p.xr, p.ldx, m0, SF_WAVES, p.M, K, lane, p.ln_eps, mean, rstd);
                     if (lane == 0) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (m0 + r * SF_WAVES < p.M) { ln_stat[m0 + r * SF_WAVES][0] = mean[r]; ln_stat[m0 + r * SF_WAVES][1] = rstd[r]; }
+                            if (m0 + r * SF_WAVES < m_end) { ln_stat[m0 + r * SF_WAVES - mz][0] = mean[r]; ln_stat[m0 + r * SF_WAVES - mz][1] = rstd[r]; }
                     }
                 }
             } else {
-                for (int m = wave; m < p.M; m += SF_WAVES) {
+                for (int m = mz + wave; m < m_end; m += SF_WAVES) {
                     float mean, rstd;
                     sf_row_stats(p.xr + (long)m * p.ldx, K, lane, p.ln_eps, mean, rstd);
-                    if (lane == 0) { ln_stat[m][0] = mean; ln_stat[m][1] = rstd; }
+                    if (lane == 0) { ln_stat[m - mz][0] = mean; ln_stat[m - mz][1] = rstd; }
                 }
             }
             __syncthreads();
         }
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
-            const int row = min(32 * t + (lane & 31), p.M - 1);
+            const int row = min(mz + 32 * t + (lane & 31), p.M - 1) - mz;     // (a tile entirely past M does not exist: the grid covers ceil(M / 32) tiles)
             r_mean[t] = has_ln ? ln_stat[row][0] : 0.f;
             r_rstd[t] = has_ln ? ln_stat[row][1] : 1.f;
         }
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
 #pragma unroll
                         for (int e = 0; e < 4; ++e) x4[e] = sf_ln_apply(x4[e], r_mean[t], r_rstd[t], g4[u][e], b4[u][e]);
                     }
-                    if (s + u >= s1 || 32 * t + (lane & 31) >= p.M) x4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (s + u >= s1 || mz + 32 * t + (lane & 31) >= p.M) x4 = f32x4{0.f, 0.f, 0.f, 0.f};
                     bx[u][t] = x4;
                 }
         }
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
     };
     // packed output: the pad rows of the last batch tile must read as zeros in the consumer
     auto pad_zero = [&](int m, int n) {
-        if (p.Np_out && m >= M && m < NB * 32 && n < p.N) p.y[f32_packed_index(m, n, p.Np_out)] = 0.f;
+        if (p.Np_out && m >= M && m < mz + NB * 32 && n < p.N) p.y[f32_packed_index(m, n, p.Np_out)] = 0.f;
     };
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -376,12 +380,12 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
 #pragma unroll
         for (int q = 0; q < EP; ++q) {
             const int idx = tid + q * 64 * SF_WAVES;
-            const int m = idx >> 5, nl = idx & 31;
-            const int n = n0 + nl;
+            const int ml = idx >> 5, nl = idx & 31;
+            const int m = mz + ml, n = n0 + nl;
             if (m < M && n < p.N) {
                 float v = 0.f;
 #pragma unroll
-                for (int w = 0; w < SF_WAVES; ++w) v += red[w][m][nl];
+                for (int w = 0; w < SF_WAVES; ++w) v += red[w][ml][nl];
                 if (nsplit == 1) epilogue(v, m, n, c, q);
                 else __hip_atomic_store(p.ws + ((long)blockIdx.y * M + m) * p.N + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else if (nsplit == 1) {
@@ -394,9 +398,10 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(p.counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned* const cnt = p.counters + blockIdx.z * gridDim.x + blockIdx.x;       // one counter per (row block, column tile)
+        const unsigned prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sm_last = prev == (unsigned)nsplit - 1;
-        if (sm_last) __hip_atomic_store(p.counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sm_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!sm_last) return;
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
 #pragma unroll
             for (int q = 0; q < EP; ++q) {
                 const int idx = tid + q * 64 * SF_WAVES;
-                const int m = min(idx >> 5, M - 1), n = min((tile0 + c) * 32 + (idx & 31), p.N - 1);      // past the edge: clamped, unused
+                const int m = min(mz + (idx >> 5), M - 1), n = min((tile0 + c) * 32 + (idx & 31), p.N - 1);      // past the edge: clamped, unused
                 rst_load_partials<4>(p.ws + (long)m * p.N + n, (long)M * p.N, ks, nsplit, t[c][q]);
             }
 #pragma unroll
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
 #pragma unroll
         for (int q = 0; q < EP; ++q) {
             const int idx = tid + q * 64 * SF_WAVES;
-            const int m = idx >> 5, n = (tile0 + c) * 32 + (idx & 31);
+            const int m = mz + (idx >> 5), n = (tile0 + c) * 32 + (idx & 31);
             if (m < M && n < p.N) epilogue(v[c][q], m, n, c, q);
             else pad_zero(m, n);
         }
@@ -473,12 +478,15 @@ int rst_launch_skinny_f32_pack_ln(const float* x, const float* gamma, const floa
 }
 
 int rst_skinny_f32_split_plan_impl(int M, int N, int K) {
-    // few workgroups (N / 32 column tiles) against MBs of weights: split K until ~128-256 workgroups run, >= 2 chunks per wave
+    // few workgroups (N / 32 column tiles x M / 32 row tiles) against MBs of weights: split K until ~128-256 workgroups run, each wave
+    // keeping >= 4 of the 8-k chunks.  K <= 512 is not split at all: 8 chunks per wave are one pass of the K loop, and the hand-off of
+    // the partials (drain, counter, read-back) costs more than it saves (64 rows, 1536 x 512: 8.2 us unsplit, 10.1 us at 4;
+    // profiles/r06_few_row_linear_probe.txt has the sweep behind this rule, 16 - 128 rows x 11 shapes x 6 splits).
     if (M < 1 || M > 128) return 1;
-    const int tiles = (N + 31) / 32, chunks = (K + 7) / 8;
-    if (tiles >= 512) return 1;
+    const int tiles = (N + 31) / 32, chunks = (K + 7) / 8, nb = (M + 31) / 32;
+    if (tiles >= 512 || chunks <= 64) return 1;
     int s = 1;
-    while (tiles * s * 2 <= 256 && chunks / (2 * s * SF_WAVES) >= 2 && s < 32) s *= 2;
+    while (tiles * nb * s * 2 <= 256 && chunks / (2 * s * SF_WAVES) >= 4 && s < 32) s *= 2;
     return s;
 }
 
@@ -491,17 +499,24 @@ int rst_launch_gemm_skinny_f32(const SkinnyF32Params& p, hipStream_t stream) {
     RST_REQUIRE(p.Np_out == 0 || (p.Np_out == p.N && p.N % 8 == 0 && !p.res), "gemm_skinny_f32: packed output needs N %% 8 == 0, Np_out = N and no residual (N=%d)", p.N);
     const dim3 block(64 * SF_WAVES);
     const int nb = (p.M + 31) / 32;
+    // row tiles as workgroups of their own (gridDim.z) instead of a loop inside one (round 6): 64 rows then cost what 32 do -- pack + GEMM
+    // 512 x 512: 10.5 -> 8.2 us, 128 rows 13.4 -> 8.4 us.  tools build: RST_SF_ZTILE=0 keeps the round-2 form (all row tiles in one workgroup)
+    static const int zt_knob = rst_knob("RST_SF_ZTILE", 1);
+    const bool zt = zt_knob != 0 && nb > 1;
     if (p.xr) {
         // row-major rows of a plain linear (+ LayerNorm): no packing launch
         RST_REQUIRE(!p.xp && p.ldx >= p.Kp && p.ldx % 4 == 0 && (uintptr_t)p.xr % 16 == 0 && (!p.ln_g == !p.ln_b) &&
                         (!p.ln_g || ((uintptr_t)p.ln_g % 16 == 0 && (uintptr_t)p.ln_b % 16 == 0)),
                     "linear_few_rows: rows must be 16-byte aligned with K %% 8 == 0 and ldx %% 4 == 0; gamma and beta come together (K=%d ldx=%d)", p.Kp, p.ldx);
-        if (nb == 1) hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 1, true>), dim3(tiles, split), block, 0, stream, p);
+        if (zt && tiles < 512) hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 1, true>), dim3(tiles, split, nb), block, 0, stream, p);
+        else if (nb == 1) hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 1, true>), dim3(tiles, split), block, 0, stream, p);
         else if (nb == 2) hipLaunchKernelGGL((gemm_skinny_f32_kernel<2, 1, true>), dim3(tiles, split), block, 0, stream, p);
         else hipLaunchKernelGGL((gemm_skinny_f32_kernel<4, 1, true>), dim3(tiles, split), block, 0, stream, p);
         return rst_check_launch("linear_few_rows");
     }
-    if (nb == 1) {
+    if (zt && tiles < 512) {
+        hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 1>), dim3(tiles, split, nb), block, 0, stream, p);
+    } else if (nb == 1) {
         if (tiles >= 512) hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 2>), dim3((tiles + 1) / 2), block, 0, stream, p);
         else hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 1>), dim3(tiles, split), block, 0, stream, p);
     } else if (nb == 2) {

@@ -118,6 +118,10 @@ def _scratch(cache: dict, device, shape_key: tuple, build):
     return sc
 
 
+# K split of the medium-row GEMMs across workgroups: None = rst_gemm_win_split_plan; an int overrides it (probes / A/B runs only)
+GEMM_WIN_SPLIT = None
+
+
 def _gemm_split_scratch(device, M: int, N: int, K: int):
     """Split-K plan + scratch of the few- / medium-row (streaming step) GEMMs, cached per (stream, shape); launches on one stream
     are ordered and the counters re-arm themselves, so layers of equal shape share the buffers."""
@@ -125,12 +129,12 @@ def _gemm_split_scratch(device, M: int, N: int, K: int):
         return 1, None, None
 
     def build():
-        sk = int(_lib.lib().rst_gemm_win_split_plan(M, N, K))
+        sk = int(_lib.lib().rst_gemm_win_split_plan(M, N, K)) if GEMM_WIN_SPLIT is None else int(GEMM_WIN_SPLIT)
         if sk > 1:
             return (sk, torch.empty(sk, M, N, device=device, dtype=torch.float32),
                     torch.zeros(int(_lib.lib().rst_gemm_win_split_tiles(M, N)), device=device, dtype=torch.int32))
         return (1, None, None)
-    return _scratch(_gemm_scratch, device, ("gemm_win", M, N, K), build)
+    return _scratch(_gemm_scratch, device, ("gemm_win", M, N, K, GEMM_WIN_SPLIT), build)
 
 
 _skinny_f32_weights = _PackedWeights()
@@ -247,7 +251,7 @@ def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, 
     def build():
         sk = int(_lib.lib().rst_skinny_f32_split_plan(M, N, K)) if SKINNY_F32_SPLIT is None else int(SKINNY_F32_SPLIT)
         return (sk, torch.empty(sk, M, N, device=dev, dtype=torch.float32),
-                torch.zeros((N + 31) // 32, device=dev, dtype=torch.int32)) if sk > 1 else (1, None, None)
+                torch.zeros(((M + 31) // 32) * ((N + 31) // 32), device=dev, dtype=torch.int32)) if sk > 1 else (1, None, None)
     sc = _scratch(_gemm_scratch, dev, ("skinny", M, N, K, SKINNY_F32_SPLIT), build)
     plain = hist is None and S == 1 and P == 0 and T_in == T_out and C_ == K and act_in == ACT_NONE
     if (SKINNY_F32_ROWS and plain and not isinstance(x, PackedRows) and K % 8 == 0 and x.data_ptr() % 16 == 0 and

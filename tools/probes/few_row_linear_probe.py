@@ -2,6 +2,8 @@
 GEMM) against the in-place route (rst_linear_few_rows_f32), with and without the LayerNorm in front.
 
     python tools/probes/few_row_linear_probe.py [--rows 64]
+
+Then the two launches of the packed route on their own, and the sweep behind rst_skinny_f32_split_plan (rows x shapes x splits).
 """
 import argparse
 import os
@@ -55,22 +57,6 @@ def main():
             print(f"  {f'{N} x {K}':14s} {str(use_ln):10s} {t[False]:14.2f} {t[True]:10.2f}")
 
 
-def split_sweep(M):
-    dev = "cuda:0"
-    print(f"{M} rows; us per linear by K split across workgroups (packed route, no LayerNorm; * = rst_skinny_f32_split_plan)")
-    from rstnet_amd import _lib
-    for N, K in ((1536, 512), (512, 512), (2048, 512), (512, 2048)):
-        x, w = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
-        plan = int(_lib.lib().rst_skinny_f32_split_plan(M, N, K))
-        row = []
-        for sk in (1, 2, 4, 8, 16):
-            ops.SKINNY_F32_SPLIT = sk
-            ops.SKINNY_F32_ROWS = False
-            row.append(f"{sk}{'*' if sk == plan else ''}: {graph_time(lambda: ops.linear(x, w)):6.2f}")
-        ops.SKINNY_F32_SPLIT = None
-        print(f"  {f'{N} x {K}':14s} " + "   ".join(row))
-
-
 def parts(M):
     """the two launches of the packed route on their own"""
     dev = "cuda:0"
@@ -91,7 +77,25 @@ def parts(M):
         print(f"  {f'{N} x {K}':14s} {t_gemm:8.2f} {t_ln:8.2f} {t_pk:8.2f}")
 
 
+def grid():
+    """the sweep behind rst_skinny_f32_split_plan: 16 - 128 rows x 11 shapes x 6 splits"""
+    dev = "cuda:0"
+    from rstnet_amd import _lib
+    for M in (16, 32, 64, 128):
+        print(f"{M} rows; pack + GEMM us by K split across workgroups (* = rst_skinny_f32_split_plan)")
+        for N, K in ((512, 512), (1536, 512), (2048, 512), (512, 2048), (1024, 8192), (512, 3072), (1024, 512), (1024, 1536), (4096, 2048), (256, 512), (512, 1024)):
+            x, w = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
+            plan = int(_lib.lib().rst_skinny_f32_split_plan(M, N, K))
+            row = []
+            for sk in (1, 2, 4, 8, 16, 32):
+                ops.SKINNY_F32_SPLIT = sk
+                ops.SKINNY_F32_ROWS = False
+                row.append(f"{sk}{'*' if sk == plan else ''}: {graph_time(lambda: ops.linear(x, w)):6.2f}")
+            ops.SKINNY_F32_SPLIT = None
+            print(f"  {f'{N} x {K}':14s} " + "   ".join(row))
+
+
 if __name__ == "__main__":
     main()
-    split_sweep(64)
     parts(64)
+    grid()
