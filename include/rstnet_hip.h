@@ -494,10 +494,12 @@ int rst_attn_decode_multi_f32(const float* q, const float* k, const float* v, fl
  * ("b t (p h d)", modules/transformer.py:376-388); q and k are rotated (interleaved RoPE at positions *pos_dev + t, modules/rope.py:37-62;
  * rope = 0: none), k / v appended to ring slots (*pos_dev + t) % cap of [B][H][cap][D] (RingKVCache.complete, transformer.py:255-262), and
  * the T queries run against the ring with the mask / slot map of rst_attention_f32(ring = 1), end_offset = *pos_dev + T.  out [B][T][H*D].
+ * out_packed_rows != 0 (= B*T rounded up to 32 / 64 / 128, the rows of rst_skinny_f32_pack_win's buffer; H*D % 8 == 0): out is written as the
+ * packed operand of the out-projection's few-row GEMM instead, rows past B*T zero (rst_gemm_skinny_f32 consumes it: no packing launch).
  * Served shapes (rst_attention_step_supported): 1 <= T <= 4, D in {32, 64, 128}, the ring's scores in LDS (cap up to ~4000 at T = 4). */
 int rst_attention_step_supported(int T, int D, int cap);
 int rst_attention_step_f32(const float* qkv, float* k, float* v, float* out, const int64_t* pos_dev, int B, int T, int H, int D, int cap,
-                           int context, int rope, float rope_coef, rst_stream_t stream);
+                           int context, int rope, float rope_coef, int out_packed_rows, rst_stream_t stream);
 
 /* sample_token (utils/sampling.py:85-105): greedy argmax, or softmax(logits/temp) -> top-k (sorted descending) ->
  * argmax_j p_j / noise_j with caller-provided Exp(1) noise [B][noise_stride] (the reference draws it with

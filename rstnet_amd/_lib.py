@@ -87,7 +87,7 @@ SIGNATURES = {
     "rst_lm_attn_decode_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _i, _p, _p],
     "rst_attn_decode_multi_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rst_attention_step_supported": [_i, _i, _i],
-    "rst_attention_step_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "rst_attention_step_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "rst_lm_sample_workspace_bytes": [_i, _i, _i, _i],
     "rst_lm_sample_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p, _f, _p, _l, _p],
     "rst_lm_ring_begin_i64": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -157,7 +157,12 @@ class StreamingMultiheadAttention(StreamingModule[_MHAState]):
             pos_dev = state.shared if state.shared is not None else state.offset
             if ops.attention_step_supported(qkv, H, state.k_cache.shape[2]):
                 # a few new positions: split, rotation, ring append and the queries against the ring in one launch
-                a = ops.attention_step(qkv, H, state.k_cache, state.v_cache, pos_dev, context=self.context, rope=use_rope, max_period=period)
+                # (on the few-row route the result is written as the out-projection's packed operand)
+                E = self.embed_dim
+                packed = (not self.weights_per_step and ops.ATTENTION_STEP_PACKED and B * T > 4 and ops._few_rows(B * T, self.out_proj.weight.shape[0], E)
+                          and E % 8 == 0)
+                a = ops.attention_step(qkv, H, state.k_cache, state.v_cache, pos_dev, context=self.context, rope=use_rope, max_period=period,
+                                       out_packed=packed)
             else:
                 q, k, v = ops.rope_split(qkv, H, k=state.k_cache, v=state.v_cache, pos0=offset, pos_dev=pos_dev, ring=True,
                                          rope=use_rope, max_period=period)

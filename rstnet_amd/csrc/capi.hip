@@ -305,8 +305,9 @@ int rst_linear_few_rows_f32(const float* x, int ldx, const float* ln_gamma, cons
 int rst_attention_step_supported(int T, int D, int cap) { return rst_attn_step_supported_impl(T, D, cap); }
 
 int rst_attention_step_f32(const float* qkv, float* k, float* v, float* out, const int64_t* pos_dev, int B, int T, int H, int D, int cap,
-                           int context, int rope, float rope_coef, rst_stream_t stream) {
+                           int context, int rope, float rope_coef, int out_packed_rows, rst_stream_t stream) {
     AttnStepParams p = {};
+    p.out_rows = out_packed_rows;
     p.qkv = qkv; p.k = k; p.v = v; p.out = out; p.pos_dev = reinterpret_cast<const long*>(pos_dev);
     p.B = B; p.T = T; p.H = H; p.D = D; p.cap = cap; p.context = context; p.rope = rope; p.rope_coef = rope_coef;
     return rst_launch_attn_step(p, (hipStream_t)stream);

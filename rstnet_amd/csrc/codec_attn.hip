@@ -170,7 +170,14 @@ __global__ __launch_bounds__(AS_THREADS) void attn_step_kernel(const AttnStepPar
         for (int c = 0; c < NC; ++c) Oq += opart[(c * T + t) * D + d];
         const float* ws = wred + AS_WAVES * T + t;
         const float Lq = (ws[0] + ws[T]) + (ws[2 * T] + ws[3 * T]);
-        p.out[(long)(b * T + t) * E + h * D + d] = Lq > 0.f ? Oq / Lq : 0.f;
+        const float r = Lq > 0.f ? Oq / Lq : 0.f;
+        // out_rows: the result is the out-projection's operand in the few-row GEMM's packed order (no packing launch, no strided row reads)
+        if (p.out_rows) p.out[f32_packed_index(b * T + t, h * D + d, E)] = r;
+        else p.out[(long)(b * T + t) * E + h * D + d] = r;
+    }
+    if (p.out_rows && b == 0) {          // the pad rows of the last 32-row tile read as zeros in the consumer: stream 0's workgroups clear their head's columns
+        const int M = p.B * T;
+        for (int i = tid; i < (p.out_rows - M) * D; i += AS_THREADS) p.out[f32_packed_index(M + i / D, h * D + i % D, E)] = 0.f;
     }
 }
 
@@ -190,6 +197,8 @@ int rst_launch_attn_step(const AttnStepParams& p, hipStream_t stream) {
     RST_REQUIRE(p.qkv && p.k && p.v && p.out && p.pos_dev && p.B >= 1 && p.H >= 1, "attention_step: null buffers / bad sizes");
     RST_REQUIRE(rst_attn_step_supported_impl(p.T, p.D, p.cap), "attention_step: unsupported shape (T=%d D=%d cap=%d; 1 <= T <= 4, D in 32 / 64 / 128)",
                 p.T, p.D, p.cap);
+    RST_REQUIRE(p.out_rows == 0 || (p.out_rows >= p.B * p.T && p.out_rows % 32 == 0 && (p.H * p.D) % 8 == 0),
+                "attention_step: a packed result needs whole 32-row tiles (out_rows=%d for %d rows) and H * D %% 8 == 0", p.out_rows, p.B * p.T);
     RST_REQUIRE((uintptr_t)p.qkv % 16 == 0 && (uintptr_t)p.k % 16 == 0 && (uintptr_t)p.v % 16 == 0, "attention_step: 16-byte aligned buffers required");
     const size_t lds = as_lds_bytes(p.T, p.D, p.cap);
     auto go = [&](auto kern) {

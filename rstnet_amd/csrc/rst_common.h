@@ -98,6 +98,13 @@ __device__ __forceinline__ float rst_gelu(float v) {
     return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }
 
+// element (row, k) of a few-row fp32 operand in the packed order of skinny_f32.hip: [tile of 32 rows][Kp / 8][64 lanes = 32 (k % 2) + row % 32]
+// [4 floats: (k % 8) / 2] -- shared with the producers that write that operand directly (the few-row GEMM's packed output, the
+// attention step of codec_attn.hip)
+__device__ __forceinline__ long f32_packed_index(int row, int k, int Kp) {
+    return ((((long)(row >> 5) * (Kp >> 3) + (k >> 3)) * 64) + (k & 1) * 32 + (row & 31)) * 4 + ((k & 7) >> 1);
+}
+
 // row of element r (0..15) of a 32x32 MFMA accumulator held by `lane` (column = lane & 31)
 __device__ __forceinline__ int rst_mfma32_row(int r, int lane) {
     return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);

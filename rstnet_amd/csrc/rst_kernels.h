@@ -71,9 +71,10 @@ struct AttnStepParams {
     const float* qkv;             // [B][T][3][H][D]: the in-projection's output of the T new steps
     float* k;                     // rings [B][H][cap][D]
     float* v;
-    float* out;                   // [B][T][H*D]
+    float* out;                   // [B][T][H*D], or (out_rows) [out_rows][H*D] in the packed operand order of the few-row GEMM
     const long* pos_dev;          // position of the first new step
     int B, T, H, D, cap, context, rope;
+    int out_rows;                 // 0: row-major result; else B*T rounded up to 32 (64 above 32, 128 above 64: rst_skinny_f32_pack_win's rows)
     float rope_coef;
 };
 int rst_attn_step_supported_impl(int T, int D, int cap);

@@ -15,10 +15,7 @@
 
 namespace {
 
-__device__ __forceinline__ long f32_packed_index(int row, int k, int Kp) {
-    return ((((long)(row >> 5) * (Kp >> 3) + (k >> 3)) * 64) + (k & 1) * 32 + (row & 31)) * 4 + ((k & 7) >> 1);
-}
-
+// (f32_packed_index, the packed order of both operands: rst_common.h)
 __global__ __launch_bounds__(256) void f32_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int N, int K, int Kp) {
     const long total = (long)((N + 31) / 32) * 32 * (Kp / 2);            // (row, k pair) items
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {

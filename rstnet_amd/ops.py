@@ -572,6 +572,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, pos0: int = 
 # A streaming step of a codec transformer layer's attention (a few new positions of many streams) as ONE launch: split + RoPE + ring
 # append + the queries against the ring (rst_attention_step_f32).  False: rope_split + attention, two launches (the A/B switch).
 ATTENTION_STEP = True
+ATTENTION_STEP_PACKED = True       # its result straight in the out-projection's packed operand order on the few-row route (False: row-major)
 
 
 def attention_step_supported(qkv: torch.Tensor, H: int, cap: int) -> bool:
@@ -581,9 +582,9 @@ def attention_step_supported(qkv: torch.Tensor, H: int, cap: int) -> bool:
 
 
 def attention_step(qkv: torch.Tensor, H: int, k: torch.Tensor, v: torch.Tensor, pos_dev: torch.Tensor, *, context: Optional[int] = None,
-                   rope: bool = True, max_period: float = 10000.0) -> torch.Tensor:
+                   rope: bool = True, max_period: float = 10000.0, out_packed: bool = False):
     """qkv ``[B,T,3*H*D]`` (the in-projection of the T new steps) -> ``[B,T,H*D]``; k / v ``[B,H,cap,D]`` rings, appended in place at
-    slots ``(pos_dev + t) % cap``."""
+    slots ``(pos_dev + t) % cap``.  ``out_packed``: the result as a ``PackedRows`` -- the operand of the out-projection's few-row GEMM."""
     for t, n in ((qkv, "qkv"), (k, "k"), (v, "v")):
         _chk(t, n)
     _chk(pos_dev, "pos_dev", torch.int64)
@@ -591,10 +592,14 @@ def attention_step(qkv: torch.Tensor, H: int, k: torch.Tensor, v: torch.Tensor, 
     D = E3 // (3 * H)
     if k.shape != v.shape or k.shape[0] != B or k.shape[1] != H or k.shape[3] != D:
         raise ValueError(f"rstnet_amd.ops: rings {tuple(k.shape)} / {tuple(v.shape)} do not belong to qkv {tuple(qkv.shape)} with {H} heads")
-    out = torch.empty(B, T, H * D, device=qkv.device, dtype=torch.float32)
+    M = B * T
+    rows = (32 if M <= 32 else (64 if M <= 64 else 128)) if out_packed else 0
+    if out_packed and (M > SKINNY_F32_MAX_ROWS or (H * D) % 8):
+        raise ValueError(f"rstnet_amd.ops: a packed attention result needs <= {SKINNY_F32_MAX_ROWS} rows and H * D % 8 == 0 (rows {M}, H * D {H * D})")
+    out = torch.empty((rows, H * D) if out_packed else (B, T, H * D), device=qkv.device, dtype=torch.float32)
     _lib.check(_lib.lib().rst_attention_step_f32(_ptr(qkv), _ptr(k), _ptr(v), _ptr(out), _ptr(pos_dev), B, T, H, D, k.shape[2],
-                                                 int(context) if context else 0, int(rope), rope_coef(max_period, D), _stream()))
-    return out
+                                                 int(context) if context else 0, int(rope), rope_coef(max_period, D), rows, _stream()))
+    return PackedRows(out, (B, T, H * D)) if out_packed else out
 
 
 _rope_tables: dict = {}

@@ -429,6 +429,15 @@ def test_attention_step_is_rope_split_plus_ring_attention(T, D, H, cap, context,
                 assert torch.allclose(k1, k2, rtol=0, atol=1e-6) and torch.equal(v1, v2)
             assert torch.isfinite(a).all()
             assert rel_err(a, b.cpu()) < 2e-6, (pos0, step)
+    # the same step written as the out-projection's packed operand (few-row route): the GEMM on it gives the bits of pack + GEMM
+    if (B * T) > 4 and E % 8 == 0 and ops._few_rows(B * T, E, E):
+        w = torch.randn(E, E, generator=g).to(DEV) / E ** 0.5
+        k3, v3, pos3 = k1.clone(), v1.clone(), pos1.clone()
+        a_rows = ops.attention_step(qkv, H, k1, v1, pos1, context=context)
+        a_pack = ops.attention_step(qkv, H, k3, v3, pos3, context=context, out_packed=True)
+        assert isinstance(a_pack, ops.PackedRows) and a_pack.shape == (B, T, E) and a_pack.xp.shape[0] % 32 == 0
+        monkeypatch.setattr(ops, "SKINNY_F32_ROWS", False)
+        assert torch.equal(ops.linear(a_pack, w), ops.linear(a_rows, w))
     monkeypatch.setattr(ops, "ATTENTION_STEP", False)
     assert not ops.attention_step_supported(qkv, H, cap)
 
