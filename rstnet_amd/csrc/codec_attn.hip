@@ -32,37 +32,10 @@ __global__ __launch_bounds__(AS_THREADS) void attn_step_kernel(const AttnStepPar
     float* wred = opart + 1024 * T;
     const long pos = *p.pos_dev;
 
-    // q / k / v of the head for the T new steps, q and k rotated on the way (modules/rope.py:37-62, position = pos + t; the expressions of
-    // rope_split_kernel): item = (t, part, pair)
-    const int half = D >> 1;
-    for (int i = tid; i < T * 3 * half; i += AS_THREADS) {
-        const int t = i / (3 * half), j = i - t * 3 * half, part = j / half, pr = j - part * half;
-        const float* src = p.qkv + ((long)(b * T + t) * 3 + part) * E + h * D + 2 * pr;
-        const float re = src[0], im = src[1];
-        float c = 1.0f, sn = 0.0f;
-        if (p.rope && part < 2) {
-            const float ang = expf((float)pr * p.rope_coef) * ((float)pos + (float)t);
-            c = cosf(ang);
-            sn = sinf(ang);
-        }
-        float* dst = qh + (t * 3 + part) * D + 2 * pr;
-        dst[0] = re * c - im * sn;
-        dst[1] = re * sn + im * c;
-    }
-    __syncthreads();
     float* kring = p.k + ((long)(b * H + h) * cap) * D;
     float* vring = p.v + ((long)(b * H + h) * cap) * D;
     const int GS = D >> 2, NC = AS_THREADS / GS, dq = tid % GS, cls = tid / GS;
     const int slot0 = (int)(pos % cap);            // new step t sits in slot (slot0 + t) % cap
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        int sl = slot0 + t;
-        sl -= sl >= cap ? cap : 0;
-        if ((sl & (NC - 1)) == cls) {
-            *reinterpret_cast<f32x4*>(kring + sl * D + 4 * dq) = *reinterpret_cast<const f32x4*>(qh + (t * 3 + 1) * D + 4 * dq);
-            *reinterpret_cast<f32x4*>(vring + sl * D + 4 * dq) = *reinterpret_cast<const f32x4*>(qh + (t * 3 + 2) * D + 4 * dq);
-        }
-    }
     const long end_offset = pos + T;
     const int n_used = (int)min((long)cap, end_offset);
     const int end_index = (int)(end_offset % cap);
@@ -84,8 +57,67 @@ __global__ __launch_bounds__(AS_THREADS) void attn_step_kernel(const AttnStepPar
             if (sl < n_used) vreg[j] = *reinterpret_cast<const f32x4*>(vring + sl * D + 4 * dq);
         }
     };
+    // the new steps' own slots hold the PREVIOUS pass of the ring (or nothing yet) when the first batch is requested, which is before the
+    // new rows are stored -- the first batch's round trip runs under the load + rotation of q / k / v -- so those registers take the new
+    // rows from LDS instead (the thread that owns a slot's dims stores AND patches them: no ordering question)
+    auto patch = [&](int base) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            int sl = slot0 + t;
+            sl -= sl >= cap ? cap : 0;
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+                if (base + cls + NC * j == sl) {
+                    kreg[j] = *reinterpret_cast<const f32x4*>(qh + (t * 3 + 1) * D + 4 * dq);
+                    vreg[j] = *reinterpret_cast<const f32x4*>(qh + (t * 3 + 2) * D + 4 * dq);
+                }
+        }
+    };
+    // q / k / v of the head for the T new steps: requested FIRST (loads return in order: the rotation below then starts while the ring's
+    // first batch is still on its way), rotated (modules/rope.py:37-62, position = pos + t; the expressions of rope_split_kernel) into
+    // LDS: item = (t, part, pair)
+    const int half = D >> 1;
+    const int items = T * 3 * half;
+    constexpr int NIT = (T * 3 * 64 + AS_THREADS - 1) / AS_THREADS;       // D <= 128
+    float re[NIT], im[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int i = min(tid + u * AS_THREADS, items - 1);              // clamped: unconditional loads
+        const int t = i / (3 * half), j = i - t * 3 * half, part = j / half, pr = j - part * half;
+        const float* src = p.qkv + ((long)(b * T + t) * 3 + part) * E + h * D + 2 * pr;
+        re[u] = src[0];
+        im[u] = src[1];
+    }
     k_issue(0);
     v_issue(0);
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int i = tid + u * AS_THREADS;
+        if (i < items) {
+            const int t = i / (3 * half), j = i - t * 3 * half, part = j / half, pr = j - part * half;
+            float c = 1.0f, sn = 0.0f;
+            if (p.rope && part < 2) {
+                const float ang = expf((float)pr * p.rope_coef) * ((float)pos + (float)t);
+                c = cosf(ang);
+                sn = sinf(ang);
+            }
+            float* dst = qh + (t * 3 + part) * D + 2 * pr;
+            dst[0] = re[u] * c - im[u] * sn;
+            dst[1] = re[u] * sn + im[u] * c;
+        }
+    }
+    __syncthreads();
+    // ring append: thread (dq, cls) stores dims 4 dq .. 4 dq + 3 of the new rows whose slot is of its class
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        int sl = slot0 + t;
+        sl -= sl >= cap ? cap : 0;
+        if ((sl & (NC - 1)) == cls) {
+            *reinterpret_cast<f32x4*>(kring + sl * D + 4 * dq) = *reinterpret_cast<const f32x4*>(qh + (t * 3 + 1) * D + 4 * dq);
+            *reinterpret_cast<f32x4*>(vring + sl * D + 4 * dq) = *reinterpret_cast<const f32x4*>(qh + (t * 3 + 2) * D + 4 * dq);
+        }
+    }
+    patch(0);
     f32x4 q4[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) q4[t] = *reinterpret_cast<const f32x4*>(qh + (t * 3) * D + 4 * dq);

@@ -1186,6 +1186,11 @@ int rst_launch_gemm_win(const GemmWinParams& p, hipStream_t stream) {
                             "hist=%d); ask rst_gemm_win_b3_supported", p.B, p.T_in, p.T_out, p.C, p.K, p.N, p.pad_mode, p.hist != nullptr);
                 return launch_stream_b3(p, stream);
             }
+            // fewer 128 x 128 tiles than CUs (one 80 ms frame of 32 streams at the 6 kHz level: 15 360 rows x 128 columns = 120 tiles, each
+            // 17 MFLOP on the f32 matrix instruction = 27 us of ONE CU while half the chip idles): the 32-row tiles of the medium-row
+            // form instead, four times the workgroups (round 6; 55 -> ... us for that launch)
+            static const int under_knob = rst_knob("RST_GEMM_UNDERFILL", 1);      // tools build: 0 = the 128 x 128 tile whatever the count
+            if (under_knob && tiles < gw_cu_count() && p.split_k <= 1) return launch_cfg<1, 1, 1, 4>(p, vec, stream);
             if (vec && !stream_off && p.split_k <= 1) {
                 if (tiles >= 768 && !kb32_only) return launch_stream<16>(p, tiles, stream);
                 return launch_stream<32>(p, tiles, stream);

@@ -109,6 +109,46 @@ __global__ __launch_bounds__(256) void f32_pack_ln_kernel(const float* __restric
         return;
     }
     const float* xr = x + (long)m * K;
+    if (K <= 1024) {
+        // the row, gamma and beta in registers across the three passes: ONE memory round trip instead of three dependent ones (a launch
+        // that lasts 4.7 us per call, 32 calls per 80 ms frame at 32 streams); the arithmetic -- and its order -- is sf_row_stats' and the loop's below
+        f32x4 v[4], g4[4], b4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = min(lane * 4 + 256 * j, K - 4);          // clamped: unconditional loads
+            v[j] = *reinterpret_cast<const f32x4*>(xr + i);
+            g4[j] = *reinterpret_cast<const f32x4*>(gamma + i);
+            b4[j] = *reinterpret_cast<const f32x4*>(beta + i);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane * 4 + 256 * j < K) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        const float mean = sf_wave_sum(s) / (float)K;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane * 4 + 256 * j < K) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q = fmaf(d, d, q); }
+            }
+        const float rstd = 1.0f / sqrtf(sf_wave_sum(q) / (float)K + eps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane * 4 + 256 * j;
+            if (i < Kp) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                if (i < K) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = sf_ln_apply(v[j][e], mean, rstd, g4[j][e], b4[j][e]);
+                }
+                const long base = (tile + (i >> 3)) * 64;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xp[(base + (e & 1) * 32 + (m & 31)) * 4 + (((i & 7) + e) >> 1)] = o[e];
+            }
+        }
+        return;
+    }
     float mean, rstd;
     sf_row_stats(xr, K, lane, eps, mean, rstd);
     for (int i = lane * 4; i < Kp; i += 256) {
