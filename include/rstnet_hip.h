@@ -112,15 +112,13 @@ int rst_skinny_f32_split_plan(int M, int N, int K);
 int rst_gemm_skinny_f32(const float* xp, const float* wp, const float* bias, const float* res, const float* scale, float* y, int M,
                         int N, int K, int ldy, int act_out, int split_k, float* ws, uint32_t* counters, int y_packed, rst_stream_t stream);
 /*   rst_linear_few_rows_f32 (round 6): the plain-linear case of the few-row GEMM WITHOUT a packing launch -- the rows x [M][ldx]
- *     (K % 8 == 0, ldx % 4 == 0, 16-byte aligned) are read row-major inside the GEMM, a lane picking its four k of every 8-k chunk; with
- *     ln_gamma / ln_beta [K] (both or neither) the nn.LayerNorm(K, ln_eps) in front of the linear is applied on the way, its statistics
- *     computed per workgroup with rst_skinny_f32_pack_ln's arithmetic: the result equals rst_skinny_f32_pack_ln (or _pack_win) followed by
- *     rst_gemm_skinny_f32 bit for bit.  Every Linear of a streamed transformer layer at more than two streams
- *     (modules/transformer.py:395-423 in_proj / out_proj, :540-569 norm -> linear1 -> GELU -> linear2) is one launch instead of two.
+ *     (K % 8 == 0, ldx % 4 == 0, 16-byte aligned) are read row-major inside the GEMM, a lane picking its four k of every 8-k chunk:
+ *     the result equals rst_skinny_f32_pack_win followed by rst_gemm_skinny_f32 bit for bit.  (A LayerNorm in front of the linear stays
+ *     with rst_skinny_f32_pack_ln: applied inside the GEMM it measured slower than the launch it saves.)
  *     wp, bias, res, scale, act_out, split_k, ws, counters, y_packed as rst_gemm_skinny_f32. */
-int rst_linear_few_rows_f32(const float* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* wp,
-                            const float* bias, const float* res, const float* scale, float* y, int M, int N, int K, int ldy, int act_out,
-                            int split_k, float* ws, uint32_t* counters, int y_packed, rst_stream_t stream);
+int rst_linear_few_rows_f32(const float* x, int ldx, const float* wp, const float* bias, const float* res, const float* scale, float* y,
+                            int M, int N, int K, int ldy, int act_out, int split_k, float* ws, uint32_t* counters, int y_packed,
+                            rst_stream_t stream);
 
 /* Causal Conv1d.  Replaces F.conv1d in RawStreamingConv1d.forward (modules/streaming.py:216-244) together with the
  * padding logic of StreamingConv1d.forward (modules/conv.py:232-254).

@@ -57,7 +57,7 @@ SIGNATURES = {
     "rst_skinny_f32_pack_ln": [_p, _p, _p, _f, _p, _i, _i, _p],
     "rst_skinny_f32_split_plan": [_i, _i, _i],
     "rst_gemm_skinny_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p],
-    "rst_linear_few_rows_f32": [_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p],
+    "rst_linear_few_rows_f32": [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p],
     "rst_mask_tail_f32": [_p, _p, _i, _i, _i, _i, _p],
     "rst_codec_transformer_workspace_bytes": [_i, _i, _i],
     "rst_codec_transformer_supported": [_i, _i, _i, _i, _i, _i, _i],

@@ -291,12 +291,11 @@ int rst_gemm_skinny_f32(const float* xp, const float* wp, const float* bias, con
     return rst_launch_gemm_skinny_f32(p, (hipStream_t)stream);
 }
 
-int rst_linear_few_rows_f32(const float* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* wp, const float* bias,
-                            const float* res, const float* scale, float* y, int M, int N, int K, int ldy, int act_out, int split_k, float* ws,
-                            uint32_t* counters, int y_packed, rst_stream_t stream) {
+int rst_linear_few_rows_f32(const float* x, int ldx, const float* wp, const float* bias, const float* res, const float* scale, float* y, int M,
+                            int N, int K, int ldy, int act_out, int split_k, float* ws, uint32_t* counters, int y_packed, rst_stream_t stream) {
     RST_REQUIRE(x && K > 0 && K % 8 == 0, "linear_few_rows: K %% 8 == 0 required (K=%d)", K);
     SkinnyF32Params p = {};
-    p.xr = x; p.ldx = ldx; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps;
+    p.xr = x; p.ldx = ldx;
     p.wp = wp; p.bias = bias; p.res = res; p.scale = scale; p.y = y; p.M = M; p.N = N; p.Kp = K; p.ldy = ldy;
     p.act_out = act_out; p.split_k = split_k; p.ws = ws; p.counters = counters; p.Np_out = y_packed ? N : 0;
     return rst_launch_gemm_skinny_f32(p, (hipStream_t)stream);

@@ -46,10 +46,7 @@ int rst_launch_skinny_f32_pack_ln(const float* x, const float* gamma, const floa
 struct SkinnyF32Params {
     const float* xp;              // packed activation windows (nullptr: the rows come row-major, below)
     const float* xr;              // row-major rows x [M][ldx] of a plain linear (Kp = K, K % 8 == 0): no packing launch in front of the GEMM
-    const float* ln_g;            // xr only, optional: nn.LayerNorm(K, ln_eps) applied to the rows on their way in (gamma, beta [K])
-    const float* ln_b;
     int ldx;
-    float ln_eps;
     const float* wp;              // packed weights [ceil(N/32)][Kp/8][64][4]
     const float* bias;            // [N] or nullptr
     const float* res;             // [M][ldy] or nullptr

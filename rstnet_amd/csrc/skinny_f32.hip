@@ -60,38 +60,6 @@ __device__ __forceinline__ void sf_row_stats(const float* xr, int K, int lane, f
     rstd = 1.0f / sqrtf(sf_wave_sum(q) / (float)K + eps);
 }
 
-// The same statistics for RB rows of K <= 256 KP columns at once: every row's pieces are requested before any is used (one memory
-// round trip for the batch instead of two per row), then the per-row arithmetic of sf_row_stats in the same order.
-template <int RB, int KP>
-__device__ __forceinline__ void sf_rows_stats(const float* x, int ldx, int m0, int dm, int M, int K, int lane, float eps, float (&mean)[RB], float (&rstd)[RB]) {
-    f32x4 v[RB][KP];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        const float* xr = x + (long)min(m0 + r * dm, M - 1) * ldx;
-#pragma unroll
-        for (int j = 0; j < KP; ++j) v[r][j] = *reinterpret_cast<const f32x4*>(xr + min(lane * 4 + 256 * j, K - 4));       // clamped: unconditional loads
-    }
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < KP; ++j)
-            if (lane * 4 + 256 * j < K) s += (v[r][j][0] + v[r][j][1]) + (v[r][j][2] + v[r][j][3]);
-        mean[r] = sf_wave_sum(s) / (float)K;
-    }
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < KP; ++j)
-            if (lane * 4 + 256 * j < K) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = v[r][j][e] - mean[r]; q = fmaf(d, d, q); }
-            }
-        rstd[r] = 1.0f / sqrtf(sf_wave_sum(q) / (float)K + eps);
-    }
-}
-
 // LayerNorm + pack in ONE launch (round 5): the plain-linear case of the packing below (no window, K = C) with the row's LayerNorm
 // applied on the way, so the operand is bit-identical to LayerNorm followed by the pack.
 // Every streamed transformer layer of the codec at more than two streams had a LayerNorm launch in front of each of these packs.
@@ -230,15 +198,16 @@ constexpr int SF_WAVES = 8;
 // the partial tiles go to `ws` with write-through stores, one arrival counter per column tile, and the LAST workgroup to arrive
 // sums them in split order (deterministic) and runs the epilogue (the protocol of gemm_win's split-K: cdna_hip_programming.md G16).
 // ROWS (round 6): the activation operand is NOT packed -- the rows of a plain linear are read row-major (p.xr [M][ldx], K % 8 == 0), a
-// lane picking its four k of every 8-k chunk out of two 16-byte loads, with the LayerNorm in front of the linear (p.ln_g / p.ln_b)
-// applied on the way: its statistics are computed by every workgroup for all M rows (one wave per row, a batch of rows per memory
-// round trip; M x K x 4 bytes out of L2) with the packing launch's arithmetic, so the products are the bits of LayerNorm -> pack ->
-// GEMM.  A few-row linear of a streamed transformer layer is then ONE launch instead of two (16 x 4 launches per 80 ms frame).
+// lane picking its four k of every 8-k chunk out of two 16-byte loads: no packing launch in front of the GEMM (64 rows, 512 x 512: 7.0 us
+// against 8.2 us for pack + GEMM; the same bits).  A LayerNorm in front of the linear stays in the packing launch (f32_pack_ln_kernel):
+// applying it here was built twice and measured slower both times -- statistics like the packing launch's (one wave per row, rows
+// re-read): 15.9 us against 11.3 us for LayerNorm + pack followed by the GEMM; statistics from the K slices the waves hold anyway (two
+// LDS exchanges): 10.8 us against 8.1 us after the row tiles had become workgroups.  A packing launch is 2.6 us in a dependent chain;
+// nothing that puts a reduction in front of the matrix instructions is cheaper (profiles/r06_few_row_linear_probe.txt).
 template <int NB, int CT, bool ROWS = false>
 __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const SkinnyF32Params p) {
     __shared__ float red[SF_WAVES][NB * 32][33];
     __shared__ int sm_last;
-    __shared__ float ln_stat[ROWS ? NB * 32 : 1][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = ROWS ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int tiles = (p.N + 31) / 32;
     const int tile0 = blockIdx.x * CT;
@@ -281,9 +250,8 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
     // wave's FIRST pass (weights from HBM, the rows, gamma / beta) go out before the LayerNorm statistics, whose own round trip and
     // reductions then run under them -- the rows' raw values wait in registers for mean / rstd.
     f32x4 a[UN][CT], bx[UN][NB];
-    f32x4 xlo[ROWS ? UN : 1][NB], xhi[ROWS ? UN : 1][NB], g4[ROWS ? UN : 1], b4[ROWS ? UN : 1];
+    f32x4 xlo[ROWS ? UN : 1][NB], xhi[ROWS ? UN : 1][NB];
     const float* xrow[NB];
-    const bool has_ln = ROWS && p.ln_g != nullptr;
     const bool odd = (lane >> 5) != 0;
     if (ROWS) {
 #pragma unroll
@@ -310,57 +278,10 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
                     xlo[u][t] = *reinterpret_cast<const f32x4*>(xrow[t] + k0);
                     xhi[u][t] = *reinterpret_cast<const f32x4*>(xrow[t] + k0 + 4);
                 }
-                if (has_ln) {
-                    const f32x4 glo = *reinterpret_cast<const f32x4*>(p.ln_g + k0), ghi = *reinterpret_cast<const f32x4*>(p.ln_g + k0 + 4);
-                    const f32x4 blo = *reinterpret_cast<const f32x4*>(p.ln_b + k0), bhi = *reinterpret_cast<const f32x4*>(p.ln_b + k0 + 4);
-                    g4[u] = odd ? f32x4{glo[1], glo[3], ghi[1], ghi[3]} : f32x4{glo[0], glo[2], ghi[0], ghi[2]};
-                    b4[u] = odd ? f32x4{blo[1], blo[3], bhi[1], bhi[3]} : f32x4{blo[0], blo[2], bhi[0], bhi[2]};
-                }
             }
         }
     };
-    float r_mean[NB], r_rstd[NB];
-    if (ROWS) {
-        issue(s0);
-        if (has_ln) {
-            const int K = p.Kp;
-            const int m_end = min(p.M, mz + NB * 32);       // this workgroup's rows: mz .. m_end - 1 (ln_stat is indexed from mz)
-            if (K <= 512) {              // all rows of a wave in one round trip (<= 64 rows), or two
-                for (int m0 = mz + wave; m0 < m_end; m0 += 8 * SF_WAVES) {
-                    float mean[8], rstd[8];
-                    sf_rows_stats<8, 2>(p.xr, p.ldx, m0, SF_WAVES, p.M, K, lane, p.ln_eps, mean, rstd);
-                    if (lane == 0) {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r)
-                            if (m0 + r * SF_WAVES < m_end) { ln_stat[m0 + r * SF_WAVES - mz][0] = mean[r]; ln_stat[m0 + r * SF_WAVES - mz][1] = rstd[r]; }
-                    }
-                }
-            } else if (K <= 1024) {
-                for (int m0 = mz + wave; m0 < m_end; m0 += 4 * SF_WAVES) {
-                    float mean[4], rstd[4];
-                    sf_rows_stats<4, 4>(p.xr, p.ldx, m0, SF_WAVES, p.M, K, lane, p.ln_eps, mean, rstd);
-                    if (lane == 0) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (m0 + r * SF_WAVES < m_end) { ln_stat[m0 + r * SF_WAVES - mz][0] = mean[r]; ln_stat[m0 + r * SF_WAVES - mz][1] = rstd[r]; }
-                    }
-                }
-            } else {
-                for (int m = mz + wave; m < m_end; m += SF_WAVES) {
-                    float mean, rstd;
-                    sf_row_stats(p.xr + (long)m * p.ldx, K, lane, p.ln_eps, mean, rstd);
-                    if (lane == 0) { ln_stat[m - mz][0] = mean; ln_stat[m - mz][1] = rstd; }
-                }
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            const int row = min(mz + 32 * t + (lane & 31), p.M - 1) - mz;     // (a tile entirely past M does not exist: the grid covers ceil(M / 32) tiles)
-            r_mean[t] = has_ln ? ln_stat[row][0] : 0.f;
-            r_rstd[t] = has_ln ? ln_stat[row][1] : 1.f;
-        }
-    }
+    if (ROWS) issue(s0);
     for (int s = s0; s < s1; s += UN) {
         if (!ROWS || s != s0) issue(s);
         if (ROWS) {
@@ -370,10 +291,6 @@ __global__ __launch_bounds__(64 * SF_WAVES) void gemm_skinny_f32_kernel(const Sk
                 for (int t = 0; t < NB; ++t) {
                     const f32x4 lo = xlo[u][t], hi = xhi[u][t];
                     f32x4 x4 = odd ? f32x4{lo[1], lo[3], hi[1], hi[3]} : f32x4{lo[0], lo[2], hi[0], hi[2]};
-                    if (has_ln) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) x4[e] = sf_ln_apply(x4[e], r_mean[t], r_rstd[t], g4[u][e], b4[u][e]);
-                    }
                     if (s + u >= s1 || mz + 32 * t + (lane & 31) >= p.M) x4 = f32x4{0.f, 0.f, 0.f, 0.f};
                     bx[u][t] = x4;
                 }
@@ -541,10 +458,9 @@ int rst_launch_gemm_skinny_f32(const SkinnyF32Params& p, hipStream_t stream) {
     static const int zt_knob = rst_knob("RST_SF_ZTILE", 1);
     const bool zt = zt_knob != 0 && nb > 1;
     if (p.xr) {
-        // row-major rows of a plain linear (+ LayerNorm): no packing launch
-        RST_REQUIRE(!p.xp && p.ldx >= p.Kp && p.ldx % 4 == 0 && (uintptr_t)p.xr % 16 == 0 && (!p.ln_g == !p.ln_b) &&
-                        (!p.ln_g || ((uintptr_t)p.ln_g % 16 == 0 && (uintptr_t)p.ln_b % 16 == 0)),
-                    "linear_few_rows: rows must be 16-byte aligned with K %% 8 == 0 and ldx %% 4 == 0; gamma and beta come together (K=%d ldx=%d)", p.Kp, p.ldx);
+        // row-major rows of a plain linear: no packing launch
+        RST_REQUIRE(!p.xp && p.ldx >= p.Kp && p.ldx % 4 == 0 && (uintptr_t)p.xr % 16 == 0,
+                    "linear_few_rows: rows must be 16-byte aligned with K %% 8 == 0 and ldx %% 4 == 0 (K=%d ldx=%d)", p.Kp, p.ldx);
         if (zt && tiles < 512) hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 1, true>), dim3(tiles, split, nb), block, 0, stream, p);
         else if (nb == 1) hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 1, true>), dim3(tiles, split), block, 0, stream, p);
         else if (nb == 2) hipLaunchKernelGGL((gemm_skinny_f32_kernel<2, 1, true>), dim3(tiles, split), block, 0, stream, p);

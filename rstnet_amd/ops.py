@@ -201,13 +201,10 @@ def skinny_f32_pack_weight(w: torch.Tensor) -> torch.Tensor:
 # K split of the few-row GEMMs across workgroups: None = rst_skinny_f32_split_plan; an int overrides it (probes / A/B runs only)
 SKINNY_F32_SPLIT = None
 
-# Plain few-row linears (no window: the Linears of a streamed transformer layer at more than two streams) read their rows row-major
-# inside the GEMM (rst_linear_few_rows_f32): no packing launch.  "plain" (default): the linears WITHOUT a LayerNorm in front (the
-# out-projection); True: those with one too -- the same bits, but measured SLOWER (64 rows, 512 -> 1536: 15.9 us against 11.3 us for
-# LayerNorm + pack followed by the GEMM; the statistics of all rows by every workgroup are a second memory round trip plus two
-# cross-lane reductions in front of the matrix instructions, and a 3 us packing launch is all they replace;
-# tools/probes/few_row_linear_probe.py, profiles/r06_few_row_linear_probe.txt); False: never (the A/B switch).
-SKINNY_F32_ROWS = "plain"
+# Plain few-row linears WITHOUT a LayerNorm in front (no window) read their rows row-major inside the GEMM (rst_linear_few_rows_f32): no
+# packing launch, the same bits.  False: pack, then the GEMM on the packed operand (the A/B switch of tools/probes/few_row_linear_probe.py).
+# (With a LayerNorm the packing launch stays: applying it inside the GEMM was built twice and measured slower, csrc/skinny_f32.hip.)
+SKINNY_F32_ROWS = True
 
 # LayerNorm in front of a few-row linear (streamed transformer layers at more than two streams): applied by the packing launch
 # (rst_skinny_f32_pack_ln) instead of a launch of its own.  False: LayerNorm, then pack (the A/B switch of tools/ab.py).
@@ -254,14 +251,10 @@ def _gemm_few_rows(x, hist, w, bias, res, scale, out, B, T_in, T_out, C_, K, N, 
                 torch.zeros(((M + 31) // 32) * ((N + 31) // 32), device=dev, dtype=torch.int32)) if sk > 1 else (1, None, None)
     sc = _scratch(_gemm_scratch, dev, ("skinny", M, N, K, SKINNY_F32_SPLIT), build)
     plain = hist is None and S == 1 and P == 0 and T_in == T_out and C_ == K and act_in == ACT_NONE
-    if (SKINNY_F32_ROWS and plain and not isinstance(x, PackedRows) and K % 8 == 0 and x.data_ptr() % 16 == 0 and
-            (ln is None or (SKINNY_F32_ROWS is True and ln[0].data_ptr() % 16 == 0 and ln[1].data_ptr() % 16 == 0))):
+    if SKINNY_F32_ROWS and plain and ln is None and not isinstance(x, PackedRows) and K % 8 == 0 and x.data_ptr() % 16 == 0:
         # the rows as they are: one launch
-        g, b, eps = ln if ln is not None else (None, None, 0.0)
-        _chk(g, "ln gamma")
-        _chk(b, "ln beta")
-        _lib.check(_lib.lib().rst_linear_few_rows_f32(_ptr(x), K, _ptr(g), _ptr(b), float(eps), _ptr(wp), _ptr(bias), _ptr(res), _ptr(scale),
-                                                     _ptr(out), M, N, K, N, act_out, sc[0], _ptr(sc[1]), _ptr(sc[2]), int(out_packed), _stream()))
+        _lib.check(_lib.lib().rst_linear_few_rows_f32(_ptr(x), K, _ptr(wp), _ptr(bias), _ptr(res), _ptr(scale), _ptr(out), M, N, K, N, act_out,
+                                                     sc[0], _ptr(sc[1]), _ptr(sc[2]), int(out_packed), _stream()))
         return
     if isinstance(x, PackedRows):
         xp = x.xp

@@ -106,7 +106,7 @@ def test_projected_transformer_many_streams_across_the_wrap(streams, chunk, one_
     rst_attention_step_f32, and the out-projection reading its rows in place, rst_linear_few_rows_f32 -- or the launches they replace
     with the switches off) vs the oracle's TransformerStream for 300 positions (the ring wraps at 250)."""
     monkeypatch.setattr(ops, "ATTENTION_STEP", one_launch)
-    monkeypatch.setattr(ops, "SKINNY_F32_ROWS", "plain" if one_launch else False)
+    monkeypatch.setattr(ops, "SKINNY_F32_ROWS", one_launch)
     sd = synth.mimi_state_dict(cases.MIMI_SEED, layer_scale=cases.TRANSFORMER_LAYER_SCALE)
     model, tr = _transformer(sd)
     x = cases.transformer_input(batch=streams)

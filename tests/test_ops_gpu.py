@@ -370,9 +370,9 @@ def test_few_row_linears_chain_through_the_packed_operand(M, monkeypatch):
 @pytest.mark.parametrize("M", [5, 33, 64, 100, 128])
 @pytest.mark.parametrize("N,K", [(1536, 512), (512, 512), (2048, 512), (512, 2048), (96, 1280)])
 def test_few_row_linear_reads_its_rows_in_place(M, N, K, monkeypatch):
-    """rst_linear_few_rows_f32 (round 6): a plain few-row linear reads its rows row-major inside the GEMM -- with the LayerNorm in front of
-    it, the residual / LayerScale / GELU epilogue and the packed output for the next linear -- and gives the bits of the packing launch
-    followed by the GEMM on the packed operand (modules/transformer.py:395-423,540-569 at more than two streams per step)."""
+    """rst_linear_few_rows_f32 (round 6): a plain few-row linear reads its rows row-major inside the GEMM -- with the residual / LayerScale /
+    GELU epilogue and the packed output for the next linear -- and gives the bits of the packing launch followed by the GEMM on the packed
+    operand (modules/transformer.py:395-423,540-569 at more than two streams per step); a LayerNorm in front keeps its packing launch."""
     g = torch.Generator().manual_seed(M + N + K)
     x = (torch.randn(M, K, generator=g) * 2 + 0.3).to(DEV)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
