@@ -398,7 +398,8 @@ def test_few_row_linear_reads_its_rows_in_place(M, N, K, monkeypatch):
     assert rel_err(got[0], F.linear(xc, wc)) < TOL
 
 
-@pytest.mark.parametrize("T,D,H,cap,context", [(2, 64, 8, 250, 250), (1, 64, 8, 250, 250), (4, 32, 4, 64, 40), (3, 128, 2, 300, None), (2, 64, 8, 250, 100)])
+@pytest.mark.parametrize("T,D,H,cap,context", [(2, 64, 8, 250, 250), (1, 64, 8, 250, 250), (4, 32, 4, 64, 40), (3, 128, 2, 300, None), (2, 64, 8, 250, 100),
+                                              (2, 64, 2, 3000, 750)])      # (the last: 62 KB of scores in LDS, two batches of ring slots per class)
 def test_attention_step_is_rope_split_plus_ring_attention(T, D, H, cap, context, monkeypatch):
     """rst_attention_step_f32 (round 6): split of the in-projection's output, interleaved RoPE, ring append and the T new queries against the
     ring in ONE launch vs rst_rope_split_f32 + rst_attn_decode_multi_f32 -- same ring contents, same outputs (to the summation order of the
