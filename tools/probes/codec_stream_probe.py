@@ -4,7 +4,7 @@ captured as a HIP graph of its own and replayed (us per replay), and the whole e
     python tools/probes/codec_stream_probe.py [--streams 32] [--iters 200]
 
 Module-level switches of rstnet_amd.ops can be set from the command line for an A/B inside one call: --set NAME=VALUE (repeatable),
-e.g. --set SKINNY_F32_SPLIT=1 --set CODEC_ATTN_STEP=0.
+e.g. --set SKINNY_F32_ROWS=False --set ATTENTION_STEP=False.
 """
 import argparse
 import ast
