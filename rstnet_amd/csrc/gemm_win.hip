@@ -126,11 +126,17 @@ __device__ __forceinline__ void gw_tile(const GemmWinParams& p, const int tile, 
     // when the piece is padding), the load itself is unconditional, and padding is cleared with a mask the compiler cannot see
     // through.  A load under a per-lane condition (or one feeding a select it can fold back into a condition) is branched around
     // and waited for on the spot, which turns a k-tile into RA + RB exposed round trips -- the streaming steps live on this path.
+    // (Round 6: the mask is applied when the piece is WRITTEN to LDS, after the matrix instructions of the current k-tile -- applied right
+    // behind the load it made every k-tile of an edge tile one exposed round trip: the 3072-row layers of a 32-stream frame, a third of
+    // whose tiles reach into the history, took 53 us against 32 us for the same shape without edges.)
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    auto masked_load = [&](const float* src, bool ok) -> f32x4 {
-        int m = ok ? -1 : 0;
+    int ma[RA], mb[RB];              // all ones: the piece is data; zero: padding
+    auto masked_load = [&](const float* src, bool ok, int& m) -> f32x4 {
+        m = ok ? -1 : 0;
         asm volatile("" : "+v"(m));
-        const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? src : p.w);
+        return *reinterpret_cast<const f32x4*>(ok ? src : p.w);
+    };
+    auto apply_mask = [&](const f32x4 v, const int m) -> f32x4 {
         const i32x4 b = __builtin_bit_cast(i32x4, v) & m;
         return __builtin_bit_cast(f32x4, b);
     };
@@ -156,8 +162,9 @@ __device__ __forceinline__ void gw_tile(const GemmWinParams& p, const int tile, 
                     if (p.pad_mode == 1) src = p.x + a_off[j] + TC - p.C + f % p.C;   // F.pad(mode="replicate") also replicates the right extra padding
                     else ok = false;
                 }
-                ra[j] = masked_load(src, ok);
+                ra[j] = masked_load(src, ok, ma[j]);
             } else {
+                ma[j] = -1;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (a_ok[j]) {
 #pragma unroll
@@ -172,8 +179,9 @@ __device__ __forceinline__ void gw_tile(const GemmWinParams& p, const int tile, 
             const int n = n0 + lrow + RP * j;
             const float* wp = p.w + (long)n * p.K + k;
             if (VEC) {
-                rb[j] = masked_load(wp, n < p.N && k < p.K);
+                rb[j] = masked_load(wp, n < p.N && k < p.K, mb[j]);
             } else {
+                mb[j] = -1;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (n < p.N) {
 #pragma unroll
@@ -185,12 +193,12 @@ __device__ __forceinline__ void gw_tile(const GemmWinParams& p, const int tile, 
         }
     };
 
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const bool masked = true) {      // (masked = false: the interior loop, whose loads need none)
         float* a = As + buf * BM * LDS_LD;
         float* b = Bs + buf * BN * LDS_LD;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            f32x4 v = ra[j];
+            f32x4 v = (VEC && masked) ? apply_mask(ra[j], ma[j]) : ra[j];
             if (ELU) {
                 v[0] = rst_elu(v[0]); v[1] = rst_elu(v[1]); v[2] = rst_elu(v[2]); v[3] = rst_elu(v[3]);
             }
@@ -198,7 +206,7 @@ __device__ __forceinline__ void gw_tile(const GemmWinParams& p, const int tile, 
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j)
-            *reinterpret_cast<f32x4*>(b + (lrow + RP * j) * LDS_LD + lk) = rb[j];
+            *reinterpret_cast<f32x4*>(b + (lrow + RP * j) * LDS_LD + lk) = (VEC && masked) ? apply_mask(rb[j], mb[j]) : rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -270,7 +278,7 @@ __device__ __forceinline__ void gw_tile(const GemmWinParams& p, const int tile, 
             __builtin_amdgcn_sched_barrier(0);
             // ... and their LDS writes (other buffer) are spread between the last 16 MFMAs
             mma_tile(kt & 1, KB / 8 - 1, KB / 8);
-            store_tiles((kt & 1) ^ 1);
+            store_tiles((kt & 1) ^ 1, false);
 #pragma unroll
             for (int g = 0; g < RA + RB; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, (4 * TM * TN) / (RA + RB) > 0 ? (4 * TM * TN) / (RA + RB) : 1, 0);   // MFMA
