@@ -2,6 +2,7 @@
 ``MLLM_v2/utils/compile.py:189-277``; ``NO_CUDA_GRAPH=1`` disables it as ``compile.py:168-174`` does)."""
 from __future__ import annotations
 
+import gc
 import os
 from contextlib import contextmanager
 from typing import Any, List, Optional
@@ -91,8 +92,20 @@ class Graphed:
             self.static_in = [a.clone() if isinstance(a, torch.Tensor) else a for a in args]
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.static_out = self.fn(*self.static_in)
+            # No garbage collection while the stream is capturing: a dead reference cycle that holds another session's captured graph
+            # (a finished generator, a closed pipeline) would be finalised at an arbitrary point of the capture, and destroying a graph
+            # or freeing its pool is an illegal call then -- the process aborts from inside the destructor (seen once in ~10 runs of the
+            # GPU suite, tests/test_gpt_gpu.py).  Collect such cycles BEFORE the capture starts (torch.cuda.graph no longer does by
+            # default) and keep the collector off until it has ended.
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.static_out = self.fn(*self.static_in)
+            finally:
+                if gc_was_on:
+                    gc.enable()
             # the capture itself does not execute: the replay below produces this call's result
             self.graph.replay()
             return self.static_out
